@@ -1,0 +1,119 @@
+"""Whole-model CPU restatement: SwinTransformer.forward and VisionTransformer.forward.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Functional forwards driven by a
+reference-compatible ``state_dict`` (same keys as SURVEY.md section 8(b)); the
+backward comes from torch autograd over these functions.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ref_ops as R
+
+SWIN_S = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2),
+              dims=(96, 192, 384, 768), dim_head=32, n_heads=(3, 6, 12, 24),
+              dim_ffs=(384, 768, 1536, 3072), window_size=7)
+VIT_S16 = dict(image_size=224, window_size=16, depth=12, dim=384, n_head=6, dim_ff=1536)
+
+
+def swin_drop_path_rates(depths, drop_path):
+    """dp_rate[i] = drop_path * i / n_blocks over transformer layers (swin:286-288)."""
+    n = sum(depths)
+    return [drop_path * float(i) / n for i in range(n)]
+
+
+def swin_forward(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
+    """SwinTransformer.forward (swin:370-379).
+
+    ``drop_masks``: optional list (one entry per transformer layer, network
+    order) of (mask_attn, mask_ff) per-sample keep masks in {0,1}; rates follow
+    ``swin_drop_path_rates``.  None = eval / drop_path 0.
+    """
+    depths, dims = cfg["depths"], cfg["dims"]
+    w = cfg["window_size"]
+    rates = swin_drop_path_rates(depths, drop_path)
+    x = R.swin_patch_embedding(x_nchw, sd["patch_embedding.linear.weight"],
+                               sd["patch_embedding.linear.bias"],
+                               sd["patch_embedding.norm.weight"],
+                               sd["patch_embedding.norm.bias"], q=q)
+    li = 0
+    for s in range(4):
+        blk = f"block{s + 1}"
+        j0 = 0
+        if s > 0:
+            x = R.patch_merge(x, sd[f"{blk}.0.norm.weight"], sd[f"{blk}.0.norm.bias"],
+                              sd[f"{blk}.0.linear.weight"], q=q)
+            j0 = 1
+        for i in range(depths[s]):
+            p = f"{blk}.{j0 + i}"
+            shift = i % 2 == 0                                   # swin:362
+            h = R._q(R.layer_norm(x, sd[f"{p}.norm_attn.weight"], sd[f"{p}.norm_attn.bias"], 1e-6), q)
+            a = R.window_attention(h, sd[f"{p}.attn.weight.weight"], sd[f"{p}.attn.weight.bias"],
+                                   sd[f"{p}.attn.linear.weight"], sd[f"{p}.attn.linear.bias"],
+                                   sd[f"{p}.attn.rel_pos.weight"], cfg["n_heads"][s],
+                                   cfg["dim_head"], w, shift, q=q)
+            ma, mf = (drop_masks[li] if drop_masks is not None else (None, None))
+            x = R._q(x + R.drop_path_apply(a, ma, rates[li]), q)  # swin:194
+            h = R._q(R.layer_norm(x, sd[f"{p}.norm_ff.weight"], sd[f"{p}.norm_ff.bias"], 1e-6), q)
+            f = R.feed_forward(h, sd[f"{p}.ff.0.weight"], sd[f"{p}.ff.0.bias"],
+                               sd[f"{p}.ff.3.weight"], sd[f"{p}.ff.3.bias"], q=q)
+            x = R._q(x + R.drop_path_apply(f, mf, rates[li]), q)  # swin:195
+            li += 1
+    x = R.layer_norm(x, sd["final_linear.0.weight"], sd["final_linear.0.bias"], 1e-5)
+    pooled = R._q(x.mean(dim=(1, 2)), q)                        # AdaptiveAvgPool2d(1)+Flatten, swin:281
+    return R.linear(pooled, sd["classifier.2.weight"], sd["classifier.2.bias"])
+
+
+def vit_interpolate_pos(pos_embed, n_patch):
+    """interpolate_pos_embedding (vit.py:153-175)."""
+    n_pos = pos_embed.shape[1] - 1
+    if n_patch == n_pos:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    side = int(math.sqrt(n_pos))
+    grid = pos_embed[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=math.sqrt(n_patch / n_pos), mode="bicubic",
+                         align_corners=False, recompute_scale_factor=False)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((pos_embed[:, :1], grid), 1)
+
+
+def vit_forward_feature(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
+    """VisionTransformer.forward_feature (vit.py:139-151) -> (B, dim) cls feature."""
+    depth, n_head = cfg["depth"], cfg["n_head"]
+    rates = torch.linspace(0, drop_path, depth).tolist()         # vit.py:104
+    t = R._q(R.vit_patch_embedding(x_nchw, sd["patch_embedding.linear.weight"],
+                                   sd["patch_embedding.linear.bias"], cfg["window_size"]), q)
+    B = t.shape[0]
+    x = torch.cat((sd["cls_token"].expand(B, -1, -1), t), 1)
+    x = R._q(x + vit_interpolate_pos(sd["pos_embed"], t.shape[1]), q)
+    for i in range(depth):
+        p = f"layers.{i}"
+        h = R._q(R.layer_norm(x, sd[f"{p}.norm_attn.weight"], sd[f"{p}.norm_attn.bias"], 1e-6), q)
+        a = R.global_attention(h, sd[f"{p}.attn.qkv.weight"], sd[f"{p}.attn.qkv.bias"],
+                               sd[f"{p}.attn.linear.weight"], sd[f"{p}.attn.linear.bias"], n_head, q=q)
+        ma, mf = (drop_masks[i] if drop_masks is not None else (None, None))
+        x = R._q(x + R.drop_path_apply(a, ma, rates[i]), q)       # vit.py:60
+        h = R._q(R.layer_norm(x, sd[f"{p}.norm_ff.weight"], sd[f"{p}.norm_ff.bias"], 1e-6), q)
+        f = R.feed_forward(h, sd[f"{p}.ff.0.weight"], sd[f"{p}.ff.0.bias"],
+                           sd[f"{p}.ff.3.weight"], sd[f"{p}.ff.3.bias"], q=q)
+        x = R._q(x + R.drop_path_apply(f, mf, rates[i]), q)       # vit.py:61
+    x = R.layer_norm(x[:, 0], sd["norm.weight"], sd["norm.bias"], 1e-6)   # norm then [:,0] == [:,0] then norm
+    return x
+
+
+def vit_forward(sd, inputs, cfg, head=None, **kw):
+    """VisionTransformer.forward (vit.py:177-203): group consecutive same-size crops."""
+    if not isinstance(inputs, (list, tuple)):
+        inputs = [inputs]
+    outs, start = [], 0
+    sizes = [int(i.shape[-1]) for i in inputs]
+    while start < len(inputs):
+        end = start
+        while end < len(inputs) and sizes[end] == sizes[start]:
+            end += 1
+        outs.append(vit_forward_feature(sd, torch.cat(inputs[start:end]), cfg, **kw))
+        start = end
+    out = torch.cat(outs)
+    return head(out) if head is not None else out

@@ -1,0 +1,206 @@
+"""CPU restatement of the reference's ViT / Swin hot-path operators.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Pure PyTorch CPU math written
+from the reference's semantics, one function per SURVEY.md section 8(a) row,
+each citing the reference lines it follows.  Backward passes come from torch
+autograd over these forwards (fp32 or fp64), which is the "plain fp32
+reference of the same op" for floating-point kernels.
+
+``q`` (optional callable) is applied wherever the bf16 product path stores a
+tensor in bf16 (GEMM outputs, LayerNorm outputs, attention probabilities and
+outputs); passing ``q=bf16_round`` turns the fp32 oracle into a tight model of
+the bf16 kernels' rounding points.  ``q=None`` is the exact reference math.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import tables
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _q(t, q):
+    return t if q is None else q(t)
+
+
+# --------------------------------------------------------------------------- A4
+def layer_norm(x, weight, bias, eps):
+    """Row-wise LayerNorm, biased variance (nn.LayerNorm; vit.py:13, swin:12,206,221,277)."""
+    mu = x.mean(-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps) * weight + bias
+
+
+def linear(x, weight, bias=None):
+    """y = x W^T + b (nn.Linear)."""
+    y = x @ weight.t()
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+# --------------------------------------------------------------------------- A3
+def feed_forward(x, w1, b1, w2, b2, q=None):
+    """PositionwiseFeedForward: Linear -> SiLU -> Dropout(0) -> Linear (layer.py:186-196)."""
+    z = _q(linear(x, w1, b1), q)
+    h = _q(silu(z), q)
+    return linear(h, w2, b2)
+
+
+# --------------------------------------------------------------------------- A12
+def drop_path_apply(branch, keep_mask, p):
+    """DropPath with an injected per-sample mask (layer.py:172-180): x / (1-p) * mask."""
+    if keep_mask is None or p == 0:
+        return branch
+    shape = [branch.shape[0]] + [1] * (branch.ndim - 1)
+    return branch / (1.0 - p) * keep_mask.reshape(shape).to(branch.dtype)
+
+
+# --------------------------------------------------------------------------- A2
+def global_attention(x, w_qkv, b_qkv, w_o, b_o, n_head, q=None):
+    """vit.MultiHeadedAttention.forward (vit.py:27-45).
+
+    qkv channel order is [q|k|v][head][d] (reshape (B,L,3,h,d), vit.py:30-34);
+    the 1/sqrt(d) scale is applied to the product (vit.py:37).
+    """
+    B, L, C = x.shape
+    d = C // n_head
+    qkv = _q(linear(x, w_qkv, b_qkv), q)
+    out = x.new_zeros(B, L, C)
+    for h in range(n_head):
+        Q = qkv[..., 0 * C + h * d:0 * C + (h + 1) * d]
+        K = qkv[..., 1 * C + h * d:1 * C + (h + 1) * d]
+        V = qkv[..., 2 * C + h * d:2 * C + (h + 1) * d]
+        S = torch.einsum("bid,bjd->bij", Q, K) / math.sqrt(d)
+        P = _q(torch.softmax(S, -1), q)
+        out[..., h * d:(h + 1) * d] = torch.einsum("bij,bjd->bid", P, V)
+    out = _q(out, q)
+    return linear(out, w_o, b_o)
+
+
+# --------------------------------------------------------------------------- A7
+def patchify(x, s):
+    """NHWC (B,H,W,C) -> (B,H/s,W/s,s*s*C), flatten order (py,px,c) (swin:15-22)."""
+    B, H, W, C = x.shape
+    out = x.new_empty(B, H // s, W // s, s * s * C)
+    for py in range(s):
+        for px in range(s):
+            o = (py * s + px) * C
+            out[..., o:o + C] = x[:, py::s, px::s, :]
+    return out
+
+
+def window_token_index(H, W, window, shift):
+    """Flat token index (y*W+x, original frame) of every window token, (nW, w*w).
+
+    SURVEY "A9 semantic specification": roll commutes with per-token layers, so
+    window (i,j) token (ay,ax) of a shifted layer is the original token at
+    ((i*w+ay-r) mod H, (j*w+ax-r) mod W), r = -floor(w/2) (swin:109-111,157-158).
+    """
+    Y, X = tables.window_coords((H, W), window, shift)
+    return torch.from_numpy(Y * W + X)
+
+
+# --------------------------------------------------------------------------- A9
+def window_attention(x, w_qkv, b_qkv, w_o, b_o, rel_pos, n_head, dim_head,
+                     window, shift, q=None):
+    """swin.MultiHeadedLocalAttention.forward (swin:103-160), roll-free form.
+
+    x: (B,H,W,C) NHWC.  rel_pos: ((2w-1)^2, n_head).  pos / local_mask are
+    rebuilt from oracle.tables (bit-exact vs the reference buffers, test G1/G2).
+    """
+    B, H, W, C = x.shape
+    hd = n_head * dim_head
+    pos_np, mask_np = tables.make_pos_mask((H, W), window, shift)
+    pos = torch.from_numpy(pos_np)
+    idx = window_token_index(H, W, window, shift)            # (nW, ww)
+    nW, ww = idx.shape
+    qkv = _q(linear(x, w_qkv, b_qkv), q).reshape(B, H * W, 3 * hd)
+    g = qkv[:, idx.reshape(-1)].reshape(B, nW, ww, 3 * hd)   # gather window tokens
+    bias = rel_pos[pos.reshape(-1)].reshape(ww, ww, n_head)  # swin:135
+    o = x.new_zeros(B, nW, ww, hd)
+    for h in range(n_head):
+        Q = g[..., 0 * hd + h * dim_head:0 * hd + (h + 1) * dim_head]
+        K = g[..., 1 * hd + h * dim_head:1 * hd + (h + 1) * dim_head]
+        V = g[..., 2 * hd + h * dim_head:2 * hd + (h + 1) * dim_head]
+        S = torch.einsum("bnid,bnjd->bnij", Q, K) / math.sqrt(dim_head)   # swin:134
+        S = S + bias[..., h]
+        if shift:
+            S = S.masked_fill(torch.from_numpy(mask_np)[None], float("-inf"))  # swin:138-141
+        P = _q(torch.softmax(S, -1), q)
+        o[..., h * dim_head:(h + 1) * dim_head] = torch.einsum("bnij,bnjd->bnid", P, V)
+    o = _q(o, q)
+    out_tok = x.new_zeros(B, H * W, hd)
+    out_tok[:, idx.reshape(-1)] = o.reshape(B, nW * ww, hd)  # inverse partition + roll back
+    y = linear(out_tok, w_o, b_o)
+    return y.reshape(B, H, W, -1)
+
+
+# --------------------------------------------------------------------------- A7/A10
+def swin_patch_embedding(x_nchw, w, b, ln_w, ln_b, q=None):
+    """permute -> patchify(4) -> Linear(48->C) -> LayerNorm(eps 1e-5) (swin:208-213,371)."""
+    x = x_nchw.permute(0, 2, 3, 1)
+    t = _q(linear(patchify(x, 4), w, b), q)
+    return layer_norm(t, ln_w, ln_b, 1e-5)
+
+
+def patch_merge(x, ln_w, ln_b, w, q=None):
+    """patchify(2) -> LayerNorm(4C, eps 1e-5) -> Linear(4C->C', no bias) (swin:216-229)."""
+    t = _q(layer_norm(patchify(x, 2), ln_w, ln_b, 1e-5), q)
+    return linear(t, w, None)
+
+
+def vit_patch_embedding(x_nchw, w, b, patch):
+    """Conv2d(3,C,k=p,s=p) -> flatten(2).transpose(1,2) (vit.py:73,76) as an im2col GEMM.
+
+    Row (b, i, j); column order (c, py, px) = the conv weight's own flattening.
+    """
+    B, Cin, H, W = x_nchw.shape
+    gh, gw = H // patch, W // patch
+    cols = (x_nchw.reshape(B, Cin, gh, patch, gw, patch)
+            .permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * patch * patch))
+    return linear(cols, w.reshape(w.shape[0], -1), b)
+
+
+# --------------------------------------------------------------------------- A13
+def mix_loss(logits, t1, t2, ratio, eps):
+    """MixLoss (loss.py:53-86): KL(sum)/B between log_softmax and the mixed smoothed one-hots."""
+    B, K = logits.shape
+    logp = torch.log_softmax(logits, -1)
+    on, off = 1 - eps + eps / K, eps / K
+    d1 = torch.full_like(logp, off)
+    d1[torch.arange(B), t1] = on
+    d2 = torch.full_like(logp, off)
+    d2[torch.arange(B), t2] = on
+    r = ratio.reshape(B, 1).to(logp.dtype)
+    td = r * d1 + (1 - r) * d2
+    kl = torch.where(td > 0, td * (td.log() - logp), torch.zeros_like(td))
+    return kl.sum() / B
+
+
+def clip_grad_norm(grads, max_norm):
+    """nn.utils.clip_grad_norm_ (train.py:296): total L2 norm, coef = max/(total+1e-6) clamped to 1."""
+    total = torch.sqrt(sum((g.to(torch.float64) ** 2).sum() for g in grads)).to(grads[0].dtype)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads], total
+
+
+def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
+    """torch.optim.AdamW single-tensor update (decoupled decay first)."""
+    p = p * (1 - lr * wd)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)) + eps
+    p = p - (lr / bc1) * m / denom
+    return p, m, v

@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Authoring-container only: imports /root/reference (read-only, never copied, never
+shipped).  The fixtures hold the reference's OUTPUTS (and captured DropPath masks);
+all inputs/weights are closed-form (oracle/formula.py), so nothing of the reference
+travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
+
+Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
+fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("VTX_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+# --- the reference only uses tensorfn.config.config_model as a registration decorator
+tf = types.ModuleType("tensorfn")
+tfc = types.ModuleType("tensorfn.config")
+tfc.config_model = lambda *a, **k: (lambda f: f)
+tf.config = tfc
+sys.modules["tensorfn"] = tf
+sys.modules["tensorfn.config"] = tfc
+
+import warnings
+warnings.filterwarnings("ignore")
+
+from models import swin_transformer as ref_swin   # noqa: E402  (reference)
+from models import vit as ref_vit                 # noqa: E402  (reference)
+from models import layer as ref_layer             # noqa: E402  (reference)
+import loss as ref_loss                           # noqa: E402  (reference)
+
+from oracle.formula import fill, fill_state_dict, summarize, name_seed  # noqa: E402
+from oracle.ref_models import SWIN_S, VIT_S16     # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def save(name, rec):
+    flat = {}
+    for k, v in rec.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}/{kk}"] = np.asarray(vv)
+        else:
+            flat[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB, {len(flat)} arrays)")
+
+
+def load_formula(module, rel_pos_scale=0.5):
+    module.load_state_dict(fill_state_dict(module.state_dict(), rel_pos_scale))
+    return module
+
+
+def grads_of(module):
+    return {n: p.grad for n, p in module.named_parameters() if p.grad is not None}
+
+
+# ------------------------------------------------------------------ G1 / G2
+def gen_tables():
+    rec = {}
+    cases = [((56, 56), 7), ((28, 28), 7), ((14, 14), 7), ((7, 7), 7), ((8, 12), 4),
+             ((12, 8), 4), ((6, 6), 3), ((10, 15), 5), ((16, 16), 8)]
+    for (size, w) in cases:
+        for shift in (False, True):
+            m = ref_swin.MultiHeadedLocalAttention(32, 1, 32, size, w, shift)
+            key = f"{size[0]}x{size[1]}_w{w}_s{int(shift)}"
+            pos = m.pos.numpy()
+            assert pos.min() >= 0 and pos.max() < 32767
+            rec[f"pos_{key}"] = pos.astype(np.int16)
+            if shift:
+                lm = m.local_mask.numpy()
+                rec[f"maskshape_{key}"] = np.array(lm.shape, dtype=np.int64)
+                rec[f"mask_{key}"] = np.packbits(lm.reshape(-1))
+    save("g1_g2_tables", rec)
+
+
+# ------------------------------------------------------------------ G3
+def run_module(mod, x, name, rec, extra_inputs_grad=True):
+    x = x.clone().requires_grad_(extra_inputs_grad)
+    out = mod(x)
+    cot = fill(out.shape, name_seed(name + ".cot"), 1.0)
+    (out * cot).sum().backward()
+    rec[f"{name}.out"] = summarize(out)
+    if extra_inputs_grad:
+        rec[f"{name}.dx"] = summarize(x.grad)
+    for n, g in grads_of(mod).items():
+        rec[f"{name}.d.{n}"] = summarize(g)
+
+
+def gen_modules():
+    rec = {}
+    # window attention: generic shifted / unshifted + the single-window wrap case (stage-4 quirk)
+    for (size, shift, tag) in [((14, 14), True, "s1"), ((14, 14), False, "s0"), ((7, 7), True, "wrap")]:
+        m = load_formula(ref_swin.MultiHeadedLocalAttention(96, 3, 32, size, 7, shift)).double()
+        x = fill((2, size[0], size[1], 96), 11, 1.0, dtype=torch.float64)
+        run_module(m, x, f"local_attn_{tag}", rec)
+    # global attention L=197 and L=37
+    for L in (197, 37):
+        m = load_formula(ref_vit.MultiHeadedAttention(384, 6)).double()
+        x = fill((2, L, 384), 12, 1.0, dtype=torch.float64)
+        run_module(m, x, f"global_attn_L{L}", rec)
+    m = load_formula(ref_layer.PositionwiseFeedForward(96, 384)).double()
+    run_module(m, fill((2, 49, 96), 13, 1.0, dtype=torch.float64), "ffn", rec)
+    m = load_formula(ref_vit.PatchEmbedding(3, 384, 16)).double()
+    run_module(m, fill((2, 3, 224, 224), 14, 1.0, dtype=torch.float64), "vit_patch", rec, False)
+    m = load_formula(ref_swin.PatchEmbedding(3, 96, 4)).double()
+    xin = fill((2, 3, 224, 224), 14, 1.0, dtype=torch.float64).permute(0, 2, 3, 1).contiguous()
+    run_module(m, xin, "swin_patch", rec, False)
+    m = load_formula(ref_swin.PatchMerge(96, 192, 2)).double()
+    run_module(m, fill((2, 14, 14, 96), 15, 1.0, dtype=torch.float64), "patch_merge", rec)
+    for eps, tag in ((1e-6, "e6"), (1e-5, "e5")):
+        m = torch.nn.LayerNorm(96, eps=eps)
+        m.load_state_dict({"weight": fill((96,), 3, 0.1, 1.0), "bias": fill((96,), 4, 0.02)})
+        run_module(m.double(), fill((2, 49, 96), 16, 2.0, 0.3, dtype=torch.float64), f"ln_{tag}", rec)
+    # a full Swin TransformerLayer (LN + attn + residual + LN + ffn + residual)
+    m = load_formula(ref_swin.TransformerLayer(96, 3, 32, 384, (14, 14), 7, True)).double()
+    run_module(m, fill((2, 14, 14, 96), 17, 1.0, dtype=torch.float64), "swin_layer", rec)
+    m = load_formula(ref_vit.TransformerLayer(384, 6, 1536, 0.0, 0.0, 0.0, 0.0)).double()
+    run_module(m, fill((2, 197, 384), 18, 1.0, dtype=torch.float64), "vit_layer", rec)
+    save("g3_modules", rec)
+
+
+# ------------------------------------------------------------------ G4
+def model_record(model, x, name, rec, train):
+    model.train(train)
+    model.zero_grad(set_to_none=True)
+    out = model(x)
+    rec[f"{name}.logits"] = summarize(out)
+    if train:
+        cot = fill(out.shape, name_seed(name + ".cot"), 1.0, dtype=out.dtype)
+        (out * cot).sum().backward()
+        names, norms = [], []
+        for n, p in model.named_parameters():
+            names.append(n)
+            norms.append(p.grad.double().norm().item())
+        rec[f"{name}.grad_names"] = np.array(names)
+        rec[f"{name}.grad_norms"] = np.array(norms, dtype=np.float64)
+        for n, p in model.named_parameters():
+            if any(s in n for s in ("patch_embedding.linear.weight", "rel_pos", "cls_token",
+                                    "pos_embed", "block3.5.attn.weight.weight",
+                                    "layers.5.attn.qkv.weight", "classifier.2.weight",
+                                    "block2.0.linear.weight", "head.weight")):
+                rec[f"{name}.grad.{n}"] = summarize(p.grad)
+
+
+def capture_bernoulli():
+    """Record every DropPath mask the reference draws (layer.py:177)."""
+    masks = []
+    orig = torch.Tensor.bernoulli_
+
+    def wrapped(self, *a, **k):
+        r = orig(self, *a, **k)
+        masks.append(r.detach().clone().reshape(-1))
+        return r
+
+    torch.Tensor.bernoulli_ = wrapped
+    return masks, (lambda: setattr(torch.Tensor, "bernoulli_", orig))
+
+
+def gen_models():
+    rec = {}
+    x = fill((2, 3, 224, 224), 21, 1.0)
+    swin = load_formula(ref_swin.SwinTransformer(**SWIN_S, drop_path=0.0))
+    model_record(swin, x, "swin_s.eval", rec, False)
+    model_record(swin, x, "swin_s.train", rec, True)
+    # fp64 run of the same model = the noise-floor reference for tolerances
+    swin64 = load_formula(ref_swin.SwinTransformer(**SWIN_S, drop_path=0.0)).double()
+    model_record(swin64, x.double(), "swin_s.train64", rec, True)
+    # with DropPath (masks captured from the reference's own RNG draws)
+    swin.set_dropout(None, 0.3)
+    masks, restore = capture_bernoulli()
+    torch.manual_seed(1234)
+    try:
+        model_record(swin, x, "swin_s.dp", rec, True)
+    finally:
+        restore()
+    rec["swin_s.dp.masks"] = torch.stack(masks).numpy().astype(np.uint8)
+    print("captured", len(masks), "drop-path masks")
+
+    head = torch.nn.Linear(384, 1000)
+    vit = ref_vit.VisionTransformer(head, VIT_S16["image_size"], VIT_S16["window_size"],
+                                    VIT_S16["depth"], VIT_S16["dim"], VIT_S16["n_head"],
+                                    VIT_S16["dim_ff"], 0.0, 0.0, 0.0, 0.0)
+    load_formula(vit)
+    model_record(vit, x, "vit_s16.eval", rec, False)
+    model_record(vit, x, "vit_s16.train", rec, True)
+    vit64 = ref_vit.VisionTransformer(torch.nn.Linear(384, 1000), 224, 16, 12, 384, 6, 1536,
+                                      0.0, 0.0, 0.0, 0.0)
+    load_formula(vit64).double()
+    model_record(vit64, x.double(), "vit_s16.train64", rec, True)
+    save("g4_models", rec)
+
+    # ---------------------------------------------------------------- G5 multi-crop
+    rec = {}
+    vit.head = None
+    crops = [fill((1, 3, 224, 224), 31, 1.0), fill((1, 3, 224, 224), 32, 1.0),
+             fill((1, 3, 96, 96), 33, 1.0), fill((1, 3, 96, 96), 34, 1.0)]
+    vit.train(True)
+    vit.zero_grad(set_to_none=True)
+    out = vit(crops)
+    rec["multicrop.out"] = summarize(out)
+    cot = fill(out.shape, name_seed("multicrop.cot"), 1.0)
+    (out * cot).sum().backward()
+    rec["multicrop.d.pos_embed"] = summarize(vit.pos_embed.grad)
+    rec["multicrop.d.cls_token"] = summarize(vit.cls_token.grad)
+    rec["multicrop.d.patch_w"] = summarize(vit.patch_embedding.linear.weight.grad)
+    pe = vit.interpolate_pos_embedding(torch.zeros(1, 37, 384), vit.pos_embed)
+    rec["multicrop.pos36"] = summarize(pe)
+    save("g5_multicrop", rec)
+
+
+# ------------------------------------------------------------------ G6
+def gen_train_step():
+    rec = {}
+    B = 2
+    x = fill((B, 3, 224, 224), 41, 1.0)
+    l1 = torch.tensor([3, 977])
+    l2 = torch.tensor([977, 3])
+    ratio = torch.tensor([0.3, 0.85], dtype=torch.float32)
+    model = load_formula(ref_swin.SwinTransformer(**SWIN_S, drop_path=0.0))
+    model.train()
+    crit = ref_loss.MixLoss(eps=0.1)
+    skip = lambda n, p: ("bias" in n or "cls" in n or "norm" in n or p.ndim == 1)  # factory.py:33-34
+    nodecay = [p for n, p in model.named_parameters() if skip(n, p)]
+    decay = [p for n, p in model.named_parameters() if not skip(n, p)]
+    opt = torch.optim.AdamW([{"params": nodecay, "weight_decay": 0.0},
+                             {"params": decay, "weight_decay": 0.05}], lr=1e-3)
+    out = model(x)
+    loss = crit(out, l1, l2, ratio)
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(list(model.parameters()), 5.0)
+    rec["loss"] = np.float64(loss.item())
+    rec["total_norm"] = np.float64(total.item())
+    rec["dlogits_check"] = summarize(out)
+    opt.step()
+    names, norms = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        norms.append(p.detach().double().norm().item())
+    rec["param_names"] = np.array(names)
+    rec["param_norms_after"] = np.array(norms, dtype=np.float64)
+    rec["p.classifier.2.bias"] = summarize(model.classifier[2].bias)
+    rec["p.block1.0.attn.rel_pos.weight"] = summarize(model.block1[0].attn.rel_pos.weight)
+    rec["p.patch_embedding.linear.weight"] = summarize(model.patch_embedding.linear.weight)
+    # MixLoss alone (value + grad) on formula logits
+    lg = fill((4, 1000), 51, 3.0).requires_grad_(True)
+    t1 = torch.tensor([1, 500, 999, 0]); t2 = torch.tensor([7, 500, 3, 998])
+    r = torch.tensor([0.1, 0.5, 1.0, 0.0])
+    lv = crit(lg, t1, t2, r)
+    lv.backward()
+    rec["mixloss.value"] = np.float64(lv.item())
+    rec["mixloss.grad"] = summarize(lg.grad)
+    save("g6_train_step", rec)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tables", "modules", "models", "step"]
+    if "tables" in which:
+        gen_tables()
+    if "modules" in which:
+        gen_modules()
+    if "models" in which:
+        gen_models()
+    if "step" in which:
+        gen_train_step()
+    # make sure nothing was written into the reference tree
+    assert not os.path.exists(os.path.join(REF, "models", "__pycache__")), "pycache leaked into reference"
