@@ -1,0 +1,78 @@
+/* vtx.h -- C ABI of libvtx.so: hand-written gfx950 (MI355X / CDNA4) kernels for the ViT / Swin
+ * training hot path of rosinality/vision-transformers-pytorch.
+ *
+ * The reference has no FFI layer: its boundary is the Python nn.Module surface (SURVEY.md
+ * section 8(b)).  These entry points are what the MI355X-native nn.Modules in
+ * vision-transformers-pytorch_amd/models/ call (through ctypes, vtx/_lib.py) in place of the stock
+ * PyTorch op compositions of the reference; each declaration cites the reference lines it replaces.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative VTX_ERR_* code otherwise (vtx_strerror); never throw, never exit
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator), including
+ *     workspaces whose size comes from the matching vtx_*_workspace(); no ownership transfer
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise and keep
+ *     no global mutable state: re-entrant across streams / threads (autograd's backward thread)
+ *   - dtype: VTX_F32 (parity mode, exact-fp32 MFMA) or VTX_BF16 (training mode: bf16 storage,
+ *     fp32 accumulation / statistics); parameters, their gradients and all statistics are fp32
+ *   - activations are row-major [rows, C] (tokens x channels) = NHWC / (B, L, C)
+ */
+#ifndef VTX_H_
+#define VTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTX_F32 0
+#define VTX_BF16 1
+
+#define VTX_OK 0
+#define VTX_ERR_SHAPE (-1)
+#define VTX_ERR_DTYPE (-2)
+#define VTX_ERR_ALIGN (-3)
+#define VTX_ERR_LAUNCH (-4)
+#define VTX_ERR_WORKSPACE (-5)
+#define VTX_ERR_NULL (-6)
+
+const char* vtx_strerror(int code);
+/* ABI version of the library (bumped on any signature change). */
+int vtx_abi_version(void);
+
+/* ---- LayerNorm (reference: nn.LayerNorm at models/vit.py:13, models/swin_transformer.py:12,
+ * 206, 221, 277).  y = (x - mean) * rstd * gamma + beta over the last dim, biased variance.
+ * merge != 0: x is (B, H, W, C/4) NHWC and row (b, i, j) is the 2x2 patchify gather of
+ * PatchMerge (models/swin_transformer.py:15-22, 224) -- the 4C-wide row is never materialised.
+ * Saves mean / rstd [rows] for the backward. */
+int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int64_t rows, int C, float eps, int dtype, int merge, int H, int W, void* stream);
+size_t vtx_layernorm_bwd_workspace(int64_t rows, int C);
+/* dx = dres + LN'(dy)  (dres optional, plain layout only), dgamma / dbeta fp32 [C] (overwritten). */
+int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                      int64_t rows, int C, int dtype, int merge, int H, int W, void* stream);
+
+/* ---- Linear layers (reference: nn.Linear / nn.Conv2d-as-GEMM at models/vit.py:23-25, 73,
+ * models/swin_transformer.py:34-35, 205, 222, 281, models/layer.py:191-196) with fused epilogues.
+ *   mode 0 (forward): C[M,N] = epi( A[M,K] . B[N,K]^T )        A = activations, B = weight
+ *   mode 1 (dgrad)  : C[M,N] = epi( A[M,K] . B[K,N]   )        A = dy, B = weight [K = out, N = in]
+ *   epi(v): v += bias[col]; act 1: aux_out = v, v = silu(v); act 2: v *= silu'(aux_in);
+ *           v *= rowscale[row / rows_per_scale] (DropPath, models/layer.py:172-180);
+ *           v += resid[row, col] (residual add, models/vit.py:60-61, swin_transformer.py:194-195)
+ * bias / resid / rowscale / aux_* may be NULL.  lda/ldb/ldc in elements. */
+int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
+             int64_t ldb, int64_t ldc, const float* bias, const void* resid, const float* rowscale,
+             int rows_per_scale, void* aux_out, const void* aux_in, int act, void* stream);
+size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
+/* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional).
+ * s = rowscale[m / rows_per_scale] or 1.  Deterministic (split-K slabs + fixed-order reduce). */
+int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
+              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace,
+              size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTX_H_ */

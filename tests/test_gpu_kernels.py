@@ -1,0 +1,152 @@
+"""-m gpu: each HIP kernel through the C ABI vs the CPU oracle on the same seeded inputs."""
+import pytest
+import torch
+
+from gpu_util import TOL, check, dev
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _mk(shape, seed, dtype, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.randn(shape, generator=g) * scale).to(dtype)
+    return t
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(98, 96), (392, 192), (197 * 2, 384), (130, 768), (50, 1536), (7, 1024)])
+def test_layernorm_fwd_bwd(dtype, rows, C):
+    from vtx import ops
+    d = dev()
+    x = _mk((rows, C), 1, dtype, 2.0) + 0.3
+    dy = _mk((rows, C), 2, dtype)
+    dres = _mk((rows, C), 3, dtype)
+    g = 1 + 0.1 * _mk((C,), 4, torch.float32)
+    b = 0.1 * _mk((C,), 5, torch.float32)
+    y, mean, rstd = ops.layernorm_fwd(x.to(d), g.to(d), b.to(d), 1e-6)
+    dx, dg, db = ops.layernorm_bwd(dy.to(d), x.to(d), mean, rstd, g.to(d), dres=dres.to(d))
+    xr = x.double().requires_grad_(True)
+    gr = g.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = R.layer_norm(xr, gr, br, 1e-6)
+    dxr, dgr, dbr = torch.autograd.grad(yr, [xr, gr, br], dy.double())
+    t = TOL[dtype]
+    check(f"layernorm fwd {dtype} {rows}x{C}", y, yr, t["out"])
+    check(f"layernorm dx {dtype} {rows}x{C}", dx, dxr + dres.double(), t["out"])
+    check(f"layernorm dgamma {dtype} {rows}x{C}", dg, dgr, 1e-5 if dtype == torch.float32 else 2e-4)
+    check(f"layernorm dbeta {dtype} {rows}x{C}", db, dbr, 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_merge_gather(dtype):
+    """PatchMerge's patchify(2) folded into the LN row addressing (swin_transformer.py:216-229)."""
+    from vtx import ops
+    d = dev()
+    B, H, W, Cs = 2, 14, 14, 96
+    x = _mk((B, H, W, Cs), 6, dtype)
+    g = 1 + 0.1 * _mk((4 * Cs,), 7, torch.float32)
+    b = 0.1 * _mk((4 * Cs,), 8, torch.float32)
+    dy = _mk((B, H // 2, W // 2, 4 * Cs), 9, dtype)
+    y, mean, rstd = ops.layernorm_fwd(x.to(d), g.to(d), b.to(d), 1e-5, merge_hw=(H, W))
+    dx, dg, db = ops.layernorm_bwd(dy.to(d), x.to(d), mean, rstd, g.to(d), merge_hw=(H, W))
+    xr = x.double().requires_grad_(True)
+    yr = R.layer_norm(R.patchify(xr, 2), g.double(), b.double(), 1e-5)
+    (dxr,) = torch.autograd.grad(yr, [xr], dy.double())
+    t = TOL[dtype]
+    check(f"merge-LN fwd {dtype}", y, yr, t["out"])
+    check(f"merge-LN dx {dtype}", dx, dxr, t["out"])
+
+
+GEMM_SHAPES = [  # (M, N, K)
+    (256, 128, 64), (128, 96, 96), (98, 288, 96), (394, 1152, 384), (130, 384, 1536),
+    (98, 2304, 768), (2, 1000, 768), (392, 192, 384), (6272, 96, 64),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_forward_plain(dtype, M, N, K):
+    from vtx import ops
+    d = dev()
+    a = _mk((M, K), 11, dtype)
+    w = _mk((N, K), 12, dtype, 0.1)
+    bias = _mk((N,), 13, torch.float32)
+    c = ops.gemm(a.to(d), w.to(d), 0, bias=bias.to(d))
+    ref = a.double() @ w.double().t() + bias.double()
+    check(f"gemm NT {dtype} {M}x{N}x{K}", c, ref, TOL[dtype]["out"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(394, 384, 1152), (98, 96, 288), (130, 1536, 384), (2, 768, 1000)])
+def test_gemm_dgrad(dtype, M, N, K):
+    """dx[M,N] = dy[M,K] @ W[K,N]  (mode 1: contraction over the weight's rows)."""
+    from vtx import ops
+    d = dev()
+    dy = _mk((M, K), 21, dtype)
+    w = _mk((K, N), 22, dtype, 0.1)
+    c = ops.gemm(dy.to(d), w.to(d), 1)
+    check(f"gemm NN {dtype} {M}x{N}x{K}", c, dy.double() @ w.double(), TOL[dtype]["out"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype):
+    from vtx import ops
+    d = dev()
+    B, T, Cin, Cff = 3, 49, 96, 384
+    M = B * T
+    x = _mk((M, Cin), 31, dtype)
+    w1 = _mk((Cff, Cin), 32, dtype, 0.1)
+    b1 = _mk((Cff,), 33, torch.float32, 0.1)
+    w2 = _mk((Cin, Cff), 34, dtype, 0.1)
+    b2 = _mk((Cin,), 35, torch.float32, 0.1)
+    res = _mk((M, Cin), 36, dtype)
+    scale = torch.tensor([0.0, 1.0 / 0.8, 1.0 / 0.8])
+    t = TOL[dtype]
+    q = (lambda v: v.to(dtype).double())
+    # fc1 + SiLU (aux = pre-activation)
+    h, z = ops.gemm(x.to(d), w1.to(d), 0, bias=b1.to(d), act=ops.ACT_SILU, want_aux=True)
+    zr = x.double() @ w1.double().t() + b1.double()
+    check(f"fc1 z {dtype}", z, zr, t["out"])
+    check(f"fc1 silu {dtype}", h, R.silu(q(zr)), t["out"])
+    # fc2 + bias + DropPath scale + residual
+    hq = h.cpu()
+    y = ops.gemm(h, w2.to(d), 0, bias=b2.to(d), resid=res.to(d), rowscale=scale.to(d), rows_per_scale=T)
+    yr = res.double() + scale.double().repeat_interleave(T)[:, None] * (hq.double() @ w2.double().t() + b2.double())
+    check(f"fc2 resid+droppath {dtype}", y, yr, t["out"])
+    # dgrad through SiLU: dz = (dh) * silu'(z)
+    dyv = _mk((M, Cin), 37, dtype)
+    zq = z.cpu()
+    dz = ops.gemm(dyv.to(d), w2.to(d), 1, act=ops.ACT_DSILU, aux_in=z, rowscale=scale.to(d), rows_per_scale=T)
+    s = torch.sigmoid(zq.double())
+    dzr = scale.double().repeat_interleave(T)[:, None] * (dyv.double() @ w2.double()) * (s * (1 + zq.double() * (1 - s)))
+    check(f"dgrad dsilu {dtype}", dz, dzr, t["out"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(394, 1152, 384), (98, 96, 384), (6272, 288, 96), (130, 768, 3072), (2, 1000, 768),
+                                   (25088, 384, 384)])
+def test_wgrad(dtype, M, N, K):
+    from vtx import ops
+    d = dev()
+    dy = _mk((M, N), 41, dtype)
+    x = _mk((M, K), 42, dtype)
+    dW, db = ops.wgrad(dy.to(d), x.to(d))
+    check(f"wgrad dW {dtype} {M}x{N}x{K}", dW, dy.double().t() @ x.double(), 2e-5)
+    check(f"wgrad db {dtype} {M}x{N}x{K}", db, dy.double().sum(0), 2e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_droppath_scale(dtype):
+    from vtx import ops
+    d = dev()
+    B, T, N, K = 4, 49, 96, 384
+    dy = _mk((B * T, N), 43, dtype)
+    x = _mk((B * T, K), 44, dtype)
+    scale = torch.tensor([1.25, 0.0, 1.25, 0.0])
+    dW, db = ops.wgrad(dy.to(d), x.to(d), rowscale=scale.to(d), rows_per_scale=T)
+    sd = (scale.double().repeat_interleave(T)[:, None] * dy.double()).to(dtype).double()
+    check(f"wgrad scaled dW {dtype}", dW, sd.t() @ x.double(), 2e-5 if dtype == torch.float32 else 3e-3)
+    check(f"wgrad scaled db {dtype}", db, (scale.double().repeat_interleave(T)[:, None] * dy.double()).sum(0), 2e-5)

@@ -1,0 +1,268 @@
+// LayerNorm forward / backward for gfx950 -- HBM-bound row kernels.
+//
+// Replaces nn.LayerNorm on the hot path (reference: models/vit.py:13, models/swin_transformer.py:12
+// block norms eps 1e-6; swin_transformer.py:206,221,277 embed / merge / final norms eps 1e-5).
+// A row of C elements is owned by a sub-wave group of G lanes (16/32/64), each lane holding NV
+// 8-element vectors in registers, so x is read from HBM exactly once; mean / variance use two
+// register passes (biased variance, fp32 statistics) and sub-wave __shfl_xor reductions.
+// "merge" addressing folds PatchMerge's 2x2 patchify gather (swin_transformer.py:15-22,224) into
+// the row load (forward) and the dx scatter (backward): the 4C-wide row never exists in HBM.
+#include "vtx_common.h"
+
+struct LnAddr {
+  int merge;   // 0: x is [rows, C];  1: x is (B, H, W, Cs) with C = 4*Cs and row = (b, i, j) of the H/2 x W/2 grid
+  int H, W, Cs;
+};
+
+__device__ __forceinline__ int64_t ln_src_offset(const LnAddr& a, int64_t row, int col, int C) {
+  if (!a.merge) return row * (int64_t)C + col;
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const int j = (int)(row % Wo);
+  const int64_t t = row / Wo;
+  const int i = (int)(t % Ho);
+  const int64_t b = t / Ho;
+  const int s = col / a.Cs, c = col - s * a.Cs;        // segment order (py, px), swin_transformer.py:19-21
+  const int py = s >> 1, px = s & 1;
+  return ((b * a.H + 2 * i + py) * a.W + 2 * j + px) * (int64_t)a.Cs + c;
+}
+
+template <typename T, int G, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, T* __restrict__ y,
+                                                    float* __restrict__ mean, float* __restrict__ rstd,
+                                                    int64_t rows, int C, float eps, LnAddr addr) {
+  constexpr int GPB = 256 / G;
+  const int lig = threadIdx.x % G, grp = threadIdx.x / G;
+  const int nvec = C >> 3;
+  float gm[NV][8], bt[NV][8];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lig + k * G;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gm[k][e] = v < nvec ? gamma[v * 8 + e] : 0.f;
+      bt[k][e] = v < nvec ? beta[v * 8 + e] : 0.f;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  for (int64_t row = (int64_t)blockIdx.x * GPB + grp; row < rows; row += (int64_t)gridDim.x * GPB) {
+    float xv[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lig + k * G;
+      if (v < nvec) {
+        Vec8<T> t = load8<T>(x + ln_src_offset(addr, row, v * 8, C));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[k][e] = t.get(e); s += xv[k][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[k][e] = 0.f;
+      }
+    }
+    const float mu = group_sum<G>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lig + k * G;
+      if (v < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[k][e] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lig + k * G;
+      if (v < nvec) {
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, (xv[k][e] - mu) * rs * gm[k][e] + bt[k][e]);
+        store8<T>(y + row * (int64_t)C + v * 8, o);
+      }
+    }
+    if (lig == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma  (+ dres: the residual-stream
+// gradient that bypasses the norm, fused so the stream gradient is written once).
+// dgamma / dbeta: per-lane register accumulation over the block's rows, LDS reduce across the
+// block's groups, one deterministic partial row per block; ln_colreduce_kernel sums the partials.
+template <typename T, int G, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                    T* __restrict__ dx, float* __restrict__ part,
+                                                    int64_t rows, int C, LnAddr addr) {
+  constexpr int GPB = 256 / G;
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [2][GPB][C]
+  const int lig = threadIdx.x % G, grp = threadIdx.x / G;
+  const int nvec = C >> 3;
+  float gm[NV][8], dg[NV][8], db[NV][8];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lig + k * G;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gm[k][e] = v < nvec ? gamma[v * 8 + e] : 0.f;
+      dg[k][e] = 0.f; db[k][e] = 0.f;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  for (int64_t row = (int64_t)blockIdx.x * GPB + grp; row < rows; row += (int64_t)gridDim.x * GPB) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NV][8], gv[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lig + k * G;
+      if (v < nvec) {
+        Vec8<T> tx = load8<T>(x + ln_src_offset(addr, row, v * 8, C));
+        Vec8<T> td = load8<T>(dy + row * (int64_t)C + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = td.get(e);
+          xh[k][e] = (tx.get(e) - mu) * rs;
+          gv[k][e] = d * gm[k][e];
+          s1 += gv[k][e];
+          s2 += gv[k][e] * xh[k][e];
+          dg[k][e] += d * xh[k][e];
+          db[k][e] += d;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[k][e] = 0.f; gv[k][e] = 0.f; }
+      }
+    }
+    const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lig + k * G;
+      if (v < nvec) {
+        const int64_t off = ln_src_offset(addr, row, v * 8, C);
+        Vec8<T> o;
+        if (dres != nullptr) {
+          Vec8<T> r = load8<T>(dres + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.set(e, r.get(e) + rs * (gv[k][e] - c1 - xh[k][e] * c2));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.set(e, rs * (gv[k][e] - c1 - xh[k][e] * c2));
+        }
+        store8<T>(dx + off, o);
+      }
+    }
+  }
+  float* sg = ln_smem;
+  float* sb = ln_smem + GPB * C;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lig + k * G;
+    if (v < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sg[grp * C + v * 8 + e] = dg[k][e]; sb[grp * C + v * 8 + e] = db[k][e]; }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int g = 0; g < GPB; ++g) { a += sg[g * C + c]; b += sb[g * C + c]; }
+    part[(int64_t)blockIdx.x * 2 * C + c] = a;
+    part[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+  }
+}
+
+static int ln_grid(int64_t rows, int gpb) {
+  int64_t nb = (rows + gpb - 1) / gpb;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+template <typename T, int G, int NV>
+static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int64_t rows, int C, float eps, LnAddr a, hipStream_t st) {
+  const int nb = ln_grid(rows, 256 / G);
+  hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
+                     rstd, rows, C, eps, a);
+  return vtx_check_launch();
+}
+
+template <typename T, int G, int NV>
+static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C,
+                         LnAddr a, hipStream_t st) {
+  const int nb = ln_grid(rows, 256 / G);
+  const size_t smem = (size_t)2 * (256 / G) * C * sizeof(float);
+  hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                     gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+  int rc = vtx_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
+  return vtx_check_launch();
+}
+
+#define LN_DISPATCH(FN, T, ...)                                          \
+  do {                                                                   \
+    const int nvec = C >> 3;                                             \
+    if (nvec <= 16) return FN<T, 16, 1>(__VA_ARGS__);                    \
+    if (nvec <= 32) return FN<T, 32, 1>(__VA_ARGS__);                    \
+    if (nvec <= 64) return FN<T, 64, 1>(__VA_ARGS__);                    \
+    if (nvec <= 128) return FN<T, 64, 2>(__VA_ARGS__);                   \
+    if (nvec <= 192) return FN<T, 64, 3>(__VA_ARGS__);                   \
+    if (nvec <= 256) return FN<T, 64, 4>(__VA_ARGS__);                   \
+    return VTX_ERR_SHAPE;                                                \
+  } while (0)
+
+static int ln_make_addr(LnAddr& a, int64_t rows, int C, int merge, int H, int W) {
+  a.merge = merge; a.H = H; a.W = W; a.Cs = C / 4;
+  if (C <= 0 || (C & 7)) return VTX_ERR_SHAPE;
+  if (merge) {
+    if ((C & 31) || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return VTX_ERR_SHAPE;
+    if (rows % ((int64_t)(H / 2) * (W / 2))) return VTX_ERR_SHAPE;
+  }
+  return VTX_OK;
+}
+
+extern "C" {
+
+int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int64_t rows, int C, float eps, int dtype, int merge, int H, int W, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return VTX_ERR_NULL;
+  if (rows <= 0) return VTX_OK;
+  LnAddr a;
+  int rc = ln_make_addr(a, rows, C, merge, H, W);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16) LN_DISPATCH(ln_fwd_launch, bf16, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
+  if (dtype == VTX_F32) LN_DISPATCH(ln_fwd_launch, float, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
+  return VTX_ERR_DTYPE;
+}
+
+size_t vtx_layernorm_bwd_workspace(int64_t rows, int C) {
+  (void)rows;
+  return (size_t)1024 * 2 * (size_t)C * sizeof(float);
+}
+
+int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                      int64_t rows, int C, int dtype, int merge, int H, int W, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return VTX_ERR_NULL;
+  if (ws_bytes < vtx_layernorm_bwd_workspace(rows, C)) return VTX_ERR_WORKSPACE;
+  LnAddr a;
+  int rc = ln_make_addr(a, rows, C, merge, H, W);
+  if (rc) return rc;
+  if (merge && dres) return VTX_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  if (rows <= 0) return VTX_OK;
+  if (dtype == VTX_BF16)
+    LN_DISPATCH(ln_bwd_launch, bf16, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
+  if (dtype == VTX_F32)
+    LN_DISPATCH(ln_bwd_launch, float, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
+  return VTX_ERR_DTYPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the ViT / Swin hot path.
+//
+// Every kernel is templated on ONE element type T in {float, bf16}:
+//   * bf16  = the benchmark / training mode (bf16 storage, fp32 accumulation, fp32 statistics)
+//   * float = the parity mode (exact-fp32 MFMA, used to check against the CPU oracle at 1e-3 rel)
+// gfx950 only: 64-wide wavefronts, v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define VTX_WAVE 64
+
+enum { VTX_OK = 0, VTX_ERR_SHAPE = -1, VTX_ERR_DTYPE = -2, VTX_ERR_ALIGN = -3, VTX_ERR_LAUNCH = -4,
+       VTX_ERR_WORKSPACE = -5, VTX_ERR_NULL = -6 };
+enum { VTX_F32 = 0, VTX_BF16 = 1 };
+
+// ---------------------------------------------------------------- 8-element vectors of T
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  float v[8];
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct alignas(16) Vec8<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T> __device__ __forceinline__ Vec8<T> vec8_zero() {
+  Vec8<T> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.set(i, 0.f);
+  return r;
+}
+// 8 consecutive T from global / LDS memory (16 B for bf16, 32 B for float); p must be 16-B aligned
+template <typename T> __device__ __forceinline__ Vec8<T> load8(const T* p);
+template <> __device__ __forceinline__ Vec8<bf16> load8<bf16>(const bf16* p) {
+  Vec8<bf16> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r;
+}
+template <> __device__ __forceinline__ Vec8<float> load8<float>(const float* p) {
+  Vec8<float> r;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r.v[i] = a[i]; r.v[4 + i] = b[i]; }
+  return r;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const Vec8<T>& x);
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const Vec8<bf16>& x) {
+  *reinterpret_cast<bf16x8*>(p) = x.v;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const Vec8<float>& x) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = x.v[i]; b[i] = x.v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+// value as the product path would store it (round to T, back to fp32)
+template <typename T> __device__ __forceinline__ float round_to(float x) { return (float)((T)x); }
+
+// ---------------------------------------------------------------- MFMA 16x16 "k-slot" contraction
+// acc[r] (row 4*(lane>>4)+r, col lane&15) += sum over g in 0..3, j in 0..7 of
+//        A(lane with lane&15 == row, lane>>4 == g)[j] * B(lane with lane&15 == col, lane>>4 == g)[j]
+// i.e. each lane supplies 8 "k-slots" (g,j) of one A row / one B column; any assignment of real k
+// indices to slots is valid as long as A and B use the same one.
+//   bf16 : one v_mfma_f32_16x16x32_bf16
+//   float: eight v_mfma_f32_16x16x4_f32 (k index = lane>>4 per instruction), exact fp32
+__device__ __forceinline__ void mma16(const Vec8<bf16>& a, const Vec8<bf16>& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(const Vec8<float>& a, const Vec8<float>& b, f32x4& c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+template <int G> __device__ __forceinline__ float group_sum(float v) {   // G = 16, 32 or 64 lanes
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += shfl_xor_f(v, m);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoidf_(z); }
+__device__ __forceinline__ float dsilu_f(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
+
+// out[c] = sum_b part[b][c]  (fixed order -> run-to-run deterministic)
+static __global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
+                                 int nb, int C, int ld) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * ld + c];
+  if (c < C) out0[c] = s; else if (out1) out1[c - C] = s;
+}
+
+static inline int vtx_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VTX_OK : VTX_ERR_LAUNCH;
+}

@@ -1,0 +1,70 @@
+"""ctypes binding of libvtx.so (C ABI declared in include/vtx.h).
+
+The library is the product: there is NO fallback.  If libvtx.so is missing or a call returns a
+non-zero code this module raises -- it never routes to PyTorch ops or to the CPU oracle.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvtx.so")
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+
+class VtxError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "vtx_strerror": (c_char_p, [c_int]),
+    "vtx_abi_version": (c_int, []),
+    "vtx_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                  c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_layernorm_bwd_workspace": (c_size_t, [c_int64, c_int]),
+    "vtx_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
+    "vtx_gemm": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
+                         c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vtx_wgrad_workspace": (c_size_t, [c_int64, c_int, c_int]),
+    "vtx_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64,
+                          c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvtx.so once; raise VtxError (never fall back) if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VtxError(
+            f"{LIB_PATH} not found: the HIP extension is the product path and has no fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VtxError(f"libvtx.so does not export {name} (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vtx_abi_version() != ABI_VERSION:
+        raise VtxError(f"libvtx.so ABI {lib.vtx_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().vtx_strerror(code).decode()
+        raise VtxError(f"{what} failed: {msg} (code {code})")

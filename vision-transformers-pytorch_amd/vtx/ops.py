@@ -1,0 +1,134 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per vtx_* entry point).
+
+Every function takes contiguous DEVICE tensors, allocates outputs / workspaces through PyTorch's
+caching allocator, enqueues on torch's current HIP stream and returns tensors.  No fallback: CPU
+tensors, wrong dtypes or a missing library raise VtxError.
+"""
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, VtxError, check
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise VtxError(f"vtx: unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise VtxError("vtx: the HIP path needs device tensors (there is no CPU fallback); "
+                           "move the module / inputs to 'cuda'")
+        if not t.is_contiguous():
+            raise VtxError("vtx: tensor must be contiguous")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, what):
+    if t is not None and t.dtype != torch.float32:
+        raise VtxError(f"vtx: {what} must be float32")
+
+
+# ------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, merge_hw=None):
+    """y, mean, rstd.  merge_hw=(H, W): x is (B,H,W,Cs) and rows are PatchMerge's 2x2 gathers (C=4Cs)."""
+    _dev(x, gamma, beta)
+    _f32(gamma, "gamma"); _f32(beta, "beta")
+    lib = _lib.load()
+    if merge_hw is None:
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        merge, H, W = 0, 0, 0
+    else:
+        H, W = merge_hw
+        B, Cs = x.shape[0], x.shape[-1]
+        C = 4 * Cs
+        rows = B * (H // 2) * (W // 2)
+        y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        merge = 1
+    if gamma.numel() != C or beta.numel() != C:
+        raise VtxError("vtx: layernorm weight/bias size mismatch")
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.vtx_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
+                                _dt(x), merge, H, W, _stream()), "vtx_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, merge_hw=None):
+    """dx (= dres + LN'(dy)), dgamma, dbeta."""
+    _dev(dy, x, mean, rstd, gamma, dres)
+    lib = _lib.load()
+    C = dy.shape[-1]
+    rows = dy.numel() // C
+    if merge_hw is None:
+        merge, H, W = 0, 0, 0
+    else:
+        merge, (H, W) = 1, merge_hw
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    wsb = lib.vtx_layernorm_bwd_workspace(rows, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    check(lib.vtx_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
+                                _p(dbeta), _p(ws), wsb, rows, C, _dt(x), merge, H, W, _stream()),
+          "vtx_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------- GEMM family
+ACT_NONE, ACT_SILU, ACT_DSILU = 0, 1, 2
+
+
+def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, act=ACT_NONE, aux_in=None,
+         want_aux=False, out=None):
+    """mode 0: a[M,K] @ w[N,K]^T ; mode 1: a[M,K] @ w[K,N].  Returns C (and the pre-activation if want_aux)."""
+    _dev(a, w, bias, resid, rowscale, aux_in, out)
+    _f32(bias, "bias"); _f32(rowscale, "rowscale")
+    if a.dtype != w.dtype:
+        raise VtxError(f"vtx: gemm operand dtypes differ ({a.dtype} vs {w.dtype})")
+    lib = _lib.load()
+    K = a.shape[-1]
+    M = a.numel() // K
+    if mode == 0:
+        N, kw = w.shape
+    else:
+        kw, N = w.shape
+    if kw != K:
+        raise VtxError(f"vtx: gemm contraction mismatch ({K} vs {kw})")
+    c = out if out is not None else torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
+    aux = torch.empty_like(c) if want_aux else None
+    check(lib.vtx_gemm(mode, _dt(a), _p(a), _p(w), _p(c), M, N, K, K, w.shape[1], N, _p(bias), _p(resid),
+                       _p(rowscale), int(rows_per_scale), _p(aux), _p(aux_in), act, _stream()), "vtx_gemm")
+    return (c, aux) if want_aux else c
+
+
+def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1):
+    """dW[N,Kin] (fp32), dbias[N] (fp32 or None) from dy[M,N], x[M,Kin]."""
+    _dev(dy, x, rowscale)
+    lib = _lib.load()
+    N, Kin = dy.shape[-1], x.shape[-1]
+    M = dy.numel() // N
+    if x.numel() // Kin != M:
+        raise VtxError("vtx: wgrad token-count mismatch")
+    dW = torch.empty((N, Kin), dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
+    wsb = lib.vtx_wgrad_workspace(M, N, Kin)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
+                        int(rows_per_scale), _p(ws), wsb, _stream()), "vtx_wgrad")
+    return dW, db
