@@ -72,6 +72,26 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
               int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace,
               size_t ws_bytes, void* stream);
 
+/* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order
+ * [q|k|v][head][d] (models/vit.py:30-34, models/swin_transformer.py:128); o is [rows, nH*D].
+ *   swin == 0 (reference models/vit.py:30-42): L tokens per image, rows = B*L.
+ *   swin != 0 (reference models/swin_transformer.py:109-154): (H, W) NHWC feature map, win x win
+ *     windows (L = win*win), shift != 0 selects the rolled partition (roll by -win/2 and back are
+ *     folded into addressing); bias = [nH][L][L] fp32 from vtx_relpos_bias; mask = local_mask
+ *     buffer [nW][L][L] bytes (True = -inf) or NULL.
+ * lse [B*nW*nH*L] fp32 (log-sum-exp per query row) is saved for the backward. */
+int vtx_relpos_bias(const float* rel_pos, const int64_t* pos, float* bias, int L, int nH, void* stream);
+int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
+                      int nH, int D, int swin, int H, int W, int win, int shift, int dtype, void* stream);
+size_t vtx_attention_bwd_workspace(int B, int L, int nH, int swin, int H, int W, int win);
+/* dqkv [rows, 3*nH*D] (fully overwritten).  With bias: drel_pos [ntab, nH] fp32 = dense gradient of
+ * the rel_pos embedding (models/swin_transformer.py:46,135), scattered through the CSR (order[L*L],
+ * offsets[ntab+1]) of the pos table; deterministic (no atomics). */
+int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* bias,
+                      const uint8_t* mask, const int* csr_order, const int* csr_offsets, void* dqkv,
+                      float* drel_pos, int ntab, void* workspace, size_t ws_bytes, int B, int L, int nH, int D,
+                      int swin, int H, int W, int win, int shift, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,16 +66,16 @@ def drop_path_apply(branch, keep_mask, p):
 
 
 # --------------------------------------------------------------------------- A2
-def global_attention(x, w_qkv, b_qkv, w_o, b_o, n_head, q=None):
-    """vit.MultiHeadedAttention.forward (vit.py:27-45).
+def global_attention_core(qkv, n_head, q=None):
+    """Attention core of vit.MultiHeadedAttention (vit.py:30-42) on the QKV projection output.
 
-    qkv channel order is [q|k|v][head][d] (reshape (B,L,3,h,d), vit.py:30-34);
-    the 1/sqrt(d) scale is applied to the product (vit.py:37).
+    qkv: (B, L, 3C) with channel order [q|k|v][head][d] (vit.py:30-34); returns O (B, L, C) in
+    [head][d] channel order (vit.py:42); the 1/sqrt(d) scale is applied to the product (vit.py:37).
     """
-    B, L, C = x.shape
+    B, L, C3 = qkv.shape
+    C = C3 // 3
     d = C // n_head
-    qkv = _q(linear(x, w_qkv, b_qkv), q)
-    out = x.new_zeros(B, L, C)
+    out = qkv.new_zeros(B, L, C)
     for h in range(n_head):
         Q = qkv[..., 0 * C + h * d:0 * C + (h + 1) * d]
         K = qkv[..., 1 * C + h * d:1 * C + (h + 1) * d]
@@ -83,7 +83,13 @@ def global_attention(x, w_qkv, b_qkv, w_o, b_o, n_head, q=None):
         S = torch.einsum("bid,bjd->bij", Q, K) / math.sqrt(d)
         P = _q(torch.softmax(S, -1), q)
         out[..., h * d:(h + 1) * d] = torch.einsum("bij,bjd->bid", P, V)
-    out = _q(out, q)
+    return out
+
+
+def global_attention(x, w_qkv, b_qkv, w_o, b_o, n_head, q=None):
+    """vit.MultiHeadedAttention.forward (vit.py:27-45)."""
+    qkv = _q(linear(x, w_qkv, b_qkv), q)
+    out = _q(global_attention_core(qkv, n_head, q), q)
     return linear(out, w_o, b_o)
 
 
@@ -111,23 +117,23 @@ def window_token_index(H, W, window, shift):
 
 
 # --------------------------------------------------------------------------- A9
-def window_attention(x, w_qkv, b_qkv, w_o, b_o, rel_pos, n_head, dim_head,
-                     window, shift, q=None):
-    """swin.MultiHeadedLocalAttention.forward (swin:103-160), roll-free form.
+def window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q=None):
+    """Attention core of swin.MultiHeadedLocalAttention (swin:109-154), roll-free form.
 
-    x: (B,H,W,C) NHWC.  rel_pos: ((2w-1)^2, n_head).  pos / local_mask are
-    rebuilt from oracle.tables (bit-exact vs the reference buffers, test G1/G2).
+    qkv: (B,H,W,3*h*dh) = output of the ``weight`` Linear on the UN-rolled input (roll commutes with
+    per-token layers); returns O (B,H,W,h*dh) at original token positions (inverse partition + roll
+    back folded in).  rel_pos: ((2w-1)^2, n_head).  pos / local_mask are rebuilt from oracle.tables
+    (bit-exact vs the reference buffers, goldens G1/G2).
     """
-    B, H, W, C = x.shape
+    B, H, W, _ = qkv.shape
     hd = n_head * dim_head
     pos_np, mask_np = tables.make_pos_mask((H, W), window, shift)
     pos = torch.from_numpy(pos_np)
     idx = window_token_index(H, W, window, shift)            # (nW, ww)
     nW, ww = idx.shape
-    qkv = _q(linear(x, w_qkv, b_qkv), q).reshape(B, H * W, 3 * hd)
-    g = qkv[:, idx.reshape(-1)].reshape(B, nW, ww, 3 * hd)   # gather window tokens
+    g = qkv.reshape(B, H * W, 3 * hd)[:, idx.reshape(-1)].reshape(B, nW, ww, 3 * hd)
     bias = rel_pos[pos.reshape(-1)].reshape(ww, ww, n_head)  # swin:135
-    o = x.new_zeros(B, nW, ww, hd)
+    o = qkv.new_zeros(B, nW, ww, hd)
     for h in range(n_head):
         Q = g[..., 0 * hd + h * dim_head:0 * hd + (h + 1) * dim_head]
         K = g[..., 1 * hd + h * dim_head:1 * hd + (h + 1) * dim_head]
@@ -138,11 +144,17 @@ def window_attention(x, w_qkv, b_qkv, w_o, b_o, rel_pos, n_head, dim_head,
             S = S.masked_fill(torch.from_numpy(mask_np)[None], float("-inf"))  # swin:138-141
         P = _q(torch.softmax(S, -1), q)
         o[..., h * dim_head:(h + 1) * dim_head] = torch.einsum("bnij,bnjd->bnid", P, V)
-    o = _q(o, q)
-    out_tok = x.new_zeros(B, H * W, hd)
+    out_tok = qkv.new_zeros(B, H * W, hd)
     out_tok[:, idx.reshape(-1)] = o.reshape(B, nW * ww, hd)  # inverse partition + roll back
-    y = linear(out_tok, w_o, b_o)
-    return y.reshape(B, H, W, -1)
+    return out_tok.reshape(B, H, W, hd)
+
+
+def window_attention(x, w_qkv, b_qkv, w_o, b_o, rel_pos, n_head, dim_head,
+                     window, shift, q=None):
+    """swin.MultiHeadedLocalAttention.forward (swin:103-160).  x: (B,H,W,C) NHWC."""
+    qkv = _q(linear(x, w_qkv, b_qkv), q)
+    o = _q(window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q), q)
+    return linear(o, w_o, b_o)
 
 
 # --------------------------------------------------------------------------- A7/A10

@@ -150,3 +150,54 @@ def test_wgrad_droppath_scale(dtype):
     sd = (scale.double().repeat_interleave(T)[:, None] * dy.double()).to(dtype).double()
     check(f"wgrad scaled dW {dtype}", dW, sd.t() @ x.double(), 2e-5 if dtype == torch.float32 else 3e-3)
     check(f"wgrad scaled db {dtype}", db, (scale.double().repeat_interleave(T)[:, None] * dy.double()).sum(0), 2e-5)
+
+
+# ------------------------------------------------------------------ attention cores
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,nH,D", [(2, 197, 6, 64), (3, 37, 6, 64), (1, 49, 2, 32), (2, 64, 1, 64)])
+def test_global_attention_core(dtype, B, L, nH, D):
+    from vtx import ops
+    d = dev()
+    qkv = _mk((B, L, 3 * nH * D), 51, dtype)
+    do = _mk((B, L, nH * D), 52, dtype)
+    o, lse = ops.attention_fwd(qkv.to(d), B, L, nH, D)
+    dqkv, _ = ops.attention_bwd(qkv.to(d), o, do.to(d), lse, B, L, nH, D)
+    qr = qkv.double().requires_grad_(True)
+    orf = R.global_attention_core(qr, nH)
+    (dqr,) = torch.autograd.grad(orf, [qr], do.double())
+    t = TOL[dtype]
+    check(f"global attn fwd {dtype} L{L} h{nH} d{D}", o, orf, t["out"] * 1.5)
+    check(f"global attn dqkv {dtype} L{L} h{nH} d{D}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,nH,shift", [(2, 14, 14, 3, True), (2, 14, 14, 3, False), (3, 7, 7, 24, True),
+                                            (1, 28, 28, 6, True), (2, 56, 56, 3, True)])
+def test_window_attention_core(dtype, B, H, W, nH, shift):
+    from vtx import ops
+    from oracle import tables
+    d = dev()
+    D, win = 32, 7
+    L, ntab = win * win, (2 * win - 1) ** 2
+    qkv = _mk((B, H, W, 3 * nH * D), 61, dtype)
+    do = _mk((B, H, W, nH * D), 62, dtype)
+    rel = _mk((ntab, nH), 63, torch.float32, 0.5)
+    pos_np, mask_np = tables.make_pos_mask((H, W), win, shift)
+    pos = torch.from_numpy(pos_np)
+    mask = torch.from_numpy(mask_np).to(d) if shift else None
+    csr = tuple(t.to(d) for t in ops.pos_csr(pos, ntab))
+    bias = ops.relpos_bias(rel.to(d), pos.to(d), nH)
+    check(f"relpos bias gather h{nH}", bias, rel[pos.reshape(-1)].reshape(L, L, nH).permute(2, 0, 1), 0.0)
+    swin = (H, W, win, shift)
+    o, lse = ops.attention_fwd(qkv.to(d), B, L, nH, D, swin=swin, bias=bias, mask=mask)
+    dqkv, drel = ops.attention_bwd(qkv.to(d), o, do.to(d), lse, B, L, nH, D, swin=swin, bias=bias, mask=mask,
+                                   csr=csr, ntab=ntab)
+    qr = qkv.double().requires_grad_(True)
+    rr = rel.double().requires_grad_(True)
+    orf = R.window_attention_core(qr, rr, nH, D, win, shift)
+    dqr, drr = torch.autograd.grad(orf, [qr, rr], do.double())
+    t = TOL[dtype]
+    tag = f"{dtype} {H}x{W} h{nH} s{int(shift)}"
+    check(f"window attn fwd {tag}", o, orf, t["out"] * 1.5)
+    check(f"window attn dqkv {tag}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+    check(f"window attn drel_pos {tag}", drel, drr, 2e-5 if dtype == torch.float32 else 1e-2)

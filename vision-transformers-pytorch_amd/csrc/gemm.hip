@@ -209,15 +209,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
-// out[i] = sum_z slab[z][i]   (fixed order: deterministic wgrad)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nz) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += slabs[(int64_t)z * n + i];
-    out[i] = s;
-  }
-}
-
 // bias gradient: out[n] = sum_m scale[m / rows_per_scale] * dy[m, n]  -- two-stage, deterministic.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ part, int64_t M, int N,

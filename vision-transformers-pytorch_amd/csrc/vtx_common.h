@@ -104,6 +104,15 @@ static __global__ void colreduce_kernel(const float* __restrict__ part, float* _
   if (c < C) out0[c] = s; else if (out1) out1[c - C] = s;
 }
 
+// out[i] = sum_z slab[z][i]   (fixed order: deterministic wgrad)
+static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nz) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += slabs[(int64_t)z * n + i];
+    out[i] = s;
+  }
+}
+
 static inline int vtx_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VTX_OK : VTX_ERR_LAUNCH;

@@ -32,6 +32,13 @@ _SIGNATURES = {
     "vtx_wgrad_workspace": (c_size_t, [c_int64, c_int, c_int]),
     "vtx_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64,
                           c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "vtx_relpos_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vtx_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "vtx_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

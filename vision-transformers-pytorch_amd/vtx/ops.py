@@ -132,3 +132,61 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1):
     check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
                         int(rows_per_scale), _p(ws), wsb, _stream()), "vtx_wgrad")
     return dW, db
+
+
+# ------------------------------------------------------------------------------- attention cores
+def relpos_bias(rel_pos, pos, n_head):
+    """bias[h][a][b] = rel_pos[pos[a][b]][h]  (swin_transformer.py:135-136)."""
+    _dev(rel_pos, pos)
+    _f32(rel_pos, "rel_pos")
+    if pos.dtype != torch.int64:
+        raise VtxError("vtx: pos must be int64 (the reference's buffer dtype)")
+    L = pos.shape[0]
+    bias = torch.empty((n_head, L, L), dtype=torch.float32, device=rel_pos.device)
+    check(_lib.load().vtx_relpos_bias(_p(rel_pos), _p(pos), _p(bias), L, n_head, _stream()), "vtx_relpos_bias")
+    return bias
+
+
+def pos_csr(pos, ntab):
+    """Host-side CSR of the pos table: (a,b) pairs grouped by table index (for the dense rel_pos gradient)."""
+    flat = pos.reshape(-1).cpu()
+    order = torch.argsort(flat, stable=True).to(torch.int32)
+    counts = torch.bincount(flat, minlength=ntab)
+    offsets = torch.zeros(ntab + 1, dtype=torch.int32)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order, offsets
+
+
+def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
+    """o [rows, h*D], lse.  swin = (H, W, win, shift) for window attention, None for global."""
+    _dev(qkv, bias, mask)
+    H, W, win, shift = swin if swin is not None else (0, 0, 0, 0)
+    rows = qkv.numel() // (3 * n_head * D)
+    nW = (H // win) * (W // win) if swin is not None else 1
+    if rows != B * nW * L:
+        raise VtxError("vtx: attention rows mismatch")
+    o = torch.empty(qkv.shape[:-1] + (n_head * D,), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().vtx_attention_fwd(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
+                                        int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), _stream()),
+          "vtx_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask=None, csr=None, ntab=0):
+    """dqkv, drel_pos (None without bias)."""
+    _dev(qkv, o, dout, lse, bias, mask)
+    lib = _lib.load()
+    H, W, win, shift = swin if swin is not None else (0, 0, 0, 0)
+    dqkv = torch.empty_like(qkv)
+    drel, ws, wsb, order, offsets = None, None, 0, None, None
+    if bias is not None:
+        order, offsets = csr
+        _dev(order, offsets)
+        drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
+        wsb = lib.vtx_attention_bwd_workspace(B, L, n_head, int(swin is not None), H, W, max(win, 1))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
+    check(lib.vtx_attention_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
+                                _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
+                                H, W, win, int(bool(shift)), _dt(qkv), _stream()), "vtx_attention_bwd")
+    return dqkv, drel
