@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of a full training step (fwd + bwd + grad all-reduce + clip + AdamW step)
+of Swin-S 224x224, bf16 autocast, batch 128 per GPU, synthetic data (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; RCCL gradient all-reduce (vtx.ddp) overlapped with backward; weak scaling (per-GPU batch
+fixed).  Rank 0 prints ONE JSON line.  `roofline` = the dominant HIP kernel (MFMA GEMM family) timed with HIP
+events on its launch stream inside the timed region; `cpu_baseline` = the CPU oracle (a port of the reference's
+path, parity-checked against the reference's own outputs) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "vision-transformers-pytorch_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+SWIN_S = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2), dims=(96, 192, 384, 768), dim_head=32,
+              n_heads=(3, 6, 12, 24), dim_ffs=(384, 768, 1536, 3072), window_size=7)
+TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59}      # BASELINE.md section 2 (3 x forward GEMM FLOPs)
+PEAK_BF16_TFLOPS = 2500.0                                       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def build_model(name, drop_path):
+    from models import SwinTransformer, VisionTransformer
+    from vtx.nn import Linear
+    if name == "swin_s":
+        return SwinTransformer(**SWIN_S, drop_path=drop_path)          # config/swin-transformer-s.conf:1-12
+    return VisionTransformer(Linear(384, 1000), 224, 16, 12, 384, 6, 1536, 0.0, 0.0, 0.0, drop_path)
+
+
+def cpu_baseline(name, batch, steps):
+    """Reference path restated on the CPU (oracle/, kind 'port'), fp32, fwd + bwd + AdamW, bounded sample."""
+    from oracle import ref_models as M
+    from oracle import ref_ops as R
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    model = build_model(name, 0.0)                                      # parameter container only (CPU, never run)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
+         if torch.is_floating_point(v)}
+    if name == "swin_s":
+        fwd = lambda x: M.swin_forward(P, x, M.SWIN_S)
+    else:
+        fwd = lambda x: M.vit_forward(P, x, M.VIT_S16, head=lambda f: R.linear(f, P["head.weight"], P["head.bias"]))
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-3, weight_decay=0.05)
+    x = torch.randn(batch, 3, 224, 224)
+    l1 = torch.randint(0, 1000, (batch,)); l2 = l1.roll(1); ratio = torch.rand(batch)
+
+    def step():
+        loss = R.mix_loss(fwd(x), l1, l2, ratio, 0.1)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"{name} fwd+bwd+AdamW fp32 on CPU oracle, batch {batch}, {steps} timed steps after 1 warm-up "
+                       f"({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / 256 vit_s16)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vtx import ops
+    from vtx.ddp import GradAllReduce
+    from vtx.train_step import MixLoss, make_param_groups, train_step
+
+    batch = args.batch or (128 if args.model == "swin_s" else 256)
+    drop_path = 0.3 if args.model == "swin_s" else 0.1
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps)
+
+    torch.manual_seed(0)                       # identical init on every rank (+ rank-0 broadcast in GradAllReduce)
+    model = build_model(args.model, drop_path).to(dev).train()
+    ddp = GradAllReduce(model)
+    criterion = MixLoss(eps=0.1)
+    opt = torch.optim.AdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3, fused=True)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(batch, 3, 224, 224, device=dev, generator=g)
+    l1 = torch.randint(0, 1000, (batch,), device=dev, generator=g)
+    l2 = l1.roll(1)
+    ratio = torch.rand(batch, device=dev, generator=g)
+    data = (x, l1, l2, ratio)
+    ac = torch.bfloat16 if args.dtype == "bf16" else None
+
+    def step():
+        return train_step(model, criterion, opt, data, clip_grad_norm=5.0, autocast_dtype=ac, ddp=ddp)
+
+    for _ in range(args.warmup):
+        step()
+    timer = None
+    if not args.no_kernel_events:
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(loss).item(), "non-finite loss"
+
+    if rank == 0:
+        value = batch * world * args.steps / dt
+        roof = None
+        if timer is not None:
+            summ = timer.summary()
+            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS if ac else 157.3,
+                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if ac else 157.3), 4), traffic=None,
+                        launches_per_step=d["launches"] // args.steps,
+                        avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                        gemm_family={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                             ms_per_step=round(v["ms"] / args.steps, 3)) for k, v in summ.items()},
+                        end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[args.model] / 1e3 /
+                                              (PEAK_BF16_TFLOPS if ac else 157.3), 4))
+        line = {
+            "metric": "images/sec training (fwd+bwd+step)", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if ac else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} 224x224 train step, batch {batch}/GPU, drop_path {drop_path}, "
+                                   "MixLoss(eps 0.1), clip 5.0, AdamW(lr 1e-3, wd 0.05), grad_accum 1",
+                       "global_batch": batch * world, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

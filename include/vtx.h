@@ -92,6 +92,23 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
                       float* drel_pos, int ntab, void* workspace, size_t ws_bytes, int B, int L, int nH, int D,
                       int swin, int H, int W, int win, int shift, int dtype, void* stream);
 
+/* ---- Patch gather: NCHW fp32 image -> patch matrix [B*(H/p)*(W/p), Kp] of dtype, columns >= 3*p*p zero.
+ *   order 0: column (py, px, c)  -- Swin: permute(0,2,3,1) + patchify(4) (models/swin_transformer.py:15-22,
+ *            208-213, 371); the Linear(48, C) then runs as vtx_gemm on the padded K = Kp
+ *   order 1: column (c, py, px)  -- ViT: Conv2d(3, C, p, stride=p) as an im2col GEMM (models/vit.py:73, 76) */
+int vtx_patch_gather(const float* x, void* out, int B, int Cin, int H, int W, int p, int Kp, int order, int dtype,
+                     void* stream);
+/* ---- Token mean over Tn tokens: AdaptiveAvgPool2d(1)+Flatten of the Swin classifier
+ * (models/swin_transformer.py:281, 376-377) on NHWC features. */
+int vtx_token_mean_fwd(const void* x, void* y, int B, int Tn, int C, int dtype, void* stream);
+int vtx_token_mean_bwd(const void* dy, void* dx, int B, int Tn, int C, int dtype, void* stream);
+/* ---- ViT token assembly (models/vit.py:140-143): out[b,0] = cls + pos[0]; out[b,1+t] = patches[b,t] + pos[1+t].
+ * L = n_patch + 1; cls [C], pos [L, C] fp32.  Backward: dpatches, dcls [C], dpos [L, C] (fp32, batch sums). */
+int vtx_vit_assemble_fwd(const void* patches, const float* cls, const float* pos, void* out, int B, int L, int C,
+                         int dtype, void* stream);
+int vtx_vit_assemble_bwd(const void* dx, void* dpatches, float* dcls, float* dpos, int B, int L, int C, int dtype,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ def fill(shape, seed, scale=1.0, offset=0.0, dtype=torch.float32):
     return torch.from_numpy(v.reshape(shape)).to(dtype)
 
 
-def fill_state_dict(state_dict, rel_pos_scale=0.5):
+def fill_state_dict(state_dict, rel_pos_scale=0.5, weight_scale=0.05):
     """Formula-defined values for every floating tensor of a model state_dict.
 
     Keyed by tensor NAME (crc32) so the same name gets the same values in the
@@ -57,7 +57,7 @@ def fill_state_dict(state_dict, rel_pos_scale=0.5):
         elif "rel_pos" in k:
             t = fill(v.shape, s, rel_pos_scale)
         else:
-            t = fill(v.shape, s, 0.05)
+            t = fill(v.shape, s, weight_scale)
         out[k] = t.to(v.dtype)
     return out
 

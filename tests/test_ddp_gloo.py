@@ -1,0 +1,127 @@
+"""N > 1 path on CPU: vtx.ddp.GradAllReduce over the gloo backend, world_size 2 (runs without a GPU).
+
+Checks the reference's DDP contract (train.py:102-107): rank-0 parameters/buffers are broadcast at
+construction, and after backward every rank holds the MEAN of the per-rank gradients; also with gradient
+accumulation (all-reduce on every micro-batch, no no_sync -- SURVEY appendix item 7) and bucket boundaries.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    m = nn.Sequential(nn.Linear(24, 64), nn.SiLU(), nn.LayerNorm(64), nn.Linear(64, 33), nn.SiLU(), nn.Linear(33, 5))
+    m.register_buffer("flag", torch.tensor([seed % 2 == 0]))           # bool buffer (like local_mask)
+    m.register_buffer("table", torch.arange(6, dtype=torch.int64) + seed)  # int64 buffer (like pos)
+    return m
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vtx.ddp import GradAllReduce, assign_buckets
+        model = _model(seed=rank)                     # different init per rank: the broadcast must fix it
+        ddp = GradAllReduce(model, bucket_bytes=6000, first_bucket_bytes=1000)
+        ref = _model(seed=0)
+        for (n, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+            assert torch.equal(a, b), f"rank {rank}: {n} not broadcast from rank 0"
+        assert len(ddp.buckets) >= 3
+        assert sum(len(b.params) for b in ddp.buckets) == len(list(model.parameters()))
+        assert ddp.buckets[0].names[0] == "5.bias"    # reverse registration order
+
+        def local_grads(m, step):
+            torch.manual_seed(100 + 10 * step + rank)
+            x = torch.randn(7, 24)
+            m(x).square().sum().backward()
+
+        # expected: mean over ranks of the local gradients (computed redundantly on every rank)
+        exp = None
+        for r in range(world):
+            m2 = _model(seed=0)
+            torch.manual_seed(100 + r)
+            m2(torch.randn(7, 24)).square().sum().backward()
+            g = [p.grad.clone() for p in m2.parameters()]
+            exp = g if exp is None else [a + b for a, b in zip(exp, g)]
+        exp = [e / world for e in exp]
+
+        local_grads(model, 0)
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+
+        # second micro-batch WITHOUT zero_grad: accumulate, all-reduce again (reference: no no_sync)
+        exp2 = None
+        for r in range(world):
+            m2 = _model(seed=0)
+            torch.manual_seed(110 + r)
+            m2(torch.randn(7, 24)).square().sum().backward()
+            g = [p.grad.clone() for p in m2.parameters()]
+            exp2 = g if exp2 is None else [a + b for a, b in zip(exp2, g)]
+        exp2 = [a + b / world for a, b in zip(exp, exp2)]
+        local_grads(model, 1)
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp2):
+            assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6)
+
+        # set_to_none + a fresh backward re-arms the buckets
+        model.zero_grad(set_to_none=True)
+        local_grads(model, 0)
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_world1_is_a_bypass():
+    from vtx.ddp import GradAllReduce
+    m = _model(0)
+    ddp = GradAllReduce(m)
+    assert ddp.world == 1 and ddp.buckets == []
+    m(torch.randn(3, 24)).sum().backward()
+    ddp.finish()
+    assert all(p.grad is not None for p in m.parameters())
+
+
+def test_bucket_assignment_sizes():
+    from vtx.ddp import assign_buckets
+    m = _model(0)
+    b = assign_buckets(list(m.named_parameters()), bucket_bytes=10_000, first_bucket_bytes=100)
+    assert [x for bb in b for x in bb.names] == [n for n, _ in reversed(list(m.named_parameters()))]
+    assert b[0].numel * 4 <= 100 or len(b[0].params) == 1
+    for bb in b[1:]:
+        assert bb.numel * 4 <= 10_000 or len(bb.params) == 1

@@ -1,0 +1,243 @@
+"""Swin Transformer on the MI355X-native kernels -- drop-in for the reference's
+models/swin_transformer.py: same class names, constructor keyword signatures, forward tensor contracts
+and state_dict keys / shapes / dtypes; every forward/backward op on the
+feature tensors runs in hand-written gfx950 HIP kernels (libvtx.so), not in PyTorch op compositions.
+
+  patchify                    reference models/swin_transformer.py:15-22
+  MultiHeadedLocalAttention   reference models/swin_transformer.py:25-160
+  TransformerLayer            reference models/swin_transformer.py:163-197
+  PatchEmbedding              reference models/swin_transformer.py:200-213
+  PatchMerge                  reference models/swin_transformer.py:216-229
+  SwinTransformer             reference models/swin_transformer.py:236-379
+
+Features are NHWC (B, H, W, C) like the reference; roll, window partition and head split are address
+arithmetic inside the attention kernel.
+"""
+import math
+from typing import Tuple
+
+import torch
+from torch import nn
+
+try:  # registration decorator of the reference's config system (identity when tensorfn is absent)
+    from tensorfn.config import config_model
+except Exception:  # pragma: no cover
+    def config_model(*args, **kwargs):
+        return lambda f: f
+
+try:
+    from pydantic import StrictFloat, StrictInt
+except Exception:  # pragma: no cover
+    StrictInt, StrictFloat = int, float
+
+from vtx import functional as VF
+from vtx import tables
+from vtx.nn import LayerNorm as _LayerNorm
+from vtx.nn import Linear, drop_path_scale
+
+from .layer import DropPath, PositionwiseFeedForward, tuple2
+
+LayerNorm = lambda x: _LayerNorm(x, eps=1e-6)
+
+
+def patchify(input, size):
+    """(B,H,W,C) -> (B,H/size,W/size,size*size*C), flatten order (py, px, c).  Pure view/copy helper kept for
+    API parity; the model itself folds this gather into the patch-embed / PatchMerge kernels."""
+    batch, height, width, dim = input.shape
+    return (
+        input.view(batch, height // size, size, width // size, size, dim)
+        .permute(0, 1, 3, 2, 4, 5)
+        .reshape(batch, height // size, width // size, -1)
+    )
+
+
+class MultiHeadedLocalAttention(nn.Module):
+    def __init__(self, dim, n_head, dim_head, input_size, window_size, shift, dropout=0):
+        super().__init__()
+        self.dim_head = dim_head
+        self.n_head = n_head
+        self.weight = Linear(dim, n_head * dim_head * 3, bias=True)
+        self.linear = Linear(n_head * dim_head, dim)
+        self.input_size = tuple(input_size)
+        self.window_size = window_size
+        self.dropout = dropout
+        self.shift = shift
+
+        pos, local_mask = tables.make_pos_mask(self.input_size, window_size, shift)
+        self.register_buffer("pos", pos)
+        self.rel_pos = nn.Embedding((2 * window_size - 1) ** 2, n_head)
+        self.rel_pos.weight.detach().zero_()
+        if shift:
+            self.register_buffer("local_mask", local_mask)
+        order, offsets = tables.pos_csr(pos, (2 * window_size - 1) ** 2)
+        self.register_buffer("_csr_order", order, persistent=False)
+        self.register_buffer("_csr_offsets", offsets, persistent=False)
+
+    def meta(self, eps=1e-6):
+        w = self.window_size
+        return VF.AttentionMeta(
+            self.n_head, self.dim_head, w * w, eps=eps,
+            swin=(self.input_size[0], self.input_size[1], w, self.shift), pos=self.pos,
+            mask=self.local_mask if self.shift else None, csr=(self._csr_order, self._csr_offsets),
+            ntab=(2 * w - 1) ** 2)
+
+    def check_input(self, input):
+        if tuple(input.shape[1:3]) != self.input_size:
+            raise ValueError(f"feature map {tuple(input.shape[1:3])} != input_size {self.input_size} this layer's "
+                             "pos / local_mask tables were built for")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("vtx: attention dropout > 0 is not supported by the fused HIP path")
+
+    def forward(self, input):
+        self.check_input(input)
+        T = VF.compute_dtype(input)
+        qkv = VF.LinearFn.apply(input.to(T), self.weight.weight, self.weight.bias)
+        out = VF.AttentionCoreFn.apply(qkv, self.rel_pos.weight, self.meta())
+        return VF.LinearFn.apply(out, self.linear.weight, self.linear.bias)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, dim, n_head, dim_head, dim_ff, input_size, window_size, shift, activation=nn.SiLU,
+                 drop_ff=0, drop_attn=0, drop_path=0):
+        super().__init__()
+        self.norm_attn = LayerNorm(dim)
+        self.attn = MultiHeadedLocalAttention(dim, n_head, dim_head, input_size, window_size, shift, drop_attn)
+        self.drop_path = DropPath(drop_path)
+        self.norm_ff = LayerNorm(dim)
+        self.ff = PositionwiseFeedForward(dim, dim_ff, activation=activation, dropout=drop_ff)
+
+    def set_drop_path(self, p):
+        self.drop_path.p = p
+
+    def forward(self, input):
+        self.attn.check_input(input)
+        if not self.ff.fused_ok():
+            out = input + self.drop_path(self.attn(self.norm_attn(input)))
+            return out + self.drop_path(self.ff(self.norm_ff(out)))
+        T = VF.compute_dtype(input)
+        B = input.shape[0]
+        # two independent draws per layer, attention branch first (reference swin_transformer.py:194-195)
+        s1 = drop_path_scale(self.drop_path.p, self.training, B, input.device)
+        s2 = drop_path_scale(self.drop_path.p, self.training, B, input.device)
+        a, f = self.attn, self.ff
+        return VF.TransformerLayerFn.apply(
+            input.to(T), self.norm_attn.weight, self.norm_attn.bias, a.weight.weight, a.weight.bias,
+            a.rel_pos.weight, a.linear.weight, a.linear.bias, self.norm_ff.weight, self.norm_ff.bias,
+            f[0].weight, f[0].bias, f[3].weight, f[3].bias, s1, s2, a.meta(self.norm_attn.eps))
+
+
+class PatchEmbedding(nn.Module):
+    """Input: NHWC image (B, H, W, 3) as in the reference (its caller permutes NCHW -> NHWC first)."""
+
+    def __init__(self, in_dim, out_dim, window_size):
+        super().__init__()
+        self.window_size = window_size
+        self.linear = Linear(in_dim * window_size * window_size, out_dim)
+        self.norm = _LayerNorm(out_dim)
+
+    def forward_nchw(self, input_nchw):
+        T = VF.compute_dtype(input_nchw)
+        return VF.SwinPatchEmbedFn.apply(input_nchw, self.linear.weight, self.linear.bias, self.norm.weight,
+                                         self.norm.bias, self.window_size, self.norm.eps, T)
+
+    def forward(self, input):
+        # NHWC view of an NCHW tensor (what SwinTransformer.forward passes) maps back for free
+        return self.forward_nchw(input.permute(0, 3, 1, 2))
+
+
+class PatchMerge(nn.Module):
+    def __init__(self, in_dim, out_dim, window_size):
+        super().__init__()
+        if window_size != 2:
+            raise NotImplementedError("vtx: PatchMerge kernel supports the 2x2 reduction used by SwinTransformer")
+        self.window_size = window_size
+        self.norm = _LayerNorm(in_dim * window_size * window_size)
+        self.linear = Linear(in_dim * window_size * window_size, out_dim, bias=False)
+
+    def forward(self, input):
+        T = VF.compute_dtype(input)
+        return VF.PatchMergeFn.apply(input.to(T), self.norm.weight, self.norm.bias, self.linear.weight, self.norm.eps)
+
+
+def reduce_size(size, reduction):
+    return (size[0] // reduction, size[1] // reduction)
+
+
+@config_model(name="swin_transformer", namespace="model", use_type=True)
+class SwinTransformer(nn.Module):
+    def __init__(
+        self,
+        image_size: Tuple[StrictInt, StrictInt],
+        n_class: StrictInt,
+        depths: Tuple[StrictInt, StrictInt, StrictInt, StrictInt],
+        dims: Tuple[StrictInt, StrictInt, StrictInt, StrictInt],
+        dim_head: StrictInt,
+        n_heads: Tuple[StrictInt, StrictInt, StrictInt, StrictInt],
+        dim_ffs: Tuple[StrictInt, StrictInt, StrictInt, StrictInt],
+        window_size: StrictInt,
+        drop_ff: StrictFloat = 0.0,
+        drop_attn: StrictFloat = 0.0,
+        drop_path: StrictFloat = 0.0,
+    ):
+        super().__init__()
+        self.depths = depths
+
+        def make_block(i, in_dim, input_size, reduction):
+            return self.make_block(depths[i], in_dim, dims[i], n_heads[i], dim_head, dim_ffs[i], input_size,
+                                   window_size, reduction, drop_ff, drop_attn)
+
+        self.patch_embedding = PatchEmbedding(3, dims[0], 4)
+        self.block1 = make_block(0, 3, reduce_size(image_size, 4), 1)
+        self.block2 = make_block(1, dims[0], reduce_size(image_size, 4), 2)
+        self.block3 = make_block(2, dims[1], reduce_size(image_size, 4 * 2), 2)
+        self.block4 = make_block(3, dims[2], reduce_size(image_size, 4 * 2 * 2), 2)
+
+        self.final_linear = nn.Sequential(_LayerNorm(dims[-1]))
+        linear = Linear(dims[-1], n_class)
+        nn.init.normal_(linear.weight, std=0.02)
+        nn.init.zeros_(linear.bias)
+        self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(1), linear)
+
+        self.apply(self.init_weights)
+        self.set_dropout(None, drop_path)
+
+    def set_dropout(self, dropout, drop_path):
+        n_blocks = sum(self.depths)
+        dp_rate = [drop_path * float(i) / n_blocks for i in range(n_blocks)]
+        i = 0
+        for block in (self.block1, self.block2, self.block3, self.block4):
+            for layer in block:
+                if hasattr(layer, "set_drop_path"):   # PatchMerge has none (reference: try/except)
+                    layer.set_drop_path(dp_rate[i])
+                    i += 1
+
+    def init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            nn.init.normal_(module.weight, std=0.02)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.LayerNorm):
+            nn.init.ones_(module.weight)
+            nn.init.zeros_(module.bias)
+
+    def make_block(self, depth, in_dim, dim, n_head, dim_head, dim_ff, input_size, window_size, reduction, drop_ff,
+                   drop_attn):
+        block = []
+        if reduction > 1:
+            block.append(PatchMerge(in_dim, dim, reduction))
+        for i in range(depth):
+            block.append(TransformerLayer(dim, n_head, dim_head, dim_ff, reduce_size(input_size, reduction),
+                                          window_size, shift=i % 2 == 0, drop_ff=drop_ff, drop_attn=drop_attn))
+        return nn.Sequential(*block)
+
+    def forward(self, input):
+        out = self.patch_embedding.forward_nchw(input)       # permute(0,2,3,1) + patchify folded into the gather
+        out = self.block1(out)
+        out = self.block2(out)
+        out = self.block3(out)
+        out = self.block4(out)
+        norm = self.final_linear[0]
+        out = VF.LayerNormFn.apply(out, norm.weight, norm.bias, norm.eps)
+        out = VF.TokenMeanFn.apply(out)                       # AdaptiveAvgPool2d(1) + Flatten(1) on NHWC
+        cls = self.classifier[2]
+        return VF.LinearFn.apply(out, cls.weight, cls.bias)

@@ -39,6 +39,12 @@ _SIGNATURES = {
     "vtx_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    "vtx_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_vit_assemble_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_vit_assemble_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

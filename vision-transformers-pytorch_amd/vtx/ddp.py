@@ -1,0 +1,130 @@
+"""Data-parallel gradient all-reduce for the one-process-per-GPU training path.
+
+Counterpart of ``nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])`` in the
+reference (train.py:102-107): parameters + buffers are broadcast from rank 0 at construction, and
+during ``backward()`` the fp32 gradients are averaged across ranks in buckets, in reverse parameter
+order, as soon as every gradient of a bucket has been accumulated -- overlapped with the rest of
+backward.  The reduction itself is ``torch.distributed.all_reduce`` on the RCCL process group
+(``backend="nccl"`` IS RCCL on ROCm), which enqueues on the process group's own side HIP stream after
+waiting for the producing stream (event record / stream-wait, no host sync); ``finish()`` makes the
+compute stream wait for the last bucket before clipping / the optimizer step.
+
+Designed for MI355X xGMI (point-to-point links, ring collectives per-link bound): few, large buckets
+(default 48 MiB, first bucket 8 MiB so communication starts early in backward), one flat fp32 buffer
+per bucket filled by a single multi-tensor copy, averaged by the collective itself (ncclAvg).
+World size 1 bypasses all of it.  Works on CPU tensors with the gloo backend (used by the tests).
+"""
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+MIB = 1 << 20
+
+
+class _Bucket:
+    def __init__(self, index):
+        self.index = index
+        self.params: List[torch.nn.Parameter] = []
+        self.names: List[str] = []
+        self.numel = 0
+        self.flat = None
+        self.views = []
+        self.pending = 0
+        self.work = None
+
+
+def assign_buckets(named_params, bucket_bytes, first_bucket_bytes):
+    """Reverse registration order (gradients become ready roughly back to front), greedy fill."""
+    buckets = [_Bucket(0)]
+    cap = first_bucket_bytes
+    for name, p in reversed(list(named_params)):
+        b = buckets[-1]
+        nbytes = p.numel() * 4
+        if b.numel > 0 and (b.numel * 4 + nbytes) > cap:
+            b = _Bucket(len(buckets))
+            buckets.append(b)
+            cap = bucket_bytes
+        b.params.append(p)
+        b.names.append(name)
+        b.numel += p.numel()
+    return buckets
+
+
+class GradAllReduce:
+    def __init__(self, module, process_group=None, bucket_bytes=48 * MIB, first_bucket_bytes=8 * MIB,
+                 broadcast=True):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.parameters = [p for _, p in named]
+        self.buckets = []
+        self._handles = []
+        if self.world == 1:
+            return
+        for _, p in named:
+            if p.dtype != torch.float32:
+                raise ValueError("GradAllReduce expects fp32 master parameters")
+        if broadcast:
+            self.broadcast_state()
+        self.buckets = assign_buckets(named, bucket_bytes, first_bucket_bytes)
+        self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else None
+        for b in self.buckets:
+            dev = b.params[0].device
+            b.flat = torch.zeros(b.numel, dtype=torch.float32, device=dev)
+            off = 0
+            for p in b.params:
+                b.views.append(b.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            b.pending = len(b.params)
+            for p in b.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+
+    # -- construction-time sync (DDP broadcasts parameters and buffers from rank 0, train.py:102-107)
+    @torch.no_grad()
+    def broadcast_state(self):
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            if t.dtype == torch.bool:   # gloo/nccl have no bool broadcast: round-trip through uint8
+                u = t.to(torch.uint8)
+                dist.broadcast(u, 0, group=self.group)
+                t.copy_(u.to(torch.bool))
+            else:
+                dist.broadcast(t.data, 0, group=self.group)
+
+    def _make_hook(self, bucket):
+        def hook(param):
+            bucket.pending -= 1
+            if bucket.pending == 0:
+                self._launch(bucket)
+        return hook
+
+    def _launch(self, b):
+        grads = [p.grad for p in b.params]
+        torch._foreach_copy_(b.views, grads)          # one multi-tensor copy into the flat bucket
+        if self._avg is not None:
+            b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait (stream-wise) for every bucket, install the averaged gradients, re-arm for the next backward."""
+        if self.world == 1:
+            return
+        missing = [n for b in self.buckets if b.pending != 0 for n, p in zip(b.names, b.params) if p.grad is None]
+        if any(b.pending != 0 for b in self.buckets):
+            raise RuntimeError("GradAllReduce.finish(): parameters received no gradient in this backward "
+                               f"(unused parameters are not supported): {missing[:8]}")
+        for b in self.buckets:
+            b.work.wait()
+            if self._avg is None:
+                b.flat.div_(self.world)
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+            b.work = None
+            b.pending = len(b.params)
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

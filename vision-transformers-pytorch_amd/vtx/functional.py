@@ -1,0 +1,295 @@
+"""autograd.Functions that bind the HIP kernels into PyTorch's autograd graph.
+
+One Function per fused block of the reference's forward; each backward is
+the hand-written kernel sequence, so parameters stay fp32 leaf nn.Parameters that accumulate
+``.grad`` through autograd exactly as in the reference (DDP hooks, clip_grad_norm_, any torch
+optimizer keep working).  Activations are stored in the compute dtype T (fp32, or bf16 under
+``torch.autocast(dtype=torch.bfloat16)``); statistics / parameter gradients are fp32.
+"""
+import weakref
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import ACT_DSILU, ACT_SILU, VtxError
+
+
+def compute_dtype(x):
+    """fp32, or bf16 inside torch.autocast(bf16) -- the only knob, same as the reference's train.py:273."""
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.bfloat16:
+            return torch.bfloat16
+        raise VtxError(f"vtx: autocast dtype {dt} unsupported on the MI355X path (use torch.bfloat16)")
+    if x.dtype in (torch.float32, torch.bfloat16):
+        return x.dtype
+    raise VtxError(f"vtx: unsupported activation dtype {x.dtype}")
+
+
+_cast_cache = {}
+
+
+def cast(p, dtype):
+    """Parameter in the compute dtype; bf16 copies are cached until the parameter is updated in place."""
+    if p is None:
+        return None
+    if p.dtype == dtype:
+        return p.detach()
+    key = id(p)
+    ent = _cast_cache.get(key)
+    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2].dtype == dtype \
+            and ent[2].device == p.device:
+        return ent[2]
+    t = p.detach().to(dtype)
+    if len(_cast_cache) > 4096:
+        _cast_cache.clear()
+    _cast_cache[key] = (weakref.ref(p), p._version, t)
+    return t
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, weight.detach(), bias.detach(), eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(_c(dy), x, mean, rstd, weight.detach())
+        return dx, dg, db, None
+
+
+class LinearFn(Function):
+    """y = x W^T + b  (nn.Linear).  Output dtype = x dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        w = cast(weight, x.dtype)
+        y = ops.gemm(x, w, 0, bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        w = cast(weight, x.dtype)
+        dW, db = ops.wgrad(dy, x, want_bias=ctx.has_bias)
+        dx = ops.gemm(dy, w, 1) if ctx.needs_input_grad[0] else None
+        return dx, dW.view_as(weight), db
+
+
+class FeedForwardFn(Function):
+    """PositionwiseFeedForward (reference models/layer.py:186-196): Linear -> SiLU -> Linear, SiLU fused
+    into the first GEMM's epilogue, silu' into the second GEMM's dgrad epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = _c(x)
+        T = x.dtype
+        h, z = ops.gemm(x, cast(w1, T), 0, bias=b1.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, cast(w2, T), 0, bias=b2.detach())
+        ctx.save_for_backward(x, w1, w2, z, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, z, h = ctx.saved_tensors
+        T = x.dtype
+        dy = _c(dy)
+        dW2, db2 = ops.wgrad(dy, h)
+        dz = ops.gemm(dy, cast(w2, T), 1, act=ACT_DSILU, aux_in=z)
+        dW1, db1 = ops.wgrad(dz, x)
+        dx = ops.gemm(dz, cast(w1, T), 1)
+        return dx, dW1, db1, dW2, db2
+
+
+class AttentionMeta:
+    """Static description of one attention module (geometry + integer tables on the device)."""
+
+    def __init__(self, n_head, dim_head, L, eps=1e-6, swin=None, pos=None, mask=None, csr=None, ntab=0):
+        self.n_head, self.dim_head, self.L, self.eps = n_head, dim_head, L, eps
+        self.swin, self.pos, self.mask, self.csr, self.ntab = swin, pos, mask, csr, ntab
+
+
+class AttentionCoreFn(Function):
+    """softmax(q k^T / sqrt(d) [+ rel-pos bias, -inf mask]) v on the QKV projection output."""
+
+    @staticmethod
+    def forward(ctx, qkv, rel_pos, meta):
+        qkv = _c(qkv)
+        B = qkv.shape[0]
+        bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
+        o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias,
+                                   mask=meta.mask)
+        ctx.save_for_backward(qkv, o, lse, bias)
+        ctx.meta = meta
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, bias = ctx.saved_tensors
+        m = ctx.meta
+        dqkv, drel = ops.attention_bwd(qkv, o, _c(do), lse, qkv.shape[0], m.L, m.n_head, m.dim_head, swin=m.swin,
+                                       bias=bias, mask=m.mask, csr=m.csr, ntab=m.ntab)
+        return dqkv, drel, None
+
+
+class TransformerLayerFn(Function):
+    """One pre-LN transformer block (reference models/vit.py:59-63, models/swin_transformer.py:193-197):
+         x1 = x  + s1 * proj(attn(qkv(LN1(x))))        y = x1 + s2 * fc2(silu(fc1(LN2(x1))))
+    as 7 kernels forward (LN, GEMM, attention, GEMM+residual, LN, GEMM+SiLU, GEMM+residual); s1/s2 are
+    the per-sample DropPath scales mask/(1-p) (models/layer.py:172-180) or None."""
+
+    @staticmethod
+    def forward(ctx, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w,
+                fc2_b, s1, s2, meta):
+        x = _c(x)
+        T = x.dtype
+        B, C = x.shape[0], x.shape[-1]
+        rps = (x.numel() // C) // B
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), meta.eps)
+        qkv = ops.gemm(ln1, cast(qkv_w, T), 0, bias=qkv_b.detach())
+        bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
+        o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias,
+                                   mask=meta.mask)
+        x1 = ops.gemm(o, cast(proj_w, T), 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), meta.eps)
+        h, z = ops.gemm(ln2, cast(fc1_w, T), 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, cast(fc2_w, T), 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
+        ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
+                              mean2, rstd2, ln2, z, h, bias, s1, s2)
+        ctx.meta, ctx.rps = meta, rps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z, h,
+         bias, s1, s2) = ctx.saved_tensors
+        m, rps = ctx.meta, ctx.rps
+        T = x.dtype
+        dy = _c(dy)
+        B = x.shape[0]
+        # ---- MLP branch
+        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps)
+        dz = ops.gemm(dy, cast(fc2_w, T), 1, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
+        dW1, db1 = ops.wgrad(dz, ln2)
+        dln2 = ops.gemm(dz, cast(fc1_w, T), 1)
+        dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
+        # ---- attention branch
+        dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps)
+        do = ops.gemm(dx1, cast(proj_w, T), 1, rowscale=s1, rows_per_scale=rps)
+        dqkv, drel = ops.attention_bwd(qkv, o, do, lse, B, m.L, m.n_head, m.dim_head, swin=m.swin, bias=bias,
+                                       mask=m.mask, csr=m.csr, ntab=m.ntab)
+        dWq, dbq = ops.wgrad(dqkv, ln1)
+        dln1 = ops.gemm(dqkv, cast(qkv_w, T), 1)
+        dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+        return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None)
+
+
+class PatchMergeFn(Function):
+    """PatchMerge (reference models/swin_transformer.py:216-229): patchify(2) -> LayerNorm(4C, 1e-5) -> Linear
+    (no bias); the 2x2 gather is folded into the LayerNorm kernel's row addressing."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w, eps):
+        x = _c(x)
+        H, W = x.shape[1], x.shape[2]
+        ln, mean, rstd = ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), eps, merge_hw=(H, W))
+        y = ops.gemm(ln, cast(w, x.dtype), 0)
+        ctx.save_for_backward(x, ln_w, w, ln, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_w, w, ln, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        dW, _ = ops.wgrad(dy, ln, want_bias=False)
+        dln = ops.gemm(dy, cast(w, x.dtype), 1)
+        dx, dg, db = ops.layernorm_bwd(dln, x, mean, rstd, ln_w.detach(), merge_hw=(x.shape[1], x.shape[2]))
+        return dx, dg, db, dW, None
+
+
+class SwinPatchEmbedFn(Function):
+    """swin.PatchEmbedding on the NCHW image (reference models/swin_transformer.py:208-213 + the permute at :371):
+    (py,px,c) patch gather -> Linear(3 p^2 -> C) -> LayerNorm(C, 1e-5)."""
+
+    @staticmethod
+    def forward(ctx, x_nchw, w, b, ln_w, ln_b, patch, eps, dtype):
+        patches = ops.patch_gather(_c(x_nchw), patch, 0, dtype)
+        t = ops.gemm(patches, cast(w, dtype), 0, bias=b.detach())
+        y, mean, rstd = ops.layernorm_fwd(t, ln_w.detach(), ln_b.detach(), eps)
+        ctx.save_for_backward(patches, t, mean, rstd, ln_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        patches, t, mean, rstd, ln_w = ctx.saved_tensors
+        dt, dg, db = ops.layernorm_bwd(_c(dy), t, mean, rstd, ln_w.detach())
+        dW, dbias = ops.wgrad(dt, patches)
+        return None, dW, dbias, dg, db, None, None, None
+
+
+class VitPatchEmbedFn(Function):
+    """vit.PatchEmbedding (reference models/vit.py:69-76): Conv2d(3, C, p, stride p) + flatten + transpose as an
+    im2col gather + GEMM; output (B, n_patch, C)."""
+
+    @staticmethod
+    def forward(ctx, x_nchw, w, b, dtype):
+        C, Cin, p, _ = w.shape
+        patches = ops.patch_gather(_c(x_nchw), p, 1, dtype)
+        B, gh, gw, K = patches.shape
+        y = ops.gemm(patches.view(B, gh * gw, K), cast(w, dtype).view(C, K), 0, bias=b.detach())
+        ctx.save_for_backward(patches)
+        ctx.wshape = w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        dW, db = ops.wgrad(_c(dy), patches)
+        return None, dW.view(ctx.wshape), db, None
+
+
+class VitAssembleFn(Function):
+    """cat(cls, patches) + pos_embed (reference models/vit.py:140-143)."""
+
+    @staticmethod
+    def forward(ctx, patches, cls_token, pos_embed):
+        L, C = pos_embed.shape[-2], pos_embed.shape[-1]
+        out = ops.vit_assemble_fwd(_c(patches), _c(cls_token.detach().reshape(C)),
+                                   _c(pos_embed.detach().reshape(L, C)))
+        ctx.shapes = (cls_token.shape, pos_embed.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        dpatches, dcls, dpos = ops.vit_assemble_bwd(_c(dx))
+        return dpatches, dcls.view(ctx.shapes[0]), dpos.view(ctx.shapes[1])
+
+
+class TokenMeanFn(Function):
+    """Mean over the tokens of each image: (B, ..., C) -> (B, C)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, C = x.shape[0], x.shape[-1]
+        Tn = x.numel() // (B * C)
+        ctx.dims = (B, Tn, C, x.shape)
+        return ops.token_mean_fwd(x, B, Tn, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Tn, C, shape = ctx.dims
+        return ops.token_mean_bwd(_c(dy), B, Tn, C, shape)

@@ -90,6 +90,51 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, merge_hw=None):
     return dx, dgamma, dbeta
 
 
+# ------------------------------------------------------------------------------- kernel timing hook
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the GEMM kernels (used by bench.py for the roofline).
+
+    Events are recorded on torch's current stream = the stream the kernel is launched on.  Each record is
+    (kernel name as rocprofv3 prints it, algorithmic FLOPs of the launch, start event, end event).
+    """
+
+    def __init__(self):
+        self.records = []
+
+    def bracket(self, name, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        self.records.append((name, flops, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        """{kernel: dict(launches, flops, ms)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def gemm_kernel_name(dtype, N, mode, out_f32=False):
+    """Name of the gemm_kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm_pick_bn in gemm.hip)."""
+    t = "__bf16" if dtype == torch.bfloat16 else "float"
+    to = "float" if out_f32 else t
+    bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
+    ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
+    return f"gemm_kernel<{t}, {to}, 128, {bn}, {ta}, {tb}>"
+
+
 # ------------------------------------------------------------------------------- GEMM family
 ACT_NONE, ACT_SILU, ACT_DSILU = 0, 1, 2
 
@@ -112,8 +157,13 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
         raise VtxError(f"vtx: gemm contraction mismatch ({K} vs {kw})")
     c = out if out is not None else torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
     aux = torch.empty_like(c) if want_aux else None
+    ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode), 2.0 * M * N * K) if _timer is not None else None
+    if ev:
+        ev[0].record()
     check(lib.vtx_gemm(mode, _dt(a), _p(a), _p(w), _p(c), M, N, K, K, w.shape[1], N, _p(bias), _p(resid),
                        _p(rowscale), int(rows_per_scale), _p(aux), _p(aux_in), act, _stream()), "vtx_gemm")
+    if ev:
+        ev[1].record()
     return (c, aux) if want_aux else c
 
 
@@ -132,6 +182,56 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1):
     check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
                         int(rows_per_scale), _p(ws), wsb, _stream()), "vtx_wgrad")
     return dW, db
+
+
+# ------------------------------------------------------------------------------- data movement
+def patch_gather(x_nchw, patch, order, dtype, kp=None):
+    """NCHW fp32 image -> [B, H/p, W/p, Kp] patch matrix of `dtype` (order 0: Swin (py,px,c); 1: ViT (c,py,px))."""
+    _dev(x_nchw)
+    if x_nchw.dtype != torch.float32:
+        x_nchw = x_nchw.float()
+    B, Cin, H, W = x_nchw.shape
+    K = Cin * patch * patch
+    kp = K if kp is None else kp
+    out = torch.empty((B, H // patch, W // patch, kp), dtype=dtype, device=x_nchw.device)
+    check(_lib.load().vtx_patch_gather(_p(x_nchw), _p(out), B, Cin, H, W, patch, kp, order, _dt(out), _stream()),
+          "vtx_patch_gather")
+    return out
+
+
+def token_mean_fwd(x, B, Tn, C):
+    _dev(x)
+    y = torch.empty((B, C), dtype=x.dtype, device=x.device)
+    check(_lib.load().vtx_token_mean_fwd(_p(x), _p(y), B, Tn, C, _dt(x), _stream()), "vtx_token_mean_fwd")
+    return y
+
+
+def token_mean_bwd(dy, B, Tn, C, shape):
+    _dev(dy)
+    dx = torch.empty(shape, dtype=dy.dtype, device=dy.device)
+    check(_lib.load().vtx_token_mean_bwd(_p(dy), _p(dx), B, Tn, C, _dt(dy), _stream()), "vtx_token_mean_bwd")
+    return dx
+
+
+def vit_assemble_fwd(patches, cls, pos):
+    _dev(patches, cls, pos)
+    _f32(cls, "cls_token"); _f32(pos, "pos_embed")
+    B, n, C = patches.shape
+    out = torch.empty((B, n + 1, C), dtype=patches.dtype, device=patches.device)
+    check(_lib.load().vtx_vit_assemble_fwd(_p(patches), _p(cls), _p(pos), _p(out), B, n + 1, C, _dt(patches),
+                                           _stream()), "vtx_vit_assemble_fwd")
+    return out
+
+
+def vit_assemble_bwd(dx):
+    _dev(dx)
+    B, L, C = dx.shape
+    dpatches = torch.empty((B, L - 1, C), dtype=dx.dtype, device=dx.device)
+    dcls = torch.empty(C, dtype=torch.float32, device=dx.device)
+    dpos = torch.empty((L, C), dtype=torch.float32, device=dx.device)
+    check(_lib.load().vtx_vit_assemble_bwd(_p(dx), _p(dpatches), _p(dcls), _p(dpos), B, L, C, _dt(dx), _stream()),
+          "vtx_vit_assemble_bwd")
+    return dpatches, dcls, dpos
 
 
 # ------------------------------------------------------------------------------- attention cores

@@ -1,0 +1,50 @@
+"""Window index / mask tables of (shifted-)window attention -- integer arithmetic, bit-exact.
+
+Product-side construction of the two buffers the reference registers in
+MultiHeadedLocalAttention.__init__ / make_mask_pos (reference models/swin_transformer.py:42-53,
+55-101), in closed form ("A8 closed-form specification"):
+  * token a of window n carries original coordinates Y[n,a], X[n,a] (the feature map rolled by
+    -floor(w/2) when shifted);
+  * dy = Y[n,b] - Y[n,a], dx = X[n,b] - X[n,a] (key minus query);
+  * shifted layers: keep = |dx| < w and |dy| < w, local_mask = not keep (True -> -inf), diffs *= keep;
+  * pos = (dy[0] + w - 1) * (2w - 1) + (dx[0] + w - 1): the table of WINDOW 0 only, int64.
+"""
+import torch
+
+
+def window_coords(input_size, window, shift):
+    H, W = input_size
+    if H % window or W % window:
+        raise ValueError(f"input size {input_size} is not a multiple of the window size {window}")
+    r = -(window // 2) if shift else 0
+    ys = (torch.arange(H, dtype=torch.int64) - r) % H      # torch.roll by r: rolled[p] = orig[(p - r) mod n]
+    xs = (torch.arange(W, dtype=torch.int64) - r) % W
+    nh, nw = H // window, W // window
+    yy = ys.view(nh, 1, window, 1).expand(nh, nw, window, window)
+    xx = xs.view(1, nw, 1, window).expand(nh, nw, window, window)
+    return yy.reshape(nh * nw, window * window), xx.reshape(nh * nw, window * window)
+
+
+def make_pos_mask(input_size, window, shift):
+    """-> (pos int64 (w*w, w*w), local_mask bool (nW, w*w, w*w) or None)."""
+    Y, X = window_coords(input_size, window, shift)
+    dy = Y[:, None, :] - Y[:, :, None]
+    dx = X[:, None, :] - X[:, :, None]
+    local_mask = None
+    if shift:
+        keep = (dx.abs() < window) & (dy.abs() < window)
+        dy = dy * keep
+        dx = dx * keep
+        local_mask = ~keep
+    pos = (dy[0] + window - 1) * (2 * window - 1) + (dx[0] + window - 1)
+    return pos.contiguous(), (local_mask.contiguous() if local_mask is not None else None)
+
+
+def pos_csr(pos, ntab):
+    """CSR of the pos table: (a,b) pairs grouped by table index, for the dense rel_pos gradient."""
+    flat = pos.reshape(-1).cpu()
+    order = torch.argsort(flat, stable=True).to(torch.int32)
+    counts = torch.bincount(flat, minlength=ntab)
+    offsets = torch.zeros(ntab + 1, dtype=torch.int32)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order, offsets

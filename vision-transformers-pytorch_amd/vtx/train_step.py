@@ -1,0 +1,83 @@
+"""Counterpart of the reference's supervised train step (train.py:265-299) for the HIP modules.
+
+The reference's train.py never ships; this is the harness the benchmark and the parity tests use.
+Same op order: autocast forward -> MixLoss / grad_accum -> backward (DDP all-reduce overlapped) ->
+clip_grad_norm_ -> optimizer step -> zero_grad(set_to_none).  MixLoss, clipping and AdamW are
+O(parameters) / O(B x classes) host-launched PyTorch ops on the device.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class MixLoss(nn.Module):
+    """Label-smoothed KL between log-softmax and a mix of two one-hot targets (reference loss.py:53-86)."""
+
+    def __init__(self, eps=0, reduction="mean"):
+        super().__init__()
+        self.eps = eps
+        self.reduction = reduction
+
+    def forward(self, output, target1, target2, interpolation):
+        n_class = output.shape[-1]
+        output = F.log_softmax(output.float(), -1)
+        true_dist = torch.full_like(output, self.eps / n_class)
+        on = 1 - self.eps + self.eps / n_class
+        true1 = true_dist.scatter(1, target1.unsqueeze(1), on)
+        true2 = true_dist.scatter(1, target2.unsqueeze(1), on)
+        inter = torch.as_tensor(interpolation, device=output.device).unsqueeze(-1)
+        true_dist = inter * true1 + (1 - inter) * true2
+        loss = F.kl_div(output, true_dist.detach(), reduction="sum" if self.reduction != "none" else "none")
+        if self.reduction == "none":
+            return loss.sum(1)
+        if self.reduction == "mean":
+            loss = loss / target1.shape[0]
+        return loss
+
+
+def wd_skip(skip_type):
+    """Weight-decay skip predicate (reference factory.py:25-39)."""
+    def check(name, param):
+        if skip_type == "nfnet":
+            return "bias" in name or "gain" in name
+        if skip_type == "resnet":
+            return "bias" in name or "bn" in name or param.ndim == 1
+        if skip_type == "vit":
+            return "bias" in name or "cls" in name or "norm" in name or param.ndim == 1
+        if skip_type == "dino":
+            return "bias" in name or param.ndim == 1
+        raise ValueError(skip_type)
+    return check
+
+
+def make_param_groups(named_parameters, weight_decay, skip_type="vit"):
+    """Two AdamW groups: no-decay first, decay second (reference train_util.py:87-111)."""
+    check = wd_skip(skip_type)
+    decay, no_decay = [], []
+    for n, p in named_parameters:
+        if not p.requires_grad:
+            continue
+        (no_decay if check(n, p) else decay).append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+def train_step(model, criterion, optimizer, batch, clip_grad_norm=5.0, autocast_dtype=torch.bfloat16,
+               grad_accum=1, ddp=None):
+    """One micro-step (+ optimizer step).  ``batch`` = (input NCHW fp32, label1, label2, ratio) on the device.
+
+    ``ddp`` (vtx.ddp.GradAllReduce) overlaps the gradient all-reduce with backward; its ``finish()`` is the
+    only synchronisation point before clipping.  Returns the (unsynchronised) loss tensor.
+    """
+    x, l1, l2, ratio = batch
+    with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
+        out = model(x)
+        loss = criterion(out, l1, l2, ratio) / grad_accum
+    loss.backward()
+    if ddp is not None:
+        ddp.finish()
+    if clip_grad_norm and clip_grad_norm > 0:
+        torch.nn.utils.clip_grad_norm_(ddp.parameters if ddp is not None else list(model.parameters()),
+                                       clip_grad_norm)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return loss
