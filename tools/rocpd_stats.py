@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace into a per-kernel stats table (like --stats CSV).
+
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--steps N] [--top 40] > profiles/round1_xxx.md
+"""
+import argparse
+import re
+import sqlite3
+import subprocess
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True,
+                             text=True, check=True).stdout.split("\n")
+        return dict(zip(names, out))
+    except Exception:
+        return {n: n for n in names}
+
+
+def short(n):
+    n = re.sub(r"\(.*$", "", n)            # drop the argument list
+    n = n.replace("void ", "")
+    return n[:110]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--steps", type=int, default=0, help="divide totals by this many steps")
+    ap.add_argument("--top", type=int, default=45)
+    a = ap.parse_args()
+    c = sqlite3.connect(a.db)
+    t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [x for x in t if "kernel_dispatch" in x][0]
+    ks = [x for x in t if "kernel_symbol" in x][0]
+    rows = c.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+                     f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name").fetchall()
+    dm = demangle([r[0] for r in rows])
+    tot = sum(r[2] for r in rows)
+    rows.sort(key=lambda r: -r[2])
+    div = a.steps if a.steps else 1
+    print(f"| kernel | calls | total ms{' /step' if a.steps else ''} | avg us | min us | max us | % |")
+    print("|---|---|---|---|---|---|---|")
+    for name, n, s, mn, mx in rows[:a.top]:
+        print(f"| `{short(dm[name])}` | {n} | {s / 1e6 / div:.3f} | {s / n / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | "
+              f"{100 * s / tot:.1f} |")
+    print(f"\nTotal GPU kernel time: {tot / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches"
+          + (f" = {tot / 1e6 / div:.2f} ms/step" if a.steps else ""))
+
+
+if __name__ == "__main__":
+    main()

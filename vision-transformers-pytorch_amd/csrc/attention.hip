@@ -386,7 +386,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 
   if (HAS_BIAS) {
     // dsacc[qt][r] = sum over this block's problems of dS[q = 16 qt + 4 g_ + r][key = 16 wave + c_]
-    float* out = dbias_part + ((int64_t)blockIdx.x * g.nH + h) * g.L * g.L;
+    // per-block slab stride padded to 4 floats (vectorised slab reduce)
+    const int64_t slab = ((int64_t)g.nH * g.L * g.L + 3) & ~(int64_t)3;
+    float* out = dbias_part + (int64_t)blockIdx.x * slab + (int64_t)h * g.L * g.L;
     const int key = wave * 16 + c_;
     if (key < g.L) {
 #pragma unroll
@@ -520,7 +522,8 @@ int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, c
 size_t vtx_attention_bwd_workspace(int B, int L, int nH, int swin, int H, int W, int win) {
   const int nW = swin ? (H / win) * (W / win) : 1;
   const int nblk = attn_bwd_blocks(B * nW, nH);
-  return (size_t)(nblk + 1) * nH * L * L * sizeof(float);
+  const size_t slab = ((size_t)nH * L * L + 3) & ~(size_t)3;
+  return (size_t)(nblk + 1) * slab * sizeof(float);
 }
 
 /* dqkv [rows, 3*h*D] (every element written); drel_pos [(2w-1)^2, nH] fp32 when bias is given. */
@@ -545,10 +548,10 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
   rc = run();
   if (rc) return rc;
   if (bias) {
-    const int64_t nfull = (int64_t)nH * L * L;
+    const int64_t nfull = ((int64_t)nH * L * L + 3) & ~(int64_t)3;
     float* full = part + (int64_t)nblk * nfull;
-    int nb = (int)((nfull + 255) / 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)part, full, nfull, nblk);
+    hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(nfull), dim3(256), 0, st, (const float*)part, full, nfull,
+                       nblk);
     rc = vtx_check_launch();
     if (rc) return rc;
     const int n = ntab * nH;

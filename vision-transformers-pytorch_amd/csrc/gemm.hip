@@ -1,5 +1,5 @@
-// MFMA GEMM family for gfx950 with fused epilogues -- every dense contraction of the hot path
-// except the attention cores (QKV / proj / MLP / patch-embed / PatchMerge / classifier linears of
+// MFMA GEMM family for gfx950 with fused prologues / epilogues -- every dense contraction of the hot
+// path except the attention cores (QKV / proj / MLP / patch-embed / PatchMerge / classifier linears of
 // reference models/vit.py:23-25,31,43, models/swin_transformer.py:34-35,128,155,205,222,
 // models/layer.py:191-196) and their dgrad / wgrad.
 //
@@ -10,11 +10,14 @@
 //   dgrad    dx = dy W      : TA=0 TB=1  A=dy[M,N'] B=W[N',K'] (contraction over W's rows)
 //   wgrad    dW = dy^T x    : TA=1 TB=1  A=dy[M',N] B=x[M',K'] (contraction over tokens, split-K slabs)
 //
-// Block = 256 threads = 4 waves (2x2); block tile BM x BN, LDS k-tile of 128 bytes per row
-// (64 bf16 / 32 fp32) at a 160-byte row stride (conflict-free ds_read_b128 fragment reads);
-// global -> registers -> LDS staging with register prefetch of the next k-tile; transposed
-// operands are transposed in registers (4x8 micro-tiles) on their way into LDS so both MFMA
-// operands are always read as 8 contiguous k-slots per lane.
+// Block = 256 threads = 4 waves (2x2); block tile 128 x BN (BN = 128 / 96 / 64), LDS k-tile of 128 bytes
+// per row (64 bf16 / 32 fp32) at a 160-byte row stride (conflict-free ds_read_b128 fragment reads);
+// global -> registers -> LDS staging with register prefetch of the next k-tile; transposed operands are
+// transposed in registers (4x8 micro-tiles) on their way into LDS so both MFMA operands are always read
+// as 8 contiguous k-slots per lane.  SiLU of the MLP is applied to the OPERAND while staging (the hidden
+// activation h = silu(z) never exists in HBM); bias / silu' / DropPath scale / residual add are applied in
+// the epilogue, which goes through LDS so that every global access is a full 16-byte vector per lane.
+// Workgroup ids are remapped so that tiles sharing an operand panel run on the same XCD (private L2).
 #include "vtx_common.h"
 
 struct GemmArgs {
@@ -25,12 +28,13 @@ struct GemmArgs {
   const void* resid;        // T [M, ldc] or null: C = resid + rowscale * (acc + bias)
   const float* rowscale;    // per-sample DropPath scale on OUTPUT rows (index row / rows_per_scale) or null
   int rows_per_scale;
-  void* aux_out;            // T [M, ldc] or null: pre-activation z when act == 1
   const void* aux_in;       // T [M, ldc]: z when act == 2
-  int act;                  // 0 none | 1 C = silu(z), z = acc + bias | 2 C = acc * silu'(aux_in)
+  int act;                  // 0 none | 2 C = acc * silu'(aux_in)
+  int opnd_silu;            // bit 0: apply SiLU to operand A while staging; bit 1: to operand B
   const float* kscale;      // per-sample scale along the CONTRACTION index of a transposed A (wgrad through DropPath)
   int k_per_scale;
   int kchunk;               // contraction length per grid.z slice (multiple of the LDS k-tile)
+  float* ksum_out;          // TA only: [grid.z][M] fp32 = sum over the contraction of opA (bias gradient), or null
 };
 
 template <typename T> struct GemmGeom {
@@ -40,6 +44,11 @@ template <typename T> struct GemmGeom {
   static constexpr int KS = BK / 32;                   // mma16 k-steps per LDS tile
   static constexpr int KG = BK / 4;                    // 4-row contraction groups (transposed staging)
 };
+
+template <typename T> __device__ __forceinline__ void vec_silu(Vec8<T>& v) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v.set(e, silu_f(v.get(e)));
+}
 
 // ---- staging of one operand tile (R tile rows x BK contraction) -------------------------------
 template <typename T, int R, bool TR> struct Stage {
@@ -51,15 +60,19 @@ template <typename T, int R, bool TR> struct Stage {
 
   // global -> registers.  base: operand pointer; t0: first tile row (m or n); k0: first contraction index
   __device__ __forceinline__ void gload(const T* __restrict__ base, int64_t ld, int t0, int tdim, int k0, int kend,
-                                        const float* __restrict__ kscale, int k_per_scale) {
+                                        const float* __restrict__ kscale, int k_per_scale, bool silu) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = threadIdx.x + it * 256;
       if (!TR) {
         const int r = idx / G::VPR, kv = idx % G::VPR;
         const int row = t0 + r, k = k0 + kv * 8;
-        if (idx < NITEMS && row < tdim && k < kend) reg[it][0] = load8<T>(base + (int64_t)row * ld + k);
-        else reg[it][0] = vec8_zero<T>();
+        if (idx < NITEMS && row < tdim && k < kend) {
+          reg[it][0] = load8<T>(base + (int64_t)row * ld + k);
+          if (silu) vec_silu<T>(reg[it][0]);
+        } else {
+          reg[it][0] = vec8_zero<T>();
+        }
       } else {
         const int kg = idx % G::KG, rc = idx / G::KG;
         const int col = t0 + rc * 8;
@@ -68,6 +81,7 @@ template <typename T, int R, bool TR> struct Stage {
           const int k = k0 + kg * 4 + i;
           if (idx < NITEMS && col < tdim && k < kend) {
             Vec8<T> v = load8<T>(base + (int64_t)k * ld + col);
+            if (silu) vec_silu<T>(v);
             if (kscale != nullptr) {
               const float s = kscale[k / k_per_scale];
 #pragma unroll
@@ -117,20 +131,34 @@ template <typename T, typename TO, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   using G = GemmGeom<T>;
   constexpr int WM = BM / 32, WN = BN / 32;   // 16x16 MFMA tiles per wave along M / N
-  __shared__ __attribute__((aligned(16))) T lds[(BM + BN) * G::STRIDE];
-  T* ldsA = lds;
-  T* ldsB = lds + BM * G::STRIDE;
+  constexpr int CSTR = BN + 4;                // fp32 C-staging row stride (floats)
+  static_assert((BM + BN) * 160 >= (BM / 2) * CSTR * 4, "C staging must fit in the operand LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(BM + BN) * 160];
+  T* ldsA = reinterpret_cast<T*>(lds_raw);
+  T* ldsB = ldsA + BM * G::STRIDE;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int c_ = lane & 15, g_ = lane >> 4;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.kchunk;
+
+  // ---- XCD-aware tile mapping: dispatch id d runs on XCD d % 8; give each XCD a contiguous range of
+  //      (slice, m-tile, n-tile) ids so blocks that share an operand panel share an L2 (bijective remap).
+  const int ntn = gridDim.x, ntm = gridDim.y;
+  const int nblk = ntn * ntm * gridDim.z;
+  const int did = (blockIdx.z * ntm + blockIdx.y) * ntn + blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int tn = lid % ntn;
+  const int tm = (lid / ntn) % ntm;
+  const int tz = lid / (ntn * ntm);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = tz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nk = (kend - kbeg + G::BK - 1) / G::BK;
 
   const T* A = (const T*)p.A;
   const T* B = (const T*)p.B;
+  const bool silu_a = p.opnd_silu & 1, silu_b = p.opnd_silu & 2;
 
   f32x4 acc[WM][WN];
 #pragma unroll
@@ -140,18 +168,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   Stage<T, BM, TA> sa;
   Stage<T, BN, TB> sb;
-  sa.gload(A, p.lda, m0, p.M, kbeg, kend, TA ? p.kscale : nullptr, p.k_per_scale);
-  sb.gload(B, p.ldb, n0, p.N, kbeg, kend, nullptr, 1);
+  sa.gload(A, p.lda, m0, p.M, kbeg, kend, TA ? p.kscale : nullptr, p.k_per_scale, silu_a);
+  sb.gload(B, p.ldb, n0, p.N, kbeg, kend, nullptr, 1, silu_b);
   sa.lstore(ldsA);
   sb.lstore(ldsB);
   __syncthreads();
+
+  // bias gradient rides on the wgrad kernel: row sums of the (already DropPath-scaled) dy^T tile in LDS,
+  // done by the blocks of the first column tile only
+  const bool do_ksum = TA && p.ksum_out != nullptr && tn == 0 && threadIdx.x < BM;
+  float ksum = 0.f;
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
       const int k0 = kbeg + (kt + 1) * G::BK;
-      sa.gload(A, p.lda, m0, p.M, k0, kend, TA ? p.kscale : nullptr, p.k_per_scale);
-      sb.gload(B, p.ldb, n0, p.N, k0, kend, nullptr, 1);
+      sa.gload(A, p.lda, m0, p.M, k0, kend, TA ? p.kscale : nullptr, p.k_per_scale, silu_a);
+      sb.gload(B, p.ldb, n0, p.N, k0, kend, nullptr, 1, silu_b);
+    }
+    if (do_ksum) {
+      const T* row = ldsA + threadIdx.x * G::STRIDE;
+#pragma unroll
+      for (int v = 0; v < G::VPR; ++v) {
+        Vec8<T> t = load8<T>(row + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ksum += t.get(e);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
@@ -175,76 +217,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
   }
 
-  // ---------------- epilogue: acc[i][j][r] = C[row = .. + 4*g_ + r][col = .. + c_]
-  TO* Cout = (TO*)p.C + (int64_t)blockIdx.z * p.M * p.ldc;
+  if (do_ksum && m0 + (int)threadIdx.x < p.M) p.ksum_out[(int64_t)tz * p.M + m0 + threadIdx.x] = ksum;
+
+  // ---------------- epilogue through LDS: two passes of BM/2 rows; acc[i][j][r] = C[.. + 4*g_ + r][.. + c_]
+  TO* Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
   const T* resid = (const T*)p.resid;
   const T* aux_in = (const T*)p.aux_in;
-  T* aux_out = (T*)p.aux_out;
+  float* cbuf = reinterpret_cast<float*>(lds_raw);
+  constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
+  constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
+  for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * (BM / 2) + i * 16 + g_ * 4 + r;
-      if (row >= p.M) continue;
-      const float rsc = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
+    for (int ii = 0; ii < WM / 2; ++ii) {
+      const int i = pass * (WM / 2) + ii;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 16 + c_;
-        if (col >= p.N) continue;
-        const int64_t off = (int64_t)row * p.ldc + col;
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[col];
-        if (p.act == 1) {
-          const float z = round_to<T>(v);
-          if (aux_out) aux_out[off] = from_f32<T>(v);
-          v = silu_f(z);
-        } else if (p.act == 2) {
-          v *= dsilu_f(to_f32<T>(aux_in[off]));
-        }
-        v *= rsc;
-        if (resid) v += to_f32<T>(resid[off]);
-        Cout[off] = from_f32<TO>(v);
-      }
-    }
-  }
-}
-
-// bias gradient: out[n] = sum_m scale[m / rows_per_scale] * dy[m, n]  -- two-stage, deterministic.
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ part, int64_t M, int N,
-                                                    int64_t ld, const float* __restrict__ rowscale,
-                                                    int rows_per_scale, int rows_per_block) {
-  // thread -> 8 consecutive columns; threads of a block stride over the rows of the block's slab
-  const int nvec = N >> 3;
-  const int vpb = min(nvec, 256);                  // vectors handled side by side
-  const int rlanes = 256 / vpb;                    // row-parallelism inside the block
-  __shared__ float red[256 * 8];
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = min(M, r0 + rows_per_block);
-  for (int vbase = 0; vbase < nvec; vbase += vpb) {
-    const int v = vbase + threadIdx.x % vpb;
-    const int rl = threadIdx.x / vpb;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (v < nvec && rl < rlanes) {
-      for (int64_t r = r0 + rl; r < r1; r += rlanes) {
-        Vec8<T> t = load8<T>(dy + r * ld + v * 8);
-        const float sc = rowscale ? rowscale[r / rows_per_scale] : 1.f;
+      for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += sc * t.get(e);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
-    __syncthreads();
-    if (threadIdx.x < vpb && v < nvec) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float a = 0.f;
-        for (int q = 0; q < rlanes; ++q) a += red[(q * vpb + threadIdx.x) * 8 + e];
-        part[(int64_t)blockIdx.x * N + v * 8 + e] = a;
-      }
+        for (int r = 0; r < 4; ++r)
+          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r];
     }
     __syncthreads();
+    for (int v = threadIdx.x; v < NVEC; v += 256) {
+      const int lr = v / VROW, cv = v - lr * VROW;
+      const int w2 = lr / (BM / 4), rem = lr - w2 * (BM / 4);
+      const int row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
+      const int col = n0 + cv * 8;
+      if (row >= p.M || col >= p.N) continue;
+      const float* cp = cbuf + lr * CSTR + cv * 8;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
+      float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const int64_t off = (int64_t)row * p.ldc + col;
+      if (p.bias) {
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { val[e] += b0[e]; val[4 + e] += b1[e]; }
+      }
+      if (p.act == 2) {
+        Vec8<T> z = load8<T>(aux_in + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(z.get(e));
+      }
+      if (p.rowscale) {
+        const float rsc = p.rowscale[row / p.rows_per_scale];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] *= rsc;
+      }
+      if (resid) {
+        Vec8<T> rv = load8<T>(resid + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] += rv.get(e);
+      }
+      Vec8<TO> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, val[e]);
+      store8<TO>(Cout + off, o);
+    }
+    if (pass == 0) __syncthreads();
   }
 }
 
@@ -267,26 +296,28 @@ static int gemm_pick_bn(const GemmArgs& a, int nz, hipStream_t st) {
 static int gemm_validate(const GemmArgs& a, int mode) {
   if (!a.A || !a.B || !a.C) return VTX_ERR_NULL;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return VTX_ERR_SHAPE;
-  // contiguous-dimension granularity of the 8-element vector loads
-  if (mode == 0 && ((a.K & 7) || (a.lda & 7) || (a.ldb & 7))) return VTX_ERR_ALIGN;            // NT
-  if (mode == 1 && ((a.K & 7) || (a.N & 7) || (a.lda & 7) || (a.ldb & 7))) return VTX_ERR_ALIGN;  // NN: B[k][n]
-  if (mode == 2 && ((a.M & 7) || (a.N & 7) || (a.lda & 7) || (a.ldb & 7))) return VTX_ERR_ALIGN;  // TN
+  // 8-element vector granularity of the contiguous dimensions (loads) and of the output rows (stores)
+  if ((a.N & 7) || (a.ldc & 7) || (a.lda & 7) || (a.ldb & 7)) return VTX_ERR_ALIGN;
+  if ((mode == 0 || mode == 1) && (a.K & 7)) return VTX_ERR_ALIGN;   // A[m][k] rows
+  if (mode == 2 && (a.M & 7)) return VTX_ERR_ALIGN;                   // A^T[k][m] rows
   if (a.act == 2 && !a.aux_in) return VTX_ERR_NULL;
   return VTX_OK;
 }
 
 extern "C" {
 
-// y = epilogue(x W^T): mode 0.   dx = epilogue(dy W): mode 1.   (see GemmArgs for the fused epilogue)
+// mode 0: C = epi(opnd(A) W^T)    mode 1: C = epi(A W)     (see GemmArgs for the fused prologue / epilogue)
 int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
              int64_t ldb, int64_t ldc, const float* bias, const void* resid, const float* rowscale,
-             int rows_per_scale, void* aux_out, const void* aux_in, int act, void* stream) {
+             int rows_per_scale, const void* aux_in, int act, int a_silu, void* stream) {
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.bias = bias; a.resid = resid; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-  a.aux_out = aux_out; a.aux_in = aux_in; a.act = act; a.kscale = nullptr; a.k_per_scale = 1;
+  a.aux_in = aux_in; a.act = act; a.opnd_silu = a_silu ? 1 : 0; a.kscale = nullptr; a.k_per_scale = 1;
+  a.ksum_out = nullptr;
   a.kchunk = ((K + 127) / 128) * 128;
   if (mode != 0 && mode != 1) return VTX_ERR_SHAPE;
+  if (act != 0 && act != 2) return VTX_ERR_SHAPE;
   int rc = gemm_validate(a, mode);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -310,15 +341,13 @@ static int wgrad_slices(int64_t mtok, int N, int Kin) {
 
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
   const int nz = wgrad_slices(mtok, N, Kin);
-  size_t slabs = (size_t)nz * (size_t)N * (size_t)Kin * sizeof(float);
-  size_t bias = (size_t)1024 * (size_t)N * sizeof(float);
-  return slabs > bias ? slabs : bias;
+  return ((size_t)nz * (size_t)N * (size_t)Kin + (size_t)nz * (size_t)N) * sizeof(float);
 }
 
-// dW[N,Kin] = sum_m s[m] * dy[m,N]^T x[m,Kin]   (fp32 out);  dbias[N] = sum_m s[m] * dy[m,:] (optional)
+// dW[N,Kin] = sum_m s[m] * dy[m,N]^T f(x[m,Kin])  (fp32 out), f = SiLU if x_silu;  dbias[N] = sum_m s[m] * dy[m,:]
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
-              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace, size_t ws_bytes,
-              void* stream) {
+              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, int x_silu, void* workspace,
+              size_t ws_bytes, void* stream) {
   if (!dy || !x || !dW || !workspace) return VTX_ERR_NULL;
   if (mtok <= 0 || mtok > 0x7fffffff) return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_wgrad_workspace(mtok, N, Kin)) return VTX_ERR_WORKSPACE;
@@ -327,11 +356,14 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   GemmArgs a;
   a.A = dy; a.B = x; a.C = (nz == 1) ? (void*)dW : workspace;
   a.M = N; a.N = Kin; a.K = (int)mtok; a.lda = ld_dy; a.ldb = ld_x; a.ldc = Kin;
-  a.bias = nullptr; a.resid = nullptr; a.rowscale = nullptr; a.rows_per_scale = 1; a.aux_out = nullptr;
-  a.aux_in = nullptr; a.act = 0; a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+  a.bias = nullptr; a.resid = nullptr; a.rowscale = nullptr; a.rows_per_scale = 1;
+  a.aux_in = nullptr; a.act = 0; a.opnd_silu = x_silu ? 2 : 0;
+  a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   int64_t chunk = (mtok + nz - 1) / nz;
   chunk = ((chunk + 127) / 128) * 128;
   a.kchunk = (int)chunk;
+  float* bias_part = (float*)workspace + (size_t)nz * N * Kin;
+  a.ksum_out = dbias ? (nz == 1 ? dbias : bias_part) : nullptr;
   int rc = gemm_validate(a, 2);
   if (rc) return rc;
   if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
@@ -340,28 +372,14 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   if (rc) return rc;
   if (nz > 1) {
     const int64_t n = (int64_t)N * Kin;
-    int nb = (int)((n + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)workspace, dW, n, nz);
+    hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(n), dim3(256), 0, st, (const float*)workspace, dW, n, nz);
     rc = vtx_check_launch();
     if (rc) return rc;
-  }
-  if (dbias) {
-    if (N & 7) return VTX_ERR_ALIGN;
-    int nb = (int)((mtok + 511) / 512);
-    if (nb > 1024) nb = 1024;
-    const int rpb = (int)((mtok + nb - 1) / nb);
-    float* part = (float*)workspace;   // slabs are dead after slab_reduce (same stream => ordered)
-    if (dtype == VTX_BF16)
-      hipLaunchKernelGGL((colsum_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)dy, part, mtok, N, ld_dy,
-                         rowscale, a.k_per_scale, rpb);
-    else
-      hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dy, part, mtok, N, ld_dy,
-                         rowscale, a.k_per_scale, rpb);
-    rc = vtx_check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, dbias, (float*)nullptr, nb, N, N);
-    rc = vtx_check_launch();
+    if (dbias) {
+      hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(N), dim3(256), 0, st, (const float*)bias_part, dbias,
+                         (int64_t)N, nz);
+      rc = vtx_check_launch();
+    }
   }
   return rc;
 }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 static int ln_grid(int64_t rows, int gpb) {
   int64_t nb = (rows + gpb - 1) / gpb;
-  if (nb > 1024) nb = 1024;
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -200,7 +200,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
                      gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
   int rc = vtx_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(colreduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
+  hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(2 * C), dim3(256), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
   return vtx_check_launch();
 }
 

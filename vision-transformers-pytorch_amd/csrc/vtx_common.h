@@ -94,23 +94,46 @@ __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoidf_(z); }
 __device__ __forceinline__ float dsilu_f(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
 
-// out[c] = sum_b part[b][c]  (fixed order -> run-to-run deterministic)
+// out[c] = sum_b part[b][c] for c < C (out0) and C <= c < 2C (out1, optional).  Launch with 256 threads and
+// ceil(ncols / 32) blocks: 32 columns x 8 row lanes per block, fixed summation order (deterministic).
 static __global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                 int nb, int C, int ld) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
+                                        int nb, int C, int ld) {
+  __shared__ float red[8][33];
+  const int ncols = out1 ? 2 * C : C;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * ld + c];
-  if (c < C) out0[c] = s; else if (out1) out1[c - C] = s;
-}
-
-// out[i] = sum_z slab[z][i]   (fixed order: deterministic wgrad)
-static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nz) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += slabs[(int64_t)z * n + i];
-    out[i] = s;
+  if (c < ncols)
+    for (int b = rl; b < nb; b += 8) s += part[(int64_t)b * ld + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    if (c < C) out0[c] = t; else out1[c - C] = t;
   }
+}
+static inline dim3 colreduce_grid(int ncols) { return dim3((ncols + 31) / 32); }
+
+// out[i] = sum_z slab[z][i]   (fixed order: deterministic).  n must be a multiple of 4.
+static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nz) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + i;
+    int z = 0;
+    for (; z + 4 <= nz; z += 4) {
+      f32x4 a = p[(int64_t)z * n4], b = p[(int64_t)(z + 1) * n4], c2 = p[(int64_t)(z + 2) * n4], d = p[(int64_t)(z + 3) * n4];
+      s += a; s += b; s += c2; s += d;
+    }
+    for (; z < nz; ++z) s += p[(int64_t)z * n4];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+static inline dim3 slab_reduce_grid(int64_t n) {
+  int64_t nb = ((n >> 2) + 255) / 256;
+  return dim3((unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)));
 }
 
 static inline int vtx_check_launch() {
