@@ -56,24 +56,23 @@ int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
 
 /* ---- Linear layers (reference: nn.Linear / nn.Conv2d-as-GEMM at models/vit.py:23-25, 73,
  * models/swin_transformer.py:34-35, 205, 222, 281, models/layer.py:191-196) with fused epilogues.
- *   mode 0 (forward): C[M,N] = epi( f(A[M,K]) . B[N,K]^T )     A = activations, B = weight
+ *   mode 0 (forward): C[M,N] = epi( A[M,K] . B[N,K]^T )        A = activations, B = weight
  *   mode 1 (dgrad)  : C[M,N] = epi( A[M,K] . B[K,N]   )        A = dy, B = weight [K = out, N = in]
- *   f = SiLU when a_silu != 0 (the MLP activation is applied to the operand while it is staged, so
- *       h = silu(z) of models/layer.py:191-196 never exists in HBM), identity otherwise
- *   epi(v): v += bias[col]; act 2: v *= silu'(aux_in[row,col]);
+ *   epi(v): v += bias[col]; act 1: aux_out = z = v, v = silu(z) (MLP, models/layer.py:191-196);
+ *           act 2: v *= silu'(aux_in[row,col]);
  *           v *= rowscale[row / rows_per_scale] (DropPath, models/layer.py:172-180);
  *           v += resid[row, col] (residual add, models/vit.py:60-61, swin_transformer.py:194-195)
- * bias / resid / rowscale / aux_in may be NULL.  lda/ldb/ldc in elements; N, K and the leading dimensions
+ * bias / resid / rowscale / aux_out / aux_in may be NULL.  lda/ldb/ldc in elements; N, K and the leading dimensions
  * must be multiples of 8 (16-byte vector access everywhere). */
 int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
              int64_t ldb, int64_t ldc, const float* bias, const void* resid, const float* rowscale,
-             int rows_per_scale, const void* aux_in, int act, int a_silu, void* stream);
+             int rows_per_scale, void* aux_out, const void* aux_in, int act, void* stream);
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
-/* dW[N,Kin] = sum_m s[m] dy[m,:]^T f(x[m,:]) (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
- * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1; f = SiLU when x_silu != 0.
+/* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
+ * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.
  * Deterministic (split-K slabs + fixed-order reduce). */
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
-              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, int x_silu, void* workspace,
+              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace,
               size_t ws_bytes, void* stream);
 
 /* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order

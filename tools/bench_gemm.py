@@ -56,8 +56,8 @@ def main():
                 kw = dict(bias=bias)
                 if name in ("proj", "fc2"):
                     kw["resid"] = res
-                if name == "fc2":
-                    kw["a_silu"] = True
+                if name == "fc1":
+                    kw.update(act=ops.ACT_SILU, want_aux=True)
                 t = timeit(lambda: ops.gemm(x, w, 0, **kw), a.iters)
                 byt = 2 * (M * K + N * K + M * N * (2 if "resid" in kw else 1))
                 rows.append(("fwd", t, byt))
@@ -69,7 +69,7 @@ def main():
                 byt = 2 * (M * N + N * K + M * K * (2 if kw else 1))
                 rows.append(("dgrad", t, byt))
             if "wgrad" in what:
-                t = timeit(lambda: ops.wgrad(dy, x, x_silu=(name == "fc2")), a.iters)
+                t = timeit(lambda: ops.wgrad(dy, x), a.iters)
                 byt = 2 * (M * N + M * K) + 4 * N * K
                 rows.append(("wgrad", t, byt))
             for kind, t, byt in rows:

@@ -14,9 +14,10 @@
 // per row (64 bf16 / 32 fp32) at a 160-byte row stride (conflict-free ds_read_b128 fragment reads);
 // global -> registers -> LDS staging with register prefetch of the next k-tile; transposed operands are
 // transposed in registers (4x8 micro-tiles) on their way into LDS so both MFMA operands are always read
-// as 8 contiguous k-slots per lane.  SiLU of the MLP is applied to the OPERAND while staging (the hidden
-// activation h = silu(z) never exists in HBM); bias / silu' / DropPath scale / residual add are applied in
-// the epilogue, which goes through LDS so that every global access is a full 16-byte vector per lane.
+// as 8 contiguous k-slots per lane.  bias / SiLU (+ saved pre-activation) / silu' / DropPath scale / residual
+// add are applied in the epilogue, which goes through LDS so that every global access is a full 16-byte
+// vector per lane.  (SiLU as an operand PROLOGUE was measured 2.7x slower on fc2: the transcendental work
+// is repeated per N-tile and serialises with the staging; writing h once from fc1's epilogue is cheaper.)
 // Workgroup ids are remapped so that tiles sharing an operand panel run on the same XCD (private L2).
 #include "vtx_common.h"
 
@@ -28,9 +29,9 @@ struct GemmArgs {
   const void* resid;        // T [M, ldc] or null: C = resid + rowscale * (acc + bias)
   const float* rowscale;    // per-sample DropPath scale on OUTPUT rows (index row / rows_per_scale) or null
   int rows_per_scale;
+  void* aux_out;            // T [M, ldc] or null: pre-activation z when act == 1
   const void* aux_in;       // T [M, ldc]: z when act == 2
-  int act;                  // 0 none | 2 C = acc * silu'(aux_in)
-  int opnd_silu;            // bit 0: apply SiLU to operand A while staging; bit 1: to operand B
+  int act;                  // 0 none | 1 aux_out = z = acc + bias, C = silu(z) | 2 C = acc * silu'(aux_in)
   const float* kscale;      // per-sample scale along the CONTRACTION index of a transposed A (wgrad through DropPath)
   int k_per_scale;
   int kchunk;               // contraction length per grid.z slice (multiple of the LDS k-tile)
@@ -45,11 +46,6 @@ template <typename T> struct GemmGeom {
   static constexpr int KG = BK / 4;                    // 4-row contraction groups (transposed staging)
 };
 
-template <typename T> __device__ __forceinline__ void vec_silu(Vec8<T>& v) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v.set(e, silu_f(v.get(e)));
-}
-
 // ---- staging of one operand tile (R tile rows x BK contraction) -------------------------------
 template <typename T, int R, bool TR> struct Stage {
   using G = GemmGeom<T>;
@@ -60,19 +56,15 @@ template <typename T, int R, bool TR> struct Stage {
 
   // global -> registers.  base: operand pointer; t0: first tile row (m or n); k0: first contraction index
   __device__ __forceinline__ void gload(const T* __restrict__ base, int64_t ld, int t0, int tdim, int k0, int kend,
-                                        const float* __restrict__ kscale, int k_per_scale, bool silu) {
+                                        const float* __restrict__ kscale, int k_per_scale) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = threadIdx.x + it * 256;
       if (!TR) {
         const int r = idx / G::VPR, kv = idx % G::VPR;
         const int row = t0 + r, k = k0 + kv * 8;
-        if (idx < NITEMS && row < tdim && k < kend) {
-          reg[it][0] = load8<T>(base + (int64_t)row * ld + k);
-          if (silu) vec_silu<T>(reg[it][0]);
-        } else {
-          reg[it][0] = vec8_zero<T>();
-        }
+        if (idx < NITEMS && row < tdim && k < kend) reg[it][0] = load8<T>(base + (int64_t)row * ld + k);
+        else reg[it][0] = vec8_zero<T>();
       } else {
         const int kg = idx % G::KG, rc = idx / G::KG;
         const int col = t0 + rc * 8;
@@ -81,7 +73,6 @@ template <typename T, int R, bool TR> struct Stage {
           const int k = k0 + kg * 4 + i;
           if (idx < NITEMS && col < tdim && k < kend) {
             Vec8<T> v = load8<T>(base + (int64_t)k * ld + col);
-            if (silu) vec_silu<T>(v);
             if (kscale != nullptr) {
               const float s = kscale[k / k_per_scale];
 #pragma unroll
@@ -158,7 +149,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   const T* A = (const T*)p.A;
   const T* B = (const T*)p.B;
-  const bool silu_a = p.opnd_silu & 1, silu_b = p.opnd_silu & 2;
 
   f32x4 acc[WM][WN];
 #pragma unroll
@@ -168,8 +158,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   Stage<T, BM, TA> sa;
   Stage<T, BN, TB> sb;
-  sa.gload(A, p.lda, m0, p.M, kbeg, kend, TA ? p.kscale : nullptr, p.k_per_scale, silu_a);
-  sb.gload(B, p.ldb, n0, p.N, kbeg, kend, nullptr, 1, silu_b);
+  sa.gload(A, p.lda, m0, p.M, kbeg, kend, TA ? p.kscale : nullptr, p.k_per_scale);
+  sb.gload(B, p.ldb, n0, p.N, kbeg, kend, nullptr, 1);
   sa.lstore(ldsA);
   sb.lstore(ldsB);
   __syncthreads();
@@ -183,8 +173,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const bool more = kt + 1 < nk;
     if (more) {
       const int k0 = kbeg + (kt + 1) * G::BK;
-      sa.gload(A, p.lda, m0, p.M, k0, kend, TA ? p.kscale : nullptr, p.k_per_scale, silu_a);
-      sb.gload(B, p.ldb, n0, p.N, k0, kend, nullptr, 1, silu_b);
+      sa.gload(A, p.lda, m0, p.M, k0, kend, TA ? p.kscale : nullptr, p.k_per_scale);
+      sb.gload(B, p.ldb, n0, p.N, k0, kend, nullptr, 1);
     }
     if (do_ksum) {
       const T* row = ldsA + threadIdx.x * G::STRIDE;
@@ -223,6 +213,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   TO* Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
   const T* resid = (const T*)p.resid;
   const T* aux_in = (const T*)p.aux_in;
+  T* aux_out = (T*)p.aux_out;
   float* cbuf = reinterpret_cast<float*>(lds_raw);
   constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
   constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
@@ -253,7 +244,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { val[e] += b0[e]; val[4 + e] += b1[e]; }
       }
-      if (p.act == 2) {
+      if (p.act == 1) {
+        Vec8<T> z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { z.set(e, val[e]); val[e] = silu_f(z.get(e)); }   // silu of the ROUNDED z
+        if (aux_out) store8<T>(aux_out + off, z);
+      } else if (p.act == 2) {
         Vec8<T> z = load8<T>(aux_in + off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(z.get(e));
@@ -306,18 +302,18 @@ static int gemm_validate(const GemmArgs& a, int mode) {
 
 extern "C" {
 
-// mode 0: C = epi(opnd(A) W^T)    mode 1: C = epi(A W)     (see GemmArgs for the fused prologue / epilogue)
+// mode 0: C = epi(A W^T)    mode 1: C = epi(A W)     (see GemmArgs for the fused epilogue)
 int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
              int64_t ldb, int64_t ldc, const float* bias, const void* resid, const float* rowscale,
-             int rows_per_scale, const void* aux_in, int act, int a_silu, void* stream) {
+             int rows_per_scale, void* aux_out, const void* aux_in, int act, void* stream) {
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.bias = bias; a.resid = resid; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-  a.aux_in = aux_in; a.act = act; a.opnd_silu = a_silu ? 1 : 0; a.kscale = nullptr; a.k_per_scale = 1;
+  a.aux_out = aux_out; a.aux_in = aux_in; a.act = act; a.kscale = nullptr; a.k_per_scale = 1;
   a.ksum_out = nullptr;
   a.kchunk = ((K + 127) / 128) * 128;
   if (mode != 0 && mode != 1) return VTX_ERR_SHAPE;
-  if (act != 0 && act != 2) return VTX_ERR_SHAPE;
+  if (act < 0 || act > 2) return VTX_ERR_SHAPE;
   int rc = gemm_validate(a, mode);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -331,7 +327,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
 // Number of contraction slices the wgrad kernel will use for (Mtok tokens, N x Kin weight).
 static int wgrad_slices(int64_t mtok, int N, int Kin) {
   const int tiles = ((N + 127) / 128) * ((Kin + 127) / 128);
-  int nz = (512 + tiles - 1) / tiles;
+  int nz = (320 + tiles - 1) / tiles;
   const int64_t maxz = (mtok + 255) / 256;
   if (nz > maxz) nz = (int)maxz;
   if (nz < 1) nz = 1;
@@ -344,9 +340,9 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
   return ((size_t)nz * (size_t)N * (size_t)Kin + (size_t)nz * (size_t)N) * sizeof(float);
 }
 
-// dW[N,Kin] = sum_m s[m] * dy[m,N]^T f(x[m,Kin])  (fp32 out), f = SiLU if x_silu;  dbias[N] = sum_m s[m] * dy[m,:]
+// dW[N,Kin] = sum_m s[m] * dy[m,N]^T x[m,Kin]  (fp32 out);  dbias[N] = sum_m s[m] * dy[m,:] (same kernel)
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
-              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, int x_silu, void* workspace,
+              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace,
               size_t ws_bytes, void* stream) {
   if (!dy || !x || !dW || !workspace) return VTX_ERR_NULL;
   if (mtok <= 0 || mtok > 0x7fffffff) return VTX_ERR_SHAPE;
@@ -357,7 +353,7 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   a.A = dy; a.B = x; a.C = (nz == 1) ? (void*)dW : workspace;
   a.M = N; a.N = Kin; a.K = (int)mtok; a.lda = ld_dy; a.ldb = ld_x; a.ldc = Kin;
   a.bias = nullptr; a.resid = nullptr; a.rowscale = nullptr; a.rows_per_scale = 1;
-  a.aux_in = nullptr; a.act = 0; a.opnd_silu = x_silu ? 2 : 0;
+  a.aux_out = nullptr; a.aux_in = nullptr; a.act = 0;
   a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   int64_t chunk = (mtok + nz - 1) / nz;
   chunk = ((chunk + 127) / 128) * 128;

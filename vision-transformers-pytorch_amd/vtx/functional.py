@@ -12,7 +12,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .ops import ACT_DSILU, VtxError
+from .ops import ACT_DSILU, ACT_SILU, VtxError
 
 
 def compute_dtype(x):
@@ -97,17 +97,17 @@ class FeedForwardFn(Function):
     def forward(ctx, x, w1, b1, w2, b2):
         x = _c(x)
         T = x.dtype
-        z = ops.gemm(x, cast(w1, T), 0, bias=b1.detach())
-        y = ops.gemm(z, cast(w2, T), 0, bias=b2.detach(), a_silu=True)     # silu applied to the staged operand
-        ctx.save_for_backward(x, w1, w2, z)
+        h, z = ops.gemm(x, cast(w1, T), 0, bias=b1.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, cast(w2, T), 0, bias=b2.detach())
+        ctx.save_for_backward(x, w1, w2, z, h)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, w2, z = ctx.saved_tensors
+        x, w1, w2, z, h = ctx.saved_tensors
         T = x.dtype
         dy = _c(dy)
-        dW2, db2 = ops.wgrad(dy, z, x_silu=True)
+        dW2, db2 = ops.wgrad(dy, h)
         dz = ops.gemm(dy, cast(w2, T), 1, act=ACT_DSILU, aux_in=z)
         dW1, db1 = ops.wgrad(dz, x)
         dx = ops.gemm(dz, cast(w1, T), 1)
@@ -148,7 +148,7 @@ class AttentionCoreFn(Function):
 class TransformerLayerFn(Function):
     """One pre-LN transformer block (reference models/vit.py:59-63, models/swin_transformer.py:193-197):
          x1 = x  + s1 * proj(attn(qkv(LN1(x))))        y = x1 + s2 * fc2(silu(fc1(LN2(x1))))
-    as 7 kernels forward (LN, GEMM, attention, GEMM+residual, LN, GEMM, SiLU-prologue GEMM+residual); s1/s2 are
+    as 7 kernels forward (LN, GEMM, attention, GEMM+residual, LN, GEMM+SiLU, GEMM+residual); s1/s2 are
     the per-sample DropPath scales mask/(1-p) (models/layer.py:172-180) or None."""
 
     @staticmethod
@@ -165,24 +165,23 @@ class TransformerLayerFn(Function):
                                    mask=meta.mask)
         x1 = ops.gemm(o, cast(proj_w, T), 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), meta.eps)
-        z = ops.gemm(ln2, cast(fc1_w, T), 0, bias=fc1_b.detach())
-        y = ops.gemm(z, cast(fc2_w, T), 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps,
-                     a_silu=True)
+        h, z = ops.gemm(ln2, cast(fc1_w, T), 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, cast(fc2_w, T), 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
-                              mean2, rstd2, ln2, z, bias, s1, s2)
+                              mean2, rstd2, ln2, z, h, bias, s1, s2)
         ctx.meta, ctx.rps = meta, rps
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z,
+        (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z, h,
          bias, s1, s2) = ctx.saved_tensors
         m, rps = ctx.meta, ctx.rps
         T = x.dtype
         dy = _c(dy)
         B = x.shape[0]
         # ---- MLP branch
-        dW2, db2 = ops.wgrad(dy, z, rowscale=s2, rows_per_scale=rps, x_silu=True)
+        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps)
         dz = ops.gemm(dy, cast(fc2_w, T), 1, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
         dW1, db1 = ops.wgrad(dz, ln2)
         dln2 = ops.gemm(dz, cast(fc1_w, T), 1)

@@ -136,12 +136,12 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False):
 
 
 # ------------------------------------------------------------------------------- GEMM family
-ACT_NONE, ACT_DSILU = 0, 2
+ACT_NONE, ACT_SILU, ACT_DSILU = 0, 1, 2
 
 
 def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, act=ACT_NONE, aux_in=None,
-         a_silu=False, out=None):
-    """mode 0: f(a)[M,K] @ w[N,K]^T ; mode 1: a[M,K] @ w[K,N]; f = SiLU if a_silu.  Fused epilogue per vtx.h."""
+         want_aux=False, out=None):
+    """mode 0: a[M,K] @ w[N,K]^T ; mode 1: a[M,K] @ w[K,N].  Fused epilogue per vtx.h; returns (C, z) if want_aux."""
     _dev(a, w, bias, resid, rowscale, aux_in, out)
     _f32(bias, "bias"); _f32(rowscale, "rowscale")
     if a.dtype != w.dtype:
@@ -156,18 +156,19 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     if kw != K:
         raise VtxError(f"vtx: gemm contraction mismatch ({K} vs {kw})")
     c = out if out is not None else torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
+    aux = torch.empty_like(c) if want_aux else None
     ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode), 2.0 * M * N * K) if _timer is not None else None
     if ev:
         ev[0].record()
     check(lib.vtx_gemm(mode, _dt(a), _p(a), _p(w), _p(c), M, N, K, K, w.shape[1], N, _p(bias), _p(resid),
-                       _p(rowscale), int(rows_per_scale), _p(aux_in), act, int(bool(a_silu)), _stream()), "vtx_gemm")
+                       _p(rowscale), int(rows_per_scale), _p(aux), _p(aux_in), act, _stream()), "vtx_gemm")
     if ev:
         ev[1].record()
-    return c
+    return (c, aux) if want_aux else c
 
 
-def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, x_silu=False):
-    """dW[N,Kin] (fp32), dbias[N] (fp32 or None) from dy[M,N], f(x)[M,Kin]; f = SiLU if x_silu."""
+def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1):
+    """dW[N,Kin] (fp32), dbias[N] (fp32 or None) from dy[M,N], x[M,Kin]."""
     _dev(dy, x, rowscale)
     lib = _lib.load()
     N, Kin = dy.shape[-1], x.shape[-1]
@@ -179,7 +180,7 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, x_silu=False):
     wsb = lib.vtx_wgrad_workspace(M, N, Kin)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
-                        int(rows_per_scale), int(bool(x_silu)), _p(ws), wsb, _stream()), "vtx_wgrad")
+                        int(rows_per_scale), _p(ws), wsb, _stream()), "vtx_wgrad")
     return dW, db
 
 
