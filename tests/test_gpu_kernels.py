@@ -201,3 +201,37 @@ def test_window_attention_core(dtype, B, H, W, nH, shift):
     check(f"window attn fwd {tag}", o, orf, t["out"] * 1.5)
     check(f"window attn dqkv {tag}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"window attn drel_pos {tag}", drel, drr, 2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,nH,shift", [(2, 14, 14, 3, True), (2, 14, 14, 3, False), (3, 7, 7, 24, True),
+                                            (1, 28, 28, 6, True), (2, 56, 56, 3, True), (5, 14, 14, 12, True)])
+def test_window_attention_fast_path(dtype, B, H, W, nH, shift):
+    """One-wave-per-window kernels (attention_win.hip) vs the oracle; the rel_pos gradient must also be
+    bitwise reproducible run to run (wave-private LDS accumulation, fixed-order reduce)."""
+    from vtx import ops
+    from oracle import tables
+    d = dev()
+    D, win = 32, 7
+    L, ntab = win * win, (2 * win - 1) ** 2
+    qkv = _mk((B, H, W, 3 * nH * D), 71, dtype)
+    do = _mk((B, H, W, nH * D), 72, dtype)
+    rel = _mk((ntab, nH), 73, torch.float32, 0.5)
+    pos_np, mask_np = tables.make_pos_mask((H, W), win, shift)
+    pos = torch.from_numpy(pos_np).to(d)
+    mask = torch.from_numpy(mask_np).to(d) if shift else None
+    swin = (H, W, win, shift)
+    tb = ops.wattn_tables(rel.to(d), pos, mask, nH)
+    o, lse = ops.wattn_fwd(qkv.to(d), tb, shift, B, L, nH, swin)
+    dqkv, drel = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, tb, shift, B, L, nH, swin, ntab)
+    dqkv2, drel2 = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, tb, shift, B, L, nH, swin, ntab)
+    assert torch.equal(drel, drel2) and torch.equal(dqkv, dqkv2), "window attention backward is not deterministic"
+    qr = qkv.double().requires_grad_(True)
+    rr = rel.double().requires_grad_(True)
+    orf = R.window_attention_core(qr, rr, nH, D, win, shift)
+    dqr, drr = torch.autograd.grad(orf, [qr, rr], do.double())
+    t = TOL[dtype]
+    tag = f"{dtype} {H}x{W} h{nH} s{int(shift)} B{B}"
+    check(f"wattn fwd {tag}", o, orf, t["out"] * 1.5)
+    check(f"wattn dqkv {tag}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+    check(f"wattn drel_pos {tag}", drel, drr, 2e-5 if dtype == torch.float32 else 1e-2)

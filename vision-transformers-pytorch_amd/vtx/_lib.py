@@ -39,6 +39,13 @@ _SIGNATURES = {
     "vtx_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_wattn_tables_bytes": (c_size_t, [c_int, c_int]),
+    "vtx_wattn_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vtx_wattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_int, c_int, c_void_p]),
+    "vtx_wattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "vtx_wattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                              c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
     "vtx_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

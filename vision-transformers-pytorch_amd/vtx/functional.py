@@ -122,26 +122,41 @@ class AttentionMeta:
         self.swin, self.pos, self.mask, self.csr, self.ntab = swin, pos, mask, csr, ntab
 
 
+def _attn_forward(qkv, rel_pos, meta):
+    """-> (o, lse, aux) where aux is what the matching backward needs (bias tensor or fast-path tables)."""
+    B = qkv.shape[0]
+    if rel_pos is not None and meta.swin is not None and ops.wattn_supported(meta.dim_head, meta.swin[2]):
+        tables = ops.wattn_tables(rel_pos.detach(), meta.pos, meta.mask, meta.n_head)
+        o, lse = ops.wattn_fwd(qkv, tables, meta.mask is not None, B, meta.L, meta.n_head, meta.swin)
+        return o, lse, tables
+    bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
+    o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias, mask=meta.mask)
+    return o, lse, bias
+
+
+def _attn_backward(qkv, o, do, lse, aux, meta):
+    B = qkv.shape[0]
+    if aux is not None and aux.dtype == torch.uint8:        # fast-path tables
+        return ops.wattn_bwd(qkv, o, do, lse, aux, meta.mask is not None, B, meta.L, meta.n_head, meta.swin, meta.ntab)
+    return ops.attention_bwd(qkv, o, do, lse, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=aux,
+                             mask=meta.mask, csr=meta.csr, ntab=meta.ntab)
+
+
 class AttentionCoreFn(Function):
     """softmax(q k^T / sqrt(d) [+ rel-pos bias, -inf mask]) v on the QKV projection output."""
 
     @staticmethod
     def forward(ctx, qkv, rel_pos, meta):
         qkv = _c(qkv)
-        B = qkv.shape[0]
-        bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
-        o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias,
-                                   mask=meta.mask)
-        ctx.save_for_backward(qkv, o, lse, bias)
+        o, lse, aux = _attn_forward(qkv, rel_pos, meta)
+        ctx.save_for_backward(qkv, o, lse, aux)
         ctx.meta = meta
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse, bias = ctx.saved_tensors
-        m = ctx.meta
-        dqkv, drel = ops.attention_bwd(qkv, o, _c(do), lse, qkv.shape[0], m.L, m.n_head, m.dim_head, swin=m.swin,
-                                       bias=bias, mask=m.mask, csr=m.csr, ntab=m.ntab)
+        qkv, o, lse, aux = ctx.saved_tensors
+        dqkv, drel = _attn_backward(qkv, o, _c(do), lse, aux, ctx.meta)
         return dqkv, drel, None
 
 
@@ -160,9 +175,7 @@ class TransformerLayerFn(Function):
         rps = (x.numel() // C) // B
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), meta.eps)
         qkv = ops.gemm(ln1, cast(qkv_w, T), 0, bias=qkv_b.detach())
-        bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
-        o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias,
-                                   mask=meta.mask)
+        o, lse, bias = _attn_forward(qkv, rel_pos, meta)
         x1 = ops.gemm(o, cast(proj_w, T), 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), meta.eps)
         h, z = ops.gemm(ln2, cast(fc1_w, T), 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
@@ -189,8 +202,7 @@ class TransformerLayerFn(Function):
         # ---- attention branch
         dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps)
         do = ops.gemm(dx1, cast(proj_w, T), 1, rowscale=s1, rows_per_scale=rps)
-        dqkv, drel = ops.attention_bwd(qkv, o, do, lse, B, m.L, m.n_head, m.dim_head, swin=m.swin, bias=bias,
-                                       mask=m.mask, csr=m.csr, ntab=m.ntab)
+        dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m)
         dWq, dbq = ops.wgrad(dqkv, ln1)
         dln1 = ops.gemm(dqkv, cast(qkv_w, T), 1)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
