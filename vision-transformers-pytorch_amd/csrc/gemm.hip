@@ -19,24 +19,7 @@
 // vector per lane.  (SiLU as an operand PROLOGUE was measured 2.7x slower on fc2: the transcendental work
 // is repeated per N-tile and serialises with the staging; writing h once from fc1's epilogue is cheaper.)
 // Workgroup ids are remapped so that tiles sharing an operand panel run on the same XCD (private L2).
-#include "vtx_common.h"
-
-struct GemmArgs {
-  const void* A; const void* B; void* C;
-  int M, N, K;
-  int64_t lda, ldb, ldc;
-  const float* bias;        // [N] fp32 or null
-  const void* resid;        // T [M, ldc] or null: C = resid + rowscale * (acc + bias)
-  const float* rowscale;    // per-sample DropPath scale on OUTPUT rows (index row / rows_per_scale) or null
-  int rows_per_scale;
-  void* aux_out;            // T [M, ldc] or null: pre-activation z when act == 1
-  const void* aux_in;       // T [M, ldc]: z when act == 2
-  int act;                  // 0 none | 1 aux_out = z = acc + bias, C = silu(z) | 2 C = acc * silu'(aux_in)
-  const float* kscale;      // per-sample scale along the CONTRACTION index of a transposed A (wgrad through DropPath)
-  int k_per_scale;
-  int kchunk;               // contraction length per grid.z slice (multiple of the LDS k-tile)
-  float* ksum_out;          // TA only: [grid.z][M] fp32 = sum over the contraction of opA (bias gradient), or null
-};
+#include "gemm_common.h"
 
 template <typename T> struct GemmGeom {
   static constexpr int BK = 128 / (int)sizeof(T);      // elements per LDS k-tile row
@@ -209,68 +192,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   if (do_ksum && m0 + (int)threadIdx.x < p.M) p.ksum_out[(int64_t)tz * p.M + m0 + threadIdx.x] = ksum;
 
-  // ---------------- epilogue through LDS: two passes of BM/2 rows; acc[i][j][r] = C[.. + 4*g_ + r][.. + c_]
-  TO* Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
-  const T* resid = (const T*)p.resid;
-  const T* aux_in = (const T*)p.aux_in;
-  T* aux_out = (T*)p.aux_out;
-  float* cbuf = reinterpret_cast<float*>(lds_raw);
-  constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
-  constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int ii = 0; ii < WM / 2; ++ii) {
-      const int i = pass * (WM / 2) + ii;
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r];
-    }
-    __syncthreads();
-    for (int v = threadIdx.x; v < NVEC; v += 256) {
-      const int lr = v / VROW, cv = v - lr * VROW;
-      const int w2 = lr / (BM / 4), rem = lr - w2 * (BM / 4);
-      const int row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
-      const int col = n0 + cv * 8;
-      if (row >= p.M || col >= p.N) continue;
-      const float* cp = cbuf + lr * CSTR + cv * 8;
-      f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
-      float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const int64_t off = (int64_t)row * p.ldc + col;
-      if (p.bias) {
-        f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { val[e] += b0[e]; val[4 + e] += b1[e]; }
-      }
-      if (p.act == 1) {
-        Vec8<T> z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { z.set(e, val[e]); val[e] = silu_f(z.get(e)); }   // silu of the ROUNDED z
-        if (aux_out) store8<T>(aux_out + off, z);
-      } else if (p.act == 2) {
-        Vec8<T> z = load8<T>(aux_in + off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(z.get(e));
-      }
-      if (p.rowscale) {
-        const float rsc = p.rowscale[row / p.rows_per_scale];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] *= rsc;
-      }
-      if (resid) {
-        Vec8<T> rv = load8<T>(resid + off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] += rv.get(e);
-      }
-      Vec8<TO> o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o.set(e, val[e]);
-      store8<TO>(Cout + off, o);
-    }
-    if (pass == 0) __syncthreads();
-  }
+  gemm_epilogue<T, TO, BM, BN>(p, acc, lds_raw, m0, n0, tz, wm, wn, c_, g_);
 }
 
 template <typename T, typename TO, int BN, bool TA, bool TB>
@@ -317,6 +239,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   int rc = gemm_validate(a, mode);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16 && mode == 0 && (K % 64) == 0 && gemm_glds_enabled()) return gemm_glds_launch(a, st);
   if (dtype == VTX_BF16)
     return mode == 0 ? gemm_pick_bn<bf16, bf16, false, false>(a, 1, st) : gemm_pick_bn<bf16, bf16, false, true>(a, 1, st);
   if (dtype == VTX_F32)

@@ -48,6 +48,26 @@ def cast(p, dtype):
     return t
 
 
+def cast_t(p, dtype):
+    """Transposed ([in, out]) copy of a Linear weight in the compute dtype, cached like ``cast``."""
+    key = (id(p), "t")
+    ent = _cast_cache.get(key)
+    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2].dtype == dtype \
+            and ent[2].device == p.device:
+        return ent[2]
+    t = p.detach().t().contiguous().to(dtype)
+    _cast_cache[key] = (weakref.ref(p), p._version, t)
+    return t
+
+
+def dgrad(dy, w, T, **epi):
+    """dx = epi(dy @ W).  bf16 with out-features % 64 == 0: the LDS-DMA forward-layout kernel on a transposed
+    weight copy (made once per step); otherwise the register-staged NN kernel on W itself."""
+    if T == torch.bfloat16 and w.shape[0] % 64 == 0:
+        return ops.gemm(dy, cast_t(w, T), 0, **epi)
+    return ops.gemm(dy, cast(w, T), 1, **epi)
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -85,7 +105,7 @@ class LinearFn(Function):
         dy = _c(dy)
         w = cast(weight, x.dtype)
         dW, db = ops.wgrad(dy, x, want_bias=ctx.has_bias)
-        dx = ops.gemm(dy, w, 1) if ctx.needs_input_grad[0] else None
+        dx = dgrad(dy, weight, x.dtype) if ctx.needs_input_grad[0] else None
         return dx, dW.view_as(weight), db
 
 
@@ -108,9 +128,9 @@ class FeedForwardFn(Function):
         T = x.dtype
         dy = _c(dy)
         dW2, db2 = ops.wgrad(dy, h)
-        dz = ops.gemm(dy, cast(w2, T), 1, act=ACT_DSILU, aux_in=z)
+        dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z)
         dW1, db1 = ops.wgrad(dz, x)
-        dx = ops.gemm(dz, cast(w1, T), 1)
+        dx = dgrad(dz, w1, T)
         return dx, dW1, db1, dW2, db2
 
 
@@ -195,16 +215,16 @@ class TransformerLayerFn(Function):
         B = x.shape[0]
         # ---- MLP branch
         dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps)
-        dz = ops.gemm(dy, cast(fc2_w, T), 1, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
+        dz = dgrad(dy, fc2_w, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
         dW1, db1 = ops.wgrad(dz, ln2)
-        dln2 = ops.gemm(dz, cast(fc1_w, T), 1)
+        dln2 = dgrad(dz, fc1_w, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
         dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps)
-        do = ops.gemm(dx1, cast(proj_w, T), 1, rowscale=s1, rows_per_scale=rps)
+        do = dgrad(dx1, proj_w, T, rowscale=s1, rows_per_scale=rps)
         dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m)
         dWq, dbq = ops.wgrad(dqkv, ln1)
-        dln1 = ops.gemm(dqkv, cast(qkv_w, T), 1)
+        dln1 = dgrad(dqkv, qkv_w, T)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None)
 
@@ -227,7 +247,7 @@ class PatchMergeFn(Function):
         x, ln_w, w, ln, mean, rstd = ctx.saved_tensors
         dy = _c(dy)
         dW, _ = ops.wgrad(dy, ln, want_bias=False)
-        dln = ops.gemm(dy, cast(w, x.dtype), 1)
+        dln = dgrad(dy, w, x.dtype)
         dx, dg, db = ops.layernorm_bwd(dln, x, mean, rstd, ln_w.detach(), merge_hw=(x.shape[1], x.shape[2]))
         return dx, dg, db, dW, None
 
