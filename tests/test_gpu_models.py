@@ -238,3 +238,40 @@ def test_state_dict_round_trip_and_cpu_refusal():
     m.load_state_dict(sd)          # strict: keys / shapes identical to the reference layout
     with pytest.raises(VtxError):
         m(torch.zeros(1, 3, 224, 224))   # CPU tensors: the product path refuses, it never falls back
+
+
+def test_grad_allreduce_on_rccl_single_rank():
+    """The DDP machinery (buckets, post-accumulate hooks, foreach copy, async all_reduce(AVG) on the RCCL
+    process group's side stream, finish()) on a real GPU with a 1-rank nccl group: gradients must equal the
+    plain backward bit for bit (AVG over one rank), and a second step must re-arm correctly."""
+    import os
+    import torch.distributed as dist
+    from models import SwinTransformer
+    from vtx.ddp import GradAllReduce
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    try:
+        cfg = dict(M.SWIN_S, depths=(1, 1, 2, 1))
+        torch.manual_seed(0)
+        model = SwinTransformer(**cfg).to(dev()).train()
+        for m in model.modules():
+            if hasattr(m, "rel_pos"):
+                torch.nn.init.normal_(m.rel_pos.weight, std=0.02)
+        x = torch.randn(4, 3, 224, 224, device=dev())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model(x).float().square().sum().backward()
+        ref = [p.grad.clone() for p in model.parameters()]
+        model.zero_grad(set_to_none=True)
+        ddp = GradAllReduce(model, bucket_bytes=8 << 20, first_bucket_bytes=1 << 20, force=True)
+        assert ddp.active and len(ddp.buckets) >= 3
+        for _ in range(2):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                model(x).float().square().sum().backward()
+            ddp.finish()
+            for p, r in zip(model.parameters(), ref):
+                assert torch.equal(p.grad, r)
+            model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()

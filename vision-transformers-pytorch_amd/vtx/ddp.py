@@ -53,7 +53,9 @@ def assign_buckets(named_params, bucket_bytes, first_bucket_bytes):
 
 class GradAllReduce:
     def __init__(self, module, process_group=None, bucket_bytes=48 * MIB, first_bucket_bytes=8 * MIB,
-                 broadcast=True):
+                 broadcast=True, force=False):
+        """``force=True`` keeps the bucket / hook / collective machinery active even for a 1-rank group
+        (used to exercise the RCCL path on a single GPU); by default world size 1 bypasses everything."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -61,7 +63,8 @@ class GradAllReduce:
         self.parameters = [p for _, p in named]
         self.buckets = []
         self._handles = []
-        if self.world == 1:
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        if not self.active:
             return
         for _, p in named:
             if p.dtype != torch.float32:
@@ -109,7 +112,7 @@ class GradAllReduce:
 
     def finish(self):
         """Wait (stream-wise) for every bucket, install the averaged gradients, re-arm for the next backward."""
-        if self.world == 1:
+        if not self.active:
             return
         missing = [n for b in self.buckets if b.pending != 0 for n, p in zip(b.names, b.params) if p.grad is None]
         if any(b.pending != 0 for b in self.buckets):
