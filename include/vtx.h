@@ -69,11 +69,13 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
              int rows_per_scale, void* aux_out, const void* aux_in, int act, void* stream);
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
 /* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
- * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.
+ * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that
+ * every rowscale value is either 0 or scale_const (DropPath: mask / (1 - p)), which lets the LDS-DMA kernel
+ * skip dropped samples' rows instead of scaling; pass 0 for arbitrary scales.
  * Deterministic (split-K slabs + fixed-order reduce). */
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
-              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace,
-              size_t ws_bytes, void* stream);
+              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
+              void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order
  * [q|k|v][head][d] (models/vit.py:30-34, models/swin_transformer.py:128); o is [rows, nH*D].

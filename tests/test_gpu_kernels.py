@@ -235,3 +235,20 @@ def test_window_attention_fast_path(dtype, B, H, W, nH, shift):
     check(f"wattn fwd {tag}", o, orf, t["out"] * 1.5)
     check(f"wattn dqkv {tag}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"wattn drel_pos {tag}", drel, drr, 2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_droppath_zero_rows(dtype):
+    """DropPath through the weight gradient with scale_const: dropped samples' rows are skipped, c applied once
+    (LDS-DMA kernel for bf16 at these shapes, register-staged kernel for fp32)."""
+    from vtx import ops
+    d = dev()
+    B, T, N, K = 6, 196, 384, 1536
+    dy = _mk((B * T, N), 45, dtype)
+    x = _mk((B * T, K), 46, dtype)
+    c = 1.0 / (1.0 - 0.2)
+    scale = torch.tensor([c, 0.0, c, c, 0.0, c])
+    dW, db = ops.wgrad(dy.to(d), x.to(d), rowscale=scale.to(d), rows_per_scale=T, scale_const=c)
+    keep = (scale > 0).double().repeat_interleave(T)[:, None]
+    check(f"wgrad zero-row dW {dtype}", dW, c * (keep * dy.double()).t() @ x.double(), 2e-5)
+    check(f"wgrad zero-row db {dtype}", db, c * (keep * dy.double()).sum(0), 2e-5)

@@ -265,8 +265,8 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
 
 // dW[N,Kin] = sum_m s[m] * dy[m,N]^T x[m,Kin]  (fp32 out);  dbias[N] = sum_m s[m] * dy[m,:] (same kernel)
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
-              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, void* workspace,
-              size_t ws_bytes, void* stream) {
+              int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
+              void* workspace, size_t ws_bytes, void* stream) {
   if (!dy || !x || !dW || !workspace) return VTX_ERR_NULL;
   if (mtok <= 0 || mtok > 0x7fffffff) return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_wgrad_workspace(mtok, N, Kin)) return VTX_ERR_WORKSPACE;
@@ -285,7 +285,10 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   a.ksum_out = dbias ? (nz == 1 ? dbias : bias_part) : nullptr;
   int rc = gemm_validate(a, 2);
   if (rc) return rc;
-  if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
+  if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const))
+    rc = wgrad_glds_launch(dy, x, (float*)a.C, a.ksum_out, mtok, N, Kin, ld_dy, ld_x, rowscale, a.k_per_scale,
+                           scale_const, nz, a.kchunk, st);
+  else if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
   else if (dtype == VTX_F32) rc = gemm_pick_bn<float, float, true, true>(a, nz, st);
   else return VTX_ERR_DTYPE;
   if (rc) return rc;

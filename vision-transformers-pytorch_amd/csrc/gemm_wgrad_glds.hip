@@ -1,0 +1,198 @@
+// LDS-DMA weight-gradient GEMM for gfx950 (bf16): dW[N,Kin] = c * sum_m keep[m] dy[m,N]^T x[m,Kin], fp32 out.
+//
+// Both operands of a weight gradient are contracted over their ROW index (tokens), i.e. both are
+// "transposed" for the MFMA.  The register-staged kernel (gemm.hip, TA = TB = true) transposes 4x8
+// micro-tiles in VGPRs and pays ds_write for it; here the token-major tiles go HBM -> LDS untouched with
+// global_load_lds_dwordx4 (coalesced 256-byte rows, double-buffered, one barrier per 64-token k-tile) and
+// the transpose happens in the LDS READ: ds_read_b64_tr_b16 hands each lane 4 consecutive tokens of one
+// column, which is exactly the k-slot layout mma16 wants (semantics probed on hardware, tools/probe/).
+//   * LDS image [64 tokens][128 cols] bf16, 256-byte rows, 16-byte chunk q of row r stored in slot
+//     q ^ (((r & 3) | ((r >> 3 & 1) << 2)) << 1): the 8 rows one tr-read cycle touches land on 8 different
+//     32-byte bank groups (conflict-free), applied on the SOURCE address because LDS-DMA writes lane-linear;
+//   * DropPath: the per-sample scale is {0, c}.  Dropped samples' dy rows are fetched from a zero row
+//     (their tokens contribute nothing), c is applied once to the accumulators;
+//   * bias gradient = column sums of the dy tile, accumulated from LDS with 16-byte reads by the blocks
+//     of the first Kin tile; split-K over tokens into fp32 slabs + fixed-order reduce (deterministic).
+#include "gemm_common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __attribute__((aligned(256))) unsigned int vtx_zero_row[128];   // 512 zero bytes
+
+struct WgradArgs {
+  const bf16* dy; const bf16* x; float* C; float* ksum_out;
+  int M;            // tokens
+  int N, Kin;       // dW is [N][Kin]
+  int64_t ld_dy, ld_x;
+  const float* rowscale; int rows_per_scale; float scale_const;   // rowscale[sample] in {0, scale_const} or null
+  int kchunk;       // tokens per grid.z slice (multiple of 64)
+};
+
+__device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
+
+// 8 k-slots (tokens tok0 + 8g + {0..7}) of column `col` of a swizzled [64][128] tile, for lane (c, g)
+__device__ __forceinline__ Vec8<bf16> wg_frag(const unsigned char* tile, int tok0, int col0, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int n = col0 + ((p & 3) << 2);                   // this lane's 4-column piece (cols n..n+3)
+  s16x4 v[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = tok0 + g * 8 + half * 4 + (p >> 2);    // row supplied by this lane
+    const unsigned char* a = tile + r * 256 + ((((n >> 3) ^ wg_swz(r))) << 4) + ((n & 7) << 1);
+    v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  }
+  // whole-vector bitcasts only: element-wise short -> bf16 bit_casts of the tr-read result were miscompiled
+  // (every element became element 0) by hipcc 7.2
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 w = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  Vec8<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, w);
+  return f;
+}
+
+__global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
+  constexpr int BT = 128, BKT = 64, ROWB = 256, OPB = BKT * ROWB;   // operand tile bytes (16 KB)
+  constexpr int STAGE = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];   // [2][A | B]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c_ = lane & 15, g_ = lane >> 4;
+
+  const int ntk = gridDim.x, ntn = gridDim.y;
+  const int nblk = ntk * ntn * gridDim.z;
+  const int did = (blockIdx.z * ntn + blockIdx.y) * ntk + blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int tk = lid % ntk;                 // Kin tile
+  const int tnn = (lid / ntk) % ntn;        // N (feature) tile
+  const int tz = lid / (ntk * ntn);
+  const int n0 = tnn * BT, k0 = tk * BT;
+  const int mbeg = tz * p.kchunk;
+  const int mend = min(p.M, mbeg + p.kchunk);
+  const int nkt = (mend - mbeg + BKT - 1) / BKT;
+
+  // DMA piece geometry: one instruction = 4 rows x 256 B; wave w owns rows 16w .. 16w+15 of each operand tile
+  const int prow = lane >> 4, pslot = lane & 15;
+  const bf16* zero = reinterpret_cast<const bf16*>(vtx_zero_row);
+
+  auto issue = [&](int kt, int buf) {
+    unsigned char* sa = wg_smem + buf * STAGE + wave * 16 * ROWB;
+    unsigned char* sb = sa + OPB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 16 + j * 4 + prow;
+      const int tok = mbeg + kt * BKT + r;
+      const int q = pslot ^ wg_swz(r);
+      bool live = tok < mend;
+      const bf16* srcb = live ? p.x + (int64_t)tok * p.ld_x + k0 + (q << 3) : zero + (q << 3);
+      if (live && p.rowscale != nullptr) live = p.rowscale[tok / p.rows_per_scale] != 0.f;
+      const bf16* srca = live ? p.dy + (int64_t)tok * p.ld_dy + n0 + (q << 3) : zero + (q << 3);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // bias gradient partials: thread (chunk = tid & 15, row group = tid >> 4) sums 8 columns over rows rg, rg+16, ...
+  const bool do_ksum = p.ksum_out != nullptr && tk == 0;
+  float ks8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) {
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    const unsigned char* la = wg_smem + buf * STAGE;
+    const unsigned char* lb = la + OPB;
+    if (do_ksum) {
+      const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = rg + rr * 16;
+        Vec8<bf16> t = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + ((ch ^ wg_swz(r)) << 4)));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ks8[e] += t.get(e);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Vec8<bf16> fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = wg_frag(la, ks * 32, wm * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = wg_frag(lb, ks * 32, wn * 64 + j * 16, lane);
+#ifdef WG_DEBUG
+      if (kt == 0 && ks == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0) {
+        float* dbg = p.C + 128 * 128;     // after the tile
+        for (int e = 0; e < 8; ++e) { dbg[lane * 8 + e] = fa[0].get(e); dbg[512 + lane * 8 + e] = fb[0].get(e); }
+        dbg[1024 + lane] = (float)reinterpret_cast<const bf16*>(la + lane * 256)[0];     // raw first element of LDS row `lane`
+      }
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const float sc = p.rowscale != nullptr ? p.scale_const : 1.f;
+  if (do_ksum) {
+    float* red = reinterpret_cast<float*>(wg_smem);         // [16 row groups][128 cols]
+    const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg * 128 + ch * 8 + e] = ks8[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[q * 128 + threadIdx.x];
+      p.ksum_out[(int64_t)tz * p.N + n0 + threadIdx.x] = s * sc;
+    }
+    __syncthreads();
+  }
+  if (sc != 1.f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
+  }
+  GemmArgs e;
+  e.C = p.C; e.M = p.N; e.N = p.Kin; e.ldc = p.Kin;
+  e.bias = nullptr; e.resid = nullptr; e.rowscale = nullptr; e.rows_per_scale = 1; e.aux_out = nullptr;
+  e.aux_in = nullptr; e.act = 0;
+  gemm_epilogue<bf16, float, 128, 128>(e, acc, wg_smem, n0, k0, tz, wm, wn, c_, g_);
+}
+
+bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const) {
+  static int on = -1;
+  if (on < 0) { const char* ev = getenv("VTX_WGRAD_GLDS"); on = ev ? atoi(ev) : 1; }
+  return on && dtype == VTX_BF16 && (N % 128) == 0 && (Kin % 128) == 0 && (rowscale == nullptr || scale_const > 0.f);
+}
+
+int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, int64_t mtok, int N, int Kin,
+                      int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
+                      int nz, int kchunk, hipStream_t st) {
+  WgradArgs a;
+  a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.C = C; a.ksum_out = ksum_out; a.M = (int)mtok; a.N = N; a.Kin = Kin;
+  a.ld_dy = ld_dy; a.ld_x = ld_x; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
+  a.scale_const = scale_const; a.kchunk = kchunk;
+  dim3 grid(Kin / 128, N / 128, nz);
+  hipLaunchKernelGGL(wgrad_glds_kernel, grid, dim3(256), 65536, st, a);
+  return vtx_check_launch();
+}

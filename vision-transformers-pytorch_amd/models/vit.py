@@ -84,7 +84,8 @@ class TransformerLayer(nn.Module):
         return VF.TransformerLayerFn.apply(
             input.to(T), self.norm_attn.weight, self.norm_attn.bias, a.qkv.weight, a.qkv.bias, None,
             a.linear.weight, a.linear.bias, self.norm_ff.weight, self.norm_ff.bias, f[0].weight, f[0].bias,
-            f[3].weight, f[3].bias, s1, s2, a.meta(input.shape[1], self.norm_attn.eps))
+            f[3].weight, f[3].bias, s1, s2,
+            (1.0 / (1.0 - self.drop_path.p)) if s1 is not None else 0.0, a.meta(input.shape[1], self.norm_attn.eps))
 
     def set_drop_path(self, p):
         self.drop_path.p = p

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvtx.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class VtxError(RuntimeError):
@@ -31,7 +31,7 @@ _SIGNATURES = {
                          c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vtx_wgrad_workspace": (c_size_t, [c_int64, c_int, c_int]),
     "vtx_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64,
-                          c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+                          c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "vtx_relpos_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vtx_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -188,7 +188,7 @@ class TransformerLayerFn(Function):
 
     @staticmethod
     def forward(ctx, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w,
-                fc2_b, s1, s2, meta):
+                fc2_b, s1, s2, dp_c, meta):
         x = _c(x)
         T = x.dtype
         B, C = x.shape[0], x.shape[-1]
@@ -202,31 +202,31 @@ class TransformerLayerFn(Function):
         y = ops.gemm(h, cast(fc2_w, T), 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
                               mean2, rstd2, ln2, z, h, bias, s1, s2)
-        ctx.meta, ctx.rps = meta, rps
+        ctx.meta, ctx.rps, ctx.dp_c = meta, rps, float(dp_c)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z, h,
          bias, s1, s2) = ctx.saved_tensors
-        m, rps = ctx.meta, ctx.rps
+        m, rps, dp_c = ctx.meta, ctx.rps, ctx.dp_c
         T = x.dtype
         dy = _c(dy)
         B = x.shape[0]
         # ---- MLP branch
-        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps)
+        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
         dz = dgrad(dy, fc2_w, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
         dW1, db1 = ops.wgrad(dz, ln2)
         dln2 = dgrad(dz, fc1_w, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
-        dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps)
+        dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
         do = dgrad(dx1, proj_w, T, rowscale=s1, rows_per_scale=rps)
         dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m)
         dWq, dbq = ops.wgrad(dqkv, ln1)
         dln1 = dgrad(dqkv, qkv_w, T)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
-        return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None)
+        return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
 
 class PatchMergeFn(Function):

@@ -169,8 +169,9 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     return (c, aux) if want_aux else c
 
 
-def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1):
-    """dW[N,Kin] (fp32), dbias[N] (fp32 or None) from dy[M,N], x[M,Kin]."""
+def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.0):
+    """dW[N,Kin] (fp32), dbias[N] (fp32 or None) from dy[M,N], x[M,Kin].  scale_const > 0: every rowscale value
+    is 0 or scale_const (DropPath), see vtx.h."""
     _dev(dy, x, rowscale)
     lib = _lib.load()
     N, Kin = dy.shape[-1], x.shape[-1]
@@ -182,7 +183,7 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1):
     wsb = lib.vtx_wgrad_workspace(M, N, Kin)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
-                        int(rows_per_scale), _p(ws), wsb, _stream()), "vtx_wgrad")
+                        int(rows_per_scale), float(scale_const), _p(ws), wsb, _stream()), "vtx_wgrad")
     return dW, db
 
 
