@@ -498,6 +498,12 @@ static int attn_bwd_launch(const void* qkv, const void* oin, const void* dout, c
     return VTX_ERR_SHAPE;                                                               \
   } while (0)
 
+// bf16 / head-dim-64 / 64 < L <= 224 global attention: LDS-DMA + transpose-read kernels (attention_seq.hip)
+bool sattn_ok(int dtype, int L, int D, int swin, const void* bias);
+int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st);
+int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int L, int nH,
+                     hipStream_t st);
+
 extern "C" {
 
 int vtx_relpos_bias(const float* rel_pos, const int64_t* pos, float* bias, int L, int nH, void* stream) {
@@ -516,6 +522,7 @@ int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, c
   if (rc) return rc;
   if (B <= 0) return VTX_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (sattn_ok(dtype, L, D, swin, bias)) return sattn_fwd_launch(qkv, o, lse, B, L, nH, st);
   ATTN_DISPATCH(attn_fwd_launch, qkv, o, lse, bias, mask, B, g, st);
 }
 
@@ -538,6 +545,7 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
   if (rc) return rc;
   if (B <= 0) return VTX_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (sattn_ok(dtype, L, D, swin, bias)) return sattn_bwd_launch(qkv, o, dout, lse, dqkv, B, L, nH, st);
   const int nblk = attn_bwd_blocks(B * g.nW, nH);
   float* part = (float*)workspace;
   if (bias) {

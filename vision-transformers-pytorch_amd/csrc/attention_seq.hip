@@ -1,0 +1,386 @@
+// Global (ViT) attention for gfx950, bf16, head dim 64, sequences of <= 224 tokens (ViT-S/16: L = 197).
+//
+// Replaces reference models/vit.py:30-42 per (image, head): S = q k^T / sqrt(d), softmax, O = P v, reading
+// q/k/v from the QKV projection output [tokens, 3*h*64] and writing [tokens, h*64]; scores stay in registers.
+// One workgroup (4 waves) per (image, head):
+//   * K and V of the head (L x 64 each) are brought into LDS ONCE with global_load_lds_dwordx4 as plain
+//     row-major images (128-byte rows, 16-byte chunk q of row r in slot q ^ (r & 7)); the same image serves
+//     the row-contiguous MFMA operands (ds_read_b128) and, through ds_read_b64_tr_b16, the operands that are
+//     contracted over tokens (V in P.V; K, Q, dO in the backward) -- no transposed copies, no ds_write;
+//   * each wave owns PAIRS of 16-query tiles so every K / V fragment read from LDS feeds two MFMAs;
+//   * swapped product S^T = K Q^T: a lane holds 4 keys of every key tile for one query, so softmax is
+//     lane-local + two shuffles and P is already the A operand of P.V;
+//   * backward: phase A (waves <-> query-tile pairs, K/V in LDS) gives dQ, phase B (waves <-> key-tile pairs,
+//     Q/dO re-staged into the same LDS) gives dK, dV; P is recomputed from the saved log-sum-exp and
+//     D = rowsum(dO o O).
+// fp32 (parity mode) and other head dims use the generic kernels in attention.hip.
+#include <stdlib.h>
+
+#include "vtx_common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+#define SA_D 64
+#define SA_ROWB 128
+
+__device__ __attribute__((aligned(256))) unsigned int sa_zero_row[64];   // 256 zero bytes
+
+struct SeqGeom { int L, nH, hd; float scale; };
+
+// DMA `rows` rows x 64 bf16 of one head (token rows base .. ) into a swizzled row-major LDS image
+template <int LP>
+__device__ __forceinline__ void sa_stage(unsigned char* lds, const bf16* src, int64_t ld, int L, int wave, int lane) {
+  const int lr = lane >> 3, slot = lane & 7;
+  const bf16* zero = reinterpret_cast<const bf16*>(sa_zero_row);
+  for (int pc = wave; pc < LP / 8; pc += 4) {
+    const int r = pc * 8 + lr;
+    const int q = slot ^ (r & 7);
+    const bf16* s = r < L ? src + (int64_t)r * ld + (q << 3) : zero + (q << 3);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)s, (lds_void_t*)(lds + pc * 8 * SA_ROWB), 16, 0, 0);
+  }
+}
+
+// row-contiguous fragment: 8 d-slots (32*ds + 8g ..) of token row r
+__device__ __forceinline__ Vec8<bf16> sa_frag_row(const unsigned char* img, int r, int ds, int g) {
+  return load8<bf16>(reinterpret_cast<const bf16*>(img + r * SA_ROWB + (((ds * 4 + g) ^ (r & 7)) << 4)));
+}
+// token-contracted fragment for lane (c, g): k-slots j < 4 <-> tokens t0 + 4g + j, j >= 4 <-> t0 + 16 + 4g + (j-4)
+// (the slot <-> token map of fragments built from accumulator pairs), column d = d0 + c
+__device__ __forceinline__ Vec8<bf16> sa_frag_tr(const unsigned char* img, int t0, int d0, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int n = d0 + ((p & 3) << 2);
+  s16x4 v[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = t0 + half * 16 + g * 4 + (p >> 2);
+    const unsigned char* a = img + r * SA_ROWB + ((((n >> 3) ^ (r & 7))) << 4) + ((n & 7) << 1);
+    v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  }
+  s16x8 w = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);   // whole-vector cast only (see gemm_wgrad_glds.hip)
+  Vec8<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, w);
+  return f;
+}
+__device__ __forceinline__ Vec8<bf16> sa_frag_acc(const f32x4& lo, const f32x4& hi) {
+  Vec8<bf16> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.set(j, lo[j]); f.set(4 + j, hi[j]); }
+  return f;
+}
+__device__ __forceinline__ Vec8<bf16> sa_gload(const bf16* p, bool valid) {
+  return valid ? load8<bf16>(p) : vec8_zero<bf16>();
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NKT>
+__global__ __launch_bounds__(256) void sattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                       float* __restrict__ lse, SeqGeom g) {
+  constexpr int LP = NKT * 16, IMG = LP * SA_ROWB, KSN = NKT / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
+  unsigned char* ks = sa_smem;            // K image
+  unsigned char* vs = sa_smem + IMG;      // V image
+  const int prob = blockIdx.x;
+  const int h = prob % g.nH, b = prob / g.nH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c_ = lane & 15, g_ = lane >> 4;
+  const int64_t ld = 3 * (int64_t)g.hd;
+  const bf16* base = qkv + (int64_t)b * g.L * ld + h * SA_D;
+
+  sa_stage<LP>(ks, base + g.hd, ld, g.L, wave, lane);
+  sa_stage<LP>(vs, base + 2 * g.hd, ld, g.L, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nqt = (g.L + 15) >> 4;
+  for (int qp = wave; qp * 2 < nqt; qp += 4) {
+    Vec8<bf16> qf[2][2];
+    bool qv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q = (qp * 2 + t) * 16 + c_;
+      qv[t] = q < g.L;
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) qf[t][ds] = sa_gload(base + (int64_t)(qv[t] ? q : 0) * ld + ds * 32 + g_ * 8, qv[t]);
+    }
+    f32x4 st[2][NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      st[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        Vec8<bf16> kf = sa_frag_row(ks, kt * 16 + c_, ds, g_);
+        mma16(kf, qf[0][ds], st[0][kt]);       // st[t][kt][r] = S[q = 16(2qp+t) + c][key = 16 kt + 4g + r]
+        mma16(kf, qf[1][ds], st[1][kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float inv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s = (kt * 16 + g_ * 4 + r) < g.L ? st[t][kt][r] * g.scale : -INFINITY;
+          st[t][kt][r] = s;
+          m = fmaxf(m, s);
+        }
+      m = fmaxf(m, shfl_xor_f(m, 16));
+      m = fmaxf(m, shfl_xor_f(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[t][kt][r] = __expf(st[t][kt][r] - m); l += st[t][kt][r]; }
+      l += shfl_xor_f(l, 16);
+      l += shfl_xor_f(l, 32);
+      inv[t] = 1.f / l;
+      const int q = (qp * 2 + t) * 16 + c_;
+      if (qv[t] && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
+    }
+    f32x4 oacc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k2 = 0; k2 < KSN; ++k2) {
+      Vec8<bf16> pf0 = sa_frag_acc(st[0][2 * k2] * inv[0], st[0][2 * k2 + 1] * inv[0]);
+      Vec8<bf16> pf1 = sa_frag_acc(st[1][2 * k2] * inv[1], st[1][2 * k2 + 1] * inv[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Vec8<bf16> vf = sa_frag_tr(vs, k2 * 32, dt * 16, lane);
+        mma16(pf0, vf, oacc[0][dt]);
+        mma16(pf1, vf, oacc[1][dt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the unrolled iterations apart (register pressure)
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qo = (qp * 2 + t) * 16 + g_ * 4 + r;
+        if (qo < g.L) {
+          bf16* op = o + ((int64_t)b * g.L + qo) * g.hd + h * SA_D + c_;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) op[dt * 16] = (bf16)oacc[t][dt][r];
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int NKT>
+__global__ __launch_bounds__(256) void sattn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ oin,
+                                                       const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                       bf16* __restrict__ dqkv, SeqGeom g) {
+  constexpr int LP = NKT * 16, IMG = LP * SA_ROWB, KSN = NKT / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
+  unsigned char* im0 = sa_smem;           // K (phase A) then Q (phase B)
+  unsigned char* im1 = sa_smem + IMG;     // V (phase A) then dO (phase B)
+  float* dq_s = reinterpret_cast<float*>(sa_smem + 2 * IMG);   // D[q]
+  float* lse_s = dq_s + LP;
+  const int prob = blockIdx.x;
+  const int h = prob % g.nH, b = prob / g.nH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c_ = lane & 15, g_ = lane >> 4;
+  const int64_t ld = 3 * (int64_t)g.hd;
+  const bf16* qb = qkv + (int64_t)b * g.L * ld + h * SA_D;
+  const bf16* ob = oin + (int64_t)b * g.L * g.hd + h * SA_D;
+  const bf16* dob = dout + (int64_t)b * g.L * g.hd + h * SA_D;
+  bf16* dqb = dqkv + (int64_t)b * g.L * ld + h * SA_D;
+  const int nt = (g.L + 15) >> 4;
+
+  sa_stage<LP>(im0, qb + g.hd, ld, g.L, wave, lane);
+  sa_stage<LP>(im1, qb + 2 * g.hd, ld, g.L, wave, lane);
+  for (int i = threadIdx.x; i < LP; i += 256) lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------- phase A: wave <-> pairs of query tiles; dQ = scale * dS K
+  for (int qp = wave; qp * 2 < nt; qp += 4) {
+    Vec8<bf16> qf[2][2], dof[2][2];
+    bool qv[2];
+    float dsum[2], lq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q = (qp * 2 + t) * 16 + c_;
+      qv[t] = q < g.L;
+      const int qq = qv[t] ? q : 0;
+      float s = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        qf[t][ds] = sa_gload(qb + (int64_t)qq * ld + ds * 32 + g_ * 8, qv[t]);
+        dof[t][ds] = sa_gload(dob + (int64_t)qq * g.hd + ds * 32 + g_ * 8, qv[t]);
+        Vec8<bf16> of = sa_gload(ob + (int64_t)qq * g.hd + ds * 32 + g_ * 8, qv[t]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += of.get(e) * dof[t][ds].get(e);
+      }
+      s += shfl_xor_f(s, 16);
+      s += shfl_xor_f(s, 32);
+      dsum[t] = s;
+      lq[t] = lse_s[qq];
+      if (g_ == 0) dq_s[q] = qv[t] ? s : 0.f;       // q < LP always
+    }
+    f32x4 dqacc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dqacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int k2 = 0; k2 < KSN; ++k2) {
+      f32x4 dsv[2][2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kt = 2 * k2 + half;
+        f32x4 pt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 dpt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          Vec8<bf16> kf = sa_frag_row(im0, kt * 16 + c_, ds, g_);
+          Vec8<bf16> vf = sa_frag_row(im1, kt * 16 + c_, ds, g_);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) { mma16(kf, qf[t][ds], pt[t]); mma16(vf, dof[t][ds], dpt[t]); }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = qv[t] && (kt * 16 + g_ * 4 + r) < g.L;
+            const float p = ok ? __expf(pt[t][r] * g.scale - lq[t]) : 0.f;
+            dsv[t][half][r] = p * (dpt[t][r] - dsum[t]);
+          }
+      }
+      Vec8<bf16> dsf0 = sa_frag_acc(dsv[0][0], dsv[0][1]);
+      Vec8<bf16> dsf1 = sa_frag_acc(dsv[1][0], dsv[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Vec8<bf16> kf = sa_frag_tr(im0, k2 * 32, dt * 16, lane);
+        mma16(dsf0, kf, dqacc[0][dt]);
+        mma16(dsf1, kf, dqacc[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qo = (qp * 2 + t) * 16 + g_ * 4 + r;
+        if (qo < g.L) {
+          bf16* p = dqb + (int64_t)qo * ld + c_;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) p[dt * 16] = (bf16)(dqacc[t][dt][r] * g.scale);
+        }
+      }
+  }
+  __syncthreads();                                   // K / V images are dead; dq_s complete
+  sa_stage<LP>(im0, qb, ld, g.L, wave, lane);                       // Q
+  sa_stage<LP>(im1, dob, (int64_t)g.hd, g.L, wave, lane);           // dO
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------- phase B: wave <-> pairs of key tiles; dV = P^T dO, dK = scale * dS^T Q
+  for (int kp = wave; kp * 2 < nt; kp += 4) {
+    Vec8<bf16> kf[2][2], vf[2][2];
+    bool kv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = (kp * 2 + t) * 16 + c_;
+      kv[t] = key < g.L;
+      const int kk = kv[t] ? key : 0;
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        kf[t][ds] = sa_gload(qb + g.hd + (int64_t)kk * ld + ds * 32 + g_ * 8, kv[t]);
+        vf[t][ds] = sa_gload(qb + 2 * g.hd + (int64_t)kk * ld + ds * 32 + g_ * 8, kv[t]);
+      }
+    }
+    f32x4 dkacc[2][4], dvacc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dkacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+    for (int q2 = 0; q2 < KSN; ++q2) {
+      f32x4 pp[2][2], dss[2][2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * q2 + half;
+        f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          Vec8<bf16> qf = sa_frag_row(im0, qt * 16 + c_, ds, g_);
+          Vec8<bf16> dof = sa_frag_row(im1, qt * 16 + c_, ds, g_);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) { mma16(qf, kf[t][ds], s[t]); mma16(dof, vf[t][ds], dp[t]); }
+        }
+        const int q0 = qt * 16 + g_ * 4;                     // rows of these accumulators: q0 + r
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + q0);
+        const f32x4 dd = *reinterpret_cast<const f32x4*>(dq_s + q0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kv[t] && (q0 + r) < g.L;
+            const float p = ok ? __expf(s[t][r] * g.scale - ls[r]) : 0.f;
+            pp[t][half][r] = p;
+            dss[t][half][r] = p * (dp[t][r] - dd[r]);
+          }
+      }
+      Vec8<bf16> pf0 = sa_frag_acc(pp[0][0], pp[0][1]), pf1 = sa_frag_acc(pp[1][0], pp[1][1]);
+      Vec8<bf16> sf0 = sa_frag_acc(dss[0][0], dss[0][1]), sf1 = sa_frag_acc(dss[1][0], dss[1][1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Vec8<bf16> dotf = sa_frag_tr(im1, q2 * 32, dt * 16, lane);
+        Vec8<bf16> qtf = sa_frag_tr(im0, q2 * 32, dt * 16, lane);
+        mma16(pf0, dotf, dvacc[0][dt]);
+        mma16(pf1, dotf, dvacc[1][dt]);
+        mma16(sf0, qtf, dkacc[0][dt]);
+        mma16(sf1, qtf, dkacc[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ko = (kp * 2 + t) * 16 + g_ * 4 + r;
+        if (ko < g.L) {
+          bf16* p = dqb + (int64_t)ko * ld + c_;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            p[g.hd + dt * 16] = (bf16)(dkacc[t][dt][r] * g.scale);
+            p[2 * g.hd + dt * 16] = (bf16)dvacc[t][dt][r];
+          }
+        }
+      }
+  }
+}
+
+bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("VTX_SATTN"); on = e ? atoi(e) : 1; }
+  return on && dtype == VTX_BF16 && D == 64 && !swin && bias == nullptr && L > 64 && L <= 224;
+}
+
+int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st) {
+  SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D);
+  constexpr size_t smem = (size_t)2 * 224 * SA_ROWB;
+  hipLaunchKernelGGL((sattn_fwd_kernel<14>), dim3(B * nH), dim3(256), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
+  return vtx_check_launch();
+}
+
+int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int L, int nH,
+                     hipStream_t st) {
+  SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D);
+  constexpr size_t smem = (size_t)2 * 224 * SA_ROWB + 2 * 224 * sizeof(float);
+  hipLaunchKernelGGL((sattn_bwd_kernel<14>), dim3(B * nH), dim3(256), smem, st, (const bf16*)qkv, (const bf16*)o,
+                     (const bf16*)dout, lse, (bf16*)dqkv, g);
+  return vtx_check_launch();
+}
