@@ -65,7 +65,11 @@ def main():
                 kw = {}
                 if name == "fc2":
                     kw = dict(act=ops.ACT_DSILU, aux_in=x)      # x plays z [M, 4C]... shape [M,K]
-                t = timeit(lambda: ops.gemm(dy, w, 1, **kw), a.iters)
+                wt = w.t().contiguous()                       # the product path uses a transposed bf16 copy (functional.dgrad)
+                if N % 64 == 0:
+                    t = timeit(lambda: ops.gemm(dy, wt, 0, **kw), a.iters)
+                else:
+                    t = timeit(lambda: ops.gemm(dy, w, 1, **kw), a.iters)
                 byt = 2 * (M * N + N * K + M * K * (2 if kw else 1))
                 rows.append(("dgrad", t, byt))
             if "wgrad" in what:

@@ -18,13 +18,25 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-template <int BN>
+// swizzle of the 16-byte chunk index of LDS row r (applied on the DMA source and on the fragment read)
+template <int BK> __device__ __forceinline__ int glds_swz(int r) {
+  if constexpr (BK == 64) return r & 7;                       // 8 chunks per 128-byte row
+  else return (0x1230 >> (((r >> 2) & 3) << 2)) & 3;          // 4 chunks per 64-byte row: {0,3,2,1}[(r>>2)&3]
+}
+
+// NS-stage LDS ring: the DMA of k-tile kt+NS-1 is issued while tile kt is multiplied; a counted
+// s_waitcnt vmcnt(N) + raw s_barrier (never __syncthreads, which would drain the DMA queue) lets NS-2
+// tiles stay in flight across the barrier.
+template <int BM, int BN, int BK, int NS>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
-  constexpr int BM = 128, BK = 64, ROWB = 128;          // 64 bf16 per LDS row
+  constexpr int ROWB = BK * 2;                           // bytes per LDS row
+  constexpr int CPR = BK / 8;                            // 16-byte chunks per row
+  constexpr int PR = 1024 / ROWB;                        // rows per DMA instruction (1 KB per wave-instruction)
+  constexpr int KS = BK / 32;                            // mma16 k-steps per tile
   constexpr int WM = BM / 32, WN = BN / 32;
-  constexpr int STAGE = (BM + BN) * ROWB;               // bytes per pipeline stage
-  static_assert(2 * STAGE >= (BM / 2) * (BN + 4) * 4, "C staging must fit");
-  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];   // [2][STAGE]
+  constexpr int STAGE = (BM + BN) * ROWB;                // bytes per pipeline stage
+  static_assert(NS * STAGE >= (BM / 2) * (BN + 4) * 4, "C staging must fit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];   // [NS][STAGE]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -43,22 +55,23 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
-  // per-lane source pointers of this wave's DMA pieces (8 rows x 128 B per instruction)
-  const int lr = lane >> 3, slot = lane & 7;
-  constexpr int APW = BM / 32, BPW = BN / 32;            // pieces per wave for A / B
+  // per-lane source pointers of this wave's DMA pieces (PR rows x ROWB bytes per instruction)
+  const int lr = lane / CPR, slot = lane % CPR;
+  constexpr int APW = BM / (4 * PR), BPW = BN / (4 * PR);     // pieces per wave for A / B
+  constexpr int LPT = APW + BPW;                               // DMA instructions per wave per k-tile
   const bf16* asrc[APW];
   const bf16* bsrc[BPW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
-    const int r = wave * (BM / 4) + j * 8 + lr;
+    const int r = wave * (BM / 4) + j * PR + lr;
     const int row = min(m0 + r, p.M - 1);                // rows past M are never stored: any valid address will do
-    asrc[j] = A + (int64_t)row * p.lda + ((slot ^ (r & 7)) << 3);
+    asrc[j] = A + (int64_t)row * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
-    const int r = wave * (BN / 4) + j * 8 + lr;
+    const int r = wave * (BN / 4) + j * PR + lr;
     const int row = min(n0 + r, p.N - 1);
-    bsrc[j] = B + (int64_t)row * p.ldb + ((slot ^ (r & 7)) << 3);
+    bsrc[j] = B + (int64_t)row * p.ldb + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 
   auto issue = [&](int kt, int buf) {
@@ -66,10 +79,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
     unsigned char* sb = glds_smem + buf * STAGE + BM * ROWB + wave * (BN / 4) * ROWB;
 #pragma unroll
     for (int j = 0; j < APW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + kt * BK), (lds_void_t*)(sa + j * 8 * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + kt * BK), (lds_void_t*)(sa + j * PR * ROWB), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < BPW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + kt * BK), (lds_void_t*)(sb + j * 8 * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + kt * BK), (lds_void_t*)(sb + j * PR * ROWB), 16, 0, 0);
   };
 
   f32x4 acc[WM][WN];
@@ -78,45 +91,82 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s2 = 0; s2 < NS - 1; ++s2)
+    if (s2 < nk) issue(s2, s2);
+  if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
+  int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);             // everyone left the barrier after finishing tile kt-1
+    const bool refill = kt + NS - 1 < nk;
+    if (refill) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);   // == (kt + NS - 1) % NS: freed by the last barrier
     const unsigned char* la = glds_smem + buf * STAGE;
     const unsigned char* lb = la + BM * ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       Vec8<bf16> fa[WM], fb[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int r = wm * (BM / 2) + i * 16 + c_;
-        fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
+        fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ glds_swz<BK>(r)) << 4)));
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int r = wn * (BN / 2) + j * 16 + c_;
-        fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
+        fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ glds_swz<BK>(r)) << 4)));
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) mma16(fa[i], fb[j], acc[i][j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt+1 has landed (this wave's pieces)
-    __syncthreads();                                       // ... and everybody's; tile kt's buffer is free
+    // tile kt+1 must have landed; up to NS-2 younger tiles may stay in flight (vmcnt retires in order)
+    if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
   gemm_epilogue<bf16, bf16, BM, BN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_);
 }
 
-template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {
-  constexpr size_t smem = (size_t)2 * (128 + BN) * 128;
-  dim3 grid((a.N + BN - 1) / BN, (a.M + 127) / 128, 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<BN>), grid, dim3(256), smem, st, a);
+template <int BM, int BN, int BK, int NS> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {
+  constexpr size_t smem = (size_t)NS * (BM + BN) * BK * 2;
+  auto kern = gemm_glds_kernel<BM, BN, BK, NS>;
+  if (smem > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return VTX_ERR_LAUNCH;
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
   return vtx_check_launch();
+}
+
+// Pipeline configuration measured on MI355X (tools/bench_gemm.py, stage 3/4 forward shapes, per-step total):
+// (BK 64, 2 stages) 3.93 ms | (64, 3) 5.23 ms | (32, 3) 3.90 ms | (32, 4) 4.30 ms -- deeper rings cost
+// occupancy (LDS) and do not pay: these GEMMs (K = 384..3072) are bound by their epilogue's HBM writes and by
+// per-block prologue/epilogue, not by DMA latency.  The shipped configuration is (64, 2).
+template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_t st) {
+  return glds_launch_cfg<BM, BN, 64, 2>(a, st);
+}
+
+// Tile height: 128 rows by default; 64-row tiles when the 128-row grid would leave the 512 resident block
+// slots (256 CUs x 2) badly quantised (few "waves" of blocks with a mostly empty last one).
+static int glds_pick_bm(const GemmArgs& a, int bn) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("VTX_GLDS_BM"); force = e ? atoi(e) : 0; }
+  if (force == 64 || force == 128) return force;
+  const long tn = (a.N + bn - 1) / bn;
+  const long b128 = tn * ((a.M + 127) / 128);
+  const double waves = (double)b128 / 512.0;
+  const double eff128 = waves / (double)(long)(waves + 0.999999);
+  return (b128 < 512 || eff128 < 0.7) ? 64 : 128;
+}
+
+template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {
+  return glds_pick_bm(a, BN) == 64 ? glds_launch_t<64, BN>(a, st) : glds_launch_t<128, BN>(a, st);
 }
 
 bool gemm_glds_enabled() {

@@ -126,13 +126,17 @@ def set_kernel_timer(timer):
     _timer = timer
 
 
-def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0):
+def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
     """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip)."""
     t = "__bf16" if dtype == torch.bfloat16 else "float"
     to = "float" if out_f32 else t
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and K % 64 == 0 and K > 0:
-        return f"gemm_glds_kernel<{bn}>"
+        b128 = ((N + bn - 1) // bn) * ((M + 127) // 128)          # mirrors glds_pick_bm in gemm_glds.hip
+        waves = b128 / 512.0
+        eff = waves / max(1, int(waves + 0.999999))
+        bm = 64 if (b128 < 512 or eff < 0.7) else 128
+        return f"gemm_glds_kernel<{bm}, {bn}, 64, 2>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
     return f"gemm_kernel<{t}, {to}, 128, {bn}, {ta}, {tb}>"
 
@@ -159,7 +163,7 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
         raise VtxError(f"vtx: gemm contraction mismatch ({K} vs {kw})")
     c = out if out is not None else torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
     aux = torch.empty_like(c) if want_aux else None
-    ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K), 2.0 * M * N * K) if _timer is not None else None
+    ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M), 2.0 * M * N * K) if _timer is not None else None
     if ev:
         ev[0].record()
     check(lib.vtx_gemm(mode, _dt(a), _p(a), _p(w), _p(c), M, N, K, K, w.shape[1], N, _p(bias), _p(resid),
