@@ -45,43 +45,60 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
   }
   const float invC = 1.f / (float)C;
-  for (int64_t row = (int64_t)blockIdx.x * GPB + grp; row < rows; row += (int64_t)gridDim.x * GPB) {
-    float xv[NV][8];
-    float s = 0.f;
+  // ROWS rows per group per iteration: their loads are issued back to back before any reduction starts, so
+  // each lane keeps ROWS x NV 16-byte loads in flight (memory-level parallelism for an HBM-bound kernel)
+  constexpr int ROWS = NV == 1 ? 4 : (NV == 2 ? 2 : 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t row0 = (int64_t)blockIdx.x * GPB + grp; row0 < rows; row0 += stride * ROWS) {
+    float xv[ROWS][NV][8];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = lig + k * G;
-      if (v < nvec) {
-        Vec8<T> t = load8<T>(x + ln_src_offset(addr, row, v * 8, C));
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int64_t row = row0 + rr * stride;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { xv[k][e] = t.get(e); s += xv[k][e]; }
-      } else {
+      for (int k = 0; k < NV; ++k) {
+        const int v = lig + k * G;
+        if (v < nvec && row < rows) {
+          Vec8<T> t = load8<T>(x + ln_src_offset(addr, row, v * 8, C));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xv[k][e] = 0.f;
+          for (int e = 0; e < 8; ++e) xv[rr][k][e] = t.get(e);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[rr][k][e] = 0.f;
+        }
       }
     }
-    const float mu = group_sum<G>(s) * invC;
-    float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = lig + k * G;
-      if (v < nvec) {
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int64_t row = row0 + rr * stride;
+      if (row >= rows) break;                       // uniform within the group
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = xv[k][e] - mu; q += d * d; }
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xv[rr][k][e];
+      const float mu = group_sum<G>(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = lig + k * G;
+        if (v < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = xv[rr][k][e] - mu; q += d * d; }
+        }
       }
-    }
-    const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
+      const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = lig + k * G;
-      if (v < nvec) {
-        Vec8<T> o;
+      for (int k = 0; k < NV; ++k) {
+        const int v = lig + k * G;
+        if (v < nvec) {
+          Vec8<T> o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, (xv[k][e] - mu) * rs * gm[k][e] + bt[k][e]);
-        store8<T>(y + row * (int64_t)C + v * 8, o);
+          for (int e = 0; e < 8; ++e) o.set(e, (xv[rr][k][e] - mu) * rs * gm[k][e] + bt[k][e]);
+          store8<T>(y + row * (int64_t)C + v * 8, o);
+        }
       }
+      if (lig == 0) { mean[row] = mu; rstd[row] = rs; }
     }
-    if (lig == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
@@ -174,9 +191,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-static int ln_grid(int64_t rows, int gpb) {
+// HBM-bound row kernels want every CU full of waves (8 blocks of 256 threads per CU): the forward takes up to
+// 4096 blocks; the backward is capped at 1024 because every block writes one row of dgamma/dbeta partials.
+static int ln_grid(int64_t rows, int gpb, int cap) {
   int64_t nb = (rows + gpb - 1) / gpb;
-  if (nb > 512) nb = 512;
+  if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -184,7 +203,7 @@ static int ln_grid(int64_t rows, int gpb) {
 template <typename T, int G, int NV>
 static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int64_t rows, int C, float eps, LnAddr a, hipStream_t st) {
-  const int nb = ln_grid(rows, 256 / G);
+  const int nb = ln_grid(rows, 256 / G, 1024);
   hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
                      rstd, rows, C, eps, a);
   return vtx_check_launch();
@@ -194,7 +213,7 @@ template <typename T, int G, int NV>
 static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                          const void* dres, void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int C,
                          LnAddr a, hipStream_t st) {
-  const int nb = ln_grid(rows, 256 / G);
+  const int nb = ln_grid(rows, 256 / G, 1024);
   const size_t smem = (size_t)2 * (256 / G) * C * sizeof(float);
   hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
                      gamma, (const T*)dres, (T*)dx, ws, rows, C, a);

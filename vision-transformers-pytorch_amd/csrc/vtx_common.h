@@ -103,8 +103,19 @@ static __global__ void colreduce_kernel(const float* __restrict__ part, float* _
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < ncols)
-    for (int b = rl; b < nb; b += 8) s += part[(int64_t)b * ld + c];
+  if (c < ncols) {
+    // 4 independent accumulators in a fixed interleave: the loads of 4 rows are in flight together
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = rl;
+    for (; b + 24 < nb; b += 32) {
+      s0 += part[(int64_t)b * ld + c];
+      s1 += part[(int64_t)(b + 8) * ld + c];
+      s2 += part[(int64_t)(b + 16) * ld + c];
+      s3 += part[(int64_t)(b + 24) * ld + c];
+    }
+    for (; b < nb; b += 8) s0 += part[(int64_t)b * ld + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < ncols) {
