@@ -247,10 +247,14 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   return VTX_ERR_DTYPE;
 }
 
-// Number of contraction slices the wgrad kernel will use for (Mtok tokens, N x Kin weight).
+// Number of contraction slices (split-K over tokens) of the wgrad kernels: tiles x slices should just fill a whole
+// number of resident block rounds (256 CUs x 2 blocks) -- a partly filled round leaves CUs idle for the whole
+// kernel because every block runs the same long k-loop.
 static int wgrad_slices(int64_t mtok, int N, int Kin) {
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("VTX_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }
   const int tiles = ((N + 127) / 128) * ((Kin + 127) / 128);
-  int nz = (320 + tiles - 1) / tiles;
+  int nz = target / tiles;
   const int64_t maxz = (mtok + 255) / 256;
   if (nz > maxz) nz = (int)maxz;
   if (nz < 1) nz = 1;
