@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--stages", default="1,2,3,4")
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (hipBLASLt, no epilogue) as a comparison")
     a = ap.parse_args()
     dev = torch.device("cuda")
     what = a.what.split(",")
@@ -76,10 +77,20 @@ def main():
                 t = timeit(lambda: ops.wgrad(dy, x), a.iters)
                 byt = 2 * (M * N + M * K) + 4 * N * K
                 rows.append(("wgrad", t, byt))
+            vend = {}
+            if a.vendor:                                       # comparison only: plain library GEMMs, no fused epilogue
+                wt2 = w.t().contiguous()
+                vend["fwd"] = timeit(lambda: torch.matmul(x, w.t()), a.iters)
+                vend["dgrad"] = timeit(lambda: torch.matmul(dy, w), a.iters)
+                vend["wgrad"] = timeit(lambda: torch.matmul(dy.t(), x), a.iters)
             for kind, t, byt in rows:
                 tot[kind] = tot.get(kind, 0.0) + t * layers
+                extra = ""
+                if kind in vend:
+                    tot["vendor_" + kind] = tot.get("vendor_" + kind, 0.0) + vend[kind] * layers
+                    extra = f"  | hipBLASLt {vend[kind]:8.1f} us {flops / vend[kind] / 1e6:7.1f} TF/s"
                 print(f"stage{s} {name:4s} {kind:5s} M={M:6d} N={N:4d} K={K:4d}  {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s  "
-                      f"floor {byt / t / 1e3:7.1f} GB/s")
+                      f"floor {byt / t / 1e3:7.1f} GB/s{extra}")
     print("per-step totals (x layers):", {k: f"{v / 1e3:.2f} ms" for k, v in tot.items()})
 
 

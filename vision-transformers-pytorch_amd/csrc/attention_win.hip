@@ -14,6 +14,8 @@
 //   * the rel_pos gradient is binned per wave into 172 wave-private LDS bins (ds_add_f32; single wave,
 //     program order => deterministic) accumulated over all problems a persistent wave processes, then
 //     reduced over waves in fixed order.
+#include <stdlib.h>
+
 #include "vtx_common.h"
 
 #define WA_D 32
@@ -58,12 +60,23 @@ template <typename T> __device__ __forceinline__ Vec8<T> wa_frag_t(const T* p, i
   }
   return f;
 }
-// registers (token tile t4, lane (c, g): token 16 t4 + c, d-slots 8g..8g+7) -> transposed LDS image Xt[d][token]
+// registers (token tile t4, lane (c, g): token 16 t4 + c, d-slots 8g..8g+7) -> transposed LDS image Xt[pi(d)][token]
+// with the row permutation pi(8g + e) = 16 (e >> 2) + 4 g + (e & 3).  A product X^T-tile x F^T taken with the
+// image rows 16 dt + (0..15) as the MFMA A operand then leaves lane (c, g) holding, in accumulator dt register r,
+// the output of token (column) c for d = 8 g + 4 dt + r: eight CONTIGUOUS head channels per lane, i.e. exactly the
+// fragment layout of the loads -> one 16-byte global store per lane and tile instead of eight 2-byte ones.
 template <typename T> __device__ __forceinline__ void wa_store_t(T* xt, const Vec8<T> (&f)[4], int c, int g) {
 #pragma unroll
   for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xt[(8 * g + e) * WA_STR + 16 * t4 + c] = f[t4].v[e];
+    for (int e = 0; e < 8; ++e) xt[(16 * (e >> 2) + 4 * g + (e & 3)) * WA_STR + 16 * t4 + c] = f[t4].v[e];
+}
+// accumulators of the two d-tiles of such a transposed product -> the lane's 8 contiguous channels
+template <typename T> __device__ __forceinline__ Vec8<T> wa_out8(const f32x4& a0, const f32x4& a1, float scale) {
+  Vec8<T> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.set(j, a0[j] * scale); f.set(4 + j, a1[j] * scale); }
+  return f;
 }
 
 // ---- bias + mask tables: bm[m][h][q][k] and bmT[m][h][k][q], 64x64 padded, fp32; -inf on masked / padded keys
@@ -149,24 +162,17 @@ __global__ __launch_bounds__(64) void wattn_fwd_kernel(const T* __restrict__ qkv
     for (int ks = 0; ks < 2; ++ks) {
       Vec8<T> pf = wa_frag_acc<T>(st[2 * ks] * inv, st[2 * ks + 1] * inv);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) mma16(pf, wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), oacc[dt]);
+      for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), pf, oacc[dt]);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qo = qt * 16 + g_ * 4 + r;            // row of this accumulator register
-      if (qo < g.L) {
-        T* op = o + win_token_row(g, b, n, qo) * (int64_t)g.hd + h * WA_D + c_;
-        op[0] = from_f32<T>(oacc[0][r]);
-        op[16] = from_f32<T>(oacc[1][r]);
-      }
-    }
+    // oacc[dt][r] = O[q = 16 qt + c][d = 8 g + 4 dt + r]
+    if (val[qt]) store8<T>(o + row[qt] * (int64_t)g.hd + h * WA_D + g_ * 8, wa_out8<T>(oacc[0], oacc[1], 1.f));
   }
 }
 
 // --------------------------------------------------------------------------------------------- backward
 // grid = (nblk, nH) persistent waves; wave (x, h) walks the (image, window) pairs x, x + nblk, ... of head h.
 template <typename T>
-__global__ __launch_bounds__(64) void wattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ oin,
+__global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ oin,
                                                       const T* __restrict__ dout, const float* __restrict__ lse,
                                                       const float* __restrict__ bm, const float* __restrict__ bmT,
                                                       const int* __restrict__ posT, T* __restrict__ dqkv,
@@ -181,6 +187,13 @@ __global__ __launch_bounds__(64) void wattn_bwd_kernel(const T* __restrict__ qkv
   const int lane = threadIdx.x, c_ = lane & 15, g_ = lane >> 4;
   const int64_t ld = 3 * (int64_t)g.hd;
   for (int i = lane; i < WA_NBIN; i += 64) bins[i] = 0.f;
+  // running sum over this wave's problems of dS[q = 16 qt + 4 g + r][key = 16 kt + c] (all of head h): LDS float
+  // atomics cost ~100 LDS cycles per instruction, so the rel_pos binning is done ONCE per wave, not per problem
+  f32x4 dsacc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dsacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int bn = blockIdx.x; bn < nbn; bn += gridDim.x) {
     const int n = bn % g.nW, b = bn / g.nW;
@@ -246,17 +259,10 @@ __global__ __launch_bounds__(64) void wattn_bwd_kernel(const T* __restrict__ qkv
         }
         Vec8<T> dsf = wa_frag_acc<T>(dsv[0], dsv[1]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) mma16(dsf, wa_frag_t<T>(kt_s + (dt * 16 + c_) * WA_STR + ks * 32, g_), dqacc[dt]);
+        for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(kt_s + (dt * 16 + c_) * WA_STR + ks * 32, g_), dsf, dqacc[dt]);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qo = qt * 16 + g_ * 4 + r;
-        if (qo < g.L) {
-          T* p = dqkv + win_token_row(g, b, n, qo) * ld + h * WA_D + c_;
-          p[0] = from_f32<T>(dqacc[0][r] * g.scale);
-          p[16] = from_f32<T>(dqacc[1][r] * g.scale);
-        }
-      }
+      // dqacc[dt][r] = dQ[q = 16 qt + c][d = 8 g + 4 dt + r] / scale
+      if (val[qt]) store8<T>(dqkv + row[qt] * ld + h * WA_D + g_ * 8, wa_out8<T>(dqacc[0], dqacc[1], g.scale));
       __builtin_amdgcn_sched_barrier(0);   // keep iterations apart: no cross-iteration hoisting (register pressure)
     }
 
@@ -280,37 +286,44 @@ __global__ __launch_bounds__(64) void wattn_bwd_kernel(const T* __restrict__ qkv
           const f32x4 bb = *reinterpret_cast<const f32x4*>(bmTh + key * 64 + q0);
           const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + q0);
           const f32x4 dd = *reinterpret_cast<const f32x4*>(dq_s + q0);
-          const int4 pb = *reinterpret_cast<const int4*>(posT + key * 64 + q0);
-          const int pbin[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = (q0 + r) < g.L && val[kt];
             const float p = ok ? __expf(s[r] * g.scale + bb[r] - ls[r]) : 0.f;
             pp[half][r] = p;
             dss[half][r] = p * (dp[r] - dd[r]);
-            if (ok) atomicAdd(&bins[pbin[r]], dss[half][r]);     // ds_add_f32, wave-private => deterministic order
           }
+          dsacc[kt][qt] += dss[half];
         }
         Vec8<T> pf = wa_frag_acc<T>(pp[0], pp[1]);
         Vec8<T> dsf = wa_frag_acc<T>(dss[0], dss[1]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          mma16(pf, wa_frag_t<T>(dot_s + (dt * 16 + c_) * WA_STR + qs * 32, g_), dvacc[dt]);
-          mma16(dsf, wa_frag_t<T>(qt_s + (dt * 16 + c_) * WA_STR + qs * 32, g_), dkacc[dt]);
+          mma16(wa_frag_t<T>(dot_s + (dt * 16 + c_) * WA_STR + qs * 32, g_), pf, dvacc[dt]);
+          mma16(wa_frag_t<T>(qt_s + (dt * 16 + c_) * WA_STR + qs * 32, g_), dsf, dkacc[dt]);
         }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ko = kt * 16 + g_ * 4 + r;
-        if (ko < g.L) {
-          T* p = dqkv + win_token_row(g, b, n, ko) * ld + h * WA_D + c_;
-          p[g.hd] = from_f32<T>(dkacc[0][r] * g.scale);
-          p[g.hd + 16] = from_f32<T>(dkacc[1][r] * g.scale);
-          p[2 * g.hd] = from_f32<T>(dvacc[0][r]);
-          p[2 * g.hd + 16] = from_f32<T>(dvacc[1][r]);
-        }
+      // d{k,v}acc[dt][r] = d{K,V}[key = 16 kt + c][d = 8 g + 4 dt + r]
+      if (val[kt]) {
+        T* p = dqkv + row[kt] * ld + h * WA_D + g_ * 8;
+        store8<T>(p + g.hd, wa_out8<T>(dkacc[0], dkacc[1], g.scale));
+        store8<T>(p + 2 * g.hd, wa_out8<T>(dvacc[0], dvacc[1], 1.f));
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // bin the accumulated dS by relative-position index (ds_add_f32; single wave, program order => deterministic)
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = kt * 16 + c_;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int q0 = qt * 16 + g_ * 4;
+      const int4 pb = *reinterpret_cast<const int4*>(posT + key * 64 + q0);
+      const int pbin[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (key < g.L && q0 + r < g.L) atomicAdd(&bins[pbin[r]], dsacc[kt][qt][r]);
     }
   }
   __syncthreads();
@@ -337,11 +350,15 @@ static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift)
   return VTX_OK;
 }
 
+// Persistent waves: 2 per SIMD are resident (VGPR-bound) => 2048 on the chip; every wave of head h gets the same
+// number of (image, window) pairs (+-1) and the grid never exceeds what is resident at once.
 static int wattn_bwd_blocks(int nbn, int nH) {
-  int nblk = 4096 / nH;                 // ~16 resident waves per CU over 256 CUs
-  if (nblk < 1) nblk = 1;
-  if (nblk > nbn) nblk = nbn;
-  return nblk;
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("VTX_WATTN_WAVES"); cap = e ? atoi(e) : 2048; }
+  int per_head = cap / nH;
+  if (per_head < 1) per_head = 1;
+  const int ppw = (nbn + per_head - 1) / per_head;   // problems per wave
+  return (nbn + ppw - 1) / ppw;
 }
 
 extern "C" {
