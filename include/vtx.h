@@ -97,21 +97,24 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
                       float* drel_pos, int ntab, void* workspace, size_t ws_bytes, int B, int L, int nH, int D,
                       int swin, int H, int W, int win, int shift, int dtype, void* stream);
 
-/* ---- Window attention fast path (head dim 32, window <= 7x7): one wavefront per (image, window, head),
- * same semantics as vtx_attention_fwd/bwd with swin != 0 (reference models/swin_transformer.py:109-154).
- * `tables` (vtx_wattn_tables_bytes) holds the rel-pos bias + -inf mask pre-combined per (mask window, head)
- * as padded 64x64 fp32 tables (and transposes) plus the transposed pos table; built per call from the
- * rel_pos parameter and the pos / local_mask buffers (mask NULL for un-shifted layers => masked = 0).
- * The backward writes dqkv fully and drel_pos [(2w-1)^2, nH] (deterministic). */
-size_t vtx_wattn_tables_bytes(int nH, int nWm);
-int vtx_wattn_tables(const float* rel_pos, const int64_t* pos, const uint8_t* mask, void* tables, int L, int nH,
-                     int nW, void* stream);
-int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const void* tables, int masked, int B, int L, int nH, int H,
-                  int W, int win, int shift, int dtype, void* stream);
+/* ---- Window attention fast path (head dim 32, window <= 7x7): one wavefront per (image, window, head) problem,
+ * persistent 4-wave workgroups per head, same semantics as vtx_attention_fwd/bwd with swin != 0
+ * (reference models/swin_transformer.py:103-160: roll, partition, q k^T / sqrt(d) + rel_pos(pos) bias,
+ * masked_fill(local_mask, -inf), softmax, @ v, inverse partition, roll back).
+ *   rel_pos [(2 win - 1)^2][nH] fp32 (the nn.Embedding weight), pos [L][L] int64 (the module's `pos` buffer);
+ *   region: NULL for un-shifted layers, else [nW][64] uint8 with
+ *           local_mask[n][a][b] == (region[n][a] != region[n][b])   (swin_transformer.py:82-89, 138-141)
+ *           -- vtx.tables.mask_regions derives the ids from the module's local_mask buffer and verifies the
+ *           identity; a mask without that structure takes vtx_attention_* instead.
+ * The head's bias table is gathered into LDS once per workgroup; no per-call table kernels.
+ * The backward writes dqkv fully and drel_pos [(2 win - 1)^2][nH] (deterministic). */
+int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
+                  const uint8_t* region, int B, int L, int nH, int H, int W, int win, int shift, int dtype,
+                  void* stream);
 size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win);
-int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const void* tables, int masked,
-                  void* dqkv, float* drel_pos, void* workspace, size_t ws_bytes, int B, int L, int nH, int H, int W,
-                  int win, int shift, int dtype, void* stream);
+int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
+                  const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
+                  size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream);
 
 /* ---- Patch gather: NCHW fp32 image -> patch matrix [B*(H/p)*(W/p), Kp] of dtype, columns >= 3*p*p zero.
  *   order 0: column (py, px, c)  -- Swin: permute(0,2,3,1) + patchify(4) (models/swin_transformer.py:15-22,

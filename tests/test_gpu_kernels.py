@@ -207,8 +207,8 @@ def test_window_attention_core(dtype, B, H, W, nH, shift):
 @pytest.mark.parametrize("B,H,W,nH,shift", [(2, 14, 14, 3, True), (2, 14, 14, 3, False), (3, 7, 7, 24, True),
                                             (1, 28, 28, 6, True), (2, 56, 56, 3, True), (5, 14, 14, 12, True)])
 def test_window_attention_fast_path(dtype, B, H, W, nH, shift):
-    """One-wave-per-window kernels (attention_win.hip) vs the oracle; the rel_pos gradient must also be
-    bitwise reproducible run to run (wave-private LDS accumulation, fixed-order reduce)."""
+    """One-wave-per-window kernels (attention_win.hip; LDS-resident bias table, region-id masks) vs the oracle; the
+    rel_pos gradient must also be bitwise reproducible run to run (per-wave accumulation, fixed-order reduce)."""
     from vtx import ops
     from oracle import tables
     d = dev()
@@ -221,10 +221,15 @@ def test_window_attention_fast_path(dtype, B, H, W, nH, shift):
     pos = torch.from_numpy(pos_np).to(d)
     mask = torch.from_numpy(mask_np).to(d) if shift else None
     swin = (H, W, win, shift)
-    tb = ops.wattn_tables(rel.to(d), pos, mask, nH)
-    o, lse = ops.wattn_fwd(qkv.to(d), tb, shift, B, L, nH, swin)
-    dqkv, drel = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, tb, shift, B, L, nH, swin, ntab)
-    dqkv2, drel2 = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, tb, shift, B, L, nH, swin, ntab)
+    from vtx.tables import mask_regions
+    region = None
+    if shift:
+        region, ok = mask_regions(mask)
+        assert ok, "the reference's local_mask must have the region structure"
+    reld = rel.to(d)
+    o, lse = ops.wattn_fwd(qkv.to(d), reld, pos, region, B, L, nH, swin)
+    dqkv, drel = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, reld, pos, region, B, L, nH, swin, ntab)
+    dqkv2, drel2 = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, reld, pos, region, B, L, nH, swin, ntab)
     assert torch.equal(drel, drel2) and torch.equal(dqkv, dqkv2), "window attention backward is not deterministic"
     qr = qkv.double().requires_grad_(True)
     rr = rel.double().requires_grad_(True)

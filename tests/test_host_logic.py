@@ -130,3 +130,33 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_mask_regions_structure():
+    """The shifted-window mask is carried to the window-attention kernels as one region id per token: verify the
+    identity local_mask[n,a,b] == (region[n,a] != region[n,b]) on the reference's masks (golden G2 geometry) and that
+    an unstructured mask is rejected (-> generic kernels)."""
+    from vtx.tables import make_pos_mask, mask_regions
+    for size, win in (((56, 56), 7), ((28, 28), 7), ((14, 14), 7), ((7, 7), 7), ((8, 12), 4)):
+        _, mask = make_pos_mask(size, win, True)
+        region, ok = mask_regions(mask)
+        assert ok and region.dtype == torch.uint8 and tuple(region.shape) == (mask.shape[0], 64)
+        L = win * win
+        r = region[:, :L].long()
+        assert torch.equal(r[:, :, None] != r[:, None, :], mask)
+    _, mask = make_pos_mask((14, 14), 7, True)
+    bad = mask.clone()
+    bad[1, 3, 5] = ~bad[1, 3, 5]                      # not symmetric / transitive any more
+    assert mask_regions(bad)[1] is False
+
+
+def test_swin_region_cache_follows_buffer():
+    from models.swin_transformer import MultiHeadedLocalAttention
+    m = MultiHeadedLocalAttention(96, 3, 32, (14, 14), 7, True)
+    r1, ok1 = m.regions()
+    assert ok1 and m.regions()[0] is r1                # cached
+    with torch.no_grad():
+        m.local_mask[0, 0, 1] = ~m.local_mask[0, 0, 1]  # in-place edit bumps the buffer version
+    assert m.regions()[1] is False                     # re-derived: no region structure -> generic path
+    m2 = MultiHeadedLocalAttention(96, 3, 32, (14, 14), 7, False)
+    assert m2.regions() == (None, True)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(REPO, "vision-transformers-pytorch_amd"))
 import torch
 
 from vtx import ops
-from vtx.tables import make_pos_mask
+from vtx.tables import make_pos_mask, mask_regions
 
 GEOM = {1: (56, 3), 2: (28, 6), 3: (14, 12), 4: (7, 24)}
 LAYERS = {1: 2, 2: 2, 3: 18, 4: 2}
@@ -54,19 +54,17 @@ def main():
             rel = (torch.randn(169, nH, device=dev) * 0.5)
             qkv = torch.randn(rows, 3 * hd, device=dev).bfloat16()
             dout = torch.randn(rows, hd, device=dev).bfloat16()
-            tab = ops.wattn_tables(rel, pos, mask, nH)
+            region = mask_regions(mask)[0] if mask is not None else None
             swin = (H, H, win, shift)
-            masked = mask is not None
-            o, lse = ops.wattn_fwd(qkv, tab, masked, B, L, nH, swin)
-            tf = timeit(lambda: ops.wattn_fwd(qkv, tab, masked, B, L, nH, swin), a.iters)
-            tb = timeit(lambda: ops.wattn_bwd(qkv, o, dout, lse, tab, masked, B, L, nH, swin, 169), a.iters)
-            tt = timeit(lambda: ops.wattn_tables(rel, pos, mask, nH), a.iters)
+            o, lse = ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin)
+            tf = timeit(lambda: ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin), a.iters)
+            tb = timeit(lambda: ops.wattn_bwd(qkv, o, dout, lse, rel, pos, region, B, L, nH, swin, 169), a.iters)
             bf = 2 * rows * hd * 4
             bb = 2 * rows * hd * 8
             tot["fwd"] += tf * LAYERS[s] / 2
             tot["bwd"] += tb * LAYERS[s] / 2
             print(f"stage{s} shift={int(shift)} rows={rows:7d} heads={nH:2d}  fwd {tf:7.1f} us ({bf / tf / 1e3:6.0f} GB/s)  "
-                  f"bwd {tb:7.1f} us ({bb / tb / 1e3:6.0f} GB/s)  tables {tt:5.1f} us")
+                  f"bwd {tb:7.1f} us ({bb / tb / 1e3:6.0f} GB/s)")
     print("per-step totals (x layers):", {k: f"{v / 1e3:.2f} ms" for k, v in tot.items()})
 
 

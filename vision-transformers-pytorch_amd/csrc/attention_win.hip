@@ -9,11 +9,16 @@
 //     front, independent of each other, so a problem pays the HBM latency once;
 //   * operands that are contracted over tokens (V; K, Q, dO in the backward) are transposed through a
 //     wave-private LDS region straight from those registers (no second global read);
-//   * bias and -inf mask come pre-combined from a padded table [nWm][h][64][64] fp32 (and its transpose)
-//     built once per layer call, so the per-score lookup is one aligned 16-byte load per 4 scores;
-//   * the rel_pos gradient is binned per wave into 172 wave-private LDS bins (ds_add_f32; single wave,
-//     program order => deterministic) accumulated over all problems a persistent wave processes, then
-//     reduced over waves in fixed order.
+//   * workgroups are PERSISTENT, 4 waves that all serve one head: the head's rel-pos bias table
+//     bias[q][k] = rel_pos[pos[q][k]][h] (-inf on padded keys) is gathered ONCE per workgroup into LDS
+//     ([64][68] fp32, conflict-free for both the row-wise 16-byte and the column-wise 4-byte reads), so no score
+//     lookup ever leaves the CU -- global table loads inside the tile loops were ~25 % of the backward's time;
+//   * the shifted-window -inf mask is carried as one REGION id per token (local_mask[n][a][b] == region[n][a] !=
+//     region[n][b]; the host verifies that the module's local_mask buffer has this structure, else the generic
+//     kernels of attention.hip run): 64 bytes per problem in LDS instead of a 16 KB mask table per window;
+//   * the rel_pos gradient: dS is summed over all problems of the persistent wave in registers and binned ONCE
+//     per wave into 172 wave-private LDS bins (ds_add_f32 costs ~100 LDS cycles per instruction; single wave,
+//     program order => deterministic), then reduced over waves in fixed order.
 #include <stdlib.h>
 
 #include "vtx_common.h"
@@ -22,9 +27,11 @@
 #define WA_LP 64
 #define WA_STR 72        // transposed LDS row stride (elements)
 #define WA_NBIN 172      // (2*7-1)^2 = 169 padded to a multiple of 4
+#define WA_BSTR 68       // bias table row stride (floats)
+#define WA_WAVES 4       // waves per workgroup
 
 struct WinGeom {
-  int L, nH, hd, nW, H, W, win, shift, nWx, nWm;   // nWm = windows with distinct masks (nW if shifted else 1)
+  int L, nH, hd, nW, H, W, win, shift, nWx;
   float scale;
 };
 
@@ -79,128 +86,174 @@ template <typename T> __device__ __forceinline__ Vec8<T> wa_out8(const f32x4& a0
   return f;
 }
 
-// ---- bias + mask tables: bm[m][h][q][k] and bmT[m][h][k][q], 64x64 padded, fp32; -inf on masked / padded keys
-__global__ void win_bias_mask_kernel(const float* __restrict__ rel_pos, const int64_t* __restrict__ pos,
-                                     const uint8_t* __restrict__ mask, float* __restrict__ bm, float* __restrict__ bmT,
-                                     int L, int nH, int nWm) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = nWm * nH * 64 * 64;
-  if (idx >= total) return;
-  const int k = idx & 63, q = (idx >> 6) & 63, mh = idx >> 12;
-  const int h = mh % nH, m = mh / nH;
-  float v;
-  if (k >= L) v = -INFINITY;
-  else if (q >= L) v = 0.f;
-  else {
-    v = rel_pos[pos[q * L + k] * nH + h];
-    if (mask && mask[((int64_t)m * L + q) * L + k]) v = -INFINITY;
-  }
-  bm[idx] = v;
-  bmT[(((int64_t)mh * 64 + k) << 6) + q] = v;
+
+// wave-level ordering point for wave-private LDS traffic (DS operations of one wave execute in issue order; this
+// only stops the compiler from moving memory operations across it -- no workgroup barrier, no counter drain)
+__device__ __forceinline__ void wa_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// --------------------------------------------------------------------------------------------- forward
-template <typename T>
-__global__ __launch_bounds__(64) void wattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
-                                                      float* __restrict__ lse, const float* __restrict__ bm,
-                                                      int nprob, WinGeom g) {
-  __shared__ __attribute__((aligned(16))) T vt[WA_D * WA_STR];
-  // XCD-aware remap: consecutive problems (heads of one window share 128-B lines) stay on one XCD
-  const int did = blockIdx.x;
-  const int xq = nprob >> 3, xr = nprob & 7, xcd = did & 7;
-  const int prob = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
-  const int h = prob % g.nH;
-  const int bn = prob / g.nH;
-  const int n = bn % g.nW, b = bn / g.nW;
-  const int lane = threadIdx.x, c_ = lane & 15, g_ = lane >> 4;
-  const int64_t ld = 3 * (int64_t)g.hd;
-
-  int64_t row[4];
-  bool val[4];
-  Vec8<T> qf[4], kf[4], vf[4];
+// the head's bias table, built once per workgroup: bias_s[q][k] (row stride WA_BSTR), -inf on padded keys.
+// Column h of rel_pos goes to LDS first (relh, WA_NBIN floats) while the 16 pos loads of every thread are in flight,
+// so the build pays ONE global round trip.
+__device__ __forceinline__ void wa_build_bias(float* bias_s, float* relh, const float* __restrict__ rel_pos,
+                                              const int64_t* __restrict__ pos, int L, int nH, int h, int ntab) {
+  constexpr int PER = 64 * 64 / (64 * WA_WAVES);
+  int pidx[PER];
 #pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    const int tok = 16 * t4 + c_;
-    val[t4] = tok < g.L;
-    row[t4] = val[t4] ? win_token_row(g, b, n, tok) : 0;
-    const T* p = qkv + row[t4] * ld + h * WA_D + g_ * 8;
-    qf[t4] = wa_load<T>(p, val[t4]);
-    kf[t4] = wa_load<T>(p + g.hd, val[t4]);
-    vf[t4] = wa_load<T>(p + 2 * g.hd, val[t4]);
+  for (int i = 0; i < PER; ++i) {
+    const int idx = threadIdx.x + i * 64 * WA_WAVES;
+    const int k = idx & 63, q = idx >> 6;
+    pidx[i] = (k < L && q < L) ? (int)pos[q * L + k] : -1;
   }
-  wa_store_t<T>(vt, vf, c_, g_);
+  if ((int)threadIdx.x < ntab) relh[threadIdx.x] = rel_pos[threadIdx.x * nH + h];
   __syncthreads();
-  const float* bmh = bm + (((int64_t)(g.nWm > 1 ? n : 0) * g.nH + h) << 12);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = threadIdx.x + i * 64 * WA_WAVES;
+    const int k = idx & 63, q = idx >> 6;
+    bias_s[q * WA_BSTR + k] = k >= L ? -INFINITY : (pidx[i] >= 0 ? relh[pidx[i]] : 0.f);
+  }
+}
 
+template <typename T> struct WaSmem {
+  static constexpr int kImg = WA_D * WA_STR * (int)sizeof(T);          // one transposed operand image
+  static constexpr int kBias = 64 * WA_BSTR * 4;
+  static constexpr int kFwdWave = kImg + 64;                           // Vt + region ids
+  static constexpr int kBwdWave = 3 * kImg + 2 * WA_LP * 4 + WA_NBIN * 4 + 64;
+  static constexpr int kFwd = kBias + WA_WAVES * kFwdWave;
+  static constexpr int kBwd = kBias + WA_WAVES * kBwdWave;
+};
+
+// --------------------------------------------------------------------------------------------- forward
+// grid = (nblk, nH); wave w of block x serves the (image, window) pairs 4 x + w, 4 x + w + 4 nblk, ... of head y
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                                  float* __restrict__ lse,
+                                                                  const float* __restrict__ rel_pos,
+                                                                  const int64_t* __restrict__ pos,
+                                                                  const uint8_t* __restrict__ region, int nbn,
+                                                                  WinGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
+  float* bias_s = reinterpret_cast<float*>(wa_smem);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* wbase = wa_smem + WaSmem<T>::kBias + wave * WaSmem<T>::kFwdWave;
+  T* vt = reinterpret_cast<T*>(wbase);
+  uint8_t* reg_s = wbase + WaSmem<T>::kImg;
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
+  const int64_t ld = 3 * (int64_t)g.hd;
+  wa_build_bias(bias_s, reinterpret_cast<float*>(wa_smem + WaSmem<T>::kBias), rel_pos, pos, g.L, g.nH, h,
+                (2 * g.win - 1) * (2 * g.win - 1));
+  __syncthreads();                                    // table complete; the relh scratch (wave 0's region) is free again
+
+  for (int bn = blockIdx.x * WA_WAVES + wave; bn < nbn; bn += gridDim.x * WA_WAVES) {
+    const int n = bn % g.nW, b = bn / g.nW;
+    const int prob = bn * g.nH + h;
+    int64_t row[4];
+    bool val[4];
+    Vec8<T> qf[4], kf[4], vf[4];
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    if (qt * 16 >= g.L) break;
-    const int q = qt * 16 + c_;
-    f32x4 st[4];
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma16(kf[kt], qf[qt], st[kt]);            // st[kt][r] = S[q = 16 qt + c][key = 16 kt + 4 g + r]
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bmh + q * 64 + kt * 16 + g_ * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { st[kt][r] = st[kt][r] * g.scale + bb[r]; m = fmaxf(m, st[kt][r]); }
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int tok = 16 * t4 + c_;
+      val[t4] = tok < g.L;
+      row[t4] = val[t4] ? win_token_row(g, b, n, tok) : 0;
+      const T* p = qkv + row[t4] * ld + h * WA_D + g_ * 8;
+      qf[t4] = wa_load<T>(p, val[t4]);
+      kf[t4] = wa_load<T>(p + g.hd, val[t4]);
+      vf[t4] = wa_load<T>(p + 2 * g.hd, val[t4]);
     }
-    m = fmaxf(m, shfl_xor_f(m, 16));
-    m = fmaxf(m, shfl_xor_f(m, 32));
-    float l = 0.f;
+    uint8_t myreg = 0;
+    if (MASKED) myreg = region[(int64_t)n * 64 + lane];
+    wa_wave_sync();                                   // the previous problem's LDS readers are done
+    wa_store_t<T>(vt, vf, c_, g_);
+    if (MASKED) reg_s[lane] = myreg;
+    wa_wave_sync();
+
+    constexpr bool MK = MASKED;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int qt = 0; qt < 4; ++qt) {
+      if (qt * 16 >= g.L) break;
+      const int q = qt * 16 + c_;
+      f32x4 st[4];
+      float m = -INFINITY;
+      const unsigned rq = MK ? reg_s[q] * 0x01010101u : 0u;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); l += st[kt][r]; }
-    l += shfl_xor_f(l, 16);
-    l += shfl_xor_f(l, 32);
-    const float inv = 1.f / l;
-    if (val[qt] && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
-    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      for (int kt = 0; kt < 4; ++kt) {
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma16(kf[kt], qf[qt], st[kt]);            // st[kt][r] = S[q = 16 qt + c][key = 16 kt + 4 g + r]
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + q * WA_BSTR + kt * 16 + g_ * 4);
+        unsigned rx = 0u;                           // byte r == 0  <=>  key r is in the query's region
+        if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Vec8<T> pf = wa_frag_acc<T>(st[2 * ks] * inv, st[2 * ks + 1] * inv);
+        for (int r = 0; r < 4; ++r) {
+          float sv = st[kt][r] * g.scale + bb[r];
+          if (MK && (rx & (0xffu << (8 * r))) != 0u) sv = -INFINITY;
+          st[kt][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      }
+      m = fmaxf(m, shfl_xor_f(m, 16));
+      m = fmaxf(m, shfl_xor_f(m, 32));
+      float l = 0.f;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), pf, oacc[dt]);
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); l += st[kt][r]; }
+      l += shfl_xor_f(l, 16);
+      l += shfl_xor_f(l, 32);
+      const float inv = 1.f / l;
+      if (val[qt] && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
+      f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Vec8<T> pf = wa_frag_acc<T>(st[2 * ks] * inv, st[2 * ks + 1] * inv);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), pf, oacc[dt]);
+      }
+      // oacc[dt][r] = O[q = 16 qt + c][d = 8 g + 4 dt + r]
+      if (val[qt]) store8<T>(o + row[qt] * (int64_t)g.hd + h * WA_D + g_ * 8, wa_out8<T>(oacc[0], oacc[1], 1.f));
     }
-    // oacc[dt][r] = O[q = 16 qt + c][d = 8 g + 4 dt + r]
-    if (val[qt]) store8<T>(o + row[qt] * (int64_t)g.hd + h * WA_D + g_ * 8, wa_out8<T>(oacc[0], oacc[1], 1.f));
   }
 }
 
 // --------------------------------------------------------------------------------------------- backward
-// grid = (nblk, nH) persistent waves; wave (x, h) walks the (image, window) pairs x, x + nblk, ... of head h.
-template <typename T>
-__global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ oin,
-                                                      const T* __restrict__ dout, const float* __restrict__ lse,
-                                                      const float* __restrict__ bm, const float* __restrict__ bmT,
-                                                      const int* __restrict__ posT, T* __restrict__ dqkv,
-                                                      float* __restrict__ bins_part, int nbn, WinGeom g) {
-  __shared__ __attribute__((aligned(16))) T kt_s[WA_D * WA_STR];     // Kt[d][key]
-  __shared__ __attribute__((aligned(16))) T qt_s[WA_D * WA_STR];     // Qt[d][q]
-  __shared__ __attribute__((aligned(16))) T dot_s[WA_D * WA_STR];    // dOt[d][q]
-  __shared__ __attribute__((aligned(16))) float dq_s[WA_LP];         // D[q] = rowsum(dO o O)
-  __shared__ __attribute__((aligned(16))) float lse_s[WA_LP];
-  __shared__ float bins[WA_NBIN];
+// same persistent mapping as the forward; every wave keeps the running dS sum of its problems in registers
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ oin, const T* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ rel_pos, const int64_t* __restrict__ pos, const uint8_t* __restrict__ region,
+    T* __restrict__ dqkv, float* __restrict__ bins_part, int nbn, WinGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
+  float* bias_s = reinterpret_cast<float*>(wa_smem);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* wbase = wa_smem + WaSmem<T>::kBias + wave * WaSmem<T>::kBwdWave;
+  T* kt_s = reinterpret_cast<T*>(wbase);                              // Kt[pi(d)][key]
+  T* qt_s = reinterpret_cast<T*>(wbase + WaSmem<T>::kImg);            // Qt[pi(d)][q]
+  T* dot_s = reinterpret_cast<T*>(wbase + 2 * WaSmem<T>::kImg);       // dOt[pi(d)][q]
+  float* dq_s = reinterpret_cast<float*>(wbase + 3 * WaSmem<T>::kImg); // D[q] = rowsum(dO o O)
+  float* lse_s = dq_s + WA_LP;
+  float* bins = lse_s + WA_LP;
+  uint8_t* reg_s = reinterpret_cast<uint8_t*>(bins + WA_NBIN);
   const int h = blockIdx.y;
-  const int lane = threadIdx.x, c_ = lane & 15, g_ = lane >> 4;
+  const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
   const int64_t ld = 3 * (int64_t)g.hd;
+  wa_build_bias(bias_s, reinterpret_cast<float*>(wa_smem + WaSmem<T>::kBias), rel_pos, pos, g.L, g.nH, h,
+                (2 * g.win - 1) * (2 * g.win - 1));
+  __syncthreads();                                    // table complete; the relh scratch (wave 0's region) is free again
   for (int i = lane; i < WA_NBIN; i += 64) bins[i] = 0.f;
-  // running sum over this wave's problems of dS[q = 16 qt + 4 g + r][key = 16 kt + c] (all of head h): LDS float
-  // atomics cost ~100 LDS cycles per instruction, so the rel_pos binning is done ONCE per wave, not per problem
+  // running sum over this wave's problems of dS[q = 16 qt + 4 g + r][key = 16 kt + c] (all of head h)
   f32x4 dsacc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dsacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int bn = blockIdx.x; bn < nbn; bn += gridDim.x) {
+  for (int bn = blockIdx.x * WA_WAVES + wave; bn < nbn; bn += gridDim.x * WA_WAVES) {
     const int n = bn % g.nW, b = bn / g.nW;
     const int prob = bn * g.nH + h;
-    const int64_t mh = (int64_t)(g.nWm > 1 ? n : 0) * g.nH + h;
-    const float* bmh = bm + (mh << 12);
-    const float* bmTh = bmT + (mh << 12);
 
     int64_t row[4];
     bool val[4];
@@ -217,7 +270,7 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
       vf[t4] = wa_load<T>(p + 2 * g.hd, val[t4]);
       dof[t4] = wa_load<T>(dout + row[t4] * g.hd + h * WA_D + g_ * 8, val[t4]);
       Vec8<T> of = wa_load<T>(oin + row[t4] * g.hd + h * WA_D + g_ * 8, val[t4]);
-      lq[t4] = val[t4] ? lse[(int64_t)prob * g.L + tok] : 0.f;
+      lq[t4] = val[t4] ? lse[(int64_t)prob * g.L + tok] : INFINITY;   // padded query rows: exp(. - inf) = 0
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += of.get(e) * dof[t4].get(e);
@@ -225,7 +278,9 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
       s += shfl_xor_f(s, 32);
       dsum[t4] = s;                                   // D[q = 16 t4 + c]
     }
-    __syncthreads();                                  // previous problem's LDS readers are done (single wave: cheap)
+    uint8_t myreg = 0;
+    if (MASKED) myreg = region[(int64_t)n * 64 + lane];
+    wa_wave_sync();                                   // the previous problem's LDS readers are done
     wa_store_t<T>(kt_s, kf, c_, g_);
     wa_store_t<T>(qt_s, qf, c_, g_);
     wa_store_t<T>(dot_s, dof, c_, g_);
@@ -233,13 +288,16 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) { dq_s[16 * t4 + c_] = dsum[t4]; lse_s[16 * t4 + c_] = lq[t4]; }
     }
-    __syncthreads();
+    if (MASKED) reg_s[lane] = myreg;
+    wa_wave_sync();
 
+    constexpr bool MK = MASKED;
     // ---------------- phase A (swapped layout, per query tile): dQ = scale * dS K
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       if (qt * 16 >= g.L) break;
       const int q = qt * 16 + c_;
+      const unsigned rq = MK ? reg_s[q] * 0x01010101u : 0u;
       f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -250,10 +308,13 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
           f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
           mma16(kf[kt], qf[qt], pt);          // S [q = 16 qt + c][key = 16 kt + 4 g + r]
           mma16(vf[kt], dof[qt], dpt);        // dP[same]
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(bmh + q * 64 + kt * 16 + g_ * 4);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + q * WA_BSTR + kt * 16 + g_ * 4);
+          unsigned rx = 0u;                         // byte r == 0  <=>  key r is in the query's region
+          if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = val[qt] ? __expf(pt[r] * g.scale + bb[r] - lq[qt]) : 0.f;
+            float p = __expf(pt[r] * g.scale + bb[r] - lq[qt]);   // padded q: lse = +inf, padded key: bias = -inf
+            if (MK && (rx & (0xffu << (8 * r))) != 0u) p = 0.f;
             dsv[half][r] = p * (dpt[r] - dsum[qt]);
           }
         }
@@ -266,11 +327,12 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);   // keep iterations apart: no cross-iteration hoisting (register pressure)
     }
 
-    // ---------------- phase B (plain layout, per key tile): dV = P^T dO, dK = scale * dS^T Q, bins += dS
+    // ---------------- phase B (plain layout, per key tile): dV = P^T dO, dK = scale * dS^T Q, dsacc += dS
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       if (kt * 16 >= g.L) break;
       const int key = kt * 16 + c_;
+      const unsigned rk = MK ? reg_s[key] * 0x01010101u : 0u;
       f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -283,13 +345,15 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
           mma16(qf[qt], kf[kt], s);           // S [q = 16 qt + 4 g + r][key = 16 kt + c]
           mma16(dof[qt], vf[kt], dp);         // dP[same]
           const int q0 = qt * 16 + g_ * 4;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(bmTh + key * 64 + q0);
           const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + q0);
           const f32x4 dd = *reinterpret_cast<const f32x4*>(dq_s + q0);
+          unsigned rx = 0u;
+          if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + q0) ^ rk;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = (q0 + r) < g.L && val[kt];
-            const float p = ok ? __expf(s[r] * g.scale + bb[r] - ls[r]) : 0.f;
+            const float bb = bias_s[(q0 + r) * WA_BSTR + key];
+            float p = __expf(s[r] * g.scale + bb - ls[r]);        // padded q: lse = +inf, padded key: bias = -inf
+            if (MK && (rx & (0xffu << (8 * r))) != 0u) p = 0.f;
             pp[half][r] = p;
             dss[half][r] = p * (dp[r] - dd[r]);
           }
@@ -318,26 +382,17 @@ __global__ __launch_bounds__(64, 2) void wattn_bwd_kernel(const T* __restrict__ 
     const int key = kt * 16 + c_;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-      const int q0 = qt * 16 + g_ * 4;
-      const int4 pb = *reinterpret_cast<const int4*>(posT + key * 64 + q0);
-      const int pbin[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (key < g.L && q0 + r < g.L) atomicAdd(&bins[pbin[r]], dsacc[kt][qt][r]);
+      for (int r = 0; r < 4; ++r) {
+        const int q = qt * 16 + g_ * 4 + r;
+        if (key < g.L && q < g.L) atomicAdd(&bins[(int)pos[q * g.L + key]], dsacc[kt][qt][r]);
+      }
     }
   }
-  __syncthreads();
-  // partial layout [wave x][bin][head]: the fixed-order column reduce then yields drel_pos[(bin, head)] directly
-  float* out = bins_part + (int64_t)blockIdx.x * WA_NBIN * g.nH + h;
+  wa_wave_sync();
+  // partial layout [wave][bin][head]: the fixed-order column reduce then yields drel_pos[(bin, head)] directly
+  float* out = bins_part + ((int64_t)blockIdx.x * WA_WAVES + wave) * WA_NBIN * g.nH + h;
   for (int i = lane; i < WA_NBIN; i += 64) out[(int64_t)i * g.nH] = bins[i];
-}
-
-// transposed, padded pos table: posT[key][q] (int32, 64 x 64), 0 where out of range (those never accumulate)
-__global__ void win_pos_t_kernel(const int64_t* __restrict__ pos, int* __restrict__ posT, int L) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 64 * 64) return;
-  const int q = idx & 63, k = idx >> 6;
-  posT[idx] = (q < L && k < L) ? (int)pos[q * L + k] : 0;
 }
 
 static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift) {
@@ -345,102 +400,119 @@ static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift)
   if ((2 * win - 1) * (2 * win - 1) > WA_NBIN) return VTX_ERR_SHAPE;
   g.L = L; g.nH = nH; g.hd = nH * WA_D; g.H = H; g.W = W; g.win = win;
   g.nWx = W / win; g.nW = (H / win) * (W / win); g.shift = shift ? win / 2 : 0;
-  g.nWm = 1;
   g.scale = 1.0f / sqrtf((float)WA_D);
   return VTX_OK;
 }
 
-// Persistent waves: 2 per SIMD are resident (VGPR-bound) => 2048 on the chip; every wave of head h gets the same
-// number of (image, window) pairs (+-1) and the grid never exceeds what is resident at once.
+// Persistent grid: `cap` waves are resident on the chip (forward 4 per SIMD, backward 2 per SIMD -- VGPR-bound);
+// every wave of a head gets the same number of (image, window) pairs (+-1), waves come in workgroups of 4, and the
+// grid never exceeds what is resident at once.  Returns workgroups per head.
+static int wattn_blocks(int nbn, int nH, int cap) {
+  int per_head = cap / nH;
+  if (per_head < WA_WAVES) per_head = WA_WAVES;
+  const int ppw = (nbn + per_head - 1) / per_head;            // problems per wave
+  const int waves = (nbn + ppw - 1) / ppw;
+  return (waves + WA_WAVES - 1) / WA_WAVES;
+}
+static int wattn_cap(const char* env, int dflt) {
+  const char* e = getenv(env);
+  return e ? atoi(e) : dflt;
+}
+static int wattn_fwd_blocks(int nbn, int nH) {
+  static int cap = -1;
+  if (cap < 0) cap = wattn_cap("VTX_WATTN_FWD_WAVES", 4096);
+  return wattn_blocks(nbn, nH, cap);
+}
 static int wattn_bwd_blocks(int nbn, int nH) {
   static int cap = -1;
-  if (cap < 0) { const char* e = getenv("VTX_WATTN_WAVES"); cap = e ? atoi(e) : 2048; }
-  int per_head = cap / nH;
-  if (per_head < 1) per_head = 1;
-  const int ppw = (nbn + per_head - 1) / per_head;   // problems per wave
-  return (nbn + ppw - 1) / ppw;
+  if (cap < 0) cap = wattn_cap("VTX_WATTN_WAVES", 2048);
+  return wattn_blocks(nbn, nH, cap);
+}
+
+template <typename K> static int wa_smem_attr(K kern, int bytes) {
+  if (bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return VTX_ERR_LAUNCH;
+  return VTX_OK;
+}
+
+template <typename T, bool MASKED>
+static int wattn_fwd_launch(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
+                            const uint8_t* region, int nbn, const WinGeom& g, hipStream_t st) {
+  auto kern = wattn_fwd_kernel<T, MASKED>;
+  int rc = wa_smem_attr(kern, WaSmem<T>::kFwd);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(wattn_fwd_blocks(nbn, g.nH), g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kFwd, st,
+                     (const T*)qkv, (T*)o, lse, rel_pos, pos, region, nbn, g);
+  return vtx_check_launch();
+}
+
+template <typename T, bool MASKED>
+static int wattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
+                            const int64_t* pos, const uint8_t* region, void* dqkv, float* part, int nbn,
+                            const WinGeom& g, hipStream_t st) {
+  auto kern = wattn_bwd_kernel<T, MASKED>;
+  int rc = wa_smem_attr(kern, WaSmem<T>::kBwd);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(wattn_bwd_blocks(nbn, g.nH), g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kBwd, st,
+                     (const T*)qkv, (const T*)o, (const T*)dout, lse, rel_pos, pos, region, (T*)dqkv, part, nbn, g);
+  return vtx_check_launch();
 }
 
 extern "C" {
 
-/* Window attention (head dim 32, window <= 64 tokens) -- the Swin path.
- * tables: workspace of vtx_wattn_tables_bytes(): [bm | bmT | posT], built by vtx_wattn_tables from the rel_pos
- * parameter and the pos / local_mask buffers (mask == NULL for un-shifted layers). */
-size_t vtx_wattn_tables_bytes(int nH, int nWm) {
-  return ((size_t)2 * nWm * nH * 64 * 64) * sizeof(float) + 64 * 64 * sizeof(int);
-}
-
-int vtx_wattn_tables(const float* rel_pos, const int64_t* pos, const uint8_t* mask, void* tables, int L, int nH,
-                     int nW, void* stream) {
-  if (!rel_pos || !pos || !tables) return VTX_ERR_NULL;
-  if (L > WA_LP) return VTX_ERR_SHAPE;
-  const int nWm = mask ? nW : 1;
-  float* bm = (float*)tables;
-  float* bmT = bm + (size_t)nWm * nH * 4096;
-  int* posT = (int*)(bmT + (size_t)nWm * nH * 4096);
-  hipStream_t st = (hipStream_t)stream;
-  const int total = nWm * nH * 4096;
-  hipLaunchKernelGGL(win_bias_mask_kernel, dim3((total + 255) / 256), dim3(256), 0, st, rel_pos, pos, mask, bm, bmT, L,
-                     nH, nWm);
-  int rc = vtx_check_launch();
-  if (rc) return rc;
-  hipLaunchKernelGGL(win_pos_t_kernel, dim3(16), dim3(256), 0, st, pos, posT, L);
-  return vtx_check_launch();
-}
-
-int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const void* tables, int masked, int B, int L, int nH, int H,
-                  int W, int win, int shift, int dtype, void* stream) {
-  if (!qkv || !o || !lse || !tables) return VTX_ERR_NULL;
+/* Window attention (head dim 32, window <= 64 tokens) -- the Swin path (reference swin_transformer.py:103-160).
+ * rel_pos [(2 win - 1)^2][nH] fp32 parameter, pos [L][L] int64 buffer; region: NULL for un-shifted layers, else
+ * [nW][64] uint8 region ids with local_mask[n][a][b] == (region[n][a] != region[n][b]) (vtx.tables.mask_regions
+ * derives and verifies them from the module's local_mask buffer). */
+int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
+                  const uint8_t* region, int B, int L, int nH, int H, int W, int win, int shift, int dtype,
+                  void* stream) {
+  if (!qkv || !o || !lse || !rel_pos || !pos) return VTX_ERR_NULL;
   WinGeom g;
   int rc = win_geom(g, L, nH, H, W, win, shift);
   if (rc) return rc;
-  g.nWm = masked ? g.nW : 1;
-  const int nprob = B * g.nW * nH;
-  if (nprob <= 0) return VTX_OK;
+  const int nbn = B * g.nW;
+  if (nbn <= 0) return VTX_OK;
   hipStream_t st = (hipStream_t)stream;
-  const float* bm = (const float*)tables;
   if (dtype == VTX_BF16)
-    hipLaunchKernelGGL((wattn_fwd_kernel<bf16>), dim3(nprob), dim3(64), 0, st, (const bf16*)qkv, (bf16*)o, lse, bm, nprob, g);
-  else if (dtype == VTX_F32)
-    hipLaunchKernelGGL((wattn_fwd_kernel<float>), dim3(nprob), dim3(64), 0, st, (const float*)qkv, (float*)o, lse, bm, nprob, g);
-  else return VTX_ERR_DTYPE;
-  return vtx_check_launch();
+    return region ? wattn_fwd_launch<bf16, true>(qkv, o, lse, rel_pos, pos, region, nbn, g, st)
+                  : wattn_fwd_launch<bf16, false>(qkv, o, lse, rel_pos, pos, region, nbn, g, st);
+  if (dtype == VTX_F32)
+    return region ? wattn_fwd_launch<float, true>(qkv, o, lse, rel_pos, pos, region, nbn, g, st)
+                  : wattn_fwd_launch<float, false>(qkv, o, lse, rel_pos, pos, region, nbn, g, st);
+  return VTX_ERR_DTYPE;
 }
 
 size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win) {
   const int nbn = B * (H / win) * (W / win);
-  return (size_t)wattn_bwd_blocks(nbn, nH) * nH * WA_NBIN * sizeof(float);
+  return (size_t)wattn_bwd_blocks(nbn, nH) * WA_WAVES * nH * WA_NBIN * sizeof(float);
 }
 
-int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const void* tables, int masked,
-                  void* dqkv, float* drel_pos, void* workspace, size_t ws_bytes, int B, int L, int nH, int H, int W,
-                  int win, int shift, int dtype, void* stream) {
-  if (!qkv || !o || !dout || !lse || !tables || !dqkv || !drel_pos || !workspace) return VTX_ERR_NULL;
+int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
+                  const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
+                  size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream) {
+  if (!qkv || !o || !dout || !lse || !rel_pos || !pos || !dqkv || !drel_pos || !workspace) return VTX_ERR_NULL;
   WinGeom g;
   int rc = win_geom(g, L, nH, H, W, win, shift);
   if (rc) return rc;
-  g.nWm = masked ? g.nW : 1;
   const int nbn = B * g.nW;
   if (nbn <= 0) return VTX_OK;
   if (ws_bytes < vtx_wattn_bwd_workspace(B, nH, H, W, win)) return VTX_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = wattn_bwd_blocks(nbn, nH);
-  const float* bm = (const float*)tables;
-  const float* bmT = bm + (size_t)g.nWm * nH * 4096;
-  const int* posT = (const int*)(bmT + (size_t)g.nWm * nH * 4096);
   float* part = (float*)workspace;
   if (dtype == VTX_BF16)
-    hipLaunchKernelGGL((wattn_bwd_kernel<bf16>), dim3(nblk, nH), dim3(64), 0, st, (const bf16*)qkv, (const bf16*)o,
-                       (const bf16*)dout, lse, bm, bmT, posT, (bf16*)dqkv, part, nbn, g);
+    rc = region ? wattn_bwd_launch<bf16, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st)
+                : wattn_bwd_launch<bf16, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st);
   else if (dtype == VTX_F32)
-    hipLaunchKernelGGL((wattn_bwd_kernel<float>), dim3(nblk, nH), dim3(64), 0, st, (const float*)qkv, (const float*)o,
-                       (const float*)dout, lse, bm, bmT, posT, (float*)dqkv, part, nbn, g);
+    rc = region ? wattn_bwd_launch<float, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st)
+                : wattn_bwd_launch<float, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st);
   else return VTX_ERR_DTYPE;
-  rc = vtx_check_launch();
   if (rc) return rc;
   const int ntab = (2 * win - 1) * (2 * win - 1);
+  const int nwaves = wattn_bwd_blocks(nbn, nH) * WA_WAVES;
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(ntab * nH), dim3(256), 0, st, (const float*)part, drel_pos,
-                     (float*)nullptr, nblk, ntab * nH, WA_NBIN * nH);
+                     (float*)nullptr, nwaves, ntab * nH, WA_NBIN * nH);
   return vtx_check_launch();
 }
 

@@ -16,6 +16,6 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 4; }
+int vtx_abi_version(void) { return 5; }
 
 }  // extern "C"

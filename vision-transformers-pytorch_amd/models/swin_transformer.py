@@ -72,14 +72,28 @@ class MultiHeadedLocalAttention(nn.Module):
         order, offsets = tables.pos_csr(pos, (2 * window_size - 1) ** 2)
         self.register_buffer("_csr_order", order, persistent=False)
         self.register_buffer("_csr_offsets", offsets, persistent=False)
+        self._region = None          # (local_mask version, device, region ids, structured?) -- see regions()
+
+    def regions(self):
+        """Region ids of the CURRENT local_mask buffer for the window-attention kernels (tables.mask_regions),
+        re-derived whenever the buffer is replaced or written (load_state_dict, .to())."""
+        if not self.shift:
+            return None, True
+        m = self.local_mask
+        key = (m._version, m.device, m.data_ptr())
+        if self._region is None or self._region[0] != key:
+            region, ok = tables.mask_regions(m)
+            self._region = (key, region, ok)
+        return self._region[1], self._region[2]
 
     def meta(self, eps=1e-6):
         w = self.window_size
+        region, fast = self.regions()
         return VF.AttentionMeta(
             self.n_head, self.dim_head, w * w, eps=eps,
             swin=(self.input_size[0], self.input_size[1], w, self.shift), pos=self.pos,
             mask=self.local_mask if self.shift else None, csr=(self._csr_order, self._csr_offsets),
-            ntab=(2 * w - 1) ** 2)
+            ntab=(2 * w - 1) ** 2, region=region, fast=fast)
 
     def check_input(self, input):
         if tuple(input.shape[1:3]) != self.input_size:

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvtx.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class VtxError(RuntimeError):
@@ -39,13 +39,11 @@ _SIGNATURES = {
     "vtx_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "vtx_wattn_tables_bytes": (c_size_t, [c_int, c_int]),
-    "vtx_wattn_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "vtx_wattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                              c_int, c_int, c_int, c_void_p]),
+    "vtx_wattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                              c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_wattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "vtx_wattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                              c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_wattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
     "vtx_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -137,27 +137,36 @@ class FeedForwardFn(Function):
 class AttentionMeta:
     """Static description of one attention module (geometry + integer tables on the device)."""
 
-    def __init__(self, n_head, dim_head, L, eps=1e-6, swin=None, pos=None, mask=None, csr=None, ntab=0):
+    def __init__(self, n_head, dim_head, L, eps=1e-6, swin=None, pos=None, mask=None, csr=None, ntab=0, region=None,
+                 fast=True):
         self.n_head, self.dim_head, self.L, self.eps = n_head, dim_head, L, eps
         self.swin, self.pos, self.mask, self.csr, self.ntab = swin, pos, mask, csr, ntab
+        # window-attention fast path: region ids of the mask (tables.mask_regions); fast=False when the mask buffer
+        # does not have the region structure -> generic masked kernels
+        self.region, self.fast = region, fast
+
+
+def _wattn_ok(rel_pos, meta):
+    return (rel_pos is not None and meta.swin is not None and meta.fast and
+            ops.wattn_supported(meta.dim_head, meta.swin[2]) and (meta.mask is None or meta.region is not None))
 
 
 def _attn_forward(qkv, rel_pos, meta):
-    """-> (o, lse, aux) where aux is what the matching backward needs (bias tensor or fast-path tables)."""
+    """-> (o, lse, aux) where aux is what the matching backward needs (the bias tensor of the generic path)."""
     B = qkv.shape[0]
-    if rel_pos is not None and meta.swin is not None and ops.wattn_supported(meta.dim_head, meta.swin[2]):
-        tables = ops.wattn_tables(rel_pos.detach(), meta.pos, meta.mask, meta.n_head)
-        o, lse = ops.wattn_fwd(qkv, tables, meta.mask is not None, B, meta.L, meta.n_head, meta.swin)
-        return o, lse, tables
+    if _wattn_ok(rel_pos, meta):
+        o, lse = ops.wattn_fwd(qkv, rel_pos.detach(), meta.pos, meta.region, B, meta.L, meta.n_head, meta.swin)
+        return o, lse, None
     bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
     o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias, mask=meta.mask)
     return o, lse, bias
 
 
-def _attn_backward(qkv, o, do, lse, aux, meta):
+def _attn_backward(qkv, o, do, lse, aux, meta, rel_pos=None):
     B = qkv.shape[0]
-    if aux is not None and aux.dtype == torch.uint8:        # fast-path tables
-        return ops.wattn_bwd(qkv, o, do, lse, aux, meta.mask is not None, B, meta.L, meta.n_head, meta.swin, meta.ntab)
+    if _wattn_ok(rel_pos, meta):
+        return ops.wattn_bwd(qkv, o, do, lse, rel_pos.detach(), meta.pos, meta.region, B, meta.L, meta.n_head,
+                             meta.swin, meta.ntab)
     return ops.attention_bwd(qkv, o, do, lse, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=aux,
                              mask=meta.mask, csr=meta.csr, ntab=meta.ntab)
 
@@ -169,14 +178,14 @@ class AttentionCoreFn(Function):
     def forward(ctx, qkv, rel_pos, meta):
         qkv = _c(qkv)
         o, lse, aux = _attn_forward(qkv, rel_pos, meta)
-        ctx.save_for_backward(qkv, o, lse, aux)
+        ctx.save_for_backward(qkv, o, lse, aux, rel_pos)
         ctx.meta = meta
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse, aux = ctx.saved_tensors
-        dqkv, drel = _attn_backward(qkv, o, _c(do), lse, aux, ctx.meta)
+        qkv, o, lse, aux, rel_pos = ctx.saved_tensors
+        dqkv, drel = _attn_backward(qkv, o, _c(do), lse, aux, ctx.meta, rel_pos)
         return dqkv, drel, None
 
 
@@ -201,14 +210,14 @@ class TransformerLayerFn(Function):
         h, z = ops.gemm(ln2, cast(fc1_w, T), 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
         y = ops.gemm(h, cast(fc2_w, T), 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
-                              mean2, rstd2, ln2, z, h, bias, s1, s2)
+                              mean2, rstd2, ln2, z, h, bias, s1, s2, rel_pos)
         ctx.meta, ctx.rps, ctx.dp_c = meta, rps, float(dp_c)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z, h,
-         bias, s1, s2) = ctx.saved_tensors
+         bias, s1, s2, rel_pos) = ctx.saved_tensors
         m, rps, dp_c = ctx.meta, ctx.rps, ctx.dp_c
         T = x.dtype
         dy = _c(dy)
@@ -222,7 +231,7 @@ class TransformerLayerFn(Function):
         # ---- attention branch
         dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
         do = dgrad(dx1, proj_w, T, rowscale=s1, rows_per_scale=rps)
-        dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m)
+        dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m, rel_pos)
         dWq, dbq = ops.wgrad(dqkv, ln1)
         dln1 = dgrad(dqkv, qkv_w, T)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)

@@ -304,38 +304,30 @@ def wattn_supported(D, win):
     return D == 32 and win <= 7
 
 
-def wattn_tables(rel_pos, pos, mask, n_head):
-    """Pre-combined rel-pos bias + mask tables for the one-wave-per-window kernels (built per layer call)."""
-    _dev(rel_pos, pos, mask)
+def wattn_fwd(qkv, rel_pos, pos, region, B, L, n_head, swin):
+    """Window attention forward: region = None (un-shifted) or the uint8 [nW, 64] ids of tables.mask_regions."""
+    _dev(qkv, rel_pos, pos, region)
     _f32(rel_pos, "rel_pos")
-    lib = _lib.load()
-    L = pos.shape[0]
-    nW = mask.shape[0] if mask is not None else 1
-    nbytes = lib.vtx_wattn_tables_bytes(n_head, nW)
-    tables = torch.empty(nbytes, dtype=torch.uint8, device=rel_pos.device)
-    check(lib.vtx_wattn_tables(_p(rel_pos), _p(pos), _p(mask), _p(tables), L, n_head, nW, _stream()), "vtx_wattn_tables")
-    return tables
-
-
-def wattn_fwd(qkv, tables, masked, B, L, n_head, swin):
-    _dev(qkv, tables)
+    if pos.dtype != torch.int64:
+        raise VtxError("vtx: pos must be int64 (the reference's buffer dtype)")
     H, W, win, shift = swin
     o = torch.empty(qkv.shape[:-1] + (n_head * 32,), dtype=qkv.dtype, device=qkv.device)
     nW = (H // win) * (W // win)
     lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().vtx_wattn_fwd(_p(qkv), _p(o), _p(lse), _p(tables), int(masked), B, L, n_head, H, W, win,
+    check(_lib.load().vtx_wattn_fwd(_p(qkv), _p(o), _p(lse), _p(rel_pos), _p(pos), _p(region), B, L, n_head, H, W, win,
                                     int(bool(shift)), _dt(qkv), _stream()), "vtx_wattn_fwd")
     return o, lse
 
 
-def wattn_bwd(qkv, o, dout, lse, tables, masked, B, L, n_head, swin, ntab):
-    _dev(qkv, o, dout, lse, tables)
+def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab):
+    _dev(qkv, o, dout, lse, rel_pos, pos, region)
     lib = _lib.load()
     H, W, win, shift = swin
     dqkv = torch.empty_like(qkv)
     drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
     wsb = lib.vtx_wattn_bwd_workspace(B, n_head, H, W, win)
     ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
-    check(lib.vtx_wattn_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(tables), int(masked), _p(dqkv), _p(drel), _p(ws),
-                            wsb, B, L, n_head, H, W, win, int(bool(shift)), _dt(qkv), _stream()), "vtx_wattn_bwd")
+    check(lib.vtx_wattn_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(rel_pos), _p(pos), _p(region), _p(dqkv), _p(drel),
+                            _p(ws), wsb, B, L, n_head, H, W, win, int(bool(shift)), _dt(qkv), _stream()),
+          "vtx_wattn_bwd")
     return dqkv, drel

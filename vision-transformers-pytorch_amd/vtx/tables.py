@@ -48,3 +48,24 @@ def pos_csr(pos, ntab):
     offsets = torch.zeros(ntab + 1, dtype=torch.int32)
     offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return order, offsets
+
+
+def mask_regions(local_mask):
+    """Region ids of a shifted-window mask: -> (region uint8 (nW, 64), ok).
+
+    The reference's local_mask (swin_transformer.py:82-89) is an equivalence structure -- tokens of a window attend to
+    each other iff they come from the same side of the cyclic-shift seams -- so it is carried to the window-attention
+    kernels as ONE id per token: region[n, a] = first b with local_mask[n, a, b] == False, and
+    local_mask[n, a, b] == (region[n, a] != region[n, b]).  `ok` is False when the given buffer does not have that
+    structure (e.g. a hand-edited mask from a checkpoint); callers then use the generic masked kernels instead.
+    """
+    keep = ~local_mask.bool()
+    nW, L, _ = keep.shape
+    if L > 63:
+        return None, False
+    region = keep.to(torch.uint8).argmax(-1)                         # first attended key of every query
+    ok = bool(torch.equal(region[:, :, None] == region[:, None, :], keep))
+    out = torch.zeros((nW, 64), dtype=torch.uint8, device=local_mask.device)
+    out[:, :L] = region.to(torch.uint8)
+    out[:, 63] = local_mask.bool().flatten(1).any(1).to(torch.uint8)   # "this window has masked pairs" (L <= 49 < 64)
+    return out.contiguous(), ok
