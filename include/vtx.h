@@ -116,6 +116,15 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
                   size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream);
 
+/* ---- Multi-tensor weight cast (csrc/cast.hip): all fp32 Linear / Conv weights of a model -> bf16, plain [out][in]
+ * and transposed [in][out], in one launch per forward.  This is the per-call weight cast of the reference's bf16
+ * autocast (torch.cuda.amp.autocast around model(input), train.py:273-274) done once for the whole model.
+ * desc: device array of nmat records {const float* src; int64 off; int rows, cols, tile0, tiles_c}
+ * (vtx_cast_desc_bytes() each); ntiles = sum ceil(rows/64)*ceil(cols/64); matrix i occupies
+ * [off_i, off_i + rows_i*cols_i) of both flat bf16 outputs. */
+size_t vtx_cast_desc_bytes(void);
+int vtx_cast_weights(const void* desc, int nmat, int ntiles, void* dst, void* dst_t, void* stream);
+
 /* ---- Patch gather: NCHW fp32 image -> patch matrix [B*(H/p)*(W/p), Kp] of dtype, columns >= 3*p*p zero.
  *   order 0: column (py, px, c)  -- Swin: permute(0,2,3,1) + patchify(4) (models/swin_transformer.py:15-22,
  *            208-213, 371); the Linear(48, C) then runs as vtx_gemm on the padded K = Kp

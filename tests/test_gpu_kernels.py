@@ -257,3 +257,23 @@ def test_wgrad_droppath_zero_rows(dtype):
     keep = (scale > 0).double().repeat_interleave(T)[:, None]
     check(f"wgrad zero-row dW {dtype}", dW, c * (keep * dy.double()).t() @ x.double(), 2e-5)
     check(f"wgrad zero-row db {dtype}", db, c * (keep * dy.double()).sum(0), 2e-5)
+
+
+def test_cast_weights_multi_tensor():
+    """One-launch fp32 -> bf16 cast of a list of matrices, plain + transposed (csrc/cast.hip), incl. ragged sizes,
+    a 4-D conv weight and a weight-normed layer (whose weight is not a leaf parameter and must be skipped)."""
+    from vtx import functional as VF
+    d = dev()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(48, 96), torch.nn.Linear(96, 1000, bias=False),
+                              torch.nn.Conv2d(3, 40, 16, stride=16), torch.nn.LayerNorm(7), torch.nn.Linear(1, 1),
+                              torch.nn.utils.weight_norm(torch.nn.Linear(64, 32))).to(d)
+    plan = VF.WeightPlan(net)
+    assert len(plan.params) == 4
+    got = plan.cast_all()
+    for p in plan.params:
+        w, wt = got[id(p)]
+        assert w.shape == p.shape and w.dtype == torch.bfloat16
+        assert torch.equal(w, p.detach().to(torch.bfloat16))
+        assert torch.equal(wt, p.detach().reshape(p.shape[0], -1).t().contiguous().to(torch.bfloat16))
+        assert w.data_ptr() % 128 == 0 and wt.data_ptr() % 128 == 0

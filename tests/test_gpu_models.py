@@ -275,3 +275,45 @@ def test_grad_allreduce_on_rccl_single_rank():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_bf16_weights_follow_optimizer_updates(fused):
+    """The bf16 GEMM operands must reflect the CURRENT fp32 parameters on every forward (like the reference's
+    per-call autocast casts): torch's fused AdamW does not bump tensor version counters, `.data` EMA updates do not
+    either -- any cache keyed on them would train on stale weights.  After each optimizer step (and after a `.data`
+    update) the model's logits must equal, bit for bit, those of a freshly built model loaded with its state_dict."""
+    import copy
+    from models import SwinTransformer
+    from vtx.train_step import MixLoss, train_step
+    cfg = dict(image_size=(224, 224), n_class=16, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32,
+               n_heads=(1, 2, 4, 8), dim_ffs=(128, 256, 512, 1024), window_size=7)
+    torch.manual_seed(3)
+    model = SwinTransformer(**cfg, drop_path=0.0).to(dev()).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=fused)
+    g = torch.Generator(device=dev()).manual_seed(5)
+    x = torch.randn(4, 3, 224, 224, device=dev(), generator=g)
+    l1 = torch.randint(0, 10, (4,), device=dev(), generator=g)
+    data = (x, l1, l1.roll(1), torch.rand(4, device=dev(), generator=g))
+
+    def logits(m):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x).float()
+
+    def fresh():
+        m = SwinTransformer(**cfg, drop_path=0.0).to(dev()).train()
+        m.load_state_dict(copy.deepcopy(model.state_dict()))
+        return m
+
+    prev = logits(model)
+    for step in range(2):
+        train_step(model, MixLoss(0.1), opt, data, clip_grad_norm=5.0)
+        cur = logits(model)
+        assert not torch.equal(cur, prev), "the optimizer step did not change the bf16 forward at all"
+        assert torch.equal(cur, logits(fresh())), f"stale bf16 weights after step {step} (fused={fused})"
+        prev = cur
+    with torch.no_grad():                                        # EMA-style update through .data (train_util.py:70-84)
+        for p in model.parameters():
+            p.data.mul_(0.5)
+    assert torch.equal(logits(model), logits(fresh())), "stale bf16 weights after a .data update"

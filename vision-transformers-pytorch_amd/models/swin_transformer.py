@@ -246,13 +246,14 @@ class SwinTransformer(nn.Module):
         return nn.Sequential(*block)
 
     def forward(self, input):
-        out = self.patch_embedding.forward_nchw(input)       # permute(0,2,3,1) + patchify folded into the gather
-        out = self.block1(out)
-        out = self.block2(out)
-        out = self.block3(out)
-        out = self.block4(out)
-        norm = self.final_linear[0]
-        out = VF.LayerNormFn.apply(out, norm.weight, norm.bias, norm.eps)
-        out = VF.TokenMeanFn.apply(out)                       # AdaptiveAvgPool2d(1) + Flatten(1) on NHWC
-        cls = self.classifier[2]
-        return VF.LinearFn.apply(out, cls.weight, cls.bias)
+        with VF.weight_scope(self, input):                   # bf16: one multi-tensor cast of all weights per forward
+            out = self.patch_embedding.forward_nchw(input)   # permute(0,2,3,1) + patchify folded into the gather
+            out = self.block1(out)
+            out = self.block2(out)
+            out = self.block3(out)
+            out = self.block4(out)
+            norm = self.final_linear[0]
+            out = VF.LayerNormFn.apply(out, norm.weight, norm.bias, norm.eps)
+            out = VF.TokenMeanFn.apply(out)                   # AdaptiveAvgPool2d(1) + Flatten(1) on NHWC
+            cls = self.classifier[2]
+            return VF.LinearFn.apply(out, cls.weight, cls.bias)

@@ -174,12 +174,13 @@ class VisionTransformer(nn.Module):
         crops = torch.cumsum(
             torch.unique_consecutive(torch.tensor([i.shape[-1] for i in input]), return_counts=True)[1], 0)
         start = 0
-        for end in crops:
-            out = self.forward_feature(torch.cat(input[start:end]))
-            output = out if start == 0 else torch.cat((output, out))
-            start = end
-        if self.head is not None:
-            output = self.head(output)
+        with VF.weight_scope(self, input[0]):                # bf16: one multi-tensor cast of all weights per forward
+            for end in crops:
+                out = self.forward_feature(torch.cat(input[start:end]))
+                output = out if start == 0 else torch.cat((output, out))
+                start = end
+            if self.head is not None:
+                output = self.head(output)
         return output
 
 

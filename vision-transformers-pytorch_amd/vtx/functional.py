@@ -6,7 +6,9 @@ the hand-written kernel sequence, so parameters stay fp32 leaf nn.Parameters tha
 optimizer keep working).  Activations are stored in the compute dtype T (fp32, or bf16 under
 ``torch.autocast(dtype=torch.bfloat16)``); statistics / parameter gradients are fp32.
 """
-import weakref
+import contextlib
+import struct
+import threading
 
 import torch
 from torch.autograd import Function
@@ -27,45 +29,101 @@ def compute_dtype(x):
     raise VtxError(f"vtx: unsupported activation dtype {x.dtype}")
 
 
-_cast_cache = {}
+# ------------------------------------------------------------------------------------------- bf16 weight operands
+# Per-forward semantics, like the reference under autocast (weights are cast inside every linear call, cached only
+# for the duration of one autocast region): the bf16 operands always reflect the CURRENT fp32 parameters.  No cache
+# survives a forward pass -- tensor version counters cannot be trusted for that (torch's fused optimizers and
+# `.data` EMA updates change parameters without bumping them).  A top-level model wraps its forward in
+# ``weight_scope(self, input)``: ONE multi-tensor HIP kernel (csrc/cast.hip) casts every Linear / Conv weight, plain
+# and transposed; autograd Functions stash the pair they used for their own backward.
+_tls = threading.local()
 
 
-def cast(p, dtype):
-    """Parameter in the compute dtype; bf16 copies are cached until the parameter is updated in place."""
-    if p is None:
-        return None
+class WeightPlan:
+    """The Linear / Conv2d weights of one model and the device descriptor table of the multi-tensor cast."""
+
+    def __init__(self, module):
+        self.params = []
+        for m in module.modules():                    # leaf parameters only (weight_norm'd layers recompute theirs)
+            w = m._parameters.get("weight") if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)) else None
+            if w is not None and w.dtype == torch.float32 and w.is_cuda:
+                self.params.append(w)
+        self.key, self.desc, self.offs, self.total, self.ntiles = None, None, None, 0, 0
+
+    def _prepare(self):
+        key = tuple((p.data_ptr(), p.device) for p in self.params)
+        if key == self.key:
+            return
+        offs, recs, off, tile0 = [], [], 0, 0
+        for p in self.params:
+            rows, cols = p.shape[0], p.numel() // p.shape[0]
+            tr, tc = (rows + 63) // 64, (cols + 63) // 64
+            recs.append(struct.pack("<QqiiiI", p.data_ptr(), off, rows, cols, tile0, tc))
+            offs.append(off)
+            off += (rows * cols + 63) // 64 * 64                  # keep every matrix 128-byte aligned
+            tile0 += tr * tc
+        assert struct.calcsize("<QqiiiI") == ops.cast_desc_bytes()
+        dev = self.params[0].device
+        self.desc = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        self.key, self.offs, self.total, self.ntiles = key, offs, off, tile0
+
+    def cast_all(self):
+        """-> {id(param): (plain bf16 view [param shape], transposed bf16 view [in, out])}, fresh buffers."""
+        if not self.params:
+            return {}
+        self._prepare()
+        dev = self.params[0].device
+        flat = torch.empty(self.total, dtype=torch.bfloat16, device=dev)
+        flat_t = torch.empty(self.total, dtype=torch.bfloat16, device=dev)
+        ops.cast_weights(self.desc, len(self.params), self.ntiles, flat, flat_t)
+        out = {}
+        for p, off in zip(self.params, self.offs):
+            n, rows = p.numel(), p.shape[0]
+            out[id(p)] = (flat[off:off + n].view(p.shape), flat_t[off:off + n].view(n // rows, rows))
+        return out
+
+
+@contextlib.contextmanager
+def weight_scope(module, x):
+    """Cast all of ``module``'s matrix weights to bf16 once for this forward (no-op in fp32 mode / when nested)."""
+    if getattr(_tls, "scope", None) is not None or not x.is_cuda or compute_dtype(x) != torch.bfloat16:
+        yield
+        return
+    plan = module.__dict__.get("_vtx_weight_plan")
+    ids = [id(m) for m in module.modules()]
+    if plan is None or plan[0] != ids:
+        plan = (ids, WeightPlan(module))
+        module.__dict__["_vtx_weight_plan"] = plan
+    _tls.scope = plan[1].cast_all()
+    try:
+        yield
+    finally:
+        _tls.scope = None
+
+
+def wcast(p, dtype):
+    """Weight operand pair (plain [out, in...], transposed [in, out] or None) of parameter ``p`` in the compute dtype.
+    From the enclosing weight_scope if there is one, else cast now (the transposed copy then comes lazily, dgrad)."""
     if p.dtype == dtype:
-        return p.detach()
-    key = id(p)
-    ent = _cast_cache.get(key)
-    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2].dtype == dtype \
-            and ent[2].device == p.device:
-        return ent[2]
-    t = p.detach().to(dtype)
-    if len(_cast_cache) > 4096:
-        _cast_cache.clear()
-    _cast_cache[key] = (weakref.ref(p), p._version, t)
-    return t
+        return (p.detach(), None)
+    sc = getattr(_tls, "scope", None)
+    if sc is not None:
+        ent = sc.get(id(p))
+        if ent is not None and ent[0].dtype == dtype:
+            return ent
+    return (p.detach().to(dtype), None)
 
 
-def cast_t(p, dtype):
-    """Transposed ([in, out]) copy of a Linear weight in the compute dtype, cached like ``cast``."""
-    key = (id(p), "t")
-    ent = _cast_cache.get(key)
-    if ent is not None and ent[0]() is p and ent[1] == p._version and ent[2].dtype == dtype \
-            and ent[2].device == p.device:
-        return ent[2]
-    t = p.detach().t().contiguous().to(dtype)
-    _cast_cache[key] = (weakref.ref(p), p._version, t)
-    return t
-
-
-def dgrad(dy, w, T, **epi):
-    """dx = epi(dy @ W).  bf16 with out-features % 64 == 0: the LDS-DMA forward-layout kernel on a transposed
-    weight copy (made once per step); otherwise the register-staged NN kernel on W itself."""
-    if T == torch.bfloat16 and w.shape[0] % 64 == 0:
-        return ops.gemm(dy, cast_t(w, T), 0, **epi)
-    return ops.gemm(dy, cast(w, T), 1, **epi)
+def dgrad(dy, wp, T, **epi):
+    """dx = epi(dy @ W) for a ``wcast`` pair.  bf16 with out-features % 64 == 0: the LDS-DMA forward-layout kernel on
+    the transposed copy; otherwise the register-staged NN kernel on W itself."""
+    w, wt = wp
+    w2 = w.view(w.shape[0], -1)
+    if T == torch.bfloat16 and w2.shape[0] % 64 == 0:
+        if wt is None:
+            wt = w2.t().contiguous()
+        return ops.gemm(dy, wt, 0, **epi)
+    return ops.gemm(dy, w2, 1, **epi)
 
 
 def _c(t):
@@ -93,8 +151,8 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = _c(x)
-        w = cast(weight, x.dtype)
-        y = ops.gemm(x, w, 0, bias=None if bias is None else bias.detach())
+        ctx.wp = wcast(weight, x.dtype)
+        y = ops.gemm(x, ctx.wp[0], 0, bias=None if bias is None else bias.detach())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -103,9 +161,8 @@ class LinearFn(Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = _c(dy)
-        w = cast(weight, x.dtype)
         dW, db = ops.wgrad(dy, x, want_bias=ctx.has_bias)
-        dx = dgrad(dy, weight, x.dtype) if ctx.needs_input_grad[0] else None
+        dx = dgrad(dy, ctx.wp, x.dtype) if ctx.needs_input_grad[0] else None
         return dx, dW.view_as(weight), db
 
 
@@ -117,8 +174,9 @@ class FeedForwardFn(Function):
     def forward(ctx, x, w1, b1, w2, b2):
         x = _c(x)
         T = x.dtype
-        h, z = ops.gemm(x, cast(w1, T), 0, bias=b1.detach(), act=ACT_SILU, want_aux=True)
-        y = ops.gemm(h, cast(w2, T), 0, bias=b2.detach())
+        ctx.wp = (wcast(w1, T), wcast(w2, T))
+        h, z = ops.gemm(x, ctx.wp[0][0], 0, bias=b1.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, ctx.wp[1][0], 0, bias=b2.detach())
         ctx.save_for_backward(x, w1, w2, z, h)
         return y
 
@@ -128,9 +186,9 @@ class FeedForwardFn(Function):
         T = x.dtype
         dy = _c(dy)
         dW2, db2 = ops.wgrad(dy, h)
-        dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z)
+        dz = dgrad(dy, ctx.wp[1], T, act=ACT_DSILU, aux_in=z)
         dW1, db1 = ops.wgrad(dz, x)
-        dx = dgrad(dz, w1, T)
+        dx = dgrad(dz, ctx.wp[0], T)
         return dx, dW1, db1, dW2, db2
 
 
@@ -203,12 +261,13 @@ class TransformerLayerFn(Function):
         B, C = x.shape[0], x.shape[-1]
         rps = (x.numel() // C) // B
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), meta.eps)
-        qkv = ops.gemm(ln1, cast(qkv_w, T), 0, bias=qkv_b.detach())
+        wq, wo, w1, w2 = ctx.wp = (wcast(qkv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T))
+        qkv = ops.gemm(ln1, wq[0], 0, bias=qkv_b.detach())
         o, lse, bias = _attn_forward(qkv, rel_pos, meta)
-        x1 = ops.gemm(o, cast(proj_w, T), 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
+        x1 = ops.gemm(o, wo[0], 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), meta.eps)
-        h, z = ops.gemm(ln2, cast(fc1_w, T), 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
-        y = ops.gemm(h, cast(fc2_w, T), 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
+        h, z = ops.gemm(ln2, w1[0], 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, w2[0], 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
                               mean2, rstd2, ln2, z, h, bias, s1, s2, rel_pos)
         ctx.meta, ctx.rps, ctx.dp_c = meta, rps, float(dp_c)
@@ -219,21 +278,22 @@ class TransformerLayerFn(Function):
         (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z, h,
          bias, s1, s2, rel_pos) = ctx.saved_tensors
         m, rps, dp_c = ctx.meta, ctx.rps, ctx.dp_c
+        wq, wo, w1, w2 = ctx.wp
         T = x.dtype
         dy = _c(dy)
         B = x.shape[0]
         # ---- MLP branch
         dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
-        dz = dgrad(dy, fc2_w, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
+        dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
         dW1, db1 = ops.wgrad(dz, ln2)
-        dln2 = dgrad(dz, fc1_w, T)
+        dln2 = dgrad(dz, w1, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
         dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
-        do = dgrad(dx1, proj_w, T, rowscale=s1, rows_per_scale=rps)
+        do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
         dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m, rel_pos)
         dWq, dbq = ops.wgrad(dqkv, ln1)
-        dln1 = dgrad(dqkv, qkv_w, T)
+        dln1 = dgrad(dqkv, wq, T)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
@@ -247,7 +307,8 @@ class PatchMergeFn(Function):
         x = _c(x)
         H, W = x.shape[1], x.shape[2]
         ln, mean, rstd = ops.layernorm_fwd(x, ln_w.detach(), ln_b.detach(), eps, merge_hw=(H, W))
-        y = ops.gemm(ln, cast(w, x.dtype), 0)
+        ctx.wp = wcast(w, x.dtype)
+        y = ops.gemm(ln, ctx.wp[0], 0)
         ctx.save_for_backward(x, ln_w, w, ln, mean, rstd)
         return y
 
@@ -256,7 +317,7 @@ class PatchMergeFn(Function):
         x, ln_w, w, ln, mean, rstd = ctx.saved_tensors
         dy = _c(dy)
         dW, _ = ops.wgrad(dy, ln, want_bias=False)
-        dln = dgrad(dy, w, x.dtype)
+        dln = dgrad(dy, ctx.wp, x.dtype)
         dx, dg, db = ops.layernorm_bwd(dln, x, mean, rstd, ln_w.detach(), merge_hw=(x.shape[1], x.shape[2]))
         return dx, dg, db, dW, None
 
@@ -268,7 +329,7 @@ class SwinPatchEmbedFn(Function):
     @staticmethod
     def forward(ctx, x_nchw, w, b, ln_w, ln_b, patch, eps, dtype):
         patches = ops.patch_gather(_c(x_nchw), patch, 0, dtype)
-        t = ops.gemm(patches, cast(w, dtype), 0, bias=b.detach())
+        t = ops.gemm(patches, wcast(w, dtype)[0], 0, bias=b.detach())
         y, mean, rstd = ops.layernorm_fwd(t, ln_w.detach(), ln_b.detach(), eps)
         ctx.save_for_backward(patches, t, mean, rstd, ln_w)
         return y
@@ -290,7 +351,7 @@ class VitPatchEmbedFn(Function):
         C, Cin, p, _ = w.shape
         patches = ops.patch_gather(_c(x_nchw), p, 1, dtype)
         B, gh, gw, K = patches.shape
-        y = ops.gemm(patches.view(B, gh * gw, K), cast(w, dtype).view(C, K), 0, bias=b.detach())
+        y = ops.gemm(patches.view(B, gh * gw, K), wcast(w, dtype)[0].view(C, K), 0, bias=b.detach())
         ctx.save_for_backward(patches)
         ctx.wshape = w.shape
         return y

@@ -192,6 +192,16 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.
 
 
 # ------------------------------------------------------------------------------- data movement
+def cast_desc_bytes():
+    return _lib.load().vtx_cast_desc_bytes()
+
+
+def cast_weights(desc, nmat, ntiles, flat, flat_t):
+    """Multi-tensor fp32 -> bf16 weight cast (plain + transposed copies), one launch (csrc/cast.hip)."""
+    _dev(desc, flat, flat_t)
+    check(_lib.load().vtx_cast_weights(_p(desc), nmat, ntiles, _p(flat), _p(flat_t), _stream()), "vtx_cast_weights")
+
+
 def patch_gather(x_nchw, patch, order, dtype, kp=None):
     """NCHW fp32 image -> [B, H/p, W/p, Kp] patch matrix of `dtype` (order 0: Swin (py,px,c); 1: ViT (c,py,px))."""
     _dev(x_nchw)
