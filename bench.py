@@ -29,6 +29,23 @@ SWIN_S = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2), dims=(9
               n_heads=(3, 6, 12, 24), dim_ffs=(384, 768, 1536, 3072), window_size=7)
 TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59}      # BASELINE.md section 2 (3 x forward GEMM FLOPs)
 PEAK_BF16_TFLOPS = 2500.0                                       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3                                         # dense fp32 MFMA peak (parity mode)
+
+
+def pmc_traffic(model, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (tools/pmc_traffic.sh: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes) -- PMC collection cannot
+    run inside the timed process, so the figure comes from profiles/; None when no summary is committed."""
+    path = os.path.join(REPO, "profiles", f"round1_pmc_traffic_{model}.json")
+    try:
+        tab = json.load(open(path))
+    except OSError:
+        return None, None
+    key = kernel.replace(" ", "")
+    for k, v in tab.items():
+        if k.replace(" ", "") == key:
+            return v["fetch_x2_bytes"] + v["write_bytes"], os.path.relpath(path, REPO)
+    return None, None
 
 
 def build_model(name, drop_path):
@@ -83,7 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -154,15 +171,19 @@ def main():
         if timer is not None:
             summ = timer.summary()
             name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            peak = PEAK_BF16_TFLOPS if ac else PEAK_F32_TFLOPS
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS if ac else 157.3,
-                        unit="TFLOP/s", frac=round(ach / (PEAK_BF16_TFLOPS if ac else 157.3), 4), traffic=None,
+            traffic, tsrc = pmc_traffic(args.model, name)
+            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=traffic, traffic_source=tsrc,
+                        algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
+                        algorithmic_flops_per_launch=round(d["flops"] / d["launches"]),
                         launches_per_step=d["launches"] // args.steps,
                         avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                        hbm_gbps_algorithmic=round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
                         gemm_family={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
                                              ms_per_step=round(v["ms"] / args.steps, 3)) for k, v in summ.items()},
-                        end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[args.model] / 1e3 /
-                                              (PEAK_BF16_TFLOPS if ac else 157.3), 4))
+                        end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[args.model] / 1e3 / peak, 4))
         line = {
             "metric": "images/sec training (fwd+bwd+step)", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

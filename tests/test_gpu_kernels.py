@@ -277,3 +277,28 @@ def test_cast_weights_multi_tensor():
         assert torch.equal(w, p.detach().to(torch.bfloat16))
         assert torch.equal(wt, p.detach().reshape(p.shape[0], -1).t().contiguous().to(torch.bfloat16))
         assert w.data_ptr() % 128 == 0 and wt.data_ptr() % 128 == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N", [10, 100])
+def test_linear_ragged_out_features(dtype, N):
+    """nn.Linear with out-features that are not a multiple of the 16-byte vector (10- / 100-way classifiers)."""
+    from vtx import functional as VF
+    d = dev()
+    x = _mk((24, 768), 91, dtype)
+    w = _mk((N, 768), 92, torch.float32, 0.05)
+    b = _mk((N,), 93, torch.float32, 0.1)
+    dy = _mk((24, N), 94, dtype)
+    xd, wd, bd = x.to(d).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = VF.LinearFn.apply(xd, wd, bd)
+    assert tuple(y.shape) == (24, N)
+    gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], dy.to(d))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = R.linear(xr, wr, br)
+    rx, rw, rb = torch.autograd.grad(yr, [xr, wr, br], dy.double())
+    t = TOL[dtype]
+    check(f"linear N={N} {dtype} y", y, yr, t["out"])
+    check(f"linear N={N} {dtype} dx", gx, rx, t["grad"])
+    check(f"linear N={N} {dtype} dW", gw, rw, t["grad"])
+    check(f"linear N={N} {dtype} db", gb, rb, t["grad"])
+    assert gw.shape == w.shape and gb.shape == b.shape

@@ -14,23 +14,23 @@ for what in "$@"; do
       timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/benchq.log ;;
     profvit:*)
       tag=${what#profvit:}
-      mkdir -p gpurun_out/prof_$tag
+      mkdir -p gpurun_out/profvit_${tag}
       export TMPDIR=/tmp
-      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o trace -- \
-         python $R/bench.py --model vit_s16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_$tag/run.log 2>&1)
-      grep '"metric"' gpurun_out/prof_$tag/run.log | cut -c1-220
-      python tools/rocpd_stats.py gpurun_out/prof_$tag/trace_results.db --steps 7 --top 70 > gpurun_out/prof_$tag/kernel_stats.md
-      rm -f gpurun_out/prof_$tag/trace_results.db
-      head -16 gpurun_out/prof_$tag/kernel_stats.md | cut -c1-170 ;;
+      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profvit_${tag} -o trace -- \
+         python $R/bench.py --model vit_s16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/profvit_${tag}/run.log 2>&1)
+      grep '"metric"' gpurun_out/profvit_${tag}/run.log | cut -c1-220
+      python tools/rocpd_stats.py gpurun_out/profvit_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/profvit_${tag}/kernel_stats.md
+      rm -f gpurun_out/profvit_${tag}/trace_results.db
+      head -16 gpurun_out/profvit_${tag}/kernel_stats.md | cut -c1-170 ;;
     prof:*)
       tag=${what#prof:}
-      mkdir -p gpurun_out/prof_$tag
+      mkdir -p gpurun_out/prof_${tag}
       export TMPDIR=/tmp
-      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o trace -- \
-         python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_$tag/run.log 2>&1)
-      grep '"metric"' gpurun_out/prof_$tag/run.log | cut -c1-220
-      python tools/rocpd_stats.py gpurun_out/prof_$tag/trace_results.db --steps 7 --top 70 > gpurun_out/prof_$tag/kernel_stats.md
-      rm -f gpurun_out/prof_$tag/trace_results.db
-      head -24 gpurun_out/prof_$tag/kernel_stats.md | cut -c1-170 ;;
+      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o trace -- \
+         python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_${tag}/run.log 2>&1)
+      grep '"metric"' gpurun_out/prof_${tag}/run.log | cut -c1-220
+      python tools/rocpd_stats.py gpurun_out/prof_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/prof_${tag}/kernel_stats.md
+      rm -f gpurun_out/prof_${tag}/trace_results.db
+      head -24 gpurun_out/prof_${tag}/kernel_stats.md | cut -c1-170 ;;
   esac
 done

@@ -24,7 +24,7 @@ def main():
     rows = c.execute(q).fetchall()
     names = sorted({r[0] for r in rows})
     try:
-        dm = dict(zip(names, subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names),
+        dm = dict(zip(names, subprocess.run(["c++filt"], input="\n".join(n.replace(".kd", "").replace("DF16b", "u6__bf16") for n in names),
                                             capture_output=True, text=True).stdout.split("\n")))
     except Exception:
         dm = {n: n for n in names}

@@ -10,8 +10,9 @@ import subprocess
 
 
 def demangle(names):
+    bare = [(n[:-3] if n.endswith(".kd") else n).replace("DF16b", "u6__bf16") for n in names]   # GNU c++filt lacks __bf16      # rocprofv3 appends ".kd" (kernel descriptor)
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True,
+        out = subprocess.run(["c++filt"], input="\n".join(bare), capture_output=True,
                              text=True, check=True).stdout.split("\n")
         return dict(zip(names, out))
     except Exception:
@@ -19,8 +20,14 @@ def demangle(names):
 
 
 def short(n):
-    n = re.sub(r"\(.*$", "", n)            # drop the argument list
-    n = n.replace("void ", "")
+    n = n.replace("void ", "", 1)
+    depth = 0
+    for i, ch in enumerate(n):              # drop the argument list (the first "(" outside template brackets)
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            n = n[:i]
+            break
     return n[:110]
 
 

@@ -146,23 +146,38 @@ class LayerNormFn(Function):
 
 
 class LinearFn(Function):
-    """y = x W^T + b  (nn.Linear).  Output dtype = x dtype."""
+    """y = x W^T + b  (nn.Linear).  Output dtype = x dtype.
+
+    The kernels move 16-byte vectors, i.e. need out-features % 8 == 0 (bf16; % 4 in fp32).  Other widths (a 10- or
+    100-way classifier) run on a zero-padded weight / bias; the pad columns are sliced off the result and their
+    gradients dropped, so the module's parameters keep the reference's shapes."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = _c(x)
-        ctx.wp = wcast(weight, x.dtype)
-        y = ops.gemm(x, ctx.wp[0], 0, bias=None if bias is None else bias.detach())
+        wp = wcast(weight, x.dtype)
+        N = weight.shape[0]
+        pad = (-N) % 8
+        b = None if bias is None else bias.detach()
+        if pad:
+            wp = (torch.nn.functional.pad(wp[0], (0, 0, 0, pad)), None)
+            b = None if b is None else torch.nn.functional.pad(b, (0, pad))
+        ctx.wp, ctx.pad = wp, pad
+        y = ops.gemm(x, wp[0], 0, bias=b)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return y
+        return y[..., :N] if pad else y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = _c(dy)
+        N = weight.shape[0]
+        dy = torch.nn.functional.pad(dy, (0, ctx.pad)) if ctx.pad else _c(dy)
         dW, db = ops.wgrad(dy, x, want_bias=ctx.has_bias)
         dx = dgrad(dy, ctx.wp, x.dtype) if ctx.needs_input_grad[0] else None
+        if ctx.pad:
+            dW = dW[:N].contiguous()
+            db = None if db is None else db[:N].contiguous()
         return dx, dW.view_as(weight), db
 
 

@@ -101,19 +101,21 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def bracket(self, name, flops):
+    def bracket(self, name, flops, nbytes=0.0):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        self.records.append((name, flops, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1))
         return e0, e1
 
     def summary(self):
-        """{kernel: dict(launches, flops, ms)} -- call after torch.cuda.synchronize()."""
+        """{kernel: dict(launches, flops, bytes, ms)} -- call after torch.cuda.synchronize().  bytes = algorithmic HBM
+        bytes (every operand read once, every output written once)."""
         out = {}
-        for name, flops, e0, e1 in self.records:
-            d = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+        for name, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -163,7 +165,11 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
         raise VtxError(f"vtx: gemm contraction mismatch ({K} vs {kw})")
     c = out if out is not None else torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
     aux = torch.empty_like(c) if want_aux else None
-    ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M), 2.0 * M * N * K) if _timer is not None else None
+    ev = None
+    if _timer is not None:
+        es = a.element_size()
+        nb = es * (M * K + N * K + M * N * (1 + (resid is not None) + bool(want_aux) + (aux_in is not None)))
+        ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M), 2.0 * M * N * K, float(nb))
     if ev:
         ev[0].record()
     check(lib.vtx_gemm(mode, _dt(a), _p(a), _p(w), _p(c), M, N, K, K, w.shape[1], N, _p(bias), _p(resid),
