@@ -67,7 +67,7 @@ def main():
                 if name == "fc2":
                     kw = dict(act=ops.ACT_DSILU, aux_in=x)      # x plays z [M, 4C]... shape [M,K]
                 wt = w.t().contiguous()                       # the product path uses a transposed bf16 copy (functional.dgrad)
-                if N % 64 == 0:
+                if ops.glds_ok(K, N):
                     t = timeit(lambda: ops.gemm(dy, wt, 0, **kw), a.iters)
                 else:
                     t = timeit(lambda: ops.gemm(dy, w, 1, **kw), a.iters)

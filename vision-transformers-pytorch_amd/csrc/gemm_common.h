@@ -95,6 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 // LDS-DMA (global_load_lds) bf16 kernel for C = epi(A W^T) with K % 64 == 0 (gemm_glds.hip)
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st);
 bool gemm_glds_enabled();
+bool gemm_glds_ok(int N, int K);
 
 // LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N % 128 == 0, Kin % 128 == 0,
 // rowscale values restricted to {0, scale_const}

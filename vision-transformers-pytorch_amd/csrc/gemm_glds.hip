@@ -1,4 +1,4 @@
-// LDS-DMA GEMM for gfx950: C[M,N] = epilogue(A[M,K] . B[N,K]^T), bf16 in, fp32 accumulate, K % 64 == 0.
+// LDS-DMA GEMM for gfx950: C[M,N] = epilogue(A[M,K] . B[N,K]^T), bf16 in, fp32 accumulate, K % 64 == 0 (or K % 32 == 0 with N % 128 == 0).
 //
 // The register-staged kernel in gemm.hip is LDS-WRITE bound on these shapes: per 128x128x64 block-tile the
 // 32 KB of operands cost ~400 LDS cycles as ds_write_b128 (~79 B/clk/CU) next to ~256 cycles of fragment
@@ -148,9 +148,18 @@ template <int BM, int BN, int BK, int NS> static int glds_launch_cfg(const GemmA
 // (BK 64, 2 stages) 3.93 ms | (64, 3) 5.23 ms | (32, 3) 3.90 ms | (32, 4) 4.30 ms -- deeper rings cost
 // occupancy (LDS) and do not pay: these GEMMs (K = 384..3072) are bound by their epilogue's HBM writes and by
 // per-block prologue/epilogue, not by DMA latency.  The shipped configuration is (64, 2).
+// K % 64 != 0 but K % 32 == 0 (stage-1 K = 96): 32-deep k-tiles, 3 stages (the epilogue's C staging needs the room);
+// only with 128-column tiles -- a 32-deep tile row is 64 B, one DMA instruction covers 16 rows, and 96 / 4 waves does
+// not split into whole instructions.  Measured (stage 1, K = 96, N = 384): fc1 forward 256 -> 215 us, fc2 dgrad
+// 283 -> 203 us vs the register-staged kernel; N = 96 / 288 shapes stay on the register-staged kernel (faster there).
 template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_t st) {
+  if constexpr (BN == 128) {
+    if (a.K % 64 != 0) return glds_launch_cfg<BM, BN, 32, 3>(a, st);
+  }
   return glds_launch_cfg<BM, BN, 64, 2>(a, st);
 }
+
+bool gemm_glds_ok(int N, int K) { return (K % 64) == 0 || ((K % 32) == 0 && (N % 128) == 0); }
 
 // Tile height: 128 rows by default; 64-row tiles when the 128-row grid would leave the 512 resident block
 // slots (256 CUs x 2) badly quantised (few "waves" of blocks with a mostly empty last one).

@@ -115,11 +115,12 @@ def wcast(p, dtype):
 
 
 def dgrad(dy, wp, T, **epi):
-    """dx = epi(dy @ W) for a ``wcast`` pair.  bf16 with out-features % 64 == 0: the LDS-DMA forward-layout kernel on
-    the transposed copy; otherwise the register-staged NN kernel on W itself."""
+    """dx = epi(dy @ W) for a ``wcast`` pair.  bf16 where the LDS-DMA kernel applies to the transposed problem (K =
+    out-features, N = in-features; see ops.glds_ok): forward-layout kernel on the transposed copy; otherwise the
+    register-staged NN kernel on W itself."""
     w, wt = wp
     w2 = w.view(w.shape[0], -1)
-    if T == torch.bfloat16 and w2.shape[0] % 64 == 0:
+    if T == torch.bfloat16 and ops.glds_ok(w2.shape[1], w2.shape[0]):
         if wt is None:
             wt = w2.t().contiguous()
         return ops.gemm(dy, wt, 0, **epi)
