@@ -65,6 +65,32 @@ __device__ __forceinline__ Vec8<bf16> sa_frag_tr(const unsigned char* img, int t
   f.v = __builtin_bit_cast(bf16x8, w);
   return f;
 }
+// Same, as the A operand of a TRANSPOSED output product (O^T = V^T P^T etc.) with the row permutation that makes
+// the result store-friendly: A row c <-> column d = 32 dp + 8 (c >> 2) + 4 dtl + (c & 3), so that accumulator
+// (dp, dtl) register r of lane (c, g) is the output of token c for d = 32 dp + 8 g + 4 dtl + r -- the pair dtl = 0, 1
+// gives every lane 8 contiguous channels = one 16-byte global store (the 4 x 16 transpose-read block of each
+// 16-lane group takes its four 4-column groups from lanes p & 3 -- any four column bases are allowed).
+__device__ __forceinline__ Vec8<bf16> sa_frag_trp(const unsigned char* img, int t0, int dp, int dtl, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int n = 32 * dp + ((p & 3) << 3) + 4 * dtl;
+  s16x4 v[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = t0 + half * 16 + g * 4 + (p >> 2);
+    const unsigned char* a = img + r * SA_ROWB + ((((n >> 3) ^ (r & 7))) << 4) + ((n & 7) << 1);
+    v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  }
+  s16x8 w = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  Vec8<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, w);
+  return f;
+}
+__device__ __forceinline__ Vec8<bf16> sa_out8(const f32x4& a0, const f32x4& a1, float scale) {
+  Vec8<bf16> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.set(j, a0[j] * scale); f.set(4 + j, a1[j] * scale); }
+  return f;
+}
 __device__ __forceinline__ Vec8<bf16> sa_frag_acc(const f32x4& lo, const f32x4& hi) {
   Vec8<bf16> f;
 #pragma unroll
@@ -77,7 +103,7 @@ __device__ __forceinline__ Vec8<bf16> sa_gload(const bf16* p, bool valid) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NKT>
-__global__ __launch_bounds__(256) void sattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, SeqGeom g) {
   constexpr int LP = NKT * 16, IMG = LP * SA_ROWB, KSN = NKT / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
@@ -156,29 +182,27 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const bf16* __restrict__
       Vec8<bf16> pf1 = sa_frag_acc(st[1][2 * k2] * inv[1], st[1][2 * k2 + 1] * inv[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        Vec8<bf16> vf = sa_frag_tr(vs, k2 * 32, dt * 16, lane);
-        mma16(pf0, vf, oacc[0][dt]);
-        mma16(pf1, vf, oacc[1][dt]);
+        Vec8<bf16> vf = sa_frag_trp(vs, k2 * 32, dt >> 1, dt & 1, lane);
+        mma16(vf, pf0, oacc[0][dt]);          // oacc[t][2 dp + dtl][r] = O[q = 16 (2 qp + t) + c][32 dp + 8 g + 4 dtl + r]
+        mma16(vf, pf1, oacc[1][dt]);
       }
       __builtin_amdgcn_sched_barrier(0);     // keep the unrolled iterations apart (register pressure)
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qo = (qp * 2 + t) * 16 + g_ * 4 + r;
-        if (qo < g.L) {
-          bf16* op = o + ((int64_t)b * g.L + qo) * g.hd + h * SA_D + c_;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) op[dt * 16] = (bf16)oacc[t][dt][r];
-        }
+    for (int t = 0; t < 2; ++t) {
+      const int q = (qp * 2 + t) * 16 + c_;
+      if (qv[t]) {
+        bf16* op = o + ((int64_t)b * g.L + q) * g.hd + h * SA_D + g_ * 8;
+        store8<bf16>(op, sa_out8(oacc[t][0], oacc[t][1], 1.f));
+        store8<bf16>(op + 32, sa_out8(oacc[t][2], oacc[t][3], 1.f));
       }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
 template <int NKT>
-__global__ __launch_bounds__(256) void sattn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ oin,
+__global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ oin,
                                                        const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                        bf16* __restrict__ dqkv, SeqGeom g) {
   constexpr int LP = NKT * 16, IMG = LP * SA_ROWB, KSN = NKT / 2;
@@ -263,22 +287,20 @@ __global__ __launch_bounds__(256) void sattn_bwd_kernel(const bf16* __restrict__
       Vec8<bf16> dsf1 = sa_frag_acc(dsv[1][0], dsv[1][1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        Vec8<bf16> kf = sa_frag_tr(im0, k2 * 32, dt * 16, lane);
-        mma16(dsf0, kf, dqacc[0][dt]);
-        mma16(dsf1, kf, dqacc[1][dt]);
+        Vec8<bf16> kf = sa_frag_trp(im0, k2 * 32, dt >> 1, dt & 1, lane);
+        mma16(kf, dsf0, dqacc[0][dt]);        // dqacc[t][2 dp + dtl][r] = dQ[q = .. + c][32 dp + 8 g + 4 dtl + r] / scale
+        mma16(kf, dsf1, dqacc[1][dt]);
       }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qo = (qp * 2 + t) * 16 + g_ * 4 + r;
-        if (qo < g.L) {
-          bf16* p = dqb + (int64_t)qo * ld + c_;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) p[dt * 16] = (bf16)(dqacc[t][dt][r] * g.scale);
-        }
+    for (int t = 0; t < 2; ++t) {
+      const int q = (qp * 2 + t) * 16 + c_;
+      if (qv[t]) {
+        bf16* p = dqb + (int64_t)q * ld + g_ * 8;
+        store8<bf16>(p, sa_out8(dqacc[t][0], dqacc[t][1], g.scale));
+        store8<bf16>(p + 32, sa_out8(dqacc[t][2], dqacc[t][3], g.scale));
       }
+    }
   }
   __syncthreads();                                   // K / V images are dead; dq_s complete
   sa_stage<LP>(im0, qb, ld, g.L, wave, lane);                       // Q
@@ -338,28 +360,25 @@ __global__ __launch_bounds__(256) void sattn_bwd_kernel(const bf16* __restrict__
       Vec8<bf16> sf0 = sa_frag_acc(dss[0][0], dss[0][1]), sf1 = sa_frag_acc(dss[1][0], dss[1][1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        Vec8<bf16> dotf = sa_frag_tr(im1, q2 * 32, dt * 16, lane);
-        Vec8<bf16> qtf = sa_frag_tr(im0, q2 * 32, dt * 16, lane);
-        mma16(pf0, dotf, dvacc[0][dt]);
-        mma16(pf1, dotf, dvacc[1][dt]);
-        mma16(sf0, qtf, dkacc[0][dt]);
-        mma16(sf1, qtf, dkacc[1][dt]);
+        Vec8<bf16> dotf = sa_frag_trp(im1, q2 * 32, dt >> 1, dt & 1, lane);
+        Vec8<bf16> qtf = sa_frag_trp(im0, q2 * 32, dt >> 1, dt & 1, lane);
+        mma16(dotf, pf0, dvacc[0][dt]);       // d{k,v}acc[t][2 dp + dtl][r] = d{K,V}[key = .. + c][32 dp + 8 g + 4 dtl + r]
+        mma16(dotf, pf1, dvacc[1][dt]);
+        mma16(qtf, sf0, dkacc[0][dt]);
+        mma16(qtf, sf1, dkacc[1][dt]);
       }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ko = (kp * 2 + t) * 16 + g_ * 4 + r;
-        if (ko < g.L) {
-          bf16* p = dqb + (int64_t)ko * ld + c_;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            p[g.hd + dt * 16] = (bf16)(dkacc[t][dt][r] * g.scale);
-            p[2 * g.hd + dt * 16] = (bf16)dvacc[t][dt][r];
-          }
-        }
+    for (int t = 0; t < 2; ++t) {
+      const int key = (kp * 2 + t) * 16 + c_;
+      if (kv[t]) {
+        bf16* p = dqb + (int64_t)key * ld + g_ * 8;
+        store8<bf16>(p + g.hd, sa_out8(dkacc[t][0], dkacc[t][1], g.scale));
+        store8<bf16>(p + g.hd + 32, sa_out8(dkacc[t][2], dkacc[t][3], g.scale));
+        store8<bf16>(p + 2 * g.hd, sa_out8(dvacc[t][0], dvacc[t][1], 1.f));
+        store8<bf16>(p + 2 * g.hd + 32, sa_out8(dvacc[t][2], dvacc[t][3], 1.f));
       }
+    }
   }
 }
 

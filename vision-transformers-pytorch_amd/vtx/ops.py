@@ -123,6 +123,19 @@ class KernelTimer:
 _timer = None
 
 
+def _attn_bracket(name, nprob, L, D, rows, hd, es, bwd):
+    """HIP-event bracket of an attention launch: algorithmic FLOPs 2*2*L^2*D per problem forward (QK^T, PV), 5 products
+    backward (S, dP, dV, dQ, dK); algorithmic bytes q,k,v read + o written (forward) / q,k,v,o,do read + dq,dk,dv
+    written (backward) -- scores never touch HBM."""
+    if _timer is None:
+        return None
+    flops = (10.0 if bwd else 4.0) * nprob * L * L * D
+    nbytes = (8.0 if bwd else 4.0) * rows * hd * es
+    ev = _timer.bracket(name, flops, nbytes)
+    ev[0].record()
+    return ev
+
+
 def set_kernel_timer(timer):
     global _timer
     _timer = timer
@@ -295,9 +308,14 @@ def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
         raise VtxError("vtx: attention rows mismatch")
     o = torch.empty(qkv.shape[:-1] + (n_head * D,), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
+    fast = swin is None and qkv.dtype == torch.bfloat16 and D == 64 and 64 < L <= 224      # mirrors sattn_ok
+    ev = _attn_bracket("sattn_fwd_kernel<14>" if fast else "attn_fwd_kernel", B * nW * n_head, L, D, rows, n_head * D,
+                       qkv.element_size(), False)
     check(_lib.load().vtx_attention_fwd(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
                                         int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), _stream()),
           "vtx_attention_fwd")
+    if ev:
+        ev[1].record()
     return o, lse
 
 
@@ -314,9 +332,15 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
         drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
         wsb = lib.vtx_attention_bwd_workspace(B, L, n_head, int(swin is not None), H, W, max(win, 1))
         ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
+    rows = qkv.numel() // (3 * n_head * D)
+    fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and 64 < L <= 224
+    ev = _attn_bracket("sattn_bwd_kernel<14>" if fast else "attn_bwd_kernel", rows // L * n_head, L, D, rows,
+                       n_head * D, qkv.element_size(), True)
     check(lib.vtx_attention_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
                                 _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
                                 H, W, win, int(bool(shift)), _dt(qkv), _stream()), "vtx_attention_bwd")
+    if ev:
+        ev[1].record()
     return dqkv, drel
 
 
@@ -335,8 +359,13 @@ def wattn_fwd(qkv, rel_pos, pos, region, B, L, n_head, swin):
     o = torch.empty(qkv.shape[:-1] + (n_head * 32,), dtype=qkv.dtype, device=qkv.device)
     nW = (H // win) * (W // win)
     lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
+    tn = "__bf16" if qkv.dtype == torch.bfloat16 else "float"
+    ev = _attn_bracket(f"wattn_fwd_kernel<{tn}, {'true' if region is not None else 'false'}>", B * nW * n_head, L, 32,
+                       B * nW * L, n_head * 32, qkv.element_size(), False)
     check(_lib.load().vtx_wattn_fwd(_p(qkv), _p(o), _p(lse), _p(rel_pos), _p(pos), _p(region), B, L, n_head, H, W, win,
                                     int(bool(shift)), _dt(qkv), _stream()), "vtx_wattn_fwd")
+    if ev:
+        ev[1].record()
     return o, lse
 
 
@@ -348,7 +377,13 @@ def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab)
     drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
     wsb = lib.vtx_wattn_bwd_workspace(B, n_head, H, W, win)
     ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
+    nW = (H // win) * (W // win)
+    tn = "__bf16" if qkv.dtype == torch.bfloat16 else "float"
+    ev = _attn_bracket(f"wattn_bwd_kernel<{tn}, {'true' if region is not None else 'false'}>", B * nW * n_head, L, 32,
+                       B * nW * L, n_head * 32, qkv.element_size(), True)     # (+ the small drel_pos column reduce)
     check(lib.vtx_wattn_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(rel_pos), _p(pos), _p(region), _p(dqkv), _p(drel),
                             _p(ws), wsb, B, L, n_head, H, W, win, int(bool(shift)), _dt(qkv), _stream()),
           "vtx_wattn_bwd")
+    if ev:
+        ev[1].record()
     return dqkv, drel
