@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / 256 vit_s16)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -129,7 +130,12 @@ def main():
     model = build_model(args.model, drop_path).to(dev).train()
     ddp = GradAllReduce(model)
     criterion = MixLoss(eps=0.1)
-    opt = torch.optim.AdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3, fused=True)
+    groups = make_param_groups(model.named_parameters(), 0.05, "vit")
+    if args.optimizer == "fused":
+        from vtx.optim import FusedAdamW
+        opt = FusedAdamW(groups, lr=1e-3)                       # clip + AdamW: two multi-tensor HIP kernels
+    else:
+        opt = torch.optim.AdamW(groups, lr=1e-3, fused=True)    # torch's fused AdamW + foreach clip_grad_norm_
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(batch, 3, 224, 224, device=dev, generator=g)
     l1 = torch.randint(0, 1000, (batch,), device=dev, generator=g)

@@ -116,6 +116,20 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
                   size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream);
 
+/* ---- Fused optimizer tail (csrc/optim.hip): nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference's
+ * train step (train.py:285-299) as two multi-tensor passes.  Tensors are given as HOST arrays of n device pointers
+ * (fp32, any 4-byte alignment) and element counts; the addresses travel in kernel arguments (64 tensors per launch).
+ *   vtx_grad_sqnorm: norm_out[0] = sum over all tensors of g^2, norm_out[1] = its square root (deterministic: fixed
+ *                    summation order, no atomics); partial = sum_i ceil(numel_i / vtx_opt_chunk()) floats of workspace.
+ *   vtx_adamw_step:  step t >= 1 of AdamW (decoupled decay first, bias-corrected, eps added to sqrt(v)/sqrt(1-b2^t)),
+ *                    per-tensor lr / weight decay, on g * min(1, max_norm / (norm[1] + 1e-6)) when max_norm > 0
+ *                    (norm = vtx_grad_sqnorm's device output); gradients are not modified. */
+int vtx_opt_chunk(void);
+int vtx_grad_sqnorm(int n, const float* const* g, const int64_t* numel, float* partial, float* norm_out, void* stream);
+int vtx_adamw_step(int n, float* const* p, const float* const* g, float* const* m, float* const* v,
+                   const int64_t* numel, const float* lr, const float* wd, const float* norm, float max_norm,
+                   float beta1, float beta2, float eps, int t, void* stream);
+
 /* ---- Multi-tensor weight cast (csrc/cast.hip): all fp32 Linear / Conv weights of a model -> bf16, plain [out][in]
  * and transposed [in][out], in one launch per forward.  This is the per-call weight cast of the reference's bf16
  * autocast (torch.cuda.amp.autocast around model(input), train.py:273-274) done once for the whole model.

@@ -302,3 +302,49 @@ def test_linear_ragged_out_features(dtype, N):
     check(f"linear N={N} {dtype} dW", gw, rw, t["grad"])
     check(f"linear N={N} {dtype} db", gb, rb, t["grad"])
     assert gw.shape == w.shape and gb.shape == b.shape
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 0.05])
+def test_fused_adamw_vs_torch_and_oracle(max_norm):
+    """clip_grad_norm_ + AdamW as two multi-tensor kernels (csrc/optim.hip) vs torch.optim.AdamW (+ clip_grad_norm_) and vs
+    the oracle's restatement, 3 steps, two param groups, ragged sizes and a 4-byte-aligned view (DDP bucket style)."""
+    from vtx.optim import FusedAdamW
+    d = dev()
+    torch.manual_seed(0)
+    flat = torch.randn(3 * 507 + 8, device=d)
+    shapes = [(1000, 768), (4097,), (169, 3), (5,), (96, 48)]
+    def make():
+        ps = [torch.nn.Parameter(_mk(s, 200 + i, torch.float32, 0.3).to(d)) for i, s in enumerate(shapes)]
+        ps.append(torch.nn.Parameter(flat[1:1 + 507].clone().view(169, 3)))
+        return ps
+    pa, pb = make(), make()
+    unaligned = torch.zeros(1 + 507, device=d)[1:].view(169, 3)           # gradient living at a 4-byte offset
+    ga = lambda ps: [{"params": ps[:2], "weight_decay": 0.05}, {"params": ps[2:], "weight_decay": 0.0, "lr": 3e-3}]
+    oa = FusedAdamW(ga(pa), lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    ob = torch.optim.AdamW(ga(pb), lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    ref = [dict(p=p.detach().double().cpu(), m=torch.zeros_like(p, dtype=torch.float64, device="cpu"),
+                v=torch.zeros_like(p, dtype=torch.float64, device="cpu")) for p in pa]
+    hyp = [(1e-2, 0.05)] * 2 + [(3e-3, 0.0)] * 4
+    for step in range(1, 4):
+        grads = [_mk(tuple(p.shape), 300 + 10 * step + i, torch.float32, 0.02 * (i + 1)) for i, p in enumerate(pa)]
+        for ps in (pa, pb):
+            for p, g in zip(ps, grads):
+                p.grad = g.to(d).clone()
+        unaligned.copy_(grads[5].to(d)); pa[5].grad = unaligned
+        total = oa.step(max_grad_norm=max_norm)
+        if max_norm > 0:
+            tref = torch.nn.utils.clip_grad_norm_(pb, max_norm)
+            check(f"fused clip total norm step {step}", total, tref, 1e-6)
+        ob.step()
+        gs = [g.double() for g in grads]
+        if max_norm > 0:
+            gs, _ = R.clip_grad_norm(gs, max_norm)
+        for r, g, (lr, wd) in zip(ref, gs, hyp):
+            r["p"], r["m"], r["v"] = R.adamw_step(r["p"], g, r["m"], r["v"], step, lr, 0.9, 0.95, 1e-8, wd)
+    for i, (a, b, r) in enumerate(zip(pa, pb, ref)):
+        check(f"fused adamw vs torch p{i} clip={max_norm}", a, b, 2e-6)
+        check(f"fused adamw vs oracle p{i} clip={max_norm}", a, r["p"], 2e-6)
+        check(f"fused adamw exp_avg_sq p{i}", oa.state[a]["exp_avg_sq"], r["v"], 2e-6)
+    assert float(oa.state[pa[0]]["step"]) == 3.0
+    sd = oa.state_dict()                                                  # same state layout as torch.optim.AdamW
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}

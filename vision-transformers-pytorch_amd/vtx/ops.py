@@ -4,6 +4,8 @@ Every function takes contiguous DEVICE tensors, allocates outputs / workspaces t
 caching allocator, enqueues on torch's current HIP stream and returns tensors.  No fallback: CPU
 tensors, wrong dtypes or a missing library raise VtxError.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -213,6 +215,36 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.
     check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
                         int(rows_per_scale), float(scale_const), _p(ws), wsb, _stream()), "vtx_wgrad")
     return dW, db
+
+
+# ------------------------------------------------------------------------------- optimizer tail
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def grad_sqnorm(grads):
+    """[sum g^2, sqrt(sum g^2)] over a list of fp32 gradient tensors (deterministic two-level reduction)."""
+    _dev(*grads)
+    lib = _lib.load()
+    chunk = lib.vtx_opt_chunk()
+    numel = (ctypes.c_int64 * len(grads))(*[g.numel() for g in grads])
+    nchunks = sum((g.numel() + chunk - 1) // chunk for g in grads)
+    dev = grads[0].device
+    partial = torch.empty(max(nchunks, 1), dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    check(lib.vtx_grad_sqnorm(len(grads), _ptr_array(grads), numel, _p(partial), _p(out), _stream()), "vtx_grad_sqnorm")
+    return out
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, lrs, wds, norm, max_norm, beta1, beta2, eps, t):
+    """torch.optim.AdamW step t of the listed tensors in one multi-tensor pass (csrc/optim.hip)."""
+    _dev(*params, *grads, *exp_avg, *exp_avg_sq, norm)
+    n = len(params)
+    numel = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+    check(_lib.load().vtx_adamw_step(n, _ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg),
+                                     _ptr_array(exp_avg_sq), numel, (ctypes.c_float * n)(*lrs),
+                                     (ctypes.c_float * n)(*wds), _p(norm), float(max_norm), float(beta1), float(beta2),
+                                     float(eps), int(t), _stream()), "vtx_adamw_step")
 
 
 # ------------------------------------------------------------------------------- data movement

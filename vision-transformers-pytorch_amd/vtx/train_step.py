@@ -2,12 +2,15 @@
 
 The reference's train.py never ships; this is the harness the benchmark and the parity tests use.
 Same op order: autocast forward -> MixLoss / grad_accum -> backward (DDP all-reduce overlapped) ->
-clip_grad_norm_ -> optimizer step -> zero_grad(set_to_none).  MixLoss, clipping and AdamW are
-O(parameters) / O(B x classes) host-launched PyTorch ops on the device.
+clip_grad_norm_ -> optimizer step -> zero_grad(set_to_none).  With ``vtx.optim.FusedAdamW`` clipping + AdamW run as
+two multi-tensor HIP kernels; any torch optimizer works too (clip_grad_norm_ + step()).
+MixLoss is O(B x classes) PyTorch device ops.
 """
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+from .optim import FusedAdamW
 
 
 class MixLoss(nn.Module):
@@ -75,9 +78,12 @@ def train_step(model, criterion, optimizer, batch, clip_grad_norm=5.0, autocast_
     loss.backward()
     if ddp is not None:
         ddp.finish()
-    if clip_grad_norm and clip_grad_norm > 0:
-        torch.nn.utils.clip_grad_norm_(ddp.parameters if ddp is not None else list(model.parameters()),
-                                       clip_grad_norm)
-    optimizer.step()
+    if isinstance(optimizer, FusedAdamW):       # clip + AdamW in two multi-tensor HIP kernels (csrc/optim.hip)
+        optimizer.step(max_grad_norm=clip_grad_norm or 0.0)
+    else:
+        if clip_grad_norm and clip_grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_(ddp.parameters if ddp is not None else list(model.parameters()),
+                                           clip_grad_norm)
+        optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss
