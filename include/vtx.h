@@ -116,6 +116,35 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
                   size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream);
 
+/* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66):
+ * head dim 64, Lq queries against Lk <= 64 reduced keys per (image, head).
+ *   q [B*Lq, nH*64] (= linear_q output), kv [B*Lk, 2*nH*64] (= linear_kv output: k | v halves, pvt.py:51),
+ *   o [B*Lq, nH*64], lse [B*nH*Lq] fp32 (saved for the backward).
+ * The backward writes dq and dkv fully; key-side partials are summed in fixed order (deterministic). */
+int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int dtype,
+                   void* stream);
+size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH);
+int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                   void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int dtype, void* stream);
+
+/* ---- Non-overlapping patch gather on token-major (NHWC) features: the im2col of Conv2d(C, C', p, stride = p)
+ * (PVT patch embeddings of stages 2-4 and the spatial-reduction conv, pvt.py:26-29, 44-46, 112, 129-131).
+ *   x [B, skip + H*W, C] (the first `skip` tokens of every image -- PVT's cls token -- are not part of the grid);
+ *   out [B*(H/p)*(W/p), p*p*C] with column order (py, px, c); the conv weight is permuted to match by the host.
+ * _bwd is the inverse scatter (a permutation); accumulate != 0 adds into dx (the gradient that also arrives
+ * through the query path), rows of skipped tokens are left untouched. */
+int vtx_patchify_fwd(const void* x, void* out, int B, int H, int W, int C, int p, int skip, int dtype, void* stream);
+int vtx_patchify_bwd(const void* dout, void* dx, int B, int H, int W, int C, int p, int skip, int accumulate, int dtype,
+                     void* stream);
+
+/* ---- Position-embedding add with optional cls token (PVT PatchEmbedding, pvt.py:133-137):
+ *   out[b, 0] = cls + pos[0] (has_cls), out[b, s + t] = x[b, t] + pos[s + t], s = has_cls.
+ *   x [B, T, C] of dtype, cls [C] / pos [s + T, C] fp32; _bwd: dx = dout[:, s:], dcls = sum_b dout[b, 0],
+ *   dpos = sum_b dout[b] (fp32, deterministic). */
+int vtx_add_pos_fwd(const void* x, const float* cls, const float* pos, void* out, int B, int T, int C, int dtype,
+                    void* stream);
+int vtx_add_pos_bwd(const void* dout, void* dx, float* dcls, float* dpos, int B, int T, int C, int dtype, void* stream);
+
 /* ---- Fused optimizer tail (csrc/optim.hip): nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference's
  * train step (train.py:285-299) as two multi-tensor passes.  Tensors are given as HOST arrays of n device pointers
  * (fp32, any 4-byte alignment) and element counts; the addresses travel in kernel arguments (64 tensors per launch).

@@ -117,3 +117,41 @@ def vit_forward(sd, inputs, cfg, head=None, **kw):
         start = end
     out = torch.cat(outs)
     return head(out) if head is not None else out
+
+
+# ------------------------------------------------------------------------------------------ PVT (models/pvt.py)
+# PVT-Small hyper-parameters (not in the reference repo -- from the PVT paper)
+PVT_SMALL = dict(image_size=224, n_class=1000, in_dim=3, depths=(3, 4, 6, 3), patch_embed_dims=(64, 128, 320, 512),
+                 n_heads=(1, 2, 5, 8), dim_ffs=(512, 1024, 1280, 2048), reductions=(8, 4, 2, 1))
+PVT_PATCH = (4, 2, 2, 2)                                                # pvt.py:171
+
+
+def pvt_forward(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
+    """PyramidVisionTransformer.forward (pvt.py:262-286).  ``drop_masks`` as in swin_forward; the rates follow
+    set_drop_path (pvt.py:209-231): linspace(0, drop_path, sum(depths)) in network order."""
+    depths = cfg["depths"]
+    rates = torch.linspace(0, drop_path, sum(depths)).tolist()
+    out, li = x_nchw, 0
+    B = x_nchw.shape[0]
+    for s in range(4):
+        pe = f"patch_embedding.{s}."
+        if s > 0:                                                       # pvt.py:269, 274, 279: tokens -> NCHW
+            out = out.reshape(B, height, width, -1).permute(0, 3, 1, 2)
+        out, (height, width) = R.pvt_patch_embedding(out, sd[pe + "conv.weight"], sd[pe + "conv.bias"],
+                                                     sd[pe + "norm.weight"], sd[pe + "norm.bias"], sd[pe + "pos"],
+                                                     sd.get(pe + "cls_token"), PVT_PATCH[s])
+        out = R._q(out, q)
+        for j in range(depths[s]):
+            pre = f"block{s + 1}.{j}."
+            p = {k[len(pre + "attn."):]: v for k, v in sd.items() if k.startswith(pre + "attn.")}
+            ma, mf = drop_masks[li] if drop_masks is not None else (None, None)
+            a = R.pvt_attention(R._q(R.layer_norm(out, sd[pre + "norm_attn.weight"], sd[pre + "norm_attn.bias"], 1e-6), q),
+                                height, width, p, cfg["n_heads"][s], cfg["reductions"][s], q)
+            out = R._q(out + R.drop_path_apply(a, ma, rates[li]), q)
+            f = R.feed_forward(R._q(R.layer_norm(out, sd[pre + "norm_ff.weight"], sd[pre + "norm_ff.bias"], 1e-6), q),
+                               sd[pre + "ff.0.weight"], sd[pre + "ff.0.bias"], sd[pre + "ff.3.weight"],
+                               sd[pre + "ff.3.bias"], q)
+            out = R._q(out + R.drop_path_apply(f, mf, rates[li]), q)
+            li += 1
+    out = R.layer_norm(out[:, 0], sd["norm.weight"], sd["norm.bias"], 1e-6)   # pvt.py:283
+    return R.linear(R._q(out, q), sd["classifier.weight"], sd["classifier.bias"])

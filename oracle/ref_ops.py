@@ -216,3 +216,55 @@ def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
     denom = (v.sqrt() / math.sqrt(bc2)) + eps
     p = p - (lr / bc1) * m / denom
     return p, m, v
+
+
+# ------------------------------------------------------------------------------------------ PVT (models/pvt.py)
+def sr_attention_core(q, kv, n_head, qf=None):
+    """Attention core of pvt.MultiHeadedAttention (pvt.py:38, 51-64): q (B, Lq, C) = linear_q output, kv (B, Lk, 2C) =
+    linear_kv output whose halves are k | v (pvt.py:51), heads = contiguous channel blocks of C // n_head (pvt.py:35-37),
+    score = q k^T / sqrt(d) (pvt.py:55), softmax over keys, out (B, Lq, C) in [head][d] order (pvt.py:66)."""
+    B, Lq, C = q.shape
+    d = C // n_head
+    out = q.new_zeros(B, Lq, C)
+    for h in range(n_head):
+        Q = q[..., h * d:(h + 1) * d]
+        K = kv[..., h * d:(h + 1) * d]
+        V = kv[..., C + h * d:C + (h + 1) * d]
+        S = torch.einsum("bid,bjd->bij", Q, K) / math.sqrt(d)
+        P = _q(torch.softmax(S, -1), qf)
+        out[..., h * d:(h + 1) * d] = torch.einsum("bij,bjd->bid", P, V)
+    return out
+
+
+def pvt_reduce(x, height, width, w_conv, b_conv, g_norm, b_norm, reduction, qf=None):
+    """Spatial reduction of the key/value tokens (pvt.py:42-47): tokens -> (B, C, H, W) -> Conv2d(C, C, r, stride r) ->
+    tokens -> LayerNorm(eps 1e-6)."""
+    B, L, C = x.shape
+    img = x.transpose(1, 2).reshape(B, C, height, width)
+    red = torch.nn.functional.conv2d(img, w_conv, b_conv, stride=reduction)
+    red = _q(red.reshape(B, C, -1).transpose(1, 2), qf)
+    return layer_norm(red, g_norm, b_norm, 1e-6)
+
+
+def pvt_attention(x, height, width, p, n_head, reduction, qf=None):
+    """pvt.MultiHeadedAttention.forward (pvt.py:31-68) without the returned score; p = dict of the module's tensors
+    (linear_q.weight, linear_kv.weight, linear.weight, linear.bias [, reduce_conv.*, reduce_norm.*])."""
+    qq = _q(linear(x, p["linear_q.weight"], None), qf)
+    kvin = x
+    if reduction > 1:
+        kvin = _q(pvt_reduce(x, height, width, p["reduce_conv.weight"], p["reduce_conv.bias"], p["reduce_norm.weight"],
+                             p["reduce_norm.bias"], reduction, qf), qf)
+    kv = _q(linear(kvin, p["linear_kv.weight"], None), qf)
+    out = _q(sr_attention_core(qq, kv, n_head, qf), qf)
+    return linear(out, p["linear.weight"], p["linear.bias"])
+
+
+def pvt_patch_embedding(x_nchw, w_conv, b_conv, g_norm, b_norm, pos, cls_token, patch):
+    """pvt.PatchEmbedding.forward (pvt.py:126-140): Conv2d(in, dim, p, stride p) -> tokens -> LayerNorm(1e-6) ->
+    [cls token in front] -> + pos; returns (tokens, (height, width))."""
+    out = torch.nn.functional.conv2d(x_nchw, w_conv, b_conv, stride=patch)
+    height, width = out.shape[2:]
+    out = layer_norm(out.flatten(2).transpose(1, 2), g_norm, b_norm, 1e-6)
+    if cls_token is not None:
+        out = torch.cat((cls_token.view(1, 1, -1).expand(out.shape[0], -1, -1), out), 1)
+    return out + pos.unsqueeze(0), (height, width)

@@ -7,7 +7,7 @@ all inputs/weights are closed-form (oracle/formula.py), so nothing of the refere
 travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
 
 Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
-fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step.
+fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1).
 """
 import os
 import sys
@@ -36,10 +36,11 @@ warnings.filterwarnings("ignore")
 from models import swin_transformer as ref_swin   # noqa: E402  (reference)
 from models import vit as ref_vit                 # noqa: E402  (reference)
 from models import layer as ref_layer             # noqa: E402  (reference)
+from models import pvt as ref_pvt                 # noqa: E402  (reference)
 import loss as ref_loss                           # noqa: E402  (reference)
 
 from oracle.formula import fill, fill_state_dict, summarize, name_seed  # noqa: E402
-from oracle.ref_models import SWIN_S, VIT_S16     # noqa: E402
+from oracle.ref_models import PVT_SMALL, SWIN_S, VIT_S16     # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -223,6 +224,53 @@ def gen_models():
 
 
 # ------------------------------------------------------------------ G6
+# ------------------------------------------------------------------ G7 (PVT-Small)
+def gen_pvt():
+    rec = {}
+    # module level: spatial-reduction attention, dim 128 / 2 heads / reduction 4 on a 28 x 28 token grid
+    att = load_formula(ref_pvt.MultiHeadedAttention(128, 2, reduction=4)).double()      # fp64: tight pins
+    x = fill((2, 784, 128), 71, 1.0).double().requires_grad_(True)
+    out, _ = att(x, 28, 28)
+    cot = fill(out.shape, 72, 1.0).double()
+    (out * cot).sum().backward()
+    rec["sr_attn.out"] = summarize(out)
+    rec["sr_attn.dx"] = summarize(x.grad)
+    for n, p in att.named_parameters():
+        rec[f"sr_attn.grad.{n}"] = summarize(p.grad)
+    # stage-4 style: cls token, no reduction
+    att1 = load_formula(ref_pvt.MultiHeadedAttention(512, 8, reduction=1)).double()
+    x1 = fill((2, 50, 512), 73, 1.0).double().requires_grad_(True)
+    out1, _ = att1(x1, 7, 7)
+    (out1 * fill(out1.shape, 74, 1.0).double()).sum().backward()
+    rec["attn_r1.out"] = summarize(out1)
+    rec["attn_r1.dx"] = summarize(x1.grad)
+    # patch embedding with cls token on token-major features (stage 4 geometry)
+    pe = load_formula(ref_pvt.PatchEmbedding((14, 14), 320, 512, 2, cls_token=True)).double()
+    xi = fill((2, 320, 14, 14), 75, 1.0).double().requires_grad_(True)
+    po, hw = pe(xi)
+    (po * fill(po.shape, 76, 1.0).double()).sum().backward()
+    rec["patch_embed.out"] = summarize(po)
+    rec["patch_embed.dx"] = summarize(xi.grad)
+    for n, p in pe.named_parameters():
+        rec[f"patch_embed.grad.{n}"] = summarize(p.grad)
+    # full model
+    x = fill((2, 3, 224, 224), 21, 1.0)
+    pvt = load_formula(ref_pvt.PyramidVisionTransformer(**PVT_SMALL, drop_path=0.0))
+    rec["pvt_small.n_params"] = np.array(sum(p.numel() for p in pvt.parameters()))
+    rec["pvt_small.state_keys"] = np.array(list(pvt.state_dict().keys()))
+    rec["pvt_small.state_shapes"] = np.array([str(tuple(v.shape)) for v in pvt.state_dict().values()])
+    model_record(pvt, x, "pvt_small.eval", rec, False)
+    model_record(pvt, x, "pvt_small.train", rec, True)
+    for n, p in pvt.named_parameters():
+        if any(s in n for s in ("patch_embedding.0.conv.weight", "patch_embedding.3.cls_token", "patch_embedding.2.pos",
+                                "block2.1.attn.reduce_conv.weight", "block3.2.attn.linear_kv.weight",
+                                "block1.0.attn.linear_q.weight", "classifier.weight")):
+            rec[f"pvt_small.train.grad.{n}"] = summarize(p.grad)
+    pvt64 = load_formula(ref_pvt.PyramidVisionTransformer(**PVT_SMALL, drop_path=0.0)).double()
+    model_record(pvt64, x.double(), "pvt_small.train64", rec, True)
+    save("g7_pvt", rec)
+
+
 def gen_train_step():
     rec = {}
     B = 2
@@ -267,7 +315,7 @@ def gen_train_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "modules", "models", "step"]
+    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt"]
     if "tables" in which:
         gen_tables()
     if "modules" in which:
@@ -276,5 +324,7 @@ if __name__ == "__main__":
         gen_models()
     if "step" in which:
         gen_train_step()
+    if "pvt" in which:
+        gen_pvt()
     # make sure nothing was written into the reference tree
     assert not os.path.exists(os.path.join(REF, "models", "__pycache__")), "pycache leaked into reference"

@@ -1,0 +1,401 @@
+// Spatial-reduction (cross) attention of PVT for gfx950: head dim 64, Lq queries against Lk <= 64 reduced keys.
+//
+// Replaces reference models/pvt.py:38-66 per (image, head): q = linear_q(x) [B, Lq, h*64],
+// k | v = linear_kv(reduced).chunk(2) [B, Lk, 2*h*64]; S = q k^T / sqrt(64), softmax over the Lk keys, O = P v --
+// with the head split / merge as address arithmetic and the scores kept in registers.  PVT-Small at 224^2 has
+// Lk = 49 (stages 1-3, after the r x r reduction conv) or 50 (stage 4, cls + 7x7) and Lq = 3136 / 784 / 196 / 50.
+//
+// Same fragment algebra as attention_win.hip (64-lane waves, mma16, swapped product S^T = K Q^T so that softmax is
+// lane-local + two shuffles, outputs from transposed products so every lane stores 16 contiguous bytes), organised for
+// many queries against few keys:
+//   * a workgroup = 4 waves serves one (image, head) and a run of 64-query sub-chunks; wave w owns query tile w of
+//     every sub-chunk (forward, dQ) and KEY tile w for the key-side gradients, which it accumulates in registers over
+//     all sub-chunks of the workgroup;
+//   * K / V fragments live in registers for the whole workgroup; the token-contracted operands (V^T forward; K^T, Q^T,
+//     dO^T backward) are transposed through LDS images shared by the 4 waves;
+//   * dK / dV partials of the workgroups of one (image, head) go to fp32 slabs and are summed in fixed order
+//     (deterministic, no atomics).
+// Templated on T in {bf16, float} (float = parity mode on the exact fp32 MFMA).
+#include <stdlib.h>
+
+#include "vtx_common.h"
+
+#define SR_D 64
+#define SR_LK 64         // padded key count
+#define SR_STR 72        // transposed LDS row stride (elements)
+#define SR_QB 64         // queries per sub-chunk (4 waves x 16)
+
+struct SrGeom { int Lq, Lk, nH, hd, nsub, qc; float scale; };   // nsub = ceil(Lq / 64), qc = sub-chunks per workgroup
+
+template <typename T> __device__ __forceinline__ Vec8<T> sr_load(const T* p, bool valid) {
+  return valid ? load8<T>(p) : vec8_zero<T>();
+}
+template <typename T> __device__ __forceinline__ Vec8<T> sr_frag_acc(const f32x4& lo, const f32x4& hi) {
+  Vec8<T> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.set(j, lo[j]); f.set(4 + j, hi[j]); }
+  return f;
+}
+// fragment of a transposed image Xt[row][token]: k-slots j < 4 <-> tokens t0 + 4g + j, j >= 4 <-> t0 + 16 + 4g + (j-4)
+template <typename T> __device__ __forceinline__ Vec8<T> sr_frag_t(const T* p, int g) {
+  Vec8<T> f;
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p + 4 * g);
+    bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 16 + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  } else {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * g);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 16 + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  }
+  return f;
+}
+// One 16-token tile (lane (c, g): token t0 + c, channels 32 ds + 8 g ..+7) -> transposed image Xt[pi(d)][token]
+// with pi(32 ds + 8 g + e) = 16 (2 ds + (e >> 2)) + 4 g + (e & 3): image rows 16 j .. 16 j + 15 (j = 2 dp + dtl) used as
+// an MFMA A operand leave lane (c, g) with the outputs of token c for d = 32 dp + 8 g + 4 dtl + r.
+template <typename T> __device__ __forceinline__ void sr_store_t(T* xt, const Vec8<T> (&f)[2], int t0, int c, int g) {
+#pragma unroll
+  for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xt[(16 * (2 * ds + (e >> 2)) + 4 * g + (e & 3)) * SR_STR + t0 + c] = f[ds].v[e];
+}
+template <typename T> __device__ __forceinline__ Vec8<T> sr_out8(const f32x4& a0, const f32x4& a1, float scale) {
+  Vec8<T> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.set(j, a0[j] * scale); f.set(4 + j, a1[j] * scale); }
+  return f;
+}
+
+// --------------------------------------------------------------------------------------------- forward
+// grid = (workgroups per (image, head), B * nH)
+template <typename T>
+__global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                        T* __restrict__ o, float* __restrict__ lse, SrGeom g) {
+  __shared__ __attribute__((aligned(16))) T vt[SR_D * SR_STR];          // Vt[pi(d)][key], shared by the 4 waves
+  const int bh = blockIdx.y, h = bh % g.nH, b = bh / g.nH;
+  const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ldkv = 2 * (int64_t)g.hd;
+  const T* kb = kv + (int64_t)b * g.Lk * ldkv + h * SR_D;
+
+  Vec8<T> kf[4][2];
+  f32x4 kmask[4];                                 // 0 on real keys, -inf on padded ones (lane: keys 16 kt + 4 g + r)
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = 16 * kt + c_;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) kf[kt][ds] = sr_load<T>(kb + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kmask[kt][r] = (16 * kt + 4 * g_ + r) < g.Lk ? 0.f : -INFINITY;
+  }
+  {
+    const int key = 16 * wave + c_;               // wave w transposes V tile w for everybody
+    Vec8<T> vf[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) vf[ds] = sr_load<T>(kb + g.hd + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
+    sr_store_t<T>(vt, vf, 16 * wave, c_, g_);
+  }
+  __syncthreads();
+
+  for (int sc = 0; sc < g.qc; ++sc) {
+    const int sub = blockIdx.x * g.qc + sc;
+    if (sub >= g.nsub) break;
+    const int qi = sub * SR_QB + 16 * wave + c_;
+    const bool qv = qi < g.Lq;
+    const int64_t qrow = (int64_t)b * g.Lq + (qv ? qi : 0);
+    Vec8<T> qf[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) qf[ds] = sr_load<T>(q + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
+    f32x4 st[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) mma16(kf[kt][ds], qf[ds], st[kt]);   // S[q = c][key = 16 kt + 4 g + r]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[kt][r] = st[kt][r] * g.scale + kmask[kt][r]; m = fmaxf(m, st[kt][r]); }
+    }
+    m = fmaxf(m, shfl_xor_f(m, 16));
+    m = fmaxf(m, shfl_xor_f(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); l += st[kt][r]; }
+    l += shfl_xor_f(l, 16);
+    l += shfl_xor_f(l, 32);
+    const float inv = 1.f / l;
+    if (qv && g_ == 0) lse[(int64_t)bh * g.Lq + qi] = m + __logf(l);
+    f32x4 oacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
+                     f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Vec8<T> pf = sr_frag_acc<T>(st[2 * ks] * inv, st[2 * ks + 1] * inv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma16(sr_frag_t<T>(vt + (16 * j + c_) * SR_STR + 32 * ks, g_), pf, oacc[j]);
+    }
+    // oacc[2 dp + dtl][r] = O[q = c][d = 32 dp + 8 g + 4 dtl + r]
+    if (qv) {
+      T* op = o + qrow * g.hd + h * SR_D + 8 * g_;
+      store8<T>(op, sr_out8<T>(oacc[0], oacc[1], 1.f));
+      store8<T>(op + 32, sr_out8<T>(oacc[2], oacc[3], 1.f));
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------- backward
+// same grid; part: fp32 [B * nH][workgroups][64 keys][128] (dK channels 0..63, dV channels 64..127 of the head)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                           const T* __restrict__ oin, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse, T* __restrict__ dq,
+                                                           float* __restrict__ part, SrGeom g) {
+  __shared__ __attribute__((aligned(16))) T kt_s[SR_D * SR_STR];        // Kt[pi(d)][key]
+  __shared__ __attribute__((aligned(16))) T qt_s[SR_D * SR_STR];        // Qt[pi(d)][q of the sub-chunk]
+  __shared__ __attribute__((aligned(16))) T dot_s[SR_D * SR_STR];       // dOt[pi(d)][q]
+  __shared__ __attribute__((aligned(16))) float dq_s[SR_QB];            // D[q] = rowsum(dO o O)
+  __shared__ __attribute__((aligned(16))) float lse_s[SR_QB];
+  const int bh = blockIdx.y, h = bh % g.nH, b = bh / g.nH;
+  const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ldkv = 2 * (int64_t)g.hd;
+  const T* kb = kv + (int64_t)b * g.Lk * ldkv + h * SR_D;
+
+  Vec8<T> kf[4][2], vf[4][2];
+  f32x4 kmask[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = 16 * kt + c_;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      kf[kt][ds] = sr_load<T>(kb + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
+      vf[kt][ds] = sr_load<T>(kb + g.hd + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kmask[kt][r] = (16 * kt + 4 * g_ + r) < g.Lk ? 0.f : -INFINITY;
+  }
+  // wave w: its own key tile as the B operands of phase B, and the transposed K tile for everybody
+  Vec8<T> kw[2], vw[2];
+#pragma unroll
+  for (int ds = 0; ds < 2; ++ds) {
+    kw[ds] = kf[0][ds]; vw[ds] = vf[0][ds];
+#pragma unroll
+    for (int kt = 1; kt < 4; ++kt)
+      if (wave == kt) { kw[ds] = kf[kt][ds]; vw[ds] = vf[kt][ds]; }
+  }
+  sr_store_t<T>(kt_s, kw, 16 * wave, c_, g_);
+  const float kbias = (16 * wave + c_) < g.Lk ? 0.f : -INFINITY;         // phase B: this lane's key
+  f32x4 dkacc[4], dvacc[4];                        // [2 dp + dtl][r]: key = 16 w + c, d = 32 dp + 8 g + 4 dtl + r
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dkacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int sc = 0; sc < g.qc; ++sc) {
+    const int sub = blockIdx.x * g.qc + sc;
+    if (sub >= g.nsub) break;
+    const int q0 = sub * SR_QB;
+    // all four query tiles' Q / dO row fragments (phase B needs every tile; phase A uses tile `wave`)
+    Vec8<T> qf[4][2], dof[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int qi = q0 + 16 * t + c_;
+      const bool qv = qi < g.Lq;
+      const int64_t qrow = (int64_t)b * g.Lq + (qv ? qi : 0);
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        qf[t][ds] = sr_load<T>(q + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
+        dof[t][ds] = sr_load<T>(dout + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
+      }
+    }
+    // own tile: D[q], lse, transposed images
+    Vec8<T> qm[2], dom[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      qm[ds] = qf[0][ds]; dom[ds] = dof[0][ds];
+#pragma unroll
+      for (int t = 1; t < 4; ++t)
+        if (wave == t) { qm[ds] = qf[t][ds]; dom[ds] = dof[t][ds]; }
+    }
+    const int qi = q0 + 16 * wave + c_;
+    const bool qv = qi < g.Lq;
+    const int64_t qrow = (int64_t)b * g.Lq + (qv ? qi : 0);
+    float dsum = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      Vec8<T> of = sr_load<T>(oin + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += of.get(e) * dom[ds].get(e);
+    }
+    dsum += shfl_xor_f(dsum, 16);
+    dsum += shfl_xor_f(dsum, 32);
+    const float lq = qv ? lse[(int64_t)bh * g.Lq + qi] : INFINITY;       // padded queries: exp(. - inf) = 0
+    __syncthreads();                               // the previous sub-chunk's readers of the shared images are done
+    sr_store_t<T>(qt_s, qm, 16 * wave, c_, g_);
+    sr_store_t<T>(dot_s, dom, 16 * wave, c_, g_);
+    if (g_ == 0) { dq_s[16 * wave + c_] = dsum; lse_s[16 * wave + c_] = lq; }
+    __syncthreads();
+
+    // ---------------- phase A (wave <-> query tile `wave`): dQ = scale * dS K
+    {
+      f32x4 dqacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
+                        f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 dsv[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int kt = 2 * ks + half;
+          f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ds = 0; ds < 2; ++ds) { mma16(kf[kt][ds], qm[ds], pt); mma16(vf[kt][ds], dom[ds], dpt); }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(pt[r] * g.scale + kmask[kt][r] - lq);
+            dsv[half][r] = p * (dpt[r] - dsum);
+          }
+        }
+        Vec8<T> dsf = sr_frag_acc<T>(dsv[0], dsv[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma16(sr_frag_t<T>(kt_s + (16 * j + c_) * SR_STR + 32 * ks, g_), dsf, dqacc[j]);
+      }
+      if (qv) {
+        T* p = dq + qrow * g.hd + h * SR_D + 8 * g_;
+        store8<T>(p, sr_out8<T>(dqacc[0], dqacc[1], g.scale));
+        store8<T>(p + 32, sr_out8<T>(dqacc[2], dqacc[3], g.scale));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- phase B (wave <-> key tile `wave`): dV += P^T dO, dK += scale * dS^T Q over this sub-chunk
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x4 pp[2], dss[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * qs + half;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) { mma16(qf[t][ds], kw[ds], s); mma16(dof[t][ds], vw[ds], dp); }
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + 16 * t + 4 * g_);   // rows q = 16 t + 4 g + r
+        const f32x4 dd = *reinterpret_cast<const f32x4*>(dq_s + 16 * t + 4 * g_);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[r] * g.scale + kbias - ls[r]);
+          pp[half][r] = p;
+          dss[half][r] = p * (dp[r] - dd[r]);
+        }
+      }
+      Vec8<T> pf = sr_frag_acc<T>(pp[0], pp[1]);
+      Vec8<T> dsf = sr_frag_acc<T>(dss[0], dss[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mma16(sr_frag_t<T>(dot_s + (16 * j + c_) * SR_STR + 32 * qs, g_), pf, dvacc[j]);
+        mma16(sr_frag_t<T>(qt_s + (16 * j + c_) * SR_STR + 32 * qs, g_), dsf, dkacc[j]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // partial dK | dV of this workgroup: row key = 16 w + c, 8 contiguous channels per accumulator pair
+  float* pr = part + (((int64_t)bh * gridDim.x + blockIdx.x) * SR_LK + 16 * wave + c_) * (2 * SR_D) + 8 * g_;
+  store8<float>(pr, sr_out8<float>(dkacc[0], dkacc[1], g.scale));
+  store8<float>(pr + 32, sr_out8<float>(dkacc[2], dkacc[3], g.scale));
+  store8<float>(pr + SR_D, sr_out8<float>(dvacc[0], dvacc[1], 1.f));
+  store8<float>(pr + SR_D + 32, sr_out8<float>(dvacc[2], dvacc[3], 1.f));
+}
+
+// dkv[b * Lk + key][(k | v) * hd + h * 64 + d] = sum over workgroups (fixed order) of the partial slabs
+template <typename T>
+__global__ void srattn_reduce_kernel(const float* __restrict__ part, T* __restrict__ dkv, int nwg, int Lk, int nH,
+                                     int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over (bh, key, 128 / 4)
+  if (idx >= total) return;
+  const int c4 = (int)(idx % 32), key = (int)((idx / 32) % Lk);
+  const int64_t bh = idx / (32 * (int64_t)Lk);
+  const int h = (int)(bh % nH);
+  const int64_t b = bh / nH;
+  const float* p = part + ((bh * nwg) * SR_LK + key) * (2 * SR_D) + 4 * c4;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < nwg; ++w) s += *reinterpret_cast<const f32x4*>(p + (int64_t)w * SR_LK * 2 * SR_D);
+  const int ch = 4 * c4;                           // 0..63 dK, 64..127 dV
+  T* out = dkv + (b * Lk + key) * (2 * (int64_t)nH * SR_D) + (ch >= SR_D ? (int64_t)nH * SR_D + (ch - SR_D) : ch) + h * SR_D;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) out[e] = from_f32<T>(s[e]);
+}
+
+static int sr_geom(SrGeom& g, int Lq, int Lk, int nH, int B) {
+  if (Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0 || B <= 0) return VTX_ERR_SHAPE;
+  g.Lq = Lq; g.Lk = Lk; g.nH = nH; g.hd = nH * SR_D;
+  g.nsub = (Lq + SR_QB - 1) / SR_QB;
+  // sub-chunks per workgroup: enough workgroups to fill the chip (~2048), as few partial slabs as possible
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("VTX_SRATTN_WGS"); target = e ? atoi(e) : 2048; }
+  int64_t per_bh = target / ((int64_t)B * nH);
+  if (per_bh < 1) per_bh = 1;
+  g.qc = (int)((g.nsub + per_bh - 1) / per_bh);
+  if (g.qc < 1) g.qc = 1;
+  g.scale = 1.0f / sqrtf((float)SR_D);
+  return VTX_OK;
+}
+static int sr_wgs(const SrGeom& g) { return (g.nsub + g.qc - 1) / g.qc; }
+
+extern "C" {
+
+/* Spatial-reduction attention of PVT (reference models/pvt.py:38-66), head dim 64, Lk <= 64 keys:
+ * q [B*Lq, nH*64], kv [B*Lk, 2*nH*64] (k | v halves, head-major inside each), o [B*Lq, nH*64], lse [B*nH*Lq] fp32. */
+int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int dtype,
+                   void* stream) {
+  if (!q || !kv || !o || !lse) return VTX_ERR_NULL;
+  SrGeom g;
+  int rc = sr_geom(g, Lq, Lk, nH, B);
+  if (rc) return rc;
+  dim3 grid(sr_wgs(g), B * nH);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16)
+    hipLaunchKernelGGL((srattn_fwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)kv, (bf16*)o, lse, g);
+  else if (dtype == VTX_F32)
+    hipLaunchKernelGGL((srattn_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)o, lse, g);
+  else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
+
+size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH) {
+  SrGeom g;
+  if (sr_geom(g, Lq, Lk, nH, B)) return 0;
+  return (size_t)B * nH * sr_wgs(g) * SR_LK * 2 * SR_D * sizeof(float);
+}
+
+/* dq [B*Lq, nH*64], dkv [B*Lk, 2*nH*64]; deterministic (fixed-order slab reduction). */
+int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                   void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int dtype, void* stream) {
+  if (!q || !kv || !o || !dout || !lse || !dq || !dkv || !workspace) return VTX_ERR_NULL;
+  SrGeom g;
+  int rc = sr_geom(g, Lq, Lk, nH, B);
+  if (rc) return rc;
+  if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH)) return VTX_ERR_WORKSPACE;
+  const int nwg = sr_wgs(g);
+  dim3 grid(nwg, B * nH);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const int64_t total = (int64_t)B * nH * Lk * 32;
+  const int rb = (int)((total + 255) / 256);
+  if (dtype == VTX_BF16) {
+    hipLaunchKernelGGL((srattn_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)kv, (const bf16*)o,
+                       (const bf16*)dout, lse, (bf16*)dq, part, g);
+    rc = vtx_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL((srattn_reduce_kernel<bf16>), dim3(rb), dim3(256), 0, st, (const float*)part, (bf16*)dkv, nwg, Lk,
+                       nH, total);
+  } else if (dtype == VTX_F32) {
+    hipLaunchKernelGGL((srattn_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)kv,
+                       (const float*)o, (const float*)dout, lse, (float*)dq, part, g);
+    rc = vtx_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL((srattn_reduce_kernel<float>), dim3(rb), dim3(256), 0, st, (const float*)part, (float*)dkv, nwg, Lk,
+                       nH, total);
+  } else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
+
+}  // extern "C"

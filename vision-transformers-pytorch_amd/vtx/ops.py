@@ -217,6 +217,89 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.
     return dW, db
 
 
+# ------------------------------------------------------------------------------- PVT: spatial-reduction attention
+def srattn_fwd(q, kv, B, Lq, Lk, n_head):
+    """o [B*Lq, h*64], lse from q [B*Lq, h*64] and kv [B*Lk, 2*h*64] (k | v) -- reference models/pvt.py:38-66."""
+    _dev(q, kv)
+    if q.dtype != kv.dtype:
+        raise VtxError("vtx: srattn operand dtypes differ")
+    hd = n_head * 64
+    if q.numel() != B * Lq * hd or kv.numel() != B * Lk * 2 * hd:
+        raise VtxError("vtx: srattn shape mismatch (head dim must be 64)")
+    o = torch.empty_like(q)
+    lse = torch.empty(B * n_head * Lq, dtype=torch.float32, device=q.device)
+    tn = "__bf16" if q.dtype == torch.bfloat16 else "float"
+    ev = _attn_bracket(f"srattn_fwd_kernel<{tn}>", B * n_head, Lq, 64, B * Lq, hd, q.element_size(), False)
+    if ev is not None:                              # Lq x Lk products, not Lq x Lq
+        _timer.records[-1] = (_timer.records[-1][0], 4.0 * B * n_head * Lq * Lk * 64,
+                              q.element_size() * (2.0 * B * Lq * hd + 2.0 * B * Lk * hd)) + _timer.records[-1][3:]
+    check(_lib.load().vtx_srattn_fwd(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, _dt(q), _stream()),
+          "vtx_srattn_fwd")
+    if ev:
+        ev[1].record()
+    return o, lse
+
+
+def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head):
+    """dq, dkv (deterministic)."""
+    _dev(q, kv, o, dout, lse)
+    lib = _lib.load()
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    wsb = lib.vtx_srattn_bwd_workspace(B, Lq, Lk, n_head)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    hd = n_head * 64
+    tn = "__bf16" if q.dtype == torch.bfloat16 else "float"
+    ev = _attn_bracket(f"srattn_bwd_kernel<{tn}>", B * n_head, Lq, 64, B * Lq, hd, q.element_size(), True)
+    if ev is not None:
+        _timer.records[-1] = (_timer.records[-1][0], 10.0 * B * n_head * Lq * Lk * 64,
+                              q.element_size() * (4.0 * B * Lq * hd + 4.0 * B * Lk * hd)) + _timer.records[-1][3:]
+    check(lib.vtx_srattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head,
+                             _dt(q), _stream()), "vtx_srattn_bwd")
+    if ev:
+        ev[1].record()
+    return dq, dkv
+
+
+def patchify_fwd(x, B, H, W, C, p, skip=0):
+    """Token-major features [B, skip + H*W, C] -> patch matrix [B*(H/p)*(W/p), p*p*C], columns (py, px, c)."""
+    _dev(x)
+    out = torch.empty((B * (H // p) * (W // p), p * p * C), dtype=x.dtype, device=x.device)
+    check(_lib.load().vtx_patchify_fwd(_p(x), _p(out), B, H, W, C, p, skip, _dt(x), _stream()), "vtx_patchify_fwd")
+    return out
+
+
+def patchify_bwd(dout, dx, B, H, W, C, p, skip=0, accumulate=False):
+    """Inverse scatter of patchify_fwd into dx [B, skip + H*W, C] (optionally accumulating)."""
+    _dev(dout, dx)
+    check(_lib.load().vtx_patchify_bwd(_p(dout), _p(dx), B, H, W, C, p, skip, int(accumulate), _dt(dx), _stream()),
+          "vtx_patchify_bwd")
+    return dx
+
+
+def add_pos_fwd(x, cls, pos):
+    """x [B, T, C] + pos [s + T, C] with an optional cls token row (s = 1) in front (pvt.py:133-137)."""
+    _dev(x, cls, pos)
+    _f32(cls, "cls_token"); _f32(pos, "pos")
+    B, T, C = x.shape
+    s = 0 if cls is None else 1
+    out = torch.empty((B, T + s, C), dtype=x.dtype, device=x.device)
+    check(_lib.load().vtx_add_pos_fwd(_p(x), _p(cls), _p(pos), _p(out), B, T, C, _dt(x), _stream()), "vtx_add_pos_fwd")
+    return out
+
+
+def add_pos_bwd(dout, has_cls):
+    _dev(dout)
+    B, L, C = dout.shape
+    s = 1 if has_cls else 0
+    dx = torch.empty((B, L - s, C), dtype=dout.dtype, device=dout.device)
+    dpos = torch.empty((L, C), dtype=torch.float32, device=dout.device)
+    dcls = torch.empty(C, dtype=torch.float32, device=dout.device) if has_cls else None
+    check(_lib.load().vtx_add_pos_bwd(_p(dout), _p(dx), _p(dcls), _p(dpos), B, L - s, C, _dt(dout), _stream()),
+          "vtx_add_pos_bwd")
+    return dx, dcls, dpos
+
+
 # ------------------------------------------------------------------------------- optimizer tail
 def _ptr_array(ts):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
