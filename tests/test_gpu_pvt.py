@@ -1,0 +1,155 @@
+"""GPU parity of the PVT path through the C ABI: spatial-reduction attention, patchify
+gather, position add vs the oracle; PVT-Small whole model in fp32 vs the reference goldens (G7) and in bf16 vs the
+fp32 oracle on a seeded default-init model."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden
+from gpu_util import TOL, check, dev, report
+from oracle import ref_models as M
+from oracle import ref_ops as R
+from oracle.formula import check_summary, fill, fill_state_dict, name_seed
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _mk(shape, seed, dtype, scale=1.0):
+    return fill(shape, seed, scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Lq,Lk,nH", [(2, 784, 49, 2), (3, 50, 50, 8), (1, 3136, 49, 1), (2, 196, 49, 5), (2, 70, 17, 1)])
+def test_sr_attention_core(dtype, B, Lq, Lk, nH):
+    from vtx import ops
+    d = dev()
+    C = nH * 64
+    # random (not formula) data: the key-side gradients are sums over up to 3136 queries, and the smooth sin-hash fill
+    # cancels almost exactly there -- the bf16 rounding of P / dS would then be measured against a vanishing signal
+    gen = torch.Generator().manual_seed(401)
+    q = torch.randn((B, Lq, C), generator=gen).to(dtype)
+    kv = torch.randn((B, Lk, 2 * C), generator=gen).to(dtype)
+    do = torch.randn((B, Lq, C), generator=gen).to(dtype)
+    o, lse = ops.srattn_fwd(q.to(d), kv.to(d), B, Lq, Lk, nH)
+    dq, dkv = ops.srattn_bwd(q.to(d), kv.to(d), o, do.to(d), lse, B, Lq, Lk, nH)
+    dq2, dkv2 = ops.srattn_bwd(q.to(d), kv.to(d), o, do.to(d), lse, B, Lq, Lk, nH)
+    assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2), "sr attention backward is not deterministic"
+    qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    orf = R.sr_attention_core(qr, kvr, nH)
+    dqr, dkvr = torch.autograd.grad(orf, [qr, kvr], do.double())
+    t = TOL[dtype]
+    tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH}"
+    check(f"srattn fwd {tag}", o, orf, t["out"] * 1.5)
+    check(f"srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+    check(f"srattn dkv {tag}", dkv, dkvr, 2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,C,p,skip", [(28, 28, 128, 4, 0), (14, 14, 320, 2, 0), (8, 12, 64, 2, 1)])
+def test_patchify_and_add_pos(dtype, H, W, C, p, skip):
+    from vtx import ops
+    d = dev()
+    B = 3
+    x = _mk((B, skip + H * W, C), 411, dtype)
+    out = ops.patchify_fwd(x.to(d), B, H, W, C, p, skip)
+    ref = x[:, skip:].reshape(B, H // p, p, W // p, p, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, p * p * C)
+    assert torch.equal(out.cpu(), ref), "patchify gather is a permutation: must be exact"
+    g = _mk(tuple(out.shape), 412, dtype)
+    base = _mk(tuple(x.shape), 413, dtype)
+    dx = base.to(d).clone()
+    ops.patchify_bwd(g.to(d), dx, B, H, W, C, p, skip, accumulate=True)
+    back = g.reshape(B, H // p, W // p, p, p, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H * W, C)
+    want = base.clone().float()
+    want[:, skip:] += back.float()
+    check(f"patchify bwd accumulate {dtype}", dx, want, TOL[dtype]["out"])
+    # position add with / without cls token
+    for has_cls in (False, True):
+        T_ = H * W
+        xx = _mk((B, T_, C), 414, dtype)
+        pos = _mk((T_ + has_cls, C), 415, torch.float32, 0.1)
+        cls = _mk((C,), 416, torch.float32, 0.1) if has_cls else None
+        o = ops.add_pos_fwd(xx.to(d), None if cls is None else cls.to(d), pos.to(d))
+        want = xx.double()
+        if has_cls:
+            want = torch.cat((cls.double().view(1, 1, C).expand(B, -1, -1), want), 1)
+        want = want + pos.double()
+        check(f"add_pos fwd cls={has_cls} {dtype}", o, want, TOL[dtype]["out"])
+        go = _mk(tuple(o.shape), 417, dtype)
+        dxx, dcls, dpos = ops.add_pos_bwd(go.to(d), has_cls)
+        check(f"add_pos dx cls={has_cls} {dtype}", dxx, go[:, int(has_cls):].double(), 1e-7)
+        check(f"add_pos dpos cls={has_cls} {dtype}", dpos, go.double().sum(0), 1e-5)
+        if has_cls:
+            check(f"add_pos dcls {dtype}", dcls, go[:, 0].double().sum(0), 1e-5)
+
+
+def _pvt(drop_path=0.0):
+    from models.pvt import PyramidVisionTransformer
+    return PyramidVisionTransformer(**M.PVT_SMALL, drop_path=drop_path)
+
+
+def test_pvt_small_fp32_vs_reference():
+    """fp32 parity mode vs the reference's own outputs (golden G7): logits and all 0f the per-parameter grad norms."""
+    g = Golden("g7_pvt")
+    model = _pvt()
+    model.load_state_dict(fill_state_dict(model.state_dict()))
+    model.to(dev()).train()
+    x = fill((2, 3, 224, 224), 21, 1.0).to(dev())
+    out = model(x)
+    e = check_summary(out, g.rec("pvt_small.train64.logits"), 1e-4, "pvt logits vs reference fp64")
+    report("pvt-small fp32 logits vs reference (fp64 golden)", e, 1e-4)
+    cot = fill(out.shape, name_seed("pvt_small.train64.cot"), 1.0).to(dev())
+    (out * cot).sum().backward()
+    names = [str(n) for n in g.arr("pvt_small.train64.grad_names")]
+    norms = g.arr("pvt_small.train64.grad_norms")
+    got = dict(model.named_parameters())
+    assert names == list(got.keys())
+    worst, worst_n = 0.0, ""
+    for n, ref in zip(names, norms):
+        rel = abs(got[n].grad.double().norm().item() - ref) / max(ref, 1e-12)
+        if rel > worst:
+            worst, worst_n = rel, n
+    # fp32 through 16 layers vs an fp64 reference: the oracle's own fp32 run deviates up to ~2e-3 on the deepest small
+    # gradients (tests/test_oracle_pvt.py uses 5e-3 for the same comparison)
+    assert report(f"pvt-small fp32: worst per-param grad-norm deviation ({worst_n})", worst, 5e-3)
+    for k in g.keys("pvt_small.train64.grad."):                       # sampled gradient values (same cotangent)
+        pn = k[len("pvt_small.train64.grad."):]
+        e = check_summary(got[pn].grad, g.rec(k), 5e-3, k)
+        report(f"pvt-small fp32: grad {pn}", e, 5e-3)
+
+
+def test_pvt_small_bf16_autocast_vs_oracle():
+    from test_gpu_models import _bf16_vs_oracle, _seeded_init
+    model = _pvt()
+    sd = _seeded_init(model, 2)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(12))
+    _bf16_vs_oracle(model, lambda P, xx: M.pvt_forward(P, xx, M.PVT_SMALL), sd, x, "pvt-small")
+
+
+def test_pvt_small_drop_path_runs_and_is_deterministic_given_masks(monkeypatch):
+    """DropPath through the PVT layer (per-sample scale in the GEMM epilogues / dropped rows in wgrad) vs the oracle
+    with the same injected masks."""
+    from test_gpu_models import _seeded_init
+    model = _pvt(0.2)
+    sd = _seeded_init(model, 3)
+    model.to(dev()).train()
+    B = 4
+    gen = torch.Generator().manual_seed(5)
+    rates = torch.linspace(0, 0.2, sum(M.PVT_SMALL["depths"])).tolist()
+    masks = [(None, None) if r == 0 else ((torch.rand(B, generator=gen) < 1 - r).float(), (torch.rand(B, generator=gen) < 1 - r).float())
+             for r in rates]
+    it = iter([m for pair in masks for m in pair if m is not None])
+
+    def fake(p, training, batch, device):
+        if not training or p == 0:
+            return None
+        return next(it).to(device) / (1.0 - p)
+
+    monkeypatch.setattr("models.pvt.drop_path_scale", fake)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(13))
+    out = model(x.to(dev()))
+    P = {k: v.clone() for k, v in sd.items()}
+    ref = M.pvt_forward(P, x, M.PVT_SMALL, drop_masks=masks, drop_path=0.2)
+    check("pvt-small fp32 drop-path logits vs oracle", out, ref, 1e-4)

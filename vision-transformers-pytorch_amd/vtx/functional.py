@@ -411,3 +411,150 @@ class TokenMeanFn(Function):
     def backward(ctx, dy):
         B, Tn, C, shape = ctx.dims
         return ops.token_mean_bwd(_c(dy), B, Tn, C, shape)
+
+
+# ------------------------------------------------------------------------------------------------- PVT (models/pvt.py)
+def conv_as_rows(w):
+    """Conv2d weight (out, in, p, p) of a wcast pair -> GEMM weight (out, p*p*in) with columns in (py, px, c) order, the
+    column order of ops.patchify_fwd (token-major gather); the transposed copy is made lazily by dgrad."""
+    out_ch = w.shape[0]
+    return (w.permute(0, 2, 3, 1).reshape(out_ch, -1).contiguous(), None)
+
+
+class PvtMeta:
+    """Static description of one PVT transformer layer: heads, token grid, spatial reduction, leading cls tokens."""
+
+    def __init__(self, n_head, height, width, reduction, skip, eps=1e-6):
+        self.n_head, self.height, self.width, self.reduction, self.skip, self.eps = n_head, height, width, reduction, skip, eps
+
+
+class PvtLayerFn(Function):
+    """One PVT block (reference models/pvt.py:31-68, 99-103):
+         x1 = x  + s1 * proj(sr_attn(q(LN1 x), kv(reduce(LN1 x))))      y = x1 + s2 * fc2(silu(fc1(LN2 x1)))
+    reduce = Conv2d(C, C, r, stride r) on the token grid + LayerNorm (reduction > 1) as patchify gather + GEMM + LN.
+    Kernels forward: LN, GEMM(q), [gather, GEMM+bias, LN], GEMM(kv), attention, GEMM+residual, LN, GEMM+SiLU,
+    GEMM+residual."""
+
+    @staticmethod
+    def forward(ctx, x, ln1_w, ln1_b, q_w, kv_w, sr_w, sr_b, srn_w, srn_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b,
+                fc2_w, fc2_b, s1, s2, dp_c, meta):
+        x = _c(x)
+        T = x.dtype
+        B, L, C = x.shape
+        m = meta
+        rps = L
+        r = m.reduction
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), m.eps)
+        wq, wkv, wo, w1, w2 = wcast(q_w, T), wcast(kv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T)
+        q = ops.gemm(ln1, wq[0], 0)
+        wsr = patches = red = means = rstds = None
+        if r > 1:
+            wsr = conv_as_rows(wcast(sr_w, T)[0])
+            patches = ops.patchify_fwd(ln1, B, m.height, m.width, C, r, m.skip)
+            Lk = (m.height // r) * (m.width // r)
+            red = ops.gemm(patches, wsr[0], 0, bias=sr_b.detach())
+            kvin, means, rstds = ops.layernorm_fwd(red, srn_w.detach(), srn_b.detach(), m.eps)
+        else:
+            kvin, Lk = ln1, L
+        kv = ops.gemm(kvin, wkv[0], 0)
+        o, lse = ops.srattn_fwd(q, kv, B, L, Lk, m.n_head)
+        x1 = ops.gemm(o, wo[0], 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), m.eps)
+        h, z = ops.gemm(ln2, w1[0], 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
+        y = ops.gemm(h, w2[0], 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
+        ctx.save_for_backward(x, ln1_w, ln2_w, srn_w, mean1, rstd1, ln1, q, kv, o, lse, x1, mean2, rstd2, ln2, z, h,
+                              patches, red, means, rstds, kvin if r > 1 else None, s1, s2)
+        ctx.wp = (wq, wkv, wo, w1, w2, wsr)
+        ctx.meta, ctx.rps, ctx.dp_c, ctx.Lk, ctx.sr_shape = m, rps, float(dp_c), Lk, (None if sr_w is None else sr_w.shape)
+        return y.view(B, L, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, ln1_w, ln2_w, srn_w, mean1, rstd1, ln1, q, kv, o, lse, x1, mean2, rstd2, ln2, z, h, patches, red, means,
+         rstds, kvin, s1, s2) = ctx.saved_tensors
+        wq, wkv, wo, w1, w2, wsr = ctx.wp
+        m, rps, dp_c, Lk = ctx.meta, ctx.rps, ctx.dp_c, ctx.Lk
+        T = x.dtype
+        B, L, C = x.shape
+        r = m.reduction
+        dy = _c(dy)
+        # ---- MLP branch
+        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
+        dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
+        dW1, db1 = ops.wgrad(dz, ln2)
+        dln2 = dgrad(dz, w1, T)
+        dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
+        # ---- attention branch
+        dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
+        do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
+        dq, dkv = ops.srattn_bwd(q, kv, o, do, lse, B, L, Lk, m.n_head)
+        dWq, _ = ops.wgrad(dq, ln1, want_bias=False)
+        dWsr = dbsr = dgs = dbs = None
+        if r > 1:
+            dWkv, _ = ops.wgrad(dkv, kvin, want_bias=False)
+            dkvin = dgrad(dkv, wkv, T)
+            dred, dgs, dbs = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach())
+            dWsr, dbsr = ops.wgrad(dred, patches)
+            dpatches = dgrad(dred, wsr, T)
+            dln1 = dgrad(dq, wq, T)
+            ops.patchify_bwd(dpatches, dln1, B, m.height, m.width, C, r, m.skip, accumulate=True)
+            co, _, p, _ = ctx.sr_shape
+            dWsr = dWsr.view(co, p, p, C).permute(0, 3, 1, 2).contiguous()   # (py, px, c) columns back to (c, py, px)
+        else:
+            dWkv, _ = ops.wgrad(dkv, ln1, want_bias=False)
+            dkvin = dgrad(dkv, wkv, T)
+            dln1 = dgrad(dq, wq, T, resid=dkvin)                       # both consumers of LN1's output
+        dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+        return (dx.view(B, L, C), dg1, dbe1, dWq, dWkv, dWsr, dbsr, dgs, dbs, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2,
+                None, None, None, None)
+
+
+class PvtPatchEmbedFn(Function):
+    """pvt.PatchEmbedding (reference models/pvt.py:126-140): Conv2d(in, dim, p, stride p) -> LayerNorm(1e-6) ->
+    [cls token] + pos.  Stage 1 reads the NCHW image (im2col gather in conv-weight order); later stages read the
+    previous stage's token-major features [B, skip + H*W, C] (patchify gather, weight columns permuted to match)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, ln_w, ln_b, cls, pos, patch, grid, skip, eps, dtype):
+        T = dtype
+        out_ch = w.shape[0]
+        if x.dim() == 4:                                               # NCHW image
+            B = x.shape[0]
+            H, W = x.shape[2] // patch, x.shape[3] // patch
+            patches = ops.patch_gather(_c(x), patch, 1, T).view(B * H * W, -1)
+            wp = (wcast(w, T)[0].view(out_ch, -1), None)
+            ctx.tok = None
+        else:
+            x = _c(x)
+            B, _, C = x.shape
+            H, W = grid[0] // patch, grid[1] // patch
+            patches = ops.patchify_fwd(x, B, grid[0], grid[1], C, patch, skip)
+            wp = conv_as_rows(wcast(w, T)[0])
+            ctx.tok = (x.shape, grid, skip)
+        t = ops.gemm(patches, wp[0], 0, bias=b.detach())
+        tn, mean, rstd = ops.layernorm_fwd(t, ln_w.detach(), ln_b.detach(), eps)
+        out = ops.add_pos_fwd(tn.view(B, H * W, out_ch), None if cls is None else _c(cls.detach()), _c(pos.detach()))
+        ctx.save_for_backward(patches, t, mean, rstd, ln_w)
+        ctx.wp, ctx.patch, ctx.has_cls, ctx.wshape = wp, patch, cls is not None, w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        patches, t, mean, rstd, ln_w = ctx.saved_tensors
+        dtn, dcls, dpos = ops.add_pos_bwd(_c(dout), ctx.has_cls)
+        dt, dg, db = ops.layernorm_bwd(dtn.view(-1, dtn.shape[-1]), t, mean, rstd, ln_w.detach())
+        dW, dbias = ops.wgrad(dt, patches)
+        co, ci, p, _ = ctx.wshape
+        dx = None
+        if ctx.tok is None:
+            dW = dW.view(ctx.wshape)
+        else:
+            dW = dW.view(co, p, p, ci).permute(0, 3, 1, 2).contiguous()
+            if ctx.needs_input_grad[0]:
+                shape, grid, skip = ctx.tok
+                dpatches = dgrad(dt, ctx.wp, dt.dtype)
+                dx = torch.empty(shape, dtype=dt.dtype, device=dt.device)
+                if skip:
+                    dx[:, :skip].zero_()
+                ops.patchify_bwd(dpatches, dx, shape[0], grid[0], grid[1], shape[2], p, skip)
+        return dx, dW, dbias, dg, db, dcls, dpos, None, None, None, None, None
