@@ -27,7 +27,11 @@ import torch.distributed as dist
 
 SWIN_S = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2), dims=(96, 192, 384, 768), dim_head=32,
               n_heads=(3, 6, 12, 24), dim_ffs=(384, 768, 1536, 3072), window_size=7)
-TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59}      # BASELINE.md section 2 (3 x forward GEMM FLOPs)
+# 3 x forward GEMM FLOPs per image (pvt_small: 2*M*N*K over patch embeddings, q / kv / proj / sr-conv
+# / MLP GEMMs and the Lq x Lk attention products = 7.631 GFLOP forward = the PVT paper's 3.8 GMACs)
+PVT_SMALL = dict(image_size=224, n_class=1000, in_dim=3, depths=(3, 4, 6, 3), patch_embed_dims=(64, 128, 320, 512),
+                 n_heads=(1, 2, 5, 8), dim_ffs=(512, 1024, 1280, 2048), reductions=(8, 4, 2, 1))
+TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59, "pvt_small": 22.89}
 PEAK_BF16_TFLOPS = 2500.0                                       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_TBPS = 8.0                                              # HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3                                         # dense fp32 MFMA peak (parity mode)
@@ -54,6 +58,9 @@ def build_model(name, drop_path):
     from vtx.nn import Linear
     if name == "swin_s":
         return SwinTransformer(**SWIN_S, drop_path=drop_path)          # config/swin-transformer-s.conf:1-12
+    if name == "pvt_small":
+        from models.pvt import PyramidVisionTransformer
+        return PyramidVisionTransformer(**PVT_SMALL, drop_path=drop_path)   # BASELINE.json cfg-4 (PVT paper hyper-parameters)
     return VisionTransformer(Linear(384, 1000), 224, 16, 12, 384, 6, 1536, 0.0, 0.0, 0.0, drop_path)
 
 
@@ -68,6 +75,8 @@ def cpu_baseline(name, batch, steps):
          if torch.is_floating_point(v)}
     if name == "swin_s":
         fwd = lambda x: M.swin_forward(P, x, M.SWIN_S)
+    elif name == "pvt_small":
+        fwd = lambda x: M.pvt_forward(P, x, M.PVT_SMALL)
     else:
         fwd = lambda x: M.vit_forward(P, x, M.VIT_S16, head=lambda f: R.linear(f, P["head.weight"], P["head.bias"]))
     opt = torch.optim.AdamW(list(P.values()), lr=1e-3, weight_decay=0.05)
@@ -95,8 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / 256 vit_s16)")
+    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / pvt_small, 256 vit_s16)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +129,7 @@ def main():
     from vtx.ddp import GradAllReduce
     from vtx.train_step import MixLoss, make_param_groups, train_step
 
-    batch = args.batch or (128 if args.model == "swin_s" else 256)
+    batch = args.batch or (256 if args.model == "vit_s16" else 128)
     drop_path = 0.3 if args.model == "swin_s" else 0.1
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,16 @@ for what in "$@"; do
       timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/bench.log ;;
     benchq)
       timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/benchq.log ;;
+    profpvt:*)
+      tag=${what#profpvt:}
+      mkdir -p gpurun_out/profpvt_${tag}
+      export TMPDIR=/tmp
+      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profpvt_${tag} -o trace -- \
+         python $R/bench.py --model pvt_small --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/profpvt_${tag}/run.log 2>&1)
+      grep '"metric"' gpurun_out/profpvt_${tag}/run.log | cut -c1-220
+      python tools/rocpd_stats.py gpurun_out/profpvt_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/profpvt_${tag}/kernel_stats.md
+      rm -f gpurun_out/profpvt_${tag}/trace_results.db
+      head -16 gpurun_out/profpvt_${tag}/kernel_stats.md | cut -c1-170 ;;
     profvit:*)
       tag=${what#profvit:}
       mkdir -p gpurun_out/profvit_${tag}
