@@ -268,3 +268,40 @@ def pvt_patch_embedding(x_nchw, w_conv, b_conv, g_norm, b_norm, pos, cls_token, 
     if cls_token is not None:
         out = torch.cat((cls_token.view(1, 1, -1).expand(out.shape[0], -1, -1), out), 1)
     return out + pos.unsqueeze(0), (height, width)
+
+
+# ------------------------------------------------------------------------------------------ DINO (loss.py:89-152, vit.py:206-262)
+def dino_head(x, p, depth=3, qf=None):
+    """vit.DINOHead.forward (vit.py:255-262) without BatchNorm: mlp (Linear, exact-erf GELU, ...) -> L2 normalise ->
+    weight-normed Linear(bottleneck -> out, no bias) with w = g * v / ||v||_row (nn.utils.weight_norm, dim 0).
+    p: mlp.{0,2,4}.weight/bias (depth 3), last.weight_g (out, 1), last.weight_v (out, bottleneck)."""
+    out = x
+    for i in range(depth):
+        out = _q(linear(out, p[f"mlp.{2 * i}.weight"], p[f"mlp.{2 * i}.bias"]), qf)
+        if i < depth - 1:
+            out = _q(torch.nn.functional.gelu(out), qf)
+    out = _q(torch.nn.functional.normalize(out, dim=-1, p=2), qf)
+    v = p["last.weight_v"]
+    w = p["last.weight_g"] * v / v.norm(dim=1, keepdim=True)
+    return linear(out, w, None)
+
+
+def dino_loss(student, teacher, center, n_crop, student_temp, teacher_temp):
+    """DINOLoss.forward (loss.py:122-144): student (n_crop*B, K), teacher (2*B, K), center (1, K);
+    loss = mean over the (teacher crop iq, student crop v != iq) pairs of mean_b sum_k -q_iq log_softmax(s_v / ts)."""
+    s = (student / student_temp).chunk(n_crop)
+    q = torch.softmax((teacher - center) / teacher_temp, -1).detach().chunk(2)
+    total, n = 0, 0
+    for iq, qq in enumerate(q):
+        for v in range(n_crop):
+            if v == iq:
+                continue
+            total = total + torch.sum(-qq * torch.log_softmax(s[v], -1), -1).mean()
+            n += 1
+    return total / n
+
+
+def dino_center_update(center, teacher, momentum, world=1):
+    """DINOLoss.update_center (loss.py:146-152) for one process group of `world` ranks holding identical batches."""
+    batch_center = teacher.sum(0, keepdim=True) * world / (teacher.shape[0] * world)
+    return center * momentum + batch_center * (1 - momentum)

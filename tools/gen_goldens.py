@@ -7,7 +7,7 @@ all inputs/weights are closed-form (oracle/formula.py), so nothing of the refere
 travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
 
 Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
-fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1).
+fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1), G8 DINO head + loss (F2).
 """
 import os
 import sys
@@ -271,6 +271,39 @@ def gen_pvt():
     save("g7_pvt", rec)
 
 
+# ------------------------------------------------------------------ G8 (DINO head + loss)
+def gen_dino():
+    import torch.distributed as tdist
+    rec = {}
+    head = ref_vit.DINOHead(384, 4096, norm_last_layer=False)
+    sd = fill_state_dict(head.state_dict())
+    sd["last.weight_g"] = fill(sd["last.weight_g"].shape, name_seed("last.weight_g"), 0.3, 1.0)   # away from the all-ones init
+    head.load_state_dict(sd)
+    head.double()
+    x = fill((6, 384), 81, 1.0).double().requires_grad_(True)
+    out = head(x)
+    (out * fill(out.shape, 82, 1.0).double()).sum().backward()
+    rec["head.out"] = summarize(out)
+    rec["head.dx"] = summarize(x.grad)
+    for n, p in head.named_parameters():
+        rec[f"head.grad.{n}"] = summarize(p.grad)
+    rec["head.param_names"] = np.array([n for n, _ in head.named_parameters()])
+    # DINOLoss: 4 crops (2 global + 2 local), B = 3, K = 4096; epoch 5 of a 30-epoch teacher-temperature warm-up
+    if not tdist.is_initialized():
+        tdist.init_process_group("gloo", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+    crit = ref_loss.DINOLoss(4096, 4, 0.04, 0.07, 30, 100).double()
+    crit.center.copy_(fill((1, 4096), 83, 0.2).double())
+    student = fill((12, 4096), 84, 2.0).double().requires_grad_(True)
+    teacher = fill((6, 4096), 85, 2.0).double()
+    loss = crit(student, teacher, 5)
+    loss.backward()
+    rec["loss.value"] = np.array(loss.item())
+    rec["loss.teacher_temp"] = np.array(crit.teacher_temperature_schedule[5])
+    rec["loss.dstudent"] = summarize(student.grad)
+    rec["loss.center_after"] = summarize(crit.center)
+    save("g8_dino", rec)
+
+
 def gen_train_step():
     rec = {}
     B = 2
@@ -315,7 +348,7 @@ def gen_train_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt"]
+    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino"]
     if "tables" in which:
         gen_tables()
     if "modules" in which:
@@ -326,5 +359,7 @@ if __name__ == "__main__":
         gen_train_step()
     if "pvt" in which:
         gen_pvt()
+    if "dino" in which:
+        gen_dino()
     # make sure nothing was written into the reference tree
     assert not os.path.exists(os.path.join(REF, "models", "__pycache__")), "pycache leaked into reference"
