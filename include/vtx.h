@@ -159,6 +159,21 @@ int vtx_adamw_step(int n, float* const* p, const float* const* g, float* const* 
                    const int64_t* numel, const float* lr, const float* wd, const float* norm, float max_norm,
                    float beta1, float beta2, float eps, int t, void* stream);
 
+/* Momentum (EMA) update of the DINO teacher / an EMA model: p_i = m * p_i + (1 - m) * g_i for n fp32 tensors given as
+ * HOST arrays of device pointers (train_dino.py:258-263, train_util.py:70-76). */
+int vtx_ema_update(int n, float* const* p, const float* const* g, const int64_t* numel, float m, void* stream);
+
+/* ---- DINO loss (csrc/dino.hip; reference loss.py:122-152): forward value and gradient w.r.t. the student logits in
+ * one sweep, plus the teacher column sums of update_center.
+ *   student [n_crop*B, K], teacher [2*B, K] (dtype), center [K] fp32 (read only); K % 8 == 0;
+ *   loss_rows [n_crop*B] fp32 with loss = sum(loss_rows) / ((2 n_crop - 2) B);
+ *   dstudent [n_crop*B, K] (dtype) = gscale * d loss / d student;  batch_center [K] fp32 = sum of the teacher rows;
+ *   workspace: vtx_dino_loss_workspace(B, K) bytes. */
+size_t vtx_dino_loss_workspace(int B, int K);
+int vtx_dino_loss(const void* student, const void* teacher, const float* center, void* workspace, size_t ws_bytes,
+                  float* loss_rows, void* dstudent, float* batch_center, int n_crop, int B, int K, float student_temp,
+                  float teacher_temp, float gscale, int dtype, void* stream);
+
 /* ---- Multi-tensor weight cast (csrc/cast.hip): all fp32 Linear / Conv weights of a model -> bf16, plain [out][in]
  * and transposed [in][out], in one launch per forward.  This is the per-call weight cast of the reference's bf16
  * autocast (torch.cuda.amp.autocast around model(input), train.py:273-274) done once for the whole model.

@@ -1,0 +1,137 @@
+"""GPU parity of the DINO pieces: fused loss kernel vs the reference's own outputs (golden G8)
+and the oracle, momentum update, DINOHead on the HIP linears, and one full dino_train_step vs a torch-composed step."""
+import copy
+
+import pytest
+import torch
+
+from golden_util import Golden
+from gpu_util import TOL, check, dev, report
+from oracle import ref_ops as R
+from oracle.formula import check_summary, fill, fill_state_dict, name_seed
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dino_loss_fp32_vs_reference_golden():
+    from vtx.dino import DINOLoss
+    g = Golden("g8_dino")
+    d = dev()
+    crit = DINOLoss(4096, 4, 0.04, 0.07, 30, 100).to(d)
+    crit.center.copy_(fill((1, 4096), 83, 0.2))
+    student = fill((12, 4096), 84, 2.0).to(d).requires_grad_(True)
+    teacher = fill((6, 4096), 85, 2.0).to(d)
+    loss = crit(student, teacher, 5)
+    loss.backward()
+    ref = float(g.arr("loss.value"))
+    assert report("dino loss value vs reference", abs(loss.item() - ref) / abs(ref), 2e-6)
+    report("dino loss d student vs reference", check_summary(student.grad, g.rec("loss.dstudent"), 2e-5, "dstudent"), 2e-5)
+    report("dino center update vs reference", check_summary(crit.center, g.rec("loss.center_after"), 2e-6, "center"), 2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dino_loss_kernel_vs_oracle_full_width(dtype):
+    """K = 65536 (the configured out_dim), 10 crops, ragged batch; gradient scaled by an upstream factor."""
+    from vtx import ops
+    d = dev()
+    gen = torch.Generator().manual_seed(11)
+    B, K, n_crop = 3, 65536, 10
+    s = (torch.randn(n_crop * B, K, generator=gen) * 3).to(dtype)
+    t = (torch.randn(2 * B, K, generator=gen) * 3).to(dtype)
+    c = torch.randn(K, generator=gen) * 0.3
+    loss, ds, bc = ops.dino_loss(s.to(d), t.to(d), c.to(d), n_crop, 0.1, 0.05, gscale=0.5)
+    sr = s.double().requires_grad_(True)
+    lr = R.dino_loss(sr, t.double(), c.double().view(1, -1), n_crop, 0.1, 0.05)
+    (dr,) = torch.autograd.grad(lr * 0.5, [sr])
+    check(f"dino loss {dtype}", loss, lr, 1e-5)
+    check(f"dino dstudent {dtype}", ds, dr, 2e-5 if dtype == torch.float32 else 6e-3)
+    check(f"dino batch_center {dtype}", bc, t.double().sum(0), 1e-5)
+    loss2, ds2, _ = ops.dino_loss(s.to(d), t.to(d), c.to(d), n_crop, 0.1, 0.05, gscale=0.5)
+    assert torch.equal(loss, loss2) and torch.equal(ds, ds2)
+
+
+def test_momentum_update_and_head():
+    from models.vit import DINOHead
+    from vtx.dino import momentum_update
+    d = dev()
+    torch.manual_seed(0)
+    student = DINOHead(384, 4096, norm_last_layer=False).to(d)
+    teacher = DINOHead(384, 4096, norm_last_layer=False).to(d)       # (weight_norm modules cannot be deep-copied)
+    teacher.load_state_dict(student.state_dict())
+    with torch.no_grad():
+        for p in student.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    want = [0.99 * pt.detach().double() + 0.01 * ps.detach().double() for ps, pt in zip(student.parameters(), teacher.parameters())]
+    momentum_update(teacher, student, 0.99)
+    for i, (pt, w) in enumerate(zip(teacher.parameters(), want)):
+        check(f"momentum update p{i}", pt, w, 1e-6)
+    # DINOHead forward / backward on the HIP linears vs the oracle (fp32 parity mode), golden-pinned oracle
+    g = Golden("g8_dino")
+    head = DINOHead(384, 4096, norm_last_layer=False)
+    sd = fill_state_dict(head.state_dict())
+    sd["last.weight_g"] = fill(sd["last.weight_g"].shape, name_seed("last.weight_g"), 0.3, 1.0)
+    head.load_state_dict(sd)
+    head.to(d)
+    x = fill((6, 384), 81, 1.0).to(d).requires_grad_(True)
+    out = head(x)
+    (out * fill(out.shape, 82, 1.0).to(d)).sum().backward()
+    report("dino head out vs reference", check_summary(out, g.rec("head.out"), 2e-5, "head out"), 2e-5)
+    report("dino head dx vs reference", check_summary(x.grad, g.rec("head.dx"), 1e-4, "head dx"), 1e-4)
+    for n, p in head.named_parameters():
+        report(f"dino head grad {n}", check_summary(p.grad, g.rec(f"head.grad.{n}"), 5e-4, n), 5e-4)   # fp32 vs fp64 golden
+
+
+def test_dino_step_gradients_and_train_step():
+    """Student gradients of the fused-loss path vs the same forward with the loss composed from torch ops (fp32 parity
+    mode, multi-crop student, no_grad teacher); then dino_train_step end to end: the teacher must equal
+    m * teacher_old + (1 - m) * student_new and the centre must follow update_center.  (Parameters after an Adam step
+    are not compared across the two gradient computations: the first Adam step is lr * sign(g) wherever |g| ~ eps.)"""
+    from models.vit import dino
+    from vtx.dino import DINOLoss, dino_train_step
+    from vtx.optim import FusedAdamW
+    d = dev()
+    torch.manual_seed(1)
+    kw = dict(image_size=224, window_size=16, depth=2, dim=384, n_head=6, dim_ff=768, dropout=0.0, drop_attn=0.0,
+              drop_ff=0.0, drop_path=0.0, dim_head_out=1024, norm_last_layer=False)
+
+    def clone_of(m):
+        c = dino(**kw).to(d).train()
+        c.load_state_dict(m.state_dict())
+        return c
+
+    student = dino(**kw).to(d).train()
+    teacher, s2 = clone_of(student), clone_of(student)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    gen = torch.Generator().manual_seed(2)
+    crops = [torch.randn(2, 3, 224, 224, generator=gen).to(d) for _ in range(2)] + \
+            [torch.randn(2, 3, 96, 96, generator=gen).to(d) for _ in range(3)]
+    crit = DINOLoss(1024, 5, 0.04, 0.07, 30, 100).to(d)
+    # (1) gradients
+    with torch.no_grad():
+        tout = teacher(crops[:2])
+    loss = crit(student(crops), tout, 3)
+    loss.backward()
+    center0 = torch.zeros(1, 1024, device=d)
+    ref = R.dino_loss(s2(crops), tout, center0, 5, 0.1, crit.teacher_temperature_schedule[3])
+    ref.backward()
+    check("dino step loss", loss, ref, 1e-5)
+    check("dino step centre", crit.center, R.dino_center_update(center0, tout, 0.9), 1e-5)
+    num = den = 0.0
+    for (n, a), b in zip(student.named_parameters(), s2.parameters()):
+        num += (a.grad.double() - b.grad.double()).norm().item() ** 2
+        den += b.grad.double().norm().item() ** 2
+    assert report("dino step: all-parameter student gradient rel-L2 vs torch-composed loss", (num / den) ** 0.5, 1e-4)
+    # (2) the whole step
+    student.zero_grad(set_to_none=True)
+    t_old = [p.detach().clone() for p in teacher.parameters()]
+    opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=0.04)
+    loss2 = dino_train_step(student, teacher, crit, opt, crops, epoch=0, momentum=0.99, clip_grad_norm=3.0,
+                            freeze_last_layer=1, autocast_dtype=None)
+    assert torch.isfinite(loss2).item()
+    names = [n for n, _ in student.named_parameters()]
+    for n, ps, pt, po in zip(names, student.parameters(), teacher.parameters(), t_old):
+        check(f"dino step teacher momentum {n}", pt, 0.99 * po.double() + 0.01 * ps.detach().double(), 1e-6)
+    s_last = dict(student.named_parameters())["head.last.weight_v"]
+    assert torch.equal(s_last, dict(s2.named_parameters())["head.last.weight_v"]), \
+        "epoch < freeze_last_layer: the last layer must not move (cancel_last_layer_grad, train_util.py:25-31)"

@@ -122,6 +122,28 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(const OptPack k, const 
   }
 }
 
+// EMA / momentum-teacher update  p = m * p + (1 - m) * g   (g = the online parameter): train_dino.py:258-263,
+// train_util.py:70-76 -- one multi-tensor pass instead of two foreach launches per call
+__global__ __launch_bounds__(256) void ema_kernel(const OptPack k, float m) {
+  const OptDesc d = opt_find(k, blockIdx.x);
+  const int64_t base = (int64_t)(blockIdx.x - d.chunk0) * OPT_CHUNK;
+  const bool al = ((reinterpret_cast<uintptr_t>(d.p) | reinterpret_cast<uintptr_t>(d.g)) & 15) == 0;
+  const float w = 1.f - m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t e = base + (int64_t)(i * 256 + threadIdx.x) * 4;
+    if (al && e + 4 <= d.numel) {
+      f32x4 p = *reinterpret_cast<const f32x4*>(d.p + e);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(d.g + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = p[j] * m + g[j] * w;
+      *reinterpret_cast<f32x4*>(d.p + e) = p;
+    } else {
+      for (int64_t j = e; j < d.numel && j < e + 4; ++j) d.p[j] = d.p[j] * m + d.g[j] * w;
+    }
+  }
+}
+
 // fill a launch pack from tensors [i0, i0 + cnt); returns its number of chunks
 static int opt_pack(OptPack& k, int i0, int cnt, float* const* p, const float* const* g, float* const* m,
                     float* const* v, const int64_t* numel, const float* lr, const float* wd) {
@@ -180,6 +202,21 @@ int vtx_adamw_step(int n, float* const* p, const float* const* g, float* const* 
     if (nch > 0)
       hipLaunchKernelGGL(adamw_step_kernel, dim3(nch), dim3(256), 0, (hipStream_t)stream, k, norm, max_norm, beta1,
                          beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)));
+    int rc = vtx_check_launch();
+    if (rc) return rc;
+  }
+  return VTX_OK;
+}
+
+/* Momentum update of n fp32 tensors (HOST arrays of device pointers): p_i = m * p_i + (1 - m) * g_i. */
+int vtx_ema_update(int n, float* const* p, const float* const* g, const int64_t* numel, float m, void* stream) {
+  if (!p || !g || !numel) return VTX_ERR_NULL;
+  if (n <= 0) return VTX_ERR_SHAPE;
+  for (int i0 = 0; i0 < n; i0 += OPT_NT) {
+    OptPack k;
+    const int cnt = n - i0 < OPT_NT ? n - i0 : OPT_NT;
+    const int nch = opt_pack(k, i0, cnt, p, g, nullptr, nullptr, numel, nullptr, nullptr);
+    if (nch > 0) hipLaunchKernelGGL(ema_kernel, dim3(nch), dim3(256), 0, (hipStream_t)stream, k, m);
     int rc = vtx_check_launch();
     if (rc) return rc;
   }

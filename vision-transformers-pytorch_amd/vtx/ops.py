@@ -330,6 +330,38 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, lrs, wds, norm, max_norm, bet
                                      float(eps), int(t), _stream()), "vtx_adamw_step")
 
 
+def ema_update(targets, sources, momentum):
+    """targets[i] = momentum * targets[i] + (1 - momentum) * sources[i], one multi-tensor pass (fp32 tensors)."""
+    _dev(*targets, *sources)
+    n = len(targets)
+    if n == 0:
+        return
+    numel = (ctypes.c_int64 * n)(*[t.numel() for t in targets])
+    check(_lib.load().vtx_ema_update(n, _ptr_array(targets), _ptr_array(sources), numel, float(momentum), _stream()),
+          "vtx_ema_update")
+
+
+def dino_loss(student, teacher, center, n_crop, student_temp, teacher_temp, gscale=1.0):
+    """DINO loss forward + gradient: -> (loss scalar tensor, dstudent, batch_center [K] fp32)."""
+    _dev(student, teacher, center)
+    _f32(center, "center")
+    K = student.shape[-1]
+    rows = student.numel() // K
+    B = teacher.numel() // K // 2
+    if rows != n_crop * B or student.dtype != teacher.dtype:
+        raise VtxError("vtx: dino_loss shape / dtype mismatch")
+    lib = _lib.load()
+    wsb = lib.vtx_dino_loss_workspace(B, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=student.device)
+    loss_rows = torch.empty(rows, dtype=torch.float32, device=student.device)
+    ds = torch.empty_like(student)
+    bc = torch.empty(K, dtype=torch.float32, device=student.device)
+    check(lib.vtx_dino_loss(_p(student), _p(teacher), _p(center), _p(ws), wsb, _p(loss_rows), _p(ds), _p(bc), n_crop, B, K,
+                            float(student_temp), float(teacher_temp), float(gscale), _dt(student), _stream()),
+          "vtx_dino_loss")
+    return loss_rows.sum() / ((2 * n_crop - 2) * B), ds, bc
+
+
 # ------------------------------------------------------------------------------- data movement
 def cast_desc_bytes():
     return _lib.load().vtx_cast_desc_bytes()
