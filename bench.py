@@ -31,7 +31,11 @@ SWIN_S = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2), dims=(9
 # / MLP GEMMs and the Lq x Lk attention products = 7.631 GFLOP forward = the PVT paper's 3.8 GMACs)
 PVT_SMALL = dict(image_size=224, n_class=1000, in_dim=3, depths=(3, 4, 6, 3), patch_embed_dims=(64, 128, 320, 512),
                  n_heads=(1, 2, 5, 8), dim_ffs=(512, 1024, 1280, 2048), reductions=(8, 4, 2, 1))
-TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59, "pvt_small": 22.89}
+TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59, "pvt_small": 22.89,
+                       # DINO DeiT-S/16 per SOURCE image: student 2 x 224^2 + 8 x 96^2 crops fwd+bwd, teacher 2 x 224^2 fwd,
+                       # heads (384-2048-2048-256-65536) on 10 + 2 feature rows: 3 x (2 x 9.197 + 8 x 1.618 + 10 x 0.0449)
+                       # + (2 x 9.197 + 2 x 0.0449) = 113.8 GFLOP
+                       "dino": 113.8}
 PEAK_BF16_TFLOPS = 2500.0                                       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_TBPS = 8.0                                              # HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3                                         # dense fp32 MFMA peak (parity mode)
@@ -58,10 +62,55 @@ def build_model(name, drop_path):
     from vtx.nn import Linear
     if name == "swin_s":
         return SwinTransformer(**SWIN_S, drop_path=drop_path)          # config/swin-transformer-s.conf:1-12
+    if name == "dino":
+        from models.vit import dino                               # config/dino_deit-s-16.conf:1-19
+        return dino(image_size=224, window_size=16, depth=12, dim=384, n_head=6, dim_ff=1536, dropout=0.0, drop_attn=0.0,
+                    drop_ff=0.0, drop_path=drop_path, dim_head_out=65536, use_bn=False, norm_last_layer=False,
+                    depth_head=3, dim_head_ff=2048, dim_head_bottleneck=256)
     if name == "pvt_small":
         from models.pvt import PyramidVisionTransformer
         return PyramidVisionTransformer(**PVT_SMALL, drop_path=drop_path)   # BASELINE.json cfg-4 (PVT paper hyper-parameters)
     return VisionTransformer(Linear(384, 1000), 224, 16, 12, 384, 6, 1536, 0.0, 0.0, 0.0, drop_path)
+
+
+def cpu_baseline_dino(batch, steps, cores=None):
+    cores = cores or torch.get_num_threads()
+    return _cpu_baseline_dino(batch, steps, cores)
+
+
+def _cpu_baseline_dino(batch, steps, cores):
+    """DINO step on the CPU oracle: student on 2 x 224^2 + 8 x 96^2 crops, teacher on the 2 global crops, heads, loss,
+    backward, AdamW, momentum update -- fp32, bounded sample."""
+    from oracle import ref_models as M
+    from oracle import ref_ops as R
+    model = build_model("dino", 0.0)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items() if torch.is_floating_point(v)}
+    Tt = {k: v.detach().clone() for k, v in P.items()}
+    hp = lambda D: {k[len("head."):]: v for k, v in D.items() if k.startswith("head.")}
+    fwd = lambda D, crops: M.vit_forward(D, crops, M.VIT_S16, head=lambda f: R.dino_head(f, hp(D)))
+    opt = torch.optim.AdamW(list(P.values()), lr=5e-4, weight_decay=0.04)
+    crops = [torch.randn(batch, 3, 224, 224) for _ in range(2)] + [torch.randn(batch, 3, 96, 96) for _ in range(8)]
+    center = torch.zeros(1, 65536)
+
+    def step():
+        with torch.no_grad():
+            tout = fwd(Tt, crops[:2])
+        loss = R.dino_loss(fwd(P, crops), tout, center, 10, 0.1, 0.04)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for k in Tt:
+                Tt[k].mul_(0.996).add_(P[k].detach(), alpha=0.004)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"dino DeiT-S/16 step (10 crops/image) fp32 on CPU oracle, batch {batch}, {steps} timed steps "
+                       f"after 1 warm-up ({dt:.1f} s)")
 
 
 def cpu_baseline(name, batch, steps):
@@ -73,6 +122,8 @@ def cpu_baseline(name, batch, steps):
     model = build_model(name, 0.0)                                      # parameter container only (CPU, never run)
     P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
          if torch.is_floating_point(v)}
+    if name == "dino":
+        return cpu_baseline_dino(batch, steps, cores)
     if name == "swin_s":
         fwd = lambda x: M.swin_forward(P, x, M.SWIN_S)
     elif name == "pvt_small":
@@ -104,8 +155,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / pvt_small, 256 vit_s16)")
+    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small", "dino"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / pvt_small, 256 vit_s16, 64 dino)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,7 +180,7 @@ def main():
     from vtx.ddp import GradAllReduce
     from vtx.train_step import MixLoss, make_param_groups, train_step
 
-    batch = args.batch or (256 if args.model == "vit_s16" else 128)
+    batch = args.batch or (256 if args.model == "vit_s16" else (64 if args.model == "dino" else 128))
     drop_path = 0.3 if args.model == "swin_s" else 0.1
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -138,23 +189,46 @@ def main():
     torch.manual_seed(0)                       # identical init on every rank (+ rank-0 broadcast in GradAllReduce)
     model = build_model(args.model, drop_path).to(dev).train()
     ddp = GradAllReduce(model)
-    criterion = MixLoss(eps=0.1)
-    groups = make_param_groups(model.named_parameters(), 0.05, "vit")
-    if args.optimizer == "fused":
-        from vtx.optim import FusedAdamW
-        opt = FusedAdamW(groups, lr=1e-3)                       # clip + AdamW: two multi-tensor HIP kernels
-    else:
-        opt = torch.optim.AdamW(groups, lr=1e-3, fused=True)    # torch's fused AdamW + foreach clip_grad_norm_
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(batch, 3, 224, 224, device=dev, generator=g)
-    l1 = torch.randint(0, 1000, (batch,), device=dev, generator=g)
-    l2 = l1.roll(1)
-    ratio = torch.rand(batch, device=dev, generator=g)
-    data = (x, l1, l2, ratio)
     ac = torch.bfloat16 if args.dtype == "bf16" else None
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
 
-    def step():
-        return train_step(model, criterion, opt, data, clip_grad_norm=5.0, autocast_dtype=ac, ddp=ddp)
+    def make_opt(groups, lr):
+        if args.optimizer == "fused":
+            from vtx.optim import FusedAdamW
+            return FusedAdamW(groups, lr=lr)                      # clip + AdamW: two multi-tensor HIP kernels
+        return torch.optim.AdamW(groups, lr=lr, fused=True)       # torch's fused AdamW + foreach clip_grad_norm_
+
+    if args.model == "dino":
+        # train_dino.py:188-288 with config/dino_deit-s-16.conf: 2 global 224^2 + 8 local 96^2 crops per image, momentum
+        # teacher (no grad), DINOLoss over 65536 outputs, AdamW (wd_skip dino), clip 3.0; epoch >= freeze_last_layer
+        from vtx.dino import DINOLoss, dino_train_step
+        teacher = build_model("dino", 0.0).to(dev).train()
+        teacher.load_state_dict(model.state_dict())
+        for p in teacher.parameters():
+            p.requires_grad = False
+        criterion = DINOLoss(65536, 10, 0.04, 0.07, 30, 300).to(dev)
+        opt = make_opt(make_param_groups(model.named_parameters(), 0.04, "dino"), 5e-4)
+        crops = [torch.randn(batch, 3, 224, 224, device=dev, generator=g) for _ in range(2)] + \
+                [torch.randn(batch, 3, 96, 96, device=dev, generator=g) for _ in range(8)]
+        workload = (f"DINO DeiT-S/16 step, {batch} images/GPU x (2 x 224^2 + 8 x 96^2 crops), head 384-2048-2048-256-65536, "
+                    "momentum teacher 0.996, clip 3.0, AdamW(lr 5e-4, wd 0.04)")
+
+        def step():
+            return dino_train_step(model, teacher, criterion, opt, crops, epoch=1, momentum=0.996, clip_grad_norm=3.0,
+                                   freeze_last_layer=1, autocast_dtype=ac, ddp=ddp)
+    else:
+        criterion = MixLoss(eps=0.1)
+        opt = make_opt(make_param_groups(model.named_parameters(), 0.05, "vit"), 1e-3)
+        x = torch.randn(batch, 3, 224, 224, device=dev, generator=g)
+        l1 = torch.randint(0, 1000, (batch,), device=dev, generator=g)
+        l2 = l1.roll(1)
+        ratio = torch.rand(batch, device=dev, generator=g)
+        data = (x, l1, l2, ratio)
+        workload = (f"{args.model} 224x224 train step, batch {batch}/GPU, drop_path {drop_path}, "
+                    "MixLoss(eps 0.1), clip 5.0, AdamW(lr 1e-3, wd 0.05), grad_accum 1")
+
+        def step():
+            return train_step(model, criterion, opt, data, clip_grad_norm=5.0, autocast_dtype=ac, ddp=ddp)
 
     for _ in range(args.warmup):
         step()
@@ -216,8 +290,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if ac else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} 224x224 train step, batch {batch}/GPU, drop_path {drop_path}, "
-                                   "MixLoss(eps 0.1), clip 5.0, AdamW(lr 1e-3, wd 0.05), grad_accum 1",
+            "config": {"workload": workload,
                        "global_batch": batch * world, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu,
         }
