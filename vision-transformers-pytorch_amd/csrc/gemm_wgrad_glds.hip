@@ -135,13 +135,6 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
       for (int i = 0; i < 4; ++i) fa[i] = wg_frag(la, ks * 32, wm * 64 + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = wg_frag(lb, ks * 32, wn * 64 + j * 16, lane);
-#ifdef WG_DEBUG
-      if (kt == 0 && ks == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0) {
-        float* dbg = p.C + 128 * 128;     // after the tile
-        for (int e = 0; e < 8; ++e) { dbg[lane * 8 + e] = fa[0].get(e); dbg[512 + lane * 8 + e] = fb[0].get(e); }
-        dbg[1024 + lane] = (float)reinterpret_cast<const bf16*>(la + lane * 256)[0];     // raw first element of LDS row `lane`
-      }
-#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
