@@ -145,6 +145,18 @@ int vtx_add_pos_fwd(const void* x, const float* cls, const float* pos, void* out
                     void* stream);
 int vtx_add_pos_bwd(const void* dout, void* dx, float* dcls, float* dpos, int B, int T, int C, int dtype, void* stream);
 
+/* ---- Device-side input pipeline (csrc/input.hip): per-sample mixup / cutmix
+ * (reference mix_dataset.py:36-90) + Normalize + constant-mode RandomErasing (reference transforms.py:321-418) of a
+ * device-resident batch in one pass.  The random plan is drawn on the host in the reference's order
+ * (vtx.input_pipeline.plan_batch): device array of N records
+ *   {int partner, mode (0 none | 1 mixup | 2 cutmix); float ratio; int x1, y1, x2, y2, nrect, top[4], left[4];
+ *    short eh[4], ew[4]}   (vtx_mix_plan_bytes() = 80 bytes each; at most vtx_mix_max_rects() rectangles).
+ * x [N, C, H, W] uint8 (in_u8: scaled by 1/255 like ToTensor) or fp32, out [N, C, H, W] fp32, W % 4 == 0. */
+size_t vtx_mix_plan_bytes(void);
+int vtx_mix_max_rects(void);
+int vtx_mix_normalize_erase(const void* x, int in_u8, const void* plan, const float* mean, const float* stdv, float* out,
+                            int N, int C, int H, int W, void* stream);
+
 /* ---- Fused optimizer tail (csrc/optim.hip): nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference's
  * train step (train.py:285-299) as two multi-tensor passes.  Tensors are given as HOST arrays of n device pointers
  * (fp32, any 4-byte alignment) and element counts; the addresses travel in kernel arguments (64 tensors per launch).

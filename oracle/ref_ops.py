@@ -305,3 +305,72 @@ def dino_center_update(center, teacher, momentum, world=1):
     """DINOLoss.update_center (loss.py:146-152) for one process group of `world` ranks holding identical batches."""
     batch_center = teacher.sum(0, keepdim=True) * world / (teacher.shape[0] * world)
     return center * momentum + batch_center * (1 - momentum)
+
+
+# ------------------------------------------------------------------------------------------ F4: input pipeline
+def rand_bbox(size, ratio, rng):
+    """mix_dataset.py:10-24.  NOTE the reference passes img.shape[1:] = (H, W) for tensors and unpacks it as (w, h): the
+    names are swapped for non-square images; the returned x range indexes the LAST tensor dim, the y range dim 1."""
+    w, h = size
+    r = math.sqrt(1 - ratio)
+    cut_w, cut_h = int(w * r), int(h * r)
+    cx, cy = rng.randrange(w), rng.randrange(h)
+    x1 = min(max(cx - cut_w // 2, 0), w)
+    y1 = min(max(cy - cut_h // 2, 0), h)
+    x2 = min(max(cx + cut_w // 2, 0), w)
+    y2 = min(max(cy + cut_h // 2, 0), h)
+    return x1, y1, x2, y2
+
+
+def random_erasing_const(img, rng, p=0.5, min_area=0.02, max_area=1 / 3, min_aspect=0.3, max_aspect=None, min_count=1,
+                         max_count=None):
+    """transforms.RandomErasing._erase on one (C, H, W) tensor, mode 'const' (zeros) -- transforms.py:381-409."""
+    max_aspect = max_aspect or 1 / min_aspect
+    la = (math.log(min_aspect), math.log(max_aspect))
+    max_count = max_count or min_count
+    chan, img_h, img_w = img.shape
+    if rng.random() > p:
+        return img
+    area = img_h * img_w
+    count = min_count if min_count == max_count else rng.randint(min_count, max_count)
+    for _ in range(count):
+        for _attempt in range(10):
+            target_area = rng.uniform(min_area, max_area) * area / count
+            aspect = math.exp(rng.uniform(*la))
+            h = int(round(math.sqrt(target_area * aspect)))
+            w = int(round(math.sqrt(target_area / aspect)))
+            if w < img_w and h < img_h:
+                top = rng.randint(0, img_h - h)
+                left = rng.randint(0, img_w - w)
+                img[:, top:top + h, left:left + w] = 0
+                break
+    return img
+
+
+def mix_dataset_item(images, labels, index, mixup, cutmix, transform, rng):
+    """MixDataset.__getitem__ (mix_dataset.py:36-90) for a dataset of tensors; rng = a random.Random-like object."""
+    img1, label1 = images[index].clone(), labels[index]
+    apply_mixup, apply_cutmix, ratio = mixup > 0, cutmix > 0, 1
+    if apply_mixup or apply_cutmix:
+        index2 = index
+        while index2 == index:
+            index2 = rng.randrange(len(images))
+        img2, label2 = images[index2], labels[index2]
+    else:
+        img2, label2 = img1, label1
+    if apply_mixup and apply_cutmix:
+        if index % 2 == 0:
+            apply_cutmix = False
+        else:
+            apply_mixup = False
+    if apply_mixup:
+        ratio = rng.betavariate(mixup, mixup)
+        img1 = img1.mul(ratio).add_(img2, alpha=1 - ratio)
+    if apply_cutmix:
+        ratio = rng.uniform(0, 1) if cutmix == 1 else rng.betavariate(cutmix, cutmix)
+        x1, y1, x2, y2 = rand_bbox(img1.shape[1:], ratio, rng)
+        img1[:, y1:y2, x1:x2] = img2[:, y1:y2, x1:x2]
+        ratio = 1 - ((x2 - x1) * (y2 - y1) / (img1.shape[1] * img1.shape[2]))
+    if transform is not None:
+        img1 = transform(img1)
+    return img1, label1, label2, ratio

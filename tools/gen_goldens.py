@@ -7,7 +7,8 @@ all inputs/weights are closed-form (oracle/formula.py), so nothing of the refere
 travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
 
 Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
-fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1), G8 DINO head + loss (F2).
+fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1), G8 DINO head + loss (F2),
+G9 mixup / cutmix / RandomErasing outputs (F4).
 """
 import os
 import sys
@@ -304,6 +305,52 @@ def gen_dino():
     save("g8_dino", rec)
 
 
+# ------------------------------------------------------------------ G9 (mixup / cutmix / erasing)
+def gen_input_pipeline():
+    import random
+    tv = types.ModuleType("torchvision")          # transforms.py imports torchvision only for the PIL pipelines
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    def _ga(n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any
+    tvt.__getattr__ = _ga
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    import mix_dataset as ref_mix                 # (reference)
+    import transforms as ref_tf                   # (reference)
+    rec = {}
+    n, h, w = 8, 16, 20                           # non-square: pins the (w, h) = (H, W) quirk of rand_bbox on tensors
+    images = [fill((3, h, w), 900 + i, 0.5, 0.5) for i in range(n)]
+    labels = list(range(10, 10 + n))
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    for tag, mixup, cutmix, seed in (("both", 0.2, 1, 5), ("beta_cutmix", 0.0, 0.5, 6), ("mixup_only", 0.8, 0, 7)):
+        erase = ref_tf.RandomErasing(p=0.7, max_count=2, mode="const", device="cpu")
+        class Fresh:                              # like a decoding dataset: a new tensor per access (MixDataset's cutmix
+            def __len__(self):                    # writes into the tensor it was handed, mix_dataset.py:78)
+                return n
+
+            def __getitem__(self, i):
+                return images[i].clone(), labels[i]
+        md = ref_mix.MixDataset(Fresh(), lambda img: erase((img - mean) / std), mixup=mixup, cutmix=cutmix)
+        random.seed(seed)
+        outs, l1, l2, ratio = [], [], [], []
+        for i in range(n):
+            img, a, b, r = md[i]
+            outs.append(img.numpy()); l1.append(a); l2.append(b); ratio.append(float(r))
+        rec[f"{tag}.images"] = np.stack(outs)
+        rec[f"{tag}.label1"] = np.array(l1)
+        rec[f"{tag}.label2"] = np.array(l2)
+        rec[f"{tag}.ratio"] = np.array(ratio, dtype=np.float64)
+    save("g9_input_pipeline", rec)
+
+
 def gen_train_step():
     rec = {}
     B = 2
@@ -348,7 +395,7 @@ def gen_train_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino"]
+    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input"]
     if "tables" in which:
         gen_tables()
     if "modules" in which:
@@ -361,5 +408,7 @@ if __name__ == "__main__":
         gen_pvt()
     if "dino" in which:
         gen_dino()
+    if "input" in which:
+        gen_input_pipeline()
     # make sure nothing was written into the reference tree
     assert not os.path.exists(os.path.join(REF, "models", "__pycache__")), "pycache leaked into reference"

@@ -362,6 +362,27 @@ def dino_loss(student, teacher, center, n_crop, student_temp, teacher_temp, gsca
     return loss_rows.sum() / ((2 * n_crop - 2) * B), ds, bc
 
 
+def mix_plan_bytes():
+    return _lib.load().vtx_mix_plan_bytes()
+
+
+def mix_max_rects():
+    return _lib.load().vtx_mix_max_rects()
+
+
+def mix_normalize_erase(images, plan, mean, std):
+    """One pass over a device batch: mixup / cutmix with the partner image, normalise, zero the erase rectangles."""
+    _dev(images, plan, mean, std)
+    if images.dtype not in (torch.uint8, torch.float32):
+        raise VtxError("vtx: input images must be uint8 or float32")
+    x = images if images.is_contiguous() else images.contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().vtx_mix_normalize_erase(_p(x), int(x.dtype == torch.uint8), _p(plan), _p(mean), _p(std), _p(out), n, c,
+                                              h, w, _stream()), "vtx_mix_normalize_erase")
+    return out
+
+
 # ------------------------------------------------------------------------------- data movement
 def cast_desc_bytes():
     return _lib.load().vtx_cast_desc_bytes()
