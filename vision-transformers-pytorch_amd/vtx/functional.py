@@ -7,6 +7,7 @@ optimizer keep working).  Activations are stored in the compute dtype T (fp32, o
 ``torch.autocast(dtype=torch.bfloat16)``); statistics / parameter gradients are fp32.
 """
 import contextlib
+import os
 import struct
 import threading
 
@@ -129,6 +130,35 @@ def dgrad(dy, wp, T, **epi):
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------- weight gradients off the critical path
+# Consecutive kernels of one HIP stream run strictly one after the other: every launch pays its ramp-up and its
+# partially filled last round (~6 us per GEMM launch here, ~600 launches per step).  The weight-gradient GEMMs of a
+# layer's backward feed nothing downstream in that backward, so they go to a second stream: they fill the CUs the
+# activation-gradient chain leaves idle.  fork = the side stream waits for everything enqueued so far (its operands);
+# join (once per layer, before the gradients are handed back to autograd) = the main stream waits for the side stream.
+_side_streams = {}
+_SIDE = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
+
+
+def side_wgrad(dy, x, **kw):
+    if not _SIDE or not dy.is_cuda:
+        return ops.wgrad(dy, x, **kw)
+    dev = dy.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        return ops.wgrad(dy, x, **kw)
+
+
+def side_join(t):
+    if _SIDE and t.is_cuda:
+        side = _side_streams.get(t.device)
+        if side is not None:
+            torch.cuda.current_stream(t.device).wait_stream(side)
 
 
 class LayerNormFn(Function):
@@ -299,18 +329,19 @@ class TransformerLayerFn(Function):
         dy = _c(dy)
         B = x.shape[0]
         # ---- MLP branch
-        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
+        dW2, db2 = side_wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
         dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
-        dW1, db1 = ops.wgrad(dz, ln2)
+        dW1, db1 = side_wgrad(dz, ln2)
         dln2 = dgrad(dz, w1, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
-        dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
+        dWo, dbo = side_wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
         do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
         dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m, rel_pos)
-        dWq, dbq = ops.wgrad(dqkv, ln1)
+        dWq, dbq = side_wgrad(dqkv, ln1)
         dln1 = dgrad(dqkv, wq, T)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+        side_join(dx)
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
 
@@ -479,32 +510,34 @@ class PvtLayerFn(Function):
         r = m.reduction
         dy = _c(dy)
         # ---- MLP branch
-        dW2, db2 = ops.wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
+        dW2, db2 = side_wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
         dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
-        dW1, db1 = ops.wgrad(dz, ln2)
+        dW1, db1 = side_wgrad(dz, ln2)
         dln2 = dgrad(dz, w1, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
-        dWo, dbo = ops.wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
+        dWo, dbo = side_wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
         do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
         dq, dkv = ops.srattn_bwd(q, kv, o, do, lse, B, L, Lk, m.n_head)
-        dWq, _ = ops.wgrad(dq, ln1, want_bias=False)
+        dWq, _ = side_wgrad(dq, ln1, want_bias=False)
         dWsr = dbsr = dgs = dbs = None
         if r > 1:
-            dWkv, _ = ops.wgrad(dkv, kvin, want_bias=False)
+            dWkv, _ = side_wgrad(dkv, kvin, want_bias=False)
             dkvin = dgrad(dkv, wkv, T)
             dred, dgs, dbs = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach())
-            dWsr, dbsr = ops.wgrad(dred, patches)
+            dWsr, dbsr = side_wgrad(dred, patches)
             dpatches = dgrad(dred, wsr, T)
             dln1 = dgrad(dq, wq, T)
             ops.patchify_bwd(dpatches, dln1, B, m.height, m.width, C, r, m.skip, accumulate=True)
-            co, _, p, _ = ctx.sr_shape
-            dWsr = dWsr.view(co, p, p, C).permute(0, 3, 1, 2).contiguous()   # (py, px, c) columns back to (c, py, px)
         else:
-            dWkv, _ = ops.wgrad(dkv, ln1, want_bias=False)
+            dWkv, _ = side_wgrad(dkv, ln1, want_bias=False)
             dkvin = dgrad(dkv, wkv, T)
             dln1 = dgrad(dq, wq, T, resid=dkvin)                       # both consumers of LN1's output
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+        side_join(dx)
+        if r > 1:                                                      # (after the join: dWsr comes from the side stream)
+            co, _, p, _ = ctx.sr_shape
+            dWsr = dWsr.view(co, p, p, C).permute(0, 3, 1, 2).contiguous()   # (py, px, c) columns back to (c, py, px)
         return (dx.view(B, L, C), dg1, dbe1, dWq, dWkv, dWsr, dbsr, dgs, dbs, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2,
                 None, None, None, None)
 
