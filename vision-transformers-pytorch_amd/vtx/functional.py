@@ -139,7 +139,9 @@ def _c(t):
 # activation-gradient chain leaves idle.  fork = the side stream waits for everything enqueued so far (its operands);
 # join (once per layer, before the gradients are handed back to autograd) = the main stream waits for the side stream.
 _side_streams = {}
-_SIDE = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
+# Off by default: per-kernel durations (bench.py's roofline, rocprofv3) are no longer attributable when two GEMM kernels
+# share the chip -- the dominant kernel's measured TFLOP/s drops by ~28 % while the step gets 1.6 % faster.
+_SIDE = os.environ.get("VTX_SIDE_WGRAD", "0") != "0"
 
 
 def side_wgrad(dy, x, **kw):
