@@ -1,4 +1,4 @@
-// Global (ViT) attention for gfx950, bf16, head dim 64, sequences of <= 224 tokens (ViT-S/16: L = 197).
+// Global (ViT) attention for gfx950, bf16, head dim 64, sequences of <= 224 tokens (ViT-S/16: L = 197; 96^2 crops: 37).
 //
 // Replaces reference models/vit.py:30-42 per (image, head): S = q k^T / sqrt(d), softmax, O = P v, reading
 // q/k/v from the QKV projection output [tokens, 3*h*64] and writing [tokens, h*64]; scores stay in registers.
@@ -385,21 +385,35 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
 bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("VTX_SATTN"); on = e ? atoi(e) : 1; }
-  return on && dtype == VTX_BF16 && D == 64 && !swin && bias == nullptr && L > 64 && L <= 224;
+  return on && dtype == VTX_BF16 && D == 64 && !swin && bias == nullptr && L >= 1 && L <= 224;
 }
 
+template <int NKT> static int sattn_fwd_t(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB;
+  hipLaunchKernelGGL((sattn_fwd_kernel<NKT>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
+  return vtx_check_launch();
+}
+template <int NKT> static int sattn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                                          int B, const SeqGeom& g, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB + 2 * NKT * 16 * sizeof(float);
+  hipLaunchKernelGGL((sattn_bwd_kernel<NKT>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (const bf16*)o,
+                     (const bf16*)dout, lse, (bf16*)dqkv, g);
+  return vtx_check_launch();
+}
+
+// key-tile count of the instantiation: 14 (L <= 224: ViT-S/16 at 224^2, L = 197), 8 (L <= 128), 4 (L <= 64: the 96^2 DINO
+// crops, L = 37)
 int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st) {
   SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D);
-  constexpr size_t smem = (size_t)2 * 224 * SA_ROWB;
-  hipLaunchKernelGGL((sattn_fwd_kernel<14>), dim3(B * nH), dim3(256), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
-  return vtx_check_launch();
+  if (L <= 64) return sattn_fwd_t<4>(qkv, o, lse, B, g, st);
+  if (L <= 128) return sattn_fwd_t<8>(qkv, o, lse, B, g, st);
+  return sattn_fwd_t<14>(qkv, o, lse, B, g, st);
 }
 
 int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int L, int nH,
                      hipStream_t st) {
   SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D);
-  constexpr size_t smem = (size_t)2 * 224 * SA_ROWB + 2 * 224 * sizeof(float);
-  hipLaunchKernelGGL((sattn_bwd_kernel<14>), dim3(B * nH), dim3(256), smem, st, (const bf16*)qkv, (const bf16*)o,
-                     (const bf16*)dout, lse, (bf16*)dqkv, g);
-  return vtx_check_launch();
+  if (L <= 64) return sattn_bwd_t<4>(qkv, o, dout, lse, dqkv, B, g, st);
+  if (L <= 128) return sattn_bwd_t<8>(qkv, o, dout, lse, dqkv, B, g, st);
+  return sattn_bwd_t<14>(qkv, o, dout, lse, dqkv, B, g, st);
 }
