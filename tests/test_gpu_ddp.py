@@ -1,0 +1,89 @@
+"""The N > 1 training path on real kernels: two ranks (processes) share the one GPU of the test box and talk over gloo
+(RCCL refuses two ranks on one device; the 8-GPU RCCL run is the driver's).  Each rank trains a small Swin on its own
+half of a batch with vtx.ddp.GradAllReduce + FusedAdamW; after two steps every rank must hold the same parameters, equal
+to a single process trained on the whole batch (MixLoss is a per-sample mean, LayerNorm has no cross-sample statistics:
+the mean of the per-rank gradients IS the full-batch gradient)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(image_size=(224, 224), n_class=16, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32,
+           n_heads=(1, 2, 4, 8), dim_ffs=(128, 256, 512, 1024), window_size=7)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 3, 224, 224, generator=g)
+    l1 = torch.randint(0, 16, (n,), generator=g)
+    return x, l1, l1.roll(1), torch.rand(n, generator=g)
+
+
+def _train(model, data, steps, ddp=None):
+    from vtx.optim import FusedAdamW
+    from vtx.train_step import MixLoss, make_param_groups, train_step
+    opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3)
+    for _ in range(steps):
+        train_step(model, MixLoss(0.1), opt, data, clip_grad_norm=5.0, autocast_dtype=None, ddp=ddp)
+    return [p.detach().cpu() for p in model.parameters()]
+
+
+def _worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "vision-transformers-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from models import SwinTransformer
+        from vtx.ddp import GradAllReduce
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(10 + rank)                       # different init per rank: the broadcast must fix it
+        model = SwinTransformer(**CFG, drop_path=0.0).to(dev).train()
+        ddp = GradAllReduce(model, bucket_bytes=1 << 20, first_bucket_bytes=1 << 18)
+        x, l1, l2, r = _data(4)
+        sl = slice(2 * rank, 2 * rank + 2)
+        params = _train(model, (x[sl].to(dev), l1[sl].to(dev), l2[sl].to(dev), r[sl].to(dev)), 2, ddp)
+        q.put((rank, [t.numpy() for t in params]))       # by value (tensor handles die with the worker)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_full_batch():
+    from gpu_util import dev, report
+    from models import SwinTransformer
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: [torch.from_numpy(a) for a in ps] for r, ps in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b), "ranks diverged"
+    torch.manual_seed(10)                                  # rank 0's init = what the broadcast installs everywhere
+    model = SwinTransformer(**CFG, drop_path=0.0).to(dev()).train()
+    x, l1, l2, r = _data(4)
+    ref = _train(model, (x.to(dev()), l1.to(dev()), l2.to(dev()), r.to(dev())), 2)
+    num = sum(((a.double() - b.double()).norm() ** 2).item() for a, b in zip(got[0], ref))
+    den = sum((b.double().norm() ** 2).item() for b in ref)
+    assert report("2 ranks x half batch vs 1 process x full batch: parameters after 2 steps (rel-L2)", (num / den) ** 0.5, 2e-5)
