@@ -160,3 +160,22 @@ def test_swin_region_cache_follows_buffer():
     assert m.regions()[1] is False                     # re-derived: no region structure -> generic path
     m2 = MultiHeadedLocalAttention(96, 3, 32, (14, 14), 7, False)
     assert m2.regions() == (None, True)
+
+
+def test_bucket_assignment_keeps_the_exposed_tail_small():
+    """Reverse registration order, first bucket <= 8 MiB (early start), last bucket <= 8 MiB (the only all-reduce that
+    cannot overlap with backward), every parameter in exactly one bucket."""
+    from models import SwinTransformer
+    from vtx.ddp import MIB, assign_buckets
+    model = SwinTransformer(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2), dims=(96, 192, 384, 768), dim_head=32,
+                            n_heads=(3, 6, 12, 24), dim_ffs=(384, 768, 1536, 3072), window_size=7)
+    named = list(model.named_parameters())
+    buckets = assign_buckets(named, 48 * MIB, 8 * MIB, 8 * MIB)
+    flat = [n for b in buckets for n in b.names]
+    assert flat == [n for n, _ in reversed(named)]
+    assert sum(b.numel for b in buckets) == 49_606_258
+    assert buckets[0].numel * 4 <= 8 * MIB and buckets[-1].numel * 4 <= 8 * MIB
+    assert all(b.numel * 4 <= 48 * MIB for b in buckets)
+    assert buckets[-1].names[-1] == "patch_embedding.linear.weight"
+    legacy = assign_buckets(named, 48 * MIB, 8 * MIB)
+    assert len(buckets) == len(legacy) + 1

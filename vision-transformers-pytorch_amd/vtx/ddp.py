@@ -10,7 +10,8 @@ waiting for the producing stream (event record / stream-wait, no host sync); ``f
 compute stream wait for the last bucket before clipping / the optimizer step.
 
 Designed for MI355X xGMI (point-to-point links, ring collectives per-link bound): few, large buckets
-(default 48 MiB, first bucket 8 MiB so communication starts early in backward), one flat fp32 buffer
+(default 48 MiB; first bucket 8 MiB so communication starts early in backward, last bucket at most 8 MiB so little
+is left exposed after backward ends), one flat fp32 buffer
 per bucket filled by a single multi-tensor copy, averaged by the collective itself (ncclAvg).
 World size 1 bypasses all of it.  Works on CPU tensors with the gloo backend (used by the tests).
 """
@@ -34,7 +35,7 @@ class _Bucket:
         self.work = None
 
 
-def assign_buckets(named_params, bucket_bytes, first_bucket_bytes):
+def assign_buckets(named_params, bucket_bytes, first_bucket_bytes, last_bucket_bytes=0):
     """Reverse registration order (gradients become ready roughly back to front), greedy fill."""
     buckets = [_Bucket(0)]
     cap = first_bucket_bytes
@@ -48,12 +49,30 @@ def assign_buckets(named_params, bucket_bytes, first_bucket_bytes):
         b.params.append(p)
         b.names.append(name)
         b.numel += p.numel()
+    # The last bucket closes only when the very first layers' gradients arrive, i.e. at the end of backward: whatever it
+    # holds is all-reduced with nothing left to overlap.  Keep that exposed tail small: split the last bucket so that its
+    # final part (the earliest-registered parameters) is at most `last_bucket_bytes`.
+    last = buckets[-1]
+    if last_bucket_bytes and len(last.params) > 1 and last.numel * 4 > last_bucket_bytes:
+        tail, acc = 0, 0
+        for p in reversed(last.params):
+            if tail > 0 and (acc + p.numel()) * 4 > last_bucket_bytes:
+                break
+            acc += p.numel()
+            tail += 1
+        if 0 < tail < len(last.params):
+            nb = _Bucket(len(buckets))
+            nb.params, nb.names = last.params[-tail:], last.names[-tail:]
+            nb.numel = acc
+            last.params, last.names = last.params[:-tail], last.names[:-tail]
+            last.numel -= acc
+            buckets.append(nb)
     return buckets
 
 
 class GradAllReduce:
     def __init__(self, module, process_group=None, bucket_bytes=48 * MIB, first_bucket_bytes=8 * MIB,
-                 broadcast=True, force=False):
+                 broadcast=True, force=False, last_bucket_bytes=8 * MIB):
         """``force=True`` keeps the bucket / hook / collective machinery active even for a 1-rank group
         (used to exercise the RCCL path on a single GPU); by default world size 1 bypasses everything."""
         self.module = module
@@ -71,7 +90,7 @@ class GradAllReduce:
                 raise ValueError("GradAllReduce expects fp32 master parameters")
         if broadcast:
             self.broadcast_state()
-        self.buckets = assign_buckets(named, bucket_bytes, first_bucket_bytes)
+        self.buckets = assign_buckets(named, bucket_bytes, first_bucket_bytes, last_bucket_bytes)
         self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else None
         for b in self.buckets:
             dev = b.params[0].device
