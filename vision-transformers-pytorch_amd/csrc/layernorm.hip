@@ -38,11 +38,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int v = lig + k * G;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gm[k][e] = v < nvec ? gamma[v * 8 + e] : 0.f;
-      bt[k][e] = v < nvec ? beta[v * 8 + e] : 0.f;
+    // 16-byte loads (parameter tensors are at least 16-byte aligned; scalar loads here cost 16 load instructions per k)
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
+    if (v < nvec) {
+      g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8); g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+      b0 = *reinterpret_cast<const f32x4*>(beta + v * 8); b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gm[k][e] = g0[e]; gm[k][4 + e] = g1[e]; bt[k][e] = b0[e]; bt[k][4 + e] = b1[e]; }
   }
   const float invC = 1.f / (float)C;
   // ROWS rows per group per iteration: their loads are issued back to back before any reduction starts, so
@@ -120,11 +123,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int v = lig + k * G;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+    if (v < nvec) { g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8); g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4); }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gm[k][e] = v < nvec ? gamma[v * 8 + e] : 0.f;
-      dg[k][e] = 0.f; db[k][e] = 0.f;
-    }
+    for (int e = 0; e < 4; ++e) { gm[k][e] = g0[e]; gm[k][4 + e] = g1[e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[k][e] = 0.f; db[k][e] = 0.f; }
   }
   const float invC = 1.f / (float)C;
   for (int64_t row = (int64_t)blockIdx.x * GPB + grp; row < rows; row += (int64_t)gridDim.x * GPB) {
