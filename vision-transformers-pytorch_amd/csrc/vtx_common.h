@@ -84,9 +84,19 @@ __device__ __forceinline__ void mma16(const Vec8<float>& a, const Vec8<float>& b
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
-template <int G> __device__ __forceinline__ float group_sum(float v) {   // G = 16, 32 or 64 lanes
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v += shfl_xor_f(v, m);
+// DPP lane exchange inside a 16-lane row (no LDS round trip, unlike __shfl_xor which lowers to ds_bpermute_b32)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Sum over groups of G = 16, 32 or 64 consecutive lanes, result in every lane of the group: the four steps inside a
+// 16-lane row are DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); only the steps across rows go through LDS.
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);      // row_half_mirror: 8-lane sums
+  v += dpp_f<0x140>(v);      // row_mirror: 16-lane sums
+  if constexpr (G >= 32) v += shfl_xor_f(v, 16);
+  if constexpr (G >= 64) v += shfl_xor_f(v, 32);
   return v;
 }
 
