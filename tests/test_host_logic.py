@@ -179,3 +179,30 @@ def test_bucket_assignment_keeps_the_exposed_tail_small():
     assert buckets[-1].names[-1] == "patch_embedding.linear.weight"
     legacy = assign_buckets(named, 48 * MIB, 8 * MIB)
     assert len(buckets) == len(legacy) + 1
+
+
+def test_drop_path_scope_hands_out_one_row_per_draw():
+    """All DropPath masks of a forward come from one batched draw (vtx.nn.drop_path_scope): two rows per layer with
+    p > 0, values in {0, 1/(1-p)}, handed out in call order; a draw that does not match (other batch size, other p)
+    falls back to the per-call bernoulli_ draw."""
+    from models import SwinTransformer
+    from vtx import nn as vnn
+    m = SwinTransformer(image_size=(224, 224), n_class=8, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32,
+                        n_heads=(1, 2, 4, 8), dim_ffs=(64, 128, 256, 512), window_size=7, drop_path=0.4).train()
+    ps = [l.drop_path.p for blk in (m.block1, m.block2, m.block3, m.block4) for l in blk if hasattr(l, "drop_path")]
+    assert ps[0] == 0 and all(p > 0 for p in ps[1:])
+    torch.manual_seed(0)
+    with vnn.drop_path_scope(m, 64, torch.device("cpu")):
+        assert vnn._dp.rows.shape == (2 * (len(ps) - 1), 64)
+        assert vnn.drop_path_scale(ps[0], True, 64, "cpu") is None            # p == 0: no draw, no row consumed
+        for p in ps[1:]:
+            for _ in range(2):
+                s = vnn.drop_path_scale(p, True, 64, torch.device("cpu"))
+                assert set(s.unique().tolist()) <= {0.0, float(torch.tensor(1.0) / torch.tensor(1.0 - p))}
+        assert vnn._dp.next == 2 * (len(ps) - 1)
+        extra = vnn.drop_path_scale(0.3, True, 5, torch.device("cpu"))        # unmatched: per-call draw
+        assert extra.shape == (5,)
+    assert vnn._dp.rows is None
+    m.eval()
+    with vnn.drop_path_scope(m, 64, torch.device("cpu")):
+        assert getattr(vnn._dp, "rows", None) is None                         # eval: nothing drawn

@@ -14,6 +14,8 @@ from itertools import repeat
 import torch
 from torch import nn
 
+from vtx.nn import _DropPathBase
+
 from vtx import functional as VF
 from vtx.nn import Linear
 
@@ -33,7 +35,7 @@ def tuple2(x):
     return ensure_tuple(x, 2)
 
 
-class DropPath(nn.Module):
+class DropPath(_DropPathBase):
     """Per-sample stochastic depth: identity in eval or p == 0, else x / (1-p) * Bernoulli(1-p) mask.
 
     Inside the fused TransformerLayer the mask is folded into the GEMM epilogue as a per-sample

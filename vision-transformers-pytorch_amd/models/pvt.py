@@ -17,7 +17,7 @@ from torch import nn
 
 from vtx import functional as VF
 from vtx.nn import LayerNorm as _LayerNorm
-from vtx.nn import Linear, drop_path_scale
+from vtx.nn import Linear, drop_path_scale, drop_path_scope
 
 from .layer import DropPath, PositionwiseFeedForward, tuple2
 
@@ -177,7 +177,7 @@ class PyramidVisionTransformer(nn.Module):
         return block
 
     def forward(self, input):
-        with VF.weight_scope(self, input):                            # bf16: one multi-tensor cast of all weights per forward
+        with VF.weight_scope(self, input), drop_path_scope(self, input.shape[0], input.device):   # one cast, one mask draw
             out, (height, width) = self.patch_embedding[0](input)
             for block in self.block1:
                 out = block(out, height, width)

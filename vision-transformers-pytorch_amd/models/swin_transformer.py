@@ -33,7 +33,7 @@ except Exception:  # pragma: no cover
 from vtx import functional as VF
 from vtx import tables
 from vtx.nn import LayerNorm as _LayerNorm
-from vtx.nn import Linear, drop_path_scale
+from vtx.nn import Linear, drop_path_scale, drop_path_scope
 
 from .layer import DropPath, PositionwiseFeedForward, tuple2
 
@@ -246,7 +246,7 @@ class SwinTransformer(nn.Module):
         return nn.Sequential(*block)
 
     def forward(self, input):
-        with VF.weight_scope(self, input):                   # bf16: one multi-tensor cast of all weights per forward
+        with VF.weight_scope(self, input), drop_path_scope(self, input.shape[0], input.device):   # one cast, one mask draw
             out = self.patch_embedding.forward_nchw(input)   # permute(0,2,3,1) + patchify folded into the gather
             out = self.block1(out)
             out = self.block2(out)

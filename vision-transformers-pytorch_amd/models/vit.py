@@ -28,7 +28,7 @@ except Exception:  # pragma: no cover
 
 from vtx import functional as VF
 from vtx.nn import LayerNorm as _LayerNorm
-from vtx.nn import Linear, drop_path_scale
+from vtx.nn import Linear, drop_path_scale, drop_path_scope
 
 from .layer import DropPath, PositionwiseFeedForward, tuple2
 
@@ -146,8 +146,9 @@ class VisionTransformer(nn.Module):
         out = self.patch_embedding(input)
         pos_embed = self.interpolate_pos_embedding(out.shape[1], out.shape[-1], self.pos_embed)
         out = VF.VitAssembleFn.apply(out, self.cls_token, pos_embed)
-        for layer in self.layers:
-            out = layer(out)
+        with drop_path_scope(self, out.shape[0], out.device):    # one mask draw per crop group
+            for layer in self.layers:
+                out = layer(out)
         # reference: norm(out)[:, 0]; LayerNorm is per token, so normalising only the cls rows is identical
         return self.norm(out[:, 0])
 
