@@ -186,6 +186,12 @@ int vtx_dino_loss(const void* student, const void* teacher, const float* center,
                   float* loss_rows, void* dstudent, float* batch_center, int n_crop, int B, int K, float student_temp,
                   float teacher_temp, float gscale, int dtype, void* stream);
 
+/* ---- MixLoss of the supervised train step (csrc/dino.hip; reference loss.py:53-86, train.py:274-276): label-smoothed KL
+ * between log_softmax(logits) and r * smooth(label1) + (1 - r) * smooth(label2), reduction "mean"; value and gradient
+ * in one sweep.  logits / dlogits [B, K] (dtype), labels [B] int64, ratio [B] fp32; loss = sum(loss_rows) / B. */
+int vtx_mix_loss(const void* logits, const int64_t* label1, const int64_t* label2, const float* ratio, void* dlogits,
+                 float* loss_rows, int B, int K, float eps, float gscale, int dtype, void* stream);
+
 /* ---- Multi-tensor weight cast (csrc/cast.hip): all fp32 Linear / Conv weights of a model -> bf16, plain [out][in]
  * and transposed [in][out], in one launch per forward.  This is the per-call weight cast of the reference's bf16
  * autocast (torch.cuda.amp.autocast around model(input), train.py:273-274) done once for the whole model.

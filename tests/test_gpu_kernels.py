@@ -348,3 +348,25 @@ def test_fused_adamw_vs_torch_and_oracle(max_norm):
     assert float(oa.state[pa[0]]["step"]) == 3.0
     sd = oa.state_dict()                                                  # same state layout as torch.optim.AdamW
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,K,eps", [(128, 1000, 0.1), (7, 10, 0.0), (5, 100, 0.2)])
+def test_mix_loss_kernel(dtype, B, K, eps):
+    """Fused MixLoss (value + d logits) vs the oracle restatement of reference loss.py:53-86 (pinned by golden G6)."""
+    from vtx.train_step import MixLoss
+    d = dev()
+    gen = torch.Generator().manual_seed(21)
+    logits = (torch.randn(B, K, generator=gen) * 3).to(dtype)
+    l1 = torch.randint(0, K, (B,), generator=gen)
+    l2 = torch.randint(0, K, (B,), generator=gen)
+    r = torch.rand(B, generator=gen)
+    r[0], r[-1] = 1.0, 0.0                                   # pure targets: the 0 log 0 = 0 convention
+    x = logits.to(d).requires_grad_(True)
+    loss = MixLoss(eps)(x, l1.to(d), l2.to(d), r.to(d))
+    (loss * 0.5).backward()
+    xr = logits.double().requires_grad_(True)
+    lr = R.mix_loss(xr, l1, l2, r.double(), eps)
+    (gr,) = torch.autograd.grad(lr * 0.5, [xr])
+    check(f"mix loss {dtype} B{B} K{K}", loss, lr, 2e-6)
+    check(f"mix loss d logits {dtype} B{B} K{K}", x.grad, gr, 2e-5 if dtype == torch.float32 else 6e-3)

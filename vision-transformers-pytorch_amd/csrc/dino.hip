@@ -165,3 +165,66 @@ int vtx_dino_loss(const void* student, const void* teacher, const float* center,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// MixLoss of the supervised train step (reference loss.py:53-86, train.py:274-276): label-smoothed KL divergence between
+// log_softmax(logits) and the mixup / cutmix target  t = r * smooth(label1) + (1 - r) * smooth(label2),
+// smooth(l)[k] = 1 - eps + eps / K at k == l, eps / K elsewhere; reduction "mean" = sum over everything / B.
+//   loss_rows[b] = sum_k t_k (log t_k - logp_k)   (0 log 0 = 0)         d logits[b][k] = gscale * (p_k - t_k) / B
+// One workgroup per row; value and gradient in one sweep (the loss is a leaf of the graph).
+template <typename T>
+__global__ __launch_bounds__(256) void mix_loss_kernel(const T* __restrict__ logits, const int64_t* __restrict__ l1,
+                                                      const int64_t* __restrict__ l2, const float* __restrict__ ratio,
+                                                      T* __restrict__ dlogits, float* __restrict__ loss_rows, int K,
+                                                      float eps, float gcoef) {
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  const T* row = logits + (int64_t)b * K;
+  float m = -INFINITY, l = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float x = to_f32<T>(row[k]);
+    const float M = fmaxf(m, x);
+    l = l * __expf(m - M) + __expf(x - M);
+    m = M;
+  }
+  dino_block_ml(m, l, red);
+  const float lz = m + __logf(l);
+  const int a1 = (int)l1[b], a2 = (int)l2[b];
+  const float r = ratio[b];
+  const float off = eps / (float)K, on = 1.f - eps + off;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float logp = to_f32<T>(row[k]) - lz;
+    const float t = r * (k == a1 ? on : off) + (1.f - r) * (k == a2 ? on : off);
+    if (t > 0.f) acc += t * (__logf(t) - logp);
+    dlogits[(int64_t)b * K + k] = from_f32<T>(gcoef * (__expf(logp) - t));
+  }
+  acc = group_sum<64>(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_rows[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+extern "C" {
+
+/* logits [B, K] (dtype), label1 / label2 [B] int64, ratio [B] fp32; loss = sum(loss_rows) / B;
+ * dlogits [B, K] (dtype) = gscale * d loss / d logits. */
+int vtx_mix_loss(const void* logits, const int64_t* label1, const int64_t* label2, const float* ratio, void* dlogits,
+                 float* loss_rows, int B, int K, float eps, float gscale, int dtype, void* stream) {
+  if (!logits || !label1 || !label2 || !ratio || !dlogits || !loss_rows) return VTX_ERR_NULL;
+  if (B <= 0 || K <= 0 || eps < 0.f) return VTX_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const float gcoef = gscale / (float)B;
+  if (dtype == VTX_BF16)
+    hipLaunchKernelGGL((mix_loss_kernel<bf16>), dim3(B), dim3(256), 0, st, (const bf16*)logits, label1, label2, ratio,
+                       (bf16*)dlogits, loss_rows, K, eps, gcoef);
+  else if (dtype == VTX_F32)
+    hipLaunchKernelGGL((mix_loss_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)logits, label1, label2, ratio,
+                       (float*)dlogits, loss_rows, K, eps, gcoef);
+  else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
+
+}  // extern "C"

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "vtx_dino_loss_workspace": (c_size_t, [c_int, c_int]),
     "vtx_dino_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                               c_int, c_int, c_float, c_float, c_float, c_int, c_void_p]),
+    "vtx_mix_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,
+                             c_int, c_void_p]),
     "vtx_cast_desc_bytes": (c_size_t, []),
     "vtx_cast_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vtx_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

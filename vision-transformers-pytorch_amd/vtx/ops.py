@@ -383,6 +383,21 @@ def mix_normalize_erase(images, plan, mean, std):
     return out
 
 
+def mix_loss(logits, label1, label2, ratio, eps):
+    """MixLoss value (scalar tensor, reduction 'mean') and d loss / d logits, one kernel."""
+    _dev(logits, label1, label2, ratio)
+    x = logits if logits.is_contiguous() else logits.contiguous()
+    B, K = x.shape
+    l1 = label1.to(torch.int64).contiguous()
+    l2 = label2.to(torch.int64).contiguous()
+    r = torch.as_tensor(ratio, device=x.device).to(torch.float32).expand(B).contiguous()
+    dl = torch.empty_like(x)
+    rows = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(_lib.load().vtx_mix_loss(_p(x), _p(l1), _p(l2), _p(r), _p(dl), _p(rows), B, K, float(eps), 1.0, _dt(x), _stream()),
+          "vtx_mix_loss")
+    return rows.sum() / B, dl
+
+
 # ------------------------------------------------------------------------------- data movement
 def cast_desc_bytes():
     return _lib.load().vtx_cast_desc_bytes()

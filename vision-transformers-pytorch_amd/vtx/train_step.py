@@ -13,6 +13,22 @@ from torch.nn import functional as F
 from .optim import FusedAdamW
 
 
+class _MixLossFn(torch.autograd.Function):
+    """Value + gradient of MixLoss in one sweep (csrc/dino.hip mix_loss_kernel)."""
+
+    @staticmethod
+    def forward(ctx, output, target1, target2, interpolation, eps):
+        from . import ops
+        loss, dl = ops.mix_loss(output.detach(), target1, target2, interpolation, eps)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl.mul_(g.to(dl.dtype)), None, None, None, None
+
+
 class MixLoss(nn.Module):
     """Label-smoothed KL between log-softmax and a mix of two one-hot targets (reference loss.py:53-86)."""
 
@@ -22,6 +38,9 @@ class MixLoss(nn.Module):
         self.reduction = reduction
 
     def forward(self, output, target1, target2, interpolation):
+        if output.is_cuda and self.reduction == "mean" and output.dim() == 2 and \
+                output.dtype in (torch.float32, torch.bfloat16):
+            return _MixLossFn.apply(output, target1, target2, interpolation, float(self.eps))   # one HIP kernel
         n_class = output.shape[-1]
         output = F.log_softmax(output.float(), -1)
         true_dist = torch.full_like(output, self.eps / n_class)
