@@ -145,6 +145,11 @@ int vtx_add_pos_fwd(const void* x, const float* cls, const float* pos, void* out
                     void* stream);
 int vtx_add_pos_bwd(const void* dout, void* dx, float* dcls, float* dpos, int B, int T, int C, int dtype, void* stream);
 
+/* ---- Row-wise L2 normalisation y = x / max(||x||_2, eps) (F.normalize of the DINO head, models/vit.py:258) and its
+ * backward dx = (dy - y sum(y o dy)) / max(||x||, eps); nrm [rows] fp32 is saved by the forward. */
+int vtx_l2norm_fwd(const void* x, void* y, float* nrm, int64_t rows, int C, float eps, int dtype, void* stream);
+int vtx_l2norm_bwd(const void* dy, const void* y, const float* nrm, void* dx, int64_t rows, int C, int dtype, void* stream);
+
 /* ---- Device-side input pipeline (csrc/input.hip): per-sample mixup / cutmix
  * (reference mix_dataset.py:36-90) + Normalize + constant-mode RandomErasing (reference transforms.py:321-418) of a
  * device-resident batch in one pass.  The random plan is drawn on the host in the reference's order

@@ -218,7 +218,7 @@ static int gemm_validate(const GemmArgs& a, int mode) {
   if ((a.N & 7) || (a.ldc & 7) || (a.lda & 7) || (a.ldb & 7)) return VTX_ERR_ALIGN;
   if ((mode == 0 || mode == 1) && (a.K & 7)) return VTX_ERR_ALIGN;   // A[m][k] rows
   if (mode == 2 && (a.M & 7)) return VTX_ERR_ALIGN;                   // A^T[k][m] rows
-  if (a.act == 2 && !a.aux_in) return VTX_ERR_NULL;
+  if ((a.act == 2 || a.act == 4) && !a.aux_in) return VTX_ERR_NULL;
   return VTX_OK;
 }
 
@@ -235,7 +235,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   a.ksum_out = nullptr;
   a.kchunk = ((K + 127) / 128) * 128;
   if (mode != 0 && mode != 1) return VTX_ERR_SHAPE;
-  if (act < 0 || act > 2) return VTX_ERR_SHAPE;
+  if (act < 0 || act > 4) return VTX_ERR_SHAPE;
   int rc = gemm_validate(a, mode);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;

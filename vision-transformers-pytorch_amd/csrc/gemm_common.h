@@ -13,7 +13,7 @@ struct GemmArgs {
   int rows_per_scale;
   void* aux_out;            // T [M, ldc] or null: pre-activation z when act == 1
   const void* aux_in;       // T [M, ldc]: z when act == 2
-  int act;                  // 0 none | 1 aux_out = z = acc + bias, C = silu(z) | 2 C = acc * silu'(aux_in)
+  int act;                  // 0 none | 1 (3) aux_out = z = acc + bias, C = silu (gelu)(z) | 2 (4) C = acc * silu' (gelu')(aux_in)
   const float* kscale;      // per-sample scale along the CONTRACTION index of a transposed A (wgrad through DropPath)
   int k_per_scale;
   int kchunk;               // contraction length per grid.z slice (multiple of the LDS k-tile)
@@ -63,15 +63,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
         for (int e = 0; e < 4; ++e) { val[e] += b0[e]; val[4 + e] += b1[e]; }
       }
-      if (p.act == 1) {
+      if (p.act == 1 || p.act == 3) {
         Vec8<T> z;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { z.set(e, val[e]); val[e] = silu_f(z.get(e)); }   // silu of the ROUNDED z
+        for (int e = 0; e < 8; ++e) {                  // activation of the ROUNDED pre-activation (what the backward sees)
+          z.set(e, val[e]);
+          val[e] = p.act == 1 ? silu_f(z.get(e)) : gelu_f(z.get(e));
+        }
         if (aux_out) store8<T>(aux_out + off, z);
-      } else if (p.act == 2) {
+      } else if (p.act == 2 || p.act == 4) {
         Vec8<T> z = load8<T>(aux_in + off);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(z.get(e));
+        for (int e = 0; e < 8; ++e) val[e] *= p.act == 2 ? dsilu_f(z.get(e)) : dgelu_f(z.get(e));
       }
       if (p.rowscale) {
         const float rsc = p.rowscale[row / p.rows_per_scale];

@@ -151,3 +151,62 @@ int vtx_add_pos_bwd(const void* dout, void* dx, float* dcls, float* dpos, int B,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise L2 normalisation  y = x / max(||x||_2, eps)  (F.normalize(dim=-1, p=2) of the DINO head, reference
+// models/vit.py:258) and its backward  dx = (dy - y * sum(y o dy)) / max(||x||, eps); one wavefront per row.
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ nrm,
+                                                        int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = to_f32<T>(xr[c]); s += v * v; }
+  const float n = fmaxf(sqrtf(group_sum<64>(s)), eps);
+  const float inv = 1.f / n;
+  for (int c = lane; c < C; c += 64) y[row * C + c] = from_f32<T>(to_f32<T>(xr[c]) * inv);
+  if (lane == 0) nrm[row] = n;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                        const float* __restrict__ nrm, T* __restrict__ dx, int64_t rows,
+                                                        int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += to_f32<T>(y[row * C + c]) * to_f32<T>(dy[row * C + c]);
+  s = group_sum<64>(s);
+  const float inv = 1.f / nrm[row];
+  for (int c = lane; c < C; c += 64)
+    dx[row * C + c] = from_f32<T>((to_f32<T>(dy[row * C + c]) - to_f32<T>(y[row * C + c]) * s) * inv);
+}
+
+extern "C" {
+
+int vtx_l2norm_fwd(const void* x, void* y, float* nrm, int64_t rows, int C, float eps, int dtype, void* stream) {
+  if (!x || !y || !nrm) return VTX_ERR_NULL;
+  if (rows <= 0 || C <= 0) return VTX_ERR_SHAPE;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16) hipLaunchKernelGGL((l2norm_fwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, nrm, rows, C, eps);
+  else if (dtype == VTX_F32) hipLaunchKernelGGL((l2norm_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (float*)y, nrm, rows, C, eps);
+  else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
+
+int vtx_l2norm_bwd(const void* dy, const void* y, const float* nrm, void* dx, int64_t rows, int C, int dtype, void* stream) {
+  if (!dy || !y || !nrm || !dx) return VTX_ERR_NULL;
+  if (rows <= 0 || C <= 0) return VTX_ERR_SHAPE;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16) hipLaunchKernelGGL((l2norm_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, nrm, (bf16*)dx, rows, C);
+  else if (dtype == VTX_F32) hipLaunchKernelGGL((l2norm_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dy, (const float*)y, nrm, (float*)dx, rows, C);
+  else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
+
+}  // extern "C"

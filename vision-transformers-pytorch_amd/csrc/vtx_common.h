@@ -103,6 +103,11 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoidf_(z); }
 __device__ __forceinline__ float dsilu_f(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
+// exact (erf) GELU of nn.GELU() and its derivative 0.5 (1 + erf(z / sqrt 2)) + z exp(-z^2 / 2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+}
 
 // out[c] = sum_b part[b][c] for c < C (out0) and C <= c < 2C (out1, optional).  Launch with 256 threads and
 // ceil(ncols / 32) blocks: 32 columns x 8 row lanes per block, fixed summation order (deterministic).

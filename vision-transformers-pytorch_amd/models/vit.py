@@ -218,8 +218,16 @@ class DINOHead(nn.Module):
                 nn.init.zeros_(module.bias)
 
     def forward(self, input):
-        out = self.mlp(input)
-        out = F.normalize(out.float(), dim=-1, p=2).to(out.dtype)
+        linears = [self.mlp] if isinstance(self.mlp, nn.Linear) else list(self.mlp)
+        if input.is_cuda and all(isinstance(m, (nn.Linear, nn.GELU)) for m in linears):
+            # no BatchNorm: Linear / GELU chain with the activation in the GEMM epilogues, L2 normalisation kernel
+            T = VF.compute_dtype(input)
+            wb = [t for m in linears if isinstance(m, nn.Linear) for t in (m.weight, m.bias)]
+            out = VF.MlpChainFn.apply(input.to(T), VF.ACT_GELU, *wb)
+            out = VF.L2NormFn.apply(out, 1e-12)
+        else:
+            out = self.mlp(input)
+            out = F.normalize(out.float(), dim=-1, p=2).to(out.dtype)
         return self.last(out)
 
 

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "vtx_grad_sqnorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vtx_adamw_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "vtx_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "vtx_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vtx_mix_plan_bytes": (c_size_t, []),
     "vtx_mix_max_rects": (c_int, []),
     "vtx_mix_normalize_erase": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -15,7 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .ops import ACT_DSILU, ACT_SILU, VtxError
+from .ops import ACT_DGELU, ACT_DSILU, ACT_GELU, ACT_SILU, VtxError
 
 
 def compute_dtype(x):
@@ -238,6 +238,64 @@ class FeedForwardFn(Function):
         dW1, db1 = ops.wgrad(dz, x)
         dx = dgrad(dz, ctx.wp[0], T)
         return dx, dW1, db1, dW2, db2
+
+
+class MlpChainFn(Function):
+    """Linear -> act -> Linear -> act -> ... -> Linear with the activation (SiLU or exact GELU) fused into each GEMM's
+    epilogue and its derivative into the following dgrad's epilogue: the projection MLP of the DINO head (reference
+    models/vit.py:221-241 without BatchNorm).  args: x, act, w0, b0, w1, b1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, act, *wb):
+        x = _c(x)
+        T = x.dtype
+        n = len(wb) // 2
+        wps = [wcast(wb[2 * i], T) for i in range(n)]
+        hs, zs, h = [x], [], x
+        for i in range(n):
+            b = None if wb[2 * i + 1] is None else wb[2 * i + 1].detach()
+            if i < n - 1:
+                h, z = ops.gemm(h, wps[i][0], 0, bias=b, act=act, want_aux=True)
+                hs.append(h); zs.append(z)
+            else:
+                h = ops.gemm(h, wps[i][0], 0, bias=b)
+        ctx.save_for_backward(*hs, *zs)
+        ctx.wps, ctx.n, ctx.dact, ctx.has_bias = wps, n, (ACT_DSILU if act == ACT_SILU else ACT_DGELU), [wb[2 * i + 1] is not None for i in range(n)]
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        hs, zs = saved[:n], saved[n:]
+        T = hs[0].dtype
+        d = _c(dy)
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            dW, db = ops.wgrad(d, hs[i], want_bias=ctx.has_bias[i])
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            if i > 0:
+                d = dgrad(d, ctx.wps[i], T, act=ctx.dact, aux_in=zs[i - 1])
+            elif ctx.needs_input_grad[0]:
+                d = dgrad(d, ctx.wps[0], T)
+            else:
+                d = None
+        return (d, None, *grads)
+
+
+class L2NormFn(Function):
+    """F.normalize(x, dim=-1, p=2) (reference models/vit.py:258)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, nrm = ops.l2norm_fwd(_c(x), eps)
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        return ops.l2norm_bwd(_c(dy), y, nrm), None
 
 
 class AttentionMeta:

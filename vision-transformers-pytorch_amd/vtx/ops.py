@@ -164,7 +164,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
 
 
 # ------------------------------------------------------------------------------- GEMM family
-ACT_NONE, ACT_SILU, ACT_DSILU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_DSILU, ACT_GELU, ACT_DGELU = 0, 1, 2, 3, 4
 
 
 def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, act=ACT_NONE, aux_in=None,
@@ -396,6 +396,25 @@ def mix_loss(logits, label1, label2, ratio, eps):
     check(_lib.load().vtx_mix_loss(_p(x), _p(l1), _p(l2), _p(r), _p(dl), _p(rows), B, K, float(eps), 1.0, _dt(x), _stream()),
           "vtx_mix_loss")
     return rows.sum() / B, dl
+
+
+def l2norm_fwd(x, eps=1e-12):
+    """y = x / max(||x||_2, eps) over the last dim; returns (y, row norms)."""
+    _dev(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    nrm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().vtx_l2norm_fwd(_p(x), _p(y), _p(nrm), rows, C, float(eps), _dt(x), _stream()), "vtx_l2norm_fwd")
+    return y, nrm
+
+
+def l2norm_bwd(dy, y, nrm):
+    _dev(dy, y, nrm)
+    C = y.shape[-1]
+    dx = torch.empty_like(y)
+    check(_lib.load().vtx_l2norm_bwd(_p(dy), _p(y), _p(nrm), _p(dx), y.numel() // C, C, _dt(y), _stream()), "vtx_l2norm_bwd")
+    return dx
 
 
 # ------------------------------------------------------------------------------- data movement
