@@ -23,19 +23,61 @@ struct GemmArgs {
 
 // acc[i][j][r] = C[m0 + wm*(BM/2) + 16 i + 4 g + r][n0 + wn*(BN/2) + 16 j + c]; lds_raw: >= (BM/2)*(BN+4)*4 bytes,
 // no longer read by anybody when this is called (callers barrier after their last operand read).
+//
+// The tile goes through LDS in two passes of BM/2 rows so that every lane stores 16 contiguous bytes.  ALL global
+// reads of the epilogue (bias, z for act', residual, DropPath scale) are requested up front, before the first
+// staging pass: issued inside the store loop they cannot be hoisted above the previous iteration's stores (possible
+// aliasing), and with 8 waves per CU each of the 8 iterations then exposed a full L2 / HBM latency -- measured on
+// the stage-2 fc1 forward: 81 us of a 139 us launch with the main loop AND the stores switched off.
 template <typename T, typename TO, int BM, int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* lds_raw,
                                               int m0, int n0, int tz, int wm, int wn, int c_, int g_) {
   constexpr int WM = BM / 32, WN = BN / 32;
   constexpr int CSTR = BN + 4;                // fp32 C-staging row stride (floats)
-  // ---------------- epilogue through LDS: two passes of BM/2 rows; acc[i][j][r] = C[.. + 4*g_ + r][.. + c_]
-  TO* Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
-  const T* resid = (const T*)p.resid;
-  const T* aux_in = (const T*)p.aux_in;
-  T* aux_out = (T*)p.aux_out;
+  TO* __restrict__ Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
+  const T* __restrict__ resid = (const T*)p.resid;
+  const T* __restrict__ aux_in = (const T*)p.aux_in;
+  T* __restrict__ aux_out = (T*)p.aux_out;
   float* cbuf = reinterpret_cast<float*>(lds_raw);
   constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
   constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
+  constexpr int NIT = (NVEC + 255) / 256;            // iterations per pass
+  const bool act_fwd = p.act == 1 || p.act == 3, act_bwd = p.act == 2 || p.act == 4;
+
+  // ---------------- request every global operand of the epilogue now
+  // bias: per lane the WN columns of its accumulator tiles (added while staging); z (act') or the residual: one
+  // 16-byte vector per store iteration, both passes (they are never both present on the hot path: a residual next
+  // to act' is loaded late)
+  float bcol[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 16 + c_;
+    bcol[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+  }
+  int64_t offs[2 * NIT];
+  bool ok[2 * NIT];
+  float rsc[2 * NIT];
+  Vec8<T> ein[2 * NIT];
+  const T* __restrict__ esrc = act_bwd ? aux_in : resid;
+#pragma unroll
+  for (int q = 0; q < 2 * NIT; ++q) {
+    const int pass = q / NIT, it = q - pass * NIT;
+    const int v = threadIdx.x + 256 * it;
+    const int lr = v / VROW, cv = v - lr * VROW;
+    const int w2 = lr / (BM / 4), rem = lr - w2 * (BM / 4);
+    const int row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
+    const int col = n0 + cv * 8;
+    ok[q] = (NVEC % 256 == 0 || v < NVEC) && row < p.M && col < p.N;
+    offs[q] = (int64_t)row * p.ldc + col;
+    ein[q] = vec8_zero<T>();
+    rsc[q] = 1.f;
+    if (ok[q]) {
+      if (esrc) ein[q] = load8<T>(esrc + offs[q]);
+      if (p.rowscale) rsc[q] = p.rowscale[row / p.rows_per_scale];
+    }
+  }
+
+  // ---------------- two passes of BM/2 rows through LDS; acc[i][j][r] = C[.. + 4*g_ + r][.. + c_]
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -45,51 +87,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r];
+          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r] + bcol[j];
     }
     __syncthreads();
-    for (int v = threadIdx.x; v < NVEC; v += 256) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = pass * NIT + it;
+      if (!ok[q]) continue;
+      const int v = threadIdx.x + 256 * it;
       const int lr = v / VROW, cv = v - lr * VROW;
-      const int w2 = lr / (BM / 4), rem = lr - w2 * (BM / 4);
-      const int row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
-      const int col = n0 + cv * 8;
-      if (row >= p.M || col >= p.N) continue;
       const float* cp = cbuf + lr * CSTR + cv * 8;
       f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
       float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const int64_t off = (int64_t)row * p.ldc + col;
-      if (p.bias) {
-        f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { val[e] += b0[e]; val[4 + e] += b1[e]; }
-      }
-      if (p.act == 1 || p.act == 3) {
+      if (act_fwd) {
         Vec8<T> z;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {                  // activation of the ROUNDED pre-activation (what the backward sees)
-          z.set(e, val[e]);
-          val[e] = p.act == 1 ? silu_f(z.get(e)) : gelu_f(z.get(e));
+        for (int e = 0; e < 8; ++e) z.set(e, val[e]);  // activation of the ROUNDED pre-activation (what the backward sees)
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = silu_f(z.get(e));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = gelu_f(z.get(e));
         }
-        if (aux_out) store8<T>(aux_out + off, z);
-      } else if (p.act == 2 || p.act == 4) {
-        Vec8<T> z = load8<T>(aux_in + off);
+        if (aux_out) store8<T>(aux_out + offs[q], z);
+      } else if (act_bwd) {
+        if (p.act == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] *= p.act == 2 ? dsilu_f(z.get(e)) : dgelu_f(z.get(e));
-      }
-      if (p.rowscale) {
-        const float rsc = p.rowscale[row / p.rows_per_scale];
+          for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(ein[q].get(e));
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] *= rsc;
+          for (int e = 0; e < 8; ++e) val[e] *= dgelu_f(ein[q].get(e));
+        }
       }
-      if (resid) {
-        Vec8<T> rv = load8<T>(resid + off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) val[e] += rv.get(e);
-      }
+      Vec8<T> rv = ein[q];
+      if (act_bwd) rv = resid ? load8<T>(resid + offs[q]) : vec8_zero<T>();
       Vec8<TO> o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o.set(e, val[e]);
-      store8<TO>(Cout + off, o);
+      for (int e = 0; e < 8; ++e) o.set(e, val[e] * rsc[q] + rv.get(e));
+      store8<TO>(Cout + offs[q], o);
     }
     if (pass == 0) __syncthreads();
   }

@@ -161,17 +161,17 @@ template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_
 
 bool gemm_glds_ok(int N, int K) { return (K % 64) == 0 || ((K % 32) == 0 && (N % 128) == 0); }
 
-// Tile height: 128 rows by default; 64-row tiles when the 128-row grid would leave the 512 resident block
-// slots (256 CUs x 2) badly quantised (few "waves" of blocks with a mostly empty last one).
-static int glds_pick_bm(const GemmArgs& a, int bn) {
+// Tile height: 64 rows.  With the epilogue's global reads requested up front (gemm_common.h) these GEMMs are bound by
+// how many independent tiles a CU keeps in flight, not by operand reuse: a 64x128 tile needs 48 KB of LDS and
+// 119 registers -> 3 resident workgroups per CU instead of 2.  Measured over the 32 Swin-S fwd / dgrad shapes
+// (tools/bench_gemm.py, same box): 64-row tiles 4.62 + 4.14 ms per step, 128-row tiles 4.99 + 4.59 ms, the former
+// grid-quantisation rule (128 unless the last round of workgroups is mostly empty) 4.91 + 4.46 ms; 64x64 tiles
+// 5.18 + 4.84 ms and 32-deep k-tiles x 3 stages 5.04 + 4.74 ms are worse again.  VTX_GLDS_BM=128 forces the tall tile
+// (within 3-7 % on the four widest stage-4 shapes, slower everywhere else).
+static int glds_pick_bm(const GemmArgs&, int) {
   static int force = -1;
   if (force < 0) { const char* e = getenv("VTX_GLDS_BM"); force = e ? atoi(e) : 0; }
-  if (force == 64 || force == 128) return force;
-  const long tn = (a.N + bn - 1) / bn;
-  const long b128 = tn * ((a.M + 127) / 128);
-  const double waves = (double)b128 / 512.0;
-  const double eff128 = waves / (double)(long)(waves + 0.999999);
-  return (b128 < 512 || eff128 < 0.7) ? 64 : 128;
+  return force == 128 ? 128 : 64;
 }
 
 template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {

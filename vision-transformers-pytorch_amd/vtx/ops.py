@@ -5,6 +5,7 @@ caching allocator, enqueues on torch's current HIP stream and returns tensors.  
 tensors, wrong dtypes or a missing library raise VtxError.
 """
 import ctypes
+import os
 
 import torch
 
@@ -154,10 +155,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
     to = "float" if out_f32 else t
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
-        b128 = ((N + bn - 1) // bn) * ((M + 127) // 128)          # mirrors glds_pick_bm in gemm_glds.hip
-        waves = b128 / 512.0
-        eff = waves / max(1, int(waves + 0.999999))
-        bm = 64 if (b128 < 512 or eff < 0.7) else 128
+        bm = 128 if os.environ.get("VTX_GLDS_BM") == "128" else 64       # mirrors glds_pick_bm in gemm_glds.hip
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2>" if K % 64 == 0 else f"gemm_glds_kernel<{bm}, {bn}, 32, 3>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
     return f"gemm_kernel<{t}, {to}, 128, {bn}, {ta}, {tb}>"
