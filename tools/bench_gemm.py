@@ -74,7 +74,10 @@ def main():
                 byt = 2 * (M * N + N * K + M * K * (2 if kw else 1))
                 rows.append(("dgrad", t, byt))
             if "wgrad" in what:
-                t = timeit(lambda: ops.wgrad(dy, x), a.iters)
+                # as in the model: the branch sits behind DropPath(0.3) -> per-sample scale in {0, 1 / 0.7}
+                rps = M // B
+                rsc = (torch.rand(B, device=dev) >= 0.3).float() / 0.7
+                t = timeit(lambda: ops.wgrad(dy, x, rowscale=rsc, rows_per_scale=rps, scale_const=1 / 0.7), a.iters)
                 byt = 2 * (M * N + M * K) + 4 * N * K
                 rows.append(("wgrad", t, byt))
             vend = {}

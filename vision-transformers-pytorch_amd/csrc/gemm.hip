@@ -252,7 +252,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
 // kernel because every block runs the same long k-loop.
 static int wgrad_slices(int64_t mtok, int N, int Kin) {
   static int target = -1;
-  if (target < 0) { const char* e = getenv("VTX_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }
+  if (target < 0) { const char* e = getenv("VTX_WGRAD_BLOCKS"); target = e ? atoi(e) : wgrad_glds_resident(); }
   const int tiles = ((N + 127) / 128) * ((Kin + 127) / 128);
   int nz = target / tiles;
   const int64_t maxz = (mtok + 255) / 256;

@@ -139,6 +139,7 @@ bool gemm_glds_ok(int N, int K);
 // LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N % 128 == 0, Kin % 128 == 0,
 // rowscale values restricted to {0, scale_const}
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const);
+int wgrad_glds_resident();
 int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, int64_t mtok, int N, int Kin,
                       int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
                       int nz, int kchunk, hipStream_t st);

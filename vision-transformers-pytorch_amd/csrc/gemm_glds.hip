@@ -166,7 +166,8 @@ bool gemm_glds_ok(int N, int K) { return (K % 64) == 0 || ((K % 32) == 0 && (N %
 // 119 registers -> 3 resident workgroups per CU instead of 2.  Measured over the 32 Swin-S fwd / dgrad shapes
 // (tools/bench_gemm.py, same box): 64-row tiles 4.62 + 4.14 ms per step, 128-row tiles 4.99 + 4.59 ms, the former
 // grid-quantisation rule (128 unless the last round of workgroups is mostly empty) 4.91 + 4.46 ms; 64x64 tiles
-// 5.18 + 4.84 ms and 32-deep k-tiles x 3 stages 5.04 + 4.74 ms are worse again.  VTX_GLDS_BM=128 forces the tall tile
+// 5.18 + 4.84 ms, 32-deep k-tiles x 3 stages 5.04 + 4.74 ms and a 3-stage ring of 64-deep tiles (2 workgroups per CU)
+// 5.25 + 4.66 ms are worse again; 64x96 tiles (4 per CU) are equal.  VTX_GLDS_BM=128 forces the tall tile
 // (within 3-7 % on the four widest stage-4 shapes, slower everywhere else).
 static int glds_pick_bm(const GemmArgs&, int) {
   static int force = -1;

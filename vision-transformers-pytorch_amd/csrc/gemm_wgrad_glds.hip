@@ -53,10 +53,22 @@ __device__ __forceinline__ Vec8<bf16> wg_frag(const unsigned char* tile, int tok
   return f;
 }
 
+// BKT tokens per k-tile, NS-stage LDS ring.  The operands are streamed from HBM (activations, read once per XCD
+// through its L2), so a k-tile costs an HBM-miss latency: what matters is how many bytes each CU keeps in flight.
+// NS-1 tiles are always requested ahead (counted s_waitcnt vmcnt + raw s_barrier, never a draining __syncthreads);
+// nothing but the DMA uses vmcnt inside the loop: DropPath liveness comes from a per-workgroup LDS table.
+constexpr int WG_MAXSAMPLES = 512;
+
+template <int BKT, int NS>
 __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
-  constexpr int BT = 128, BKT = 64, ROWB = 256, OPB = BKT * ROWB;   // operand tile bytes (16 KB)
+  constexpr int BT = 128, ROWB = 256, OPB = BKT * ROWB;   // operand tile bytes
   constexpr int STAGE = 2 * OPB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];   // [2][A | B]
+  constexpr int RPW = BKT / 4;                             // tile rows per wave
+  constexpr int IPW = RPW / 4;                             // DMA instructions per wave and operand (4 rows x 256 B each)
+  constexpr int LPT = 2 * IPW;                             // DMA instructions per wave and k-tile
+  static_assert(NS * STAGE >= 64 * (BT + 4) * 4, "C staging must fit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];   // [NS][A | B]
+  __shared__ unsigned char live_tab[WG_MAXSAMPLES];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -76,24 +88,45 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
   const int mend = min(p.M, mbeg + p.kchunk);
   const int nkt = (mend - mbeg + BKT - 1) / BKT;
 
-  // DMA piece geometry: one instruction = 4 rows x 256 B; wave w owns rows 16w .. 16w+15 of each operand tile
+  // DropPath liveness of the samples this slice touches (host guarantees they fit the table)
+  const int s0 = mbeg / p.rows_per_scale;
+  if (p.rowscale != nullptr && nkt > 0) {
+    const int ns = (mend - 1) / p.rows_per_scale - s0 + 1;
+    for (int i = threadIdx.x; i < ns; i += 256) live_tab[i] = p.rowscale[s0 + i] != 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // DMA piece geometry: one instruction = 4 rows x 256 B; wave w owns rows RPW w .. RPW w + RPW - 1 of each operand tile
   const int prow = lane >> 4, pslot = lane & 15;
   const bf16* zero = reinterpret_cast<const bf16*>(vtx_zero_row);
+  // (sample - s0, token within the sample) of this lane's rows in the NEXT tile to be requested; advanced per issue
+  int smp[IPW], rem[IPW];
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) {
+    const int tok = mbeg + wave * RPW + j * 4 + prow;
+    smp[j] = tok / p.rows_per_scale - s0;
+    rem[j] = tok % p.rows_per_scale;
+  }
 
-  auto issue = [&](int kt, int buf) {
-    unsigned char* sa = wg_smem + buf * STAGE + wave * 16 * ROWB;
+  auto issue = [&](int kt, int buf) {          // called with kt = 0, 1, 2, ... in order
+    unsigned char* sa = wg_smem + buf * STAGE + wave * RPW * ROWB;
     unsigned char* sb = sa + OPB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wave * 16 + j * 4 + prow;
+    for (int j = 0; j < IPW; ++j) {
+      const int r = wave * RPW + j * 4 + prow;
       const int tok = mbeg + kt * BKT + r;
       const int q = pslot ^ wg_swz(r);
       bool live = tok < mend;
       const bf16* srcb = live ? p.x + (int64_t)tok * p.ld_x + k0 + (q << 3) : zero + (q << 3);
-      if (live && p.rowscale != nullptr) live = p.rowscale[tok / p.rows_per_scale] != 0.f;
+      if (live && p.rowscale != nullptr) live = live_tab[smp[j]] != 0;
       const bf16* srca = live ? p.dy + (int64_t)tok * p.ld_dy + n0 + (q << 3) : zero + (q << 3);
       __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+      if (p.rowscale != nullptr) {
+        rem[j] += BKT;
+        while (rem[j] >= p.rows_per_scale) { rem[j] -= p.rows_per_scale; ++smp[j]; }
+      }
     }
   };
 
@@ -107,21 +140,23 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
   const bool do_ksum = p.ksum_out != nullptr && tk == 0;
   float ks8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  if (nkt > 0) {
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
+#pragma unroll
+  for (int s2 = 0; s2 < NS - 1; ++s2)
+    if (s2 < nkt) issue(s2, s2);
+  if (nkt >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
+  int buf = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    const bool refill = kt + NS - 1 < nkt;
+    if (refill) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
     const unsigned char* la = wg_smem + buf * STAGE;
     const unsigned char* lb = la + OPB;
     if (do_ksum) {
       const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < BKT / 16; ++rr) {
         const int r = rg + rr * 16;
         Vec8<bf16> t = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + ((ch ^ wg_swz(r)) << 4)));
 #pragma unroll
@@ -129,7 +164,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BKT / 32; ++ks) {
       Vec8<bf16> fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = wg_frag(la, ks * 32, wm * 64 + i * 16, lane);
@@ -140,8 +175,12 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // tile kt+1 must have landed; up to NS-2 younger tiles stay in flight (vmcnt retires in order)
+    if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
   const float sc = p.rowscale != nullptr ? p.scale_const : 1.f;
@@ -172,10 +211,31 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
   gemm_epilogue<bf16, float, 128, 128>(e, acc, wg_smem, n0, k0, tz, wm, wn, c_, g_);
 }
 
+// Ring configuration (env VTX_WG_CFG = 642 | 324 | 323 for A/B runs): tokens per k-tile x stages
+static int wg_cfg() {
+  static int c = -1;
+  if (c < 0) { const char* e = getenv("VTX_WG_CFG"); c = e ? atoi(e) : 642; }
+  return c;
+}
+
+// workgroups the chip keeps resident (256 CUs x LDS-limited workgroups per CU): the split-K slices are sized to it
+int wgrad_glds_resident() { return wg_cfg() == 323 ? 768 : 512; }
+
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const) {
   static int on = -1;
   if (on < 0) { const char* ev = getenv("VTX_WGRAD_GLDS"); on = ev ? atoi(ev) : 1; }
   return on && dtype == VTX_BF16 && (N % 128) == 0 && (Kin % 128) == 0 && (rowscale == nullptr || scale_const > 0.f);
+}
+
+template <int BKT, int NS> static int wgrad_glds_launch_cfg(const WgradArgs& a, int nz, hipStream_t st) {
+  constexpr int smem = NS * 2 * BKT * 256;
+  auto kern = wgrad_glds_kernel<BKT, NS>;
+  if (smem + WG_MAXSAMPLES > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    return VTX_ERR_LAUNCH;
+  dim3 grid(a.Kin / 128, a.N / 128, nz);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  return vtx_check_launch();
 }
 
 int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, int64_t mtok, int N, int Kin,
@@ -185,7 +245,11 @@ int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, 
   a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.C = C; a.ksum_out = ksum_out; a.M = (int)mtok; a.N = N; a.Kin = Kin;
   a.ld_dy = ld_dy; a.ld_x = ld_x; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
   a.scale_const = scale_const; a.kchunk = kchunk;
-  dim3 grid(Kin / 128, N / 128, nz);
-  hipLaunchKernelGGL(wgrad_glds_kernel, grid, dim3(256), 65536, st, a);
-  return vtx_check_launch();
+  if (rowscale != nullptr && kchunk / rows_per_scale + 2 > WG_MAXSAMPLES) return VTX_ERR_SHAPE;
+  switch (wg_cfg()) {
+    case 642: return wgrad_glds_launch_cfg<64, 2>(a, nz, st);
+    case 323: return wgrad_glds_launch_cfg<32, 3>(a, nz, st);
+    case 324: return wgrad_glds_launch_cfg<32, 4>(a, nz, st);
+    default: return wgrad_glds_launch_cfg<64, 2>(a, nz, st);
+  }
 }
