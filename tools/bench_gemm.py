@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--stages", default="1,2,3,4")
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no-drop", action="store_true", help="weight gradients without the DropPath row scale")
     ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (hipBLASLt, no epilogue) as a comparison")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -77,7 +78,10 @@ def main():
                 # as in the model: the branch sits behind DropPath(0.3) -> per-sample scale in {0, 1 / 0.7}
                 rps = M // B
                 rsc = (torch.rand(B, device=dev) >= 0.3).float() / 0.7
-                t = timeit(lambda: ops.wgrad(dy, x, rowscale=rsc, rows_per_scale=rps, scale_const=1 / 0.7), a.iters)
+                if a.no_drop:
+                    t = timeit(lambda: ops.wgrad(dy, x), a.iters)
+                else:
+                    t = timeit(lambda: ops.wgrad(dy, x, rowscale=rsc, rows_per_scale=rps, scale_const=1 / 0.7), a.iters)
                 byt = 2 * (M * N + M * K) + 4 * N * K
                 rows.append(("wgrad", t, byt))
             vend = {}

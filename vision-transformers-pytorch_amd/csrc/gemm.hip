@@ -39,7 +39,7 @@ template <typename T, int R, bool TR> struct Stage {
 
   // global -> registers.  base: operand pointer; t0: first tile row (m or n); k0: first contraction index
   __device__ __forceinline__ void gload(const T* __restrict__ base, int64_t ld, int t0, int tdim, int k0, int kend,
-                                        const float* __restrict__ kscale, int k_per_scale) {
+                                        const float* __restrict__, int) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = threadIdx.x + it * 256;
@@ -54,20 +54,46 @@ template <typename T, int R, bool TR> struct Stage {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int k = k0 + kg * 4 + i;
-          if (idx < NITEMS && col < tdim && k < kend) {
-            Vec8<T> v = load8<T>(base + (int64_t)k * ld + col);
-            if (kscale != nullptr) {
-              const float s = kscale[k / k_per_scale];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v.set(e, v.get(e) * s);
-            }
-            reg[it][i] = v;
-          } else {
-            reg[it][i] = vec8_zero<T>();
-          }
+          if (idx < NITEMS && col < tdim && k < kend) reg[it][i] = load8<T>(base + (int64_t)k * ld + col);
+          else reg[it][i] = vec8_zero<T>();
         }
       }
     }
+  }
+
+  // transposed operand only: per-sample scale along the contraction index (weight gradient through DropPath).
+  // The scale values are requested with the tile and applied when the registers go to LDS (kscale_apply), so the
+  // prefetch of the tile itself is not waited for early.
+  float ksv[TR ? NIT : 1][4];
+  __device__ __forceinline__ void kscale_fetch(int k0, int kend, const float* __restrict__ kscale, int k_per_scale) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const int kg = idx % G::KG;
+      // the 4 contraction rows of this item are consecutive: one division, then compare
+      const int kb = k0 + kg * 4;
+      const int sq = kb / k_per_scale, sr = kb - sq * k_per_scale;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kb + i;
+        const int si = k_per_scale >= 4 ? sq + (sr + i >= k_per_scale ? 1 : 0) : k / k_per_scale;
+        ksv[it][i] = (idx < NITEMS && k < kend) ? kscale[si] : 0.f;
+      }
+    }
+  }
+  // kmask: every scale is 0 or one constant -> rows are only masked here, the caller scales its accumulators
+  __device__ __forceinline__ void kscale_apply(bool kmask) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kmask) {
+          if (ksv[it][i] == 0.f) reg[it][i] = vec8_zero<T>();
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) reg[it][i].set(e, reg[it][i].get(e) * ksv[it][i]);
+        }
+      }
   }
 
   // registers -> LDS tile [R][STRIDE]
@@ -141,8 +167,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   Stage<T, BM, TA> sa;
   Stage<T, BN, TB> sb;
-  sa.gload(A, p.lda, m0, p.M, kbeg, kend, TA ? p.kscale : nullptr, p.k_per_scale);
+  const bool kmask = TA && p.kscale != nullptr && p.kscale_const > 0.f;
+  sa.gload(A, p.lda, m0, p.M, kbeg, kend, nullptr, 1);
+  if constexpr (TA) { if (p.kscale != nullptr) sa.kscale_fetch(kbeg, kend, p.kscale, p.k_per_scale); }
   sb.gload(B, p.ldb, n0, p.N, kbeg, kend, nullptr, 1);
+  if constexpr (TA) { if (p.kscale != nullptr) sa.kscale_apply(kmask); }
   sa.lstore(ldsA);
   sb.lstore(ldsB);
   __syncthreads();
@@ -156,7 +185,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const bool more = kt + 1 < nk;
     if (more) {
       const int k0 = kbeg + (kt + 1) * G::BK;
-      sa.gload(A, p.lda, m0, p.M, k0, kend, TA ? p.kscale : nullptr, p.k_per_scale);
+      sa.gload(A, p.lda, m0, p.M, k0, kend, nullptr, 1);
+      if constexpr (TA) { if (p.kscale != nullptr) sa.kscale_fetch(k0, kend, p.kscale, p.k_per_scale); }
       sb.gload(B, p.ldb, n0, p.N, k0, kend, nullptr, 1);
     }
     if (do_ksum) {
@@ -184,12 +214,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
     __syncthreads();
     if (more) {
+      if constexpr (TA) { if (p.kscale != nullptr) sa.kscale_apply(kmask); }
       sa.lstore(ldsA);
       sb.lstore(ldsB);
       __syncthreads();
     }
   }
 
+  if (kmask) {
+    ksum *= p.kscale_const;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] *= p.kscale_const;
+  }
   if (do_ksum && m0 + (int)threadIdx.x < p.M) p.ksum_out[(int64_t)tz * p.M + m0 + threadIdx.x] = ksum;
 
   gemm_epilogue<T, TO, BM, BN>(p, acc, lds_raw, m0, n0, tz, wm, wn, c_, g_);
@@ -231,7 +269,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.bias = bias; a.resid = resid; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
-  a.aux_out = aux_out; a.aux_in = aux_in; a.act = act; a.kscale = nullptr; a.k_per_scale = 1;
+  a.aux_out = aux_out; a.aux_in = aux_in; a.act = act; a.kscale = nullptr; a.k_per_scale = 1; a.kscale_const = 0.f;
   a.ksum_out = nullptr;
   a.kchunk = ((K + 127) / 128) * 128;
   if (mode != 0 && mode != 1) return VTX_ERR_SHAPE;
@@ -281,7 +319,7 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   a.M = N; a.N = Kin; a.K = (int)mtok; a.lda = ld_dy; a.ldb = ld_x; a.ldc = Kin;
   a.bias = nullptr; a.resid = nullptr; a.rowscale = nullptr; a.rows_per_scale = 1;
   a.aux_out = nullptr; a.aux_in = nullptr; a.act = 0;
-  a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+  a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.kscale_const = scale_const;
   int64_t chunk = (mtok + nz - 1) / nz;
   chunk = ((chunk + 127) / 128) * 128;
   a.kchunk = (int)chunk;

@@ -16,6 +16,7 @@ struct GemmArgs {
   int act;                  // 0 none | 1 (3) aux_out = z = acc + bias, C = silu (gelu)(z) | 2 (4) C = acc * silu' (gelu')(aux_in)
   const float* kscale;      // per-sample scale along the CONTRACTION index of a transposed A (wgrad through DropPath)
   int k_per_scale;
+  float kscale_const;       // > 0: every kscale value is 0 or this constant (rows are masked, the constant scales the accumulators)
   int kchunk;               // contraction length per grid.z slice (multiple of the LDS k-tile)
   float* ksum_out;          // TA only: [grid.z][M] fp32 = sum over the contraction of opA (bias gradient), or null
 };
