@@ -37,15 +37,18 @@ def main():
     ap.add_argument("--stages", default="1,2,3,4")
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--act", default="silu", choices=("silu", "gelu", "none"), help="MLP activation fused in fc1 fwd / fc2 dgrad")
+    ap.add_argument("--vit", action="store_true", help="ViT-S/16 B=256 shapes (50432 tokens, C=384) instead of the Swin stages")
     ap.add_argument("--no-drop", action="store_true", help="weight gradients without the DropPath row scale")
     ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (hipBLASLt, no epilogue) as a comparison")
     a = ap.parse_args()
     dev = torch.device("cuda")
     what = a.what.split(",")
     tot = {}
-    for s in [int(x) for x in a.stages.split(",")]:
-        M, C = STAGES[s]
-        layers = (2, 2, 18, 2)[s - 1]
+    fa, ba = {"silu": (ops.ACT_SILU, ops.ACT_DSILU), "gelu": (ops.ACT_GELU, ops.ACT_DGELU), "none": (0, 0)}[a.act]
+    for s in ([0] if a.vit else [int(x) for x in a.stages.split(",")]):
+        M, C = (256 * 197, 384) if a.vit else STAGES[s]
+        layers = 12 if a.vit else (2, 2, 18, 2)[s - 1]
         for name, N, K in (("qkv", 3 * C, C), ("proj", C, C), ("fc1", 4 * C, C), ("fc2", C, 4 * C)):
             x = torch.randn(M, K, device=dev).bfloat16()
             w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
@@ -59,14 +62,14 @@ def main():
                 if name in ("proj", "fc2"):
                     kw["resid"] = res
                 if name == "fc1":
-                    kw.update(act=ops.ACT_SILU, want_aux=True)
+                    kw.update(act=fa, want_aux=bool(fa))
                 t = timeit(lambda: ops.gemm(x, w, 0, **kw), a.iters)
                 byt = 2 * (M * K + N * K + M * N * (2 if "resid" in kw else 1))
                 rows.append(("fwd", t, byt))
             if "dgrad" in what:
                 kw = {}
                 if name == "fc2":
-                    kw = dict(act=ops.ACT_DSILU, aux_in=x)      # x plays z [M, 4C]... shape [M,K]
+                    kw = dict(act=ba, aux_in=x) if ba else {}     # x plays z [M, 4C]
                 wt = w.t().contiguous()                       # the product path uses a transposed bf16 copy (functional.dgrad)
                 if ops.glds_ok(K, N):
                     t = timeit(lambda: ops.gemm(dy, wt, 0, **kw), a.iters)

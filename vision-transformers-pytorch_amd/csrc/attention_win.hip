@@ -511,7 +511,7 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
   if (rc) return rc;
   const int ntab = (2 * win - 1) * (2 * win - 1);
   const int nwaves = wattn_bwd_blocks(nbn, nH) * WA_WAVES;
-  hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(ntab * nH), dim3(256), 0, st, (const float*)part, drel_pos,
+  hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(ntab * nH), dim3(1024), 0, st, (const float*)part, drel_pos,
                      (float*)nullptr, nwaves, ntab * nH, WA_NBIN * nH);
   return vtx_check_launch();
 }

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
   if (do_ksum && m0 + (int)threadIdx.x < p.M) p.ksum_out[(int64_t)tz * p.M + m0 + threadIdx.x] = ksum;
 
-  gemm_epilogue<T, TO, BM, BN>(p, acc, lds_raw, m0, n0, tz, wm, wn, c_, g_);
+  EpiOperands<T, BM, BN> eo;
+  eo.load(p, m0, n0, wn, c_);
+  gemm_epilogue<T, TO, BM, BN>(p, acc, lds_raw, m0, n0, tz, wm, wn, c_, g_, eo);
 }
 
 template <typename T, typename TO, int BN, bool TA, bool TB>

@@ -22,63 +22,71 @@ struct GemmArgs {
 };
 
 
-// acc[i][j][r] = C[m0 + wm*(BM/2) + 16 i + 4 g + r][n0 + wn*(BN/2) + 16 j + c]; lds_raw: >= (BM/2)*(BN+4)*4 bytes,
-// no longer read by anybody when this is called (callers barrier after their last operand read).
-//
-// The tile goes through LDS in two passes of BM/2 rows so that every lane stores 16 contiguous bytes.  ALL global
-// reads of the epilogue (bias, z for act', residual, DropPath scale) are requested up front, before the first
-// staging pass: issued inside the store loop they cannot be hoisted above the previous iteration's stores (possible
-// aliasing), and with 8 waves per CU each of the 8 iterations then exposed a full L2 / HBM latency -- measured on
-// the stage-2 fc1 forward: 81 us of a 139 us launch with the main loop AND the stores switched off.
-template <typename T, typename TO, int BM, int BN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* lds_raw,
-                                              int m0, int n0, int tz, int wm, int wn, int c_, int g_) {
-  constexpr int WM = BM / 32, WN = BN / 32;
-  constexpr int CSTR = BN + 4;                // fp32 C-staging row stride (floats)
-  TO* __restrict__ Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
-  const T* __restrict__ resid = (const T*)p.resid;
-  const T* __restrict__ aux_in = (const T*)p.aux_in;
-  T* __restrict__ aux_out = (T*)p.aux_out;
-  float* cbuf = reinterpret_cast<float*>(lds_raw);
-  constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
-  constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
-  constexpr int NIT = (NVEC + 255) / 256;            // iterations per pass
-  const bool act_fwd = p.act == 1 || p.act == 3, act_bwd = p.act == 2 || p.act == 4;
-
-  // ---------------- request every global operand of the epilogue now
-  // bias: per lane the WN columns of its accumulator tiles (added while staging); z (act') or the residual: one
-  // 16-byte vector per store iteration, both passes (they are never both present on the hot path: a residual next
-  // to act' is loaded late)
+// Global operands of the epilogue, requested ahead of it (EpiOperands::load) -- by the LDS-DMA kernel before its main
+// loop, so they land under the first k-tile's wait (vmcnt retires in order: they are older than every DMA piece).
+// Issued inside the store loop they cannot be hoisted above the previous iteration's stores (possible aliasing), and
+// with 8-12 waves per CU each iteration then exposed a full L2 / HBM latency -- measured on the stage-2 fc1 forward:
+// 81 us of a 139 us launch with the main loop AND the stores switched off.
+//   bias: per lane the WN columns of its accumulator tiles (added while staging);  z (act') or the residual: one
+//   16-byte vector per store iteration, both passes (never both on the hot path: a residual next to act' is loaded late)
+template <typename T, int BM, int BN> struct EpiOperands {
+  static constexpr int WN = BN / 32;
+  static constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
+  static constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
+  static constexpr int NIT = (NVEC + 255) / 256;            // iterations per pass
   float bcol[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 16 + c_;
-    bcol[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-  }
-  int64_t offs[2 * NIT];
-  bool ok[2 * NIT];
   float rsc[2 * NIT];
   Vec8<T> ein[2 * NIT];
-  const T* __restrict__ esrc = act_bwd ? aux_in : resid;
-#pragma unroll
-  for (int q = 0; q < 2 * NIT; ++q) {
-    const int pass = q / NIT, it = q - pass * NIT;
+
+  // (row, col) of the 8-vector this thread stores in iteration it of a pass; false when it has none
+  static __device__ __forceinline__ bool where(const GemmArgs& p, int m0, int n0, int pass, int it, int& row, int& col) {
     const int v = threadIdx.x + 256 * it;
     const int lr = v / VROW, cv = v - lr * VROW;
     const int w2 = lr / (BM / 4), rem = lr - w2 * (BM / 4);
-    const int row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
-    const int col = n0 + cv * 8;
-    ok[q] = (NVEC % 256 == 0 || v < NVEC) && row < p.M && col < p.N;
-    offs[q] = (int64_t)row * p.ldc + col;
-    ein[q] = vec8_zero<T>();
-    rsc[q] = 1.f;
-    if (ok[q]) {
-      if (esrc) ein[q] = load8<T>(esrc + offs[q]);
-      if (p.rowscale) rsc[q] = p.rowscale[row / p.rows_per_scale];
-    }
+    row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
+    col = n0 + cv * 8;
+    return (NVEC % 256 == 0 || v < NVEC) && row < p.M && col < p.N;
   }
 
-  // ---------------- two passes of BM/2 rows through LDS; acc[i][j][r] = C[.. + 4*g_ + r][.. + c_]
+  __device__ __forceinline__ void load(const GemmArgs& p, int m0, int n0, int wn, int c_) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 16 + c_;
+      bcol[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+    }
+    const bool act_bwd = p.act == 2 || p.act == 4;
+    const T* __restrict__ esrc = act_bwd ? (const T*)p.aux_in : (const T*)p.resid;
+#pragma unroll
+    for (int q = 0; q < 2 * NIT; ++q) {
+      int row, col;
+      const bool ok = where(p, m0, n0, q / NIT, q % NIT, row, col);
+      ein[q] = vec8_zero<T>();
+      rsc[q] = 1.f;
+      if (ok) {
+        if (esrc) ein[q] = load8<T>(esrc + (int64_t)row * p.ldc + col);
+        if (p.rowscale) rsc[q] = p.rowscale[row / p.rows_per_scale];
+      }
+    }
+  }
+};
+
+// acc[i][j][r] = C[m0 + wm*(BM/2) + 16 i + 4 g + r][n0 + wn*(BN/2) + 16 j + c]; lds_raw: >= (BM/2)*(BN+4)*4 bytes,
+// no longer read by anybody when this is called (callers barrier after their last operand read).
+// The tile goes through LDS in two passes of BM/2 rows so that every lane stores 16 contiguous bytes.
+template <typename T, typename TO, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* lds_raw,
+                                              int m0, int n0, int tz, int wm, int wn, int c_, int g_,
+                                              const EpiOperands<T, BM, BN>& eo) {
+  constexpr int WM = BM / 32, WN = BN / 32;
+  constexpr int CSTR = BN + 4;                // fp32 C-staging row stride (floats)
+  using EO = EpiOperands<T, BM, BN>;
+  constexpr int VROW = EO::VROW, NIT = EO::NIT;
+  TO* __restrict__ Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
+  const T* __restrict__ resid = (const T*)p.resid;
+  T* __restrict__ aux_out = (T*)p.aux_out;
+  float* cbuf = reinterpret_cast<float*>(lds_raw);
+  const bool act_fwd = p.act == 1 || p.act == 3, act_bwd = p.act == 2 || p.act == 4;
+
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -88,13 +96,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r] + bcol[j];
+          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r] + eo.bcol[j];
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int q = pass * NIT + it;
-      if (!ok[q]) continue;
+      int row, col;
+      if (!EO::where(p, m0, n0, pass, it, row, col)) continue;
+      const int64_t off = (int64_t)row * p.ldc + col;
       const int v = threadIdx.x + 256 * it;
       const int lr = v / VROW, cv = v - lr * VROW;
       const float* cp = cbuf + lr * CSTR + cv * 8;
@@ -111,22 +121,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
           for (int e = 0; e < 8; ++e) val[e] = gelu_f(z.get(e));
         }
-        if (aux_out) store8<T>(aux_out + offs[q], z);
+        if (aux_out) store8<T>(aux_out + off, z);
       } else if (act_bwd) {
         if (p.act == 2) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(ein[q].get(e));
+          for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(eo.ein[q].get(e));
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) val[e] *= dgelu_f(ein[q].get(e));
+          for (int e = 0; e < 8; ++e) val[e] *= dgelu_f(eo.ein[q].get(e));
         }
       }
-      Vec8<T> rv = ein[q];
-      if (act_bwd) rv = resid ? load8<T>(resid + offs[q]) : vec8_zero<T>();
+      Vec8<T> rv = eo.ein[q];
+      if (act_bwd) rv = resid ? load8<T>(resid + off) : vec8_zero<T>();
       Vec8<TO> o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o.set(e, val[e] * rsc[q] + rv.get(e));
-      store8<TO>(Cout + offs[q], o);
+      for (int e = 0; e < 8; ++e) o.set(e, val[e] * eo.rsc[q] + rv.get(e));
+      store8<TO>(Cout + off, o);
     }
     if (pass == 0) __syncthreads();
   }

@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
+  EpiOperands<bf16, BM, BN> eo;               // bias / residual / z / DropPath scale: requested before the first DMA
+  eo.load(p, m0, n0, wn, c_);
+
   // per-lane source pointers of this wave's DMA pieces (PR rows x ROWB bytes per instruction)
   const int lr = lane / CPR, slot = lane % CPR;
   constexpr int APW = BM / (4 * PR), BPW = BN / (4 * PR);     // pieces per wave for A / B
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
-  gemm_epilogue<bf16, bf16, BM, BN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_);
+  gemm_epilogue<bf16, bf16, BM, BN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_, eo);
 }
 
 template <int BM, int BN, int BK, int NS> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
   e.C = p.C; e.M = p.N; e.N = p.Kin; e.ldc = p.Kin;
   e.bias = nullptr; e.resid = nullptr; e.rowscale = nullptr; e.rows_per_scale = 1; e.aux_out = nullptr;
   e.aux_in = nullptr; e.act = 0;
-  gemm_epilogue<bf16, float, 128, 128>(e, acc, wg_smem, n0, k0, tz, wm, wn, c_, g_);
+  EpiOperands<bf16, 128, 128> eo;
+  eo.load(e, n0, k0, wn, c_);               // no epilogue operands here: compiles to constants
+  gemm_epilogue<bf16, float, 128, 128>(e, acc, wg_smem, n0, k0, tz, wm, wn, c_, g_, eo);
 }
 
 // Ring configuration (env VTX_WG_CFG = 642 | 324 | 323 for A/B runs): tokens per k-tile x stages

@@ -223,7 +223,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
                      gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
   int rc = vtx_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(2 * C), dim3(256), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
+  hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(2 * C), dim3(1024), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
   return vtx_check_launch();
 }
 

@@ -104,18 +104,35 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoidf_(z); }
 __device__ __forceinline__ float dsilu_f(float z) { float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
-// exact (erf) GELU of nn.GELU() and its derivative 0.5 (1 + erf(z / sqrt 2)) + z exp(-z^2 / 2) / sqrt(2 pi)
-__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+// exact (erf) GELU of nn.GELU() and its derivative 0.5 (1 + erf(z / sqrt 2)) + z exp(-z^2 / 2) / sqrt(2 pi).
+// erf by Abramowitz-Stegun 7.1.26 (absolute error <= 1.5e-7, below bf16 AND fp32-parity resolution of the products it
+// feeds): branch-free, one v_exp_f32 and one v_rcp_f32 -- libm's erff is ~3x the instructions with a divergent branch,
+// and these run once per MLP hidden element in the GEMM epilogues (50432 x 384 -> 1536 MLP: fc1 forward 213 -> 186 us, fc2 dgrad 197 -> 166 us).
+// With u = z / sqrt 2 the same exponential exp(-u^2) = exp(-z^2 / 2) serves erf and the Gaussian density.
+__device__ __forceinline__ float erf_as(float au, float e) {          // au = |u|, e = exp(-u^2)  ->  erf(|u|)
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * au);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return 1.f - poly * e;
+}
+__device__ __forceinline__ float gelu_f(float z) {
+  const float au = fabsf(z) * 0.70710678118654752f;
+  const float er = copysignf(erf_as(au, __expf(-au * au)), z);
+  return 0.5f * z * (1.f + er);
+}
 __device__ __forceinline__ float dgelu_f(float z) {
-  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+  const float au = fabsf(z) * 0.70710678118654752f;
+  const float e = __expf(-au * au);
+  const float er = copysignf(erf_as(au, e), z);
+  return 0.5f * (1.f + er) + z * 0.39894228040143268f * e;
 }
 
-// out[c] = sum_b part[b][c] for c < C (out0) and C <= c < 2C (out1, optional).  Launch with 256 threads and
-// ceil(ncols / 32) blocks: 32 columns x 8 row lanes per block, fixed summation order (deterministic).
-static __global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                        int nb, int C, int ld) {
-  __shared__ float red[8][33];
+// out[c] = sum_b part[b][c] for c < C (out0) and C <= c < 2C (out1, optional).  Launch with 1024 threads and
+// ceil(ncols / 32) blocks: 32 columns x 32 row lanes per block, fixed summation order (deterministic).
+static __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                                float* __restrict__ out1, int nb, int C, int ld) {
+  __shared__ float red[32][33];
   const int ncols = out1 ? 2 * C : C;
+  const int nrl = blockDim.x >> 5;                       // row lanes: 32 with the 1024-thread launch
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
@@ -123,21 +140,20 @@ static __global__ void colreduce_kernel(const float* __restrict__ part, float* _
     // 4 independent accumulators in a fixed interleave: the loads of 4 rows are in flight together
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = rl;
-    for (; b + 24 < nb; b += 32) {
+    for (; b + 3 * nrl < nb; b += 4 * nrl) {
       s0 += part[(int64_t)b * ld + c];
-      s1 += part[(int64_t)(b + 8) * ld + c];
-      s2 += part[(int64_t)(b + 16) * ld + c];
-      s3 += part[(int64_t)(b + 24) * ld + c];
+      s1 += part[(int64_t)(b + nrl) * ld + c];
+      s2 += part[(int64_t)(b + 2 * nrl) * ld + c];
+      s3 += part[(int64_t)(b + 3 * nrl) * ld + c];
     }
-    for (; b < nb; b += 8) s0 += part[(int64_t)b * ld + c];
+    for (; b < nb; b += nrl) s0 += part[(int64_t)b * ld + c];
     s = (s0 + s1) + (s2 + s3);
   }
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < ncols) {
     float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    for (int r = 0; r < nrl; ++r) t += red[r][cl];
     if (c < C) out0[c] = t; else out1[c - C] = t;
   }
 }
