@@ -259,6 +259,51 @@ def test_wgrad_droppath_zero_rows(dtype):
     check(f"wgrad zero-row db {dtype}", db, c * (keep * dy.double()).sum(0), 2e-5)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues_gelu(dtype):
+    """GELU / GELU' epilogues (PVT MLP, DINO head): the kernels use a branch-free erf (|err| < 1e-6); the check is
+    against the exact erf GELU of the oracle at the same tolerances as the SiLU epilogues."""
+    from vtx import ops
+    d = dev()
+    M, Cin, Cff = 197, 128, 512
+    x = _mk((M, Cin), 131, dtype)
+    w1 = _mk((Cff, Cin), 132, dtype, 0.3)
+    b1 = _mk((Cff,), 133, torch.float32, 0.5)
+    w2 = _mk((Cin, Cff), 134, dtype, 0.1)
+    res = _mk((M, Cff), 136, dtype)
+    t = TOL[dtype]
+    h, z = ops.gemm(x.to(d), w1.to(d), 0, bias=b1.to(d), act=ops.ACT_GELU, want_aux=True)
+    zq = z.cpu().double()
+    check(f"fc1 gelu {dtype}", h, 0.5 * zq * (1 + torch.erf(zq / 2 ** 0.5)), t["out"])
+    dyv = _mk((M, Cin), 137, dtype)
+    dgel = 0.5 * (1 + torch.erf(zq / 2 ** 0.5)) + zq * torch.exp(-0.5 * zq * zq) / (2 * torch.pi) ** 0.5
+    dz = ops.gemm(dyv.to(d), w2.to(d), 1, act=ops.ACT_DGELU, aux_in=z)
+    check(f"dgrad dgelu {dtype}", dz, (dyv.double() @ w2.double()) * dgel, t["out"])
+    # a residual next to act' (not on the hot path: the residual is loaded late in the epilogue)
+    dz2 = ops.gemm(dyv.to(d), w2.to(d), 1, act=ops.ACT_DGELU, aux_in=z, resid=res.to(d))
+    check(f"dgrad dgelu + resid {dtype}", dz2, res.double() + (dyv.double() @ w2.double()) * dgel, t["out"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,N,K", [(5, 49, 96, 384), (7, 3, 96, 96), (9, 50, 288, 96), (40, 49, 128, 256), (300, 49, 256, 128)])
+def test_wgrad_droppath_mask_paths(dtype, B, T, N, K):
+    """scale_const weight gradients on both kernels: register-staged (ragged N / K: rows masked in the staged
+    registers, one division per 4 rows -- T = 3 takes the per-row division) and LDS-DMA (liveness table per
+    workgroup; 300 x 49 tokens span several split-K slices and many samples per slice)."""
+    from vtx import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    dy = _mk((B * T, N), 145, dtype)
+    x = _mk((B * T, K), 146, dtype)
+    c = 1.0 / (1.0 - 0.3)
+    scale = (torch.rand(B, generator=g) >= 0.3).float() * c
+    dW, db = ops.wgrad(dy.to(d), x.to(d), rowscale=scale.to(d), rows_per_scale=T, scale_const=c)
+    keep = (scale > 0).double().repeat_interleave(T)[:, None]
+    tol = 2e-5 if dtype == torch.float32 else 1e-4
+    check(f"wgrad mask dW {dtype} {B}x{T}x{N}x{K}", dW, c * (keep * dy.double()).t() @ x.double(), tol)
+    check(f"wgrad mask db {dtype} {B}x{T}x{N}x{K}", db, c * (keep * dy.double()).sum(0), tol)
+
+
 def test_cast_weights_multi_tensor():
     """One-launch fp32 -> bf16 cast of a list of matrices, plain + transposed (csrc/cast.hip), incl. ragged sizes,
     a 4-D conv weight and a weight-normed layer (whose weight is not a leaf parameter and must be skipped)."""
