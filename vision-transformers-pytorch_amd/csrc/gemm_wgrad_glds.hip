@@ -213,15 +213,12 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(WgradArgs p) {
   gemm_epilogue<bf16, float, 128, 128>(e, acc, wg_smem, n0, k0, tz, wm, wn, c_, g_, eo);
 }
 
-// Ring configuration (env VTX_WG_CFG = 642 | 324 | 323 for A/B runs): tokens per k-tile x stages
-static int wg_cfg() {
-  static int c = -1;
-  if (c < 0) { const char* e = getenv("VTX_WG_CFG"); c = e ? atoi(e) : 642; }
-  return c;
-}
-
-// workgroups the chip keeps resident (256 CUs x LDS-limited workgroups per CU): the split-K slices are sized to it
-int wgrad_glds_resident() { return wg_cfg() == 323 ? 768 : 512; }
+// workgroups the chip keeps resident (256 CUs x 2: 64 KB ring each): the split-K slices are sized to it.
+// Ring: 64-token k-tiles x 2 stages, the whole next tile requested at the top of an iteration.  Measured against it on
+// the stage-3/4 shapes (per step): 32 tokens x 4 stages 7.48 vs 6.89 ms, 32 x 3 (3 workgroups per CU, 768 slices)
+// 7.22 ms -- twice the barriers per token cost more than the deeper prefetch returns; the next tile's requests spread
+// between the MFMA rows (with or without scheduling barriers) 5.11 vs 4.60 ms -- the pieces issued late land late.
+int wgrad_glds_resident() { return 512; }
 
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const) {
   static int on = -1;
@@ -248,10 +245,5 @@ int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, 
   a.ld_dy = ld_dy; a.ld_x = ld_x; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
   a.scale_const = scale_const; a.kchunk = kchunk;
   if (rowscale != nullptr && kchunk / rows_per_scale + 2 > WG_MAXSAMPLES) return VTX_ERR_SHAPE;
-  switch (wg_cfg()) {
-    case 642: return wgrad_glds_launch_cfg<64, 2>(a, nz, st);
-    case 323: return wgrad_glds_launch_cfg<32, 3>(a, nz, st);
-    case 324: return wgrad_glds_launch_cfg<32, 4>(a, nz, st);
-    default: return wgrad_glds_launch_cfg<64, 2>(a, nz, st);
-  }
+  return wgrad_glds_launch_cfg<64, 2>(a, nz, st);
 }
