@@ -8,31 +8,23 @@ the reference's models/layer.py (same names, constructor arguments, state_dict k
 The CNN-only helpers of the reference file (ScaledActivation, WSConv2d, StochasticDepth,
 SqueezeExcite, GlobalContext) are outside the ViT / Swin hot path and are not provided.
 """
-from collections import abc
-from itertools import repeat
-
 import torch
 from torch import nn
 
-from vtx.nn import _DropPathBase
-
 from vtx import functional as VF
-from vtx.nn import Linear
+from vtx.nn import Linear, _DropPathBase, pair
 
 
 def ensure_tuple(x, n_item):
-    if isinstance(x, abc.Iterable):
-        try:
-            if len(x) != n_item:
-                raise ValueError(f"length of {x} (length: {len(x)}) does not match the expected length {n_item}")
-        except TypeError:
-            pass
-        return x
-    return tuple(repeat(x, n_item))
+    """``x`` repeated ``n_item`` times, or ``x`` itself when it already is a sequence of that length."""
+    if isinstance(x, (str, bytes)) or not hasattr(x, "__iter__"):
+        return (x,) * n_item
+    if hasattr(x, "__len__") and len(x) != n_item:
+        raise ValueError(f"length of {x} (length: {len(x)}) does not match the expected length {n_item}")
+    return x
 
 
-def tuple2(x):
-    return ensure_tuple(x, 2)
+tuple2 = pair
 
 
 class DropPath(_DropPathBase):

@@ -17,9 +17,9 @@ from torch import nn
 
 from vtx import functional as VF
 from vtx.nn import LayerNorm as _LayerNorm
-from vtx.nn import Linear, drop_path_scale, drop_path_scope
+from vtx.nn import Linear, drop_path_scale, drop_path_scope, pair, reset_transformer_parameters, stochastic_depth_rates
 
-from .layer import DropPath, PositionwiseFeedForward, tuple2
+from .layer import DropPath, PositionwiseFeedForward
 
 LayerNorm = lambda x: _LayerNorm(x, eps=1e-6)
 
@@ -86,22 +86,15 @@ class TransformerLayer(nn.Module):
 class PatchEmbedding(nn.Module):
     def __init__(self, image_size, in_dim, dim, patch_size, cls_token=False, dropout=0):
         super().__init__()
-        size = tuple2(patch_size)
-        img_size = tuple2(image_size)
-        if size[0] != size[1]:
+        (ph, pw), (ih, iw) = pair(patch_size), pair(image_size)
+        if ph != pw:
             raise NotImplementedError("vtx: square patches only")
-        self.conv = nn.Conv2d(in_dim, dim, size, stride=size)        # parameter container; runs as gather + GEMM
+        self.dim, self.patch = dim, ph
+        self.conv = nn.Conv2d(in_dim, dim, (ph, pw), stride=(ph, pw))   # parameter container; runs as gather + GEMM
         self.norm = LayerNorm(dim)
-        height, width = img_size[0] // size[0], img_size[1] // size[1]
-        n_patch = height * width
-        if cls_token:
-            n_patch += 1
-        self.pos = nn.Parameter(torch.randn(n_patch, dim) * 0.02)
-        self.cls_token = None
-        if cls_token:
-            self.cls_token = nn.Parameter(torch.randn(dim) * 0.02)
-        self.dim = dim
-        self.patch = size[0]
+        # learned positions (N(0, 0.02)) for every patch, plus one row and a class vector in the last stage
+        self.pos = nn.Parameter(0.02 * torch.randn((ih // ph) * (iw // pw) + int(bool(cls_token)), dim))
+        self.cls_token = nn.Parameter(0.02 * torch.randn(dim)) if cls_token else None
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, input, grid=None, skip=0):
@@ -128,63 +121,42 @@ class PyramidVisionTransformer(nn.Module):
                  drop_attn=0, drop_path=0):
         super().__init__()
         self.depths = depths
+        widths = list(patch_embed_dims)
+        last = len(widths) - 1
+        # stage k: patches of 4 (then 2, 2, 2) pixels of the previous map; the class token joins in the last stage
         self.patch_embedding = nn.ModuleList()
-        patch_embed_dims = list(patch_embed_dims)
-        cls_token = False
-        patch_sizes = (4, 2, 2, 2)
-        img_size = tuple2(image_size)
-        for i, (p_in, p_out, p_size) in enumerate(zip([in_dim] + patch_embed_dims[:-1], patch_embed_dims, patch_sizes)):
-            if i == len(patch_embed_dims) - 1:
-                cls_token = True
-            self.patch_embedding.append(PatchEmbedding(img_size, p_in, p_out, p_size, cls_token=cls_token,
-                                                       dropout=drop_ff))
-            img_size = (img_size[0] // p_size, img_size[1] // p_size)
-
-        def make_block(i):
-            return self.make_block(depths[i], patch_embed_dims[i], n_heads[i], dim_ffs[i], reductions[i], drop_ff,
-                                   drop_attn)
-
-        self.block1 = make_block(0)
-        self.block2 = make_block(1)
-        self.block3 = make_block(2)
-        self.block4 = make_block(3)
-        self.norm = LayerNorm(patch_embed_dims[-1])
-        self.classifier = Linear(patch_embed_dims[-1], n_class)
+        grid = pair(image_size)
+        for k, (step, c_in, c_out) in enumerate(zip((4, 2, 2, 2), [in_dim] + widths[:-1], widths)):
+            self.patch_embedding.append(PatchEmbedding(grid, c_in, c_out, step, cls_token=k == last, dropout=drop_ff))
+            grid = (grid[0] // step, grid[1] // step)
+        for k in range(4):
+            setattr(self, f"block{k + 1}",
+                    self.make_block(depths[k], widths[k], n_heads[k], dim_ffs[k], reductions[k], drop_ff, drop_attn))
+        self.norm = LayerNorm(widths[-1])
+        self.classifier = Linear(widths[-1], n_class)
         self.apply(self.init_weights)
         self.set_drop_path(drop_path)
 
-    def set_drop_path(self, drop_path):
-        p = torch.linspace(0, drop_path, sum(self.depths)).tolist()
-        i = 0
-        for blocks in (self.block1, self.block2, self.block3, self.block4):
-            for block in blocks:
-                block.set_drop_path(p[i])
-                i += 1
+    init_weights = staticmethod(reset_transformer_parameters)
 
-    def init_weights(self, module):
-        if isinstance(module, nn.Linear):
-            nn.init.normal_(module.weight, std=0.02)
-            if module.bias is not None:
-                nn.init.zeros_(module.bias)
-        elif isinstance(module, nn.LayerNorm):
-            nn.init.ones_(module.weight)
-            nn.init.zeros_(module.bias)
+    def stages(self):
+        return (self.block1, self.block2, self.block3, self.block4)
+
+    def set_drop_path(self, drop_path):
+        layers = [layer for stage in self.stages() for layer in stage]
+        for layer, rate in zip(layers, stochastic_depth_rates(drop_path, sum(self.depths), endpoint=True)):
+            layer.set_drop_path(rate)
 
     def make_block(self, depth, dim, n_head, dim_ff, reduction, drop_ff, drop_attn):
-        block = nn.ModuleList()
-        for _ in range(depth):
-            block.append(TransformerLayer(dim, n_head, dim_ff, reduction=reduction, drop_ff=drop_ff, drop_attn=drop_attn))
-        return block
+        return nn.ModuleList(TransformerLayer(dim, n_head, dim_ff, reduction=reduction, drop_ff=drop_ff,
+                                              drop_attn=drop_attn) for _ in range(depth))
 
     def forward(self, input):
         with VF.weight_scope(self, input), drop_path_scope(self, input.shape[0], input.device):   # one cast, one mask draw
-            out, (height, width) = self.patch_embedding[0](input)
-            for block in self.block1:
-                out = block(out, height, width)
-            for embed, blocks in ((self.patch_embedding[1], self.block2), (self.patch_embedding[2], self.block3),
-                                  (self.patch_embedding[3], self.block4)):
-                out, (height, width) = embed(out, grid=(height, width))       # token-major in, no NCHW round trip
-                for block in blocks:
-                    out = block(out, height, width)
+            out, grid = input, None
+            for embed, stage in zip(self.patch_embedding, self.stages()):
+                out, grid = embed(out) if grid is None else embed(out, grid=grid)   # token-major between stages
+                for layer in stage:
+                    out = layer(out, *grid)
             out = self.norm(out[:, 0])
             return self.classifier(out)

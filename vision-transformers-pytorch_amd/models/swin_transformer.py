@@ -33,9 +33,9 @@ except Exception:  # pragma: no cover
 from vtx import functional as VF
 from vtx import tables
 from vtx.nn import LayerNorm as _LayerNorm
-from vtx.nn import Linear, drop_path_scale, drop_path_scope
+from vtx.nn import Linear, drop_path_scale, drop_path_scope, reset_transformer_parameters, stochastic_depth_rates
 
-from .layer import DropPath, PositionwiseFeedForward, tuple2
+from .layer import DropPath, PositionwiseFeedForward
 
 LayerNorm = lambda x: _LayerNorm(x, eps=1e-6)
 
@@ -43,12 +43,9 @@ LayerNorm = lambda x: _LayerNorm(x, eps=1e-6)
 def patchify(input, size):
     """(B,H,W,C) -> (B,H/size,W/size,size*size*C), flatten order (py, px, c).  Pure view/copy helper kept for
     API parity; the model itself folds this gather into the patch-embed / PatchMerge kernels."""
-    batch, height, width, dim = input.shape
-    return (
-        input.view(batch, height // size, size, width // size, size, dim)
-        .permute(0, 1, 3, 2, 4, 5)
-        .reshape(batch, height // size, width // size, -1)
-    )
+    rows, cols = input.shape[1] // size, input.shape[2] // size
+    tiles = input.unflatten(2, (cols, size)).unflatten(1, (rows, size))        # (B, rows, py, cols, px, C)
+    return tiles.transpose(2, 3).flatten(3)                                     # (B, rows, cols, py * px * C)
 
 
 class MultiHeadedLocalAttention(nn.Module):
@@ -175,7 +172,7 @@ class PatchMerge(nn.Module):
 
 
 def reduce_size(size, reduction):
-    return (size[0] // reduction, size[1] // reduction)
+    return tuple(side // reduction for side in size[:2])
 
 
 @config_model(name="swin_transformer", namespace="model", use_type=True)
@@ -196,62 +193,44 @@ class SwinTransformer(nn.Module):
     ):
         super().__init__()
         self.depths = depths
-
-        def make_block(i, in_dim, input_size, reduction):
-            return self.make_block(depths[i], in_dim, dims[i], n_heads[i], dim_head, dim_ffs[i], input_size,
-                                   window_size, reduction, drop_ff, drop_attn)
-
         self.patch_embedding = PatchEmbedding(3, dims[0], 4)
-        self.block1 = make_block(0, 3, reduce_size(image_size, 4), 1)
-        self.block2 = make_block(1, dims[0], reduce_size(image_size, 4), 2)
-        self.block3 = make_block(2, dims[1], reduce_size(image_size, 4 * 2), 2)
-        self.block4 = make_block(3, dims[2], reduce_size(image_size, 4 * 2 * 2), 2)
-
+        # stage k (block1..block4): 4x4 patches first, then a 2x2 PatchMerge in front of every later stage
+        size, width = reduce_size(image_size, 4), 3
+        for k in range(4):
+            merge = 1 if k == 0 else 2
+            setattr(self, f"block{k + 1}", self.make_block(depths[k], width, dims[k], n_heads[k], dim_head, dim_ffs[k],
+                                                           size, window_size, merge, drop_ff, drop_attn))
+            size, width = reduce_size(size, merge), dims[k]
         self.final_linear = nn.Sequential(_LayerNorm(dims[-1]))
-        linear = Linear(dims[-1], n_class)
-        nn.init.normal_(linear.weight, std=0.02)
-        nn.init.zeros_(linear.bias)
-        self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(1), linear)
-
+        self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(1), Linear(dims[-1], n_class))
         self.apply(self.init_weights)
         self.set_dropout(None, drop_path)
 
-    def set_dropout(self, dropout, drop_path):
-        n_blocks = sum(self.depths)
-        dp_rate = [drop_path * float(i) / n_blocks for i in range(n_blocks)]
-        i = 0
-        for block in (self.block1, self.block2, self.block3, self.block4):
-            for layer in block:
-                if hasattr(layer, "set_drop_path"):   # PatchMerge has none (reference: try/except)
-                    layer.set_drop_path(dp_rate[i])
-                    i += 1
+    init_weights = staticmethod(reset_transformer_parameters)
 
-    def init_weights(self, module):
-        if isinstance(module, nn.Linear):
-            nn.init.normal_(module.weight, std=0.02)
-            if module.bias is not None:
-                nn.init.zeros_(module.bias)
-        elif isinstance(module, nn.LayerNorm):
-            nn.init.ones_(module.weight)
-            nn.init.zeros_(module.bias)
+    def stages(self):
+        return (self.block1, self.block2, self.block3, self.block4)
+
+    def set_dropout(self, dropout, drop_path):
+        """Linear stochastic-depth schedule over all transformer layers (PatchMerge modules are skipped); ``dropout`` is
+        accepted and ignored like in the reference (swin_transformer.py:307-319)."""
+        layers = [m for stage in self.stages() for m in stage if hasattr(m, "set_drop_path")]
+        for layer, rate in zip(layers, stochastic_depth_rates(drop_path, sum(self.depths), endpoint=False)):
+            layer.set_drop_path(rate)
 
     def make_block(self, depth, in_dim, dim, n_head, dim_head, dim_ff, input_size, window_size, reduction, drop_ff,
                    drop_attn):
-        block = []
-        if reduction > 1:
-            block.append(PatchMerge(in_dim, dim, reduction))
-        for i in range(depth):
-            block.append(TransformerLayer(dim, n_head, dim_head, dim_ff, reduce_size(input_size, reduction),
-                                          window_size, shift=i % 2 == 0, drop_ff=drop_ff, drop_attn=drop_attn))
-        return nn.Sequential(*block)
+        grid = reduce_size(input_size, reduction)
+        head = [PatchMerge(in_dim, dim, reduction)] if reduction > 1 else []
+        return nn.Sequential(*head, *(TransformerLayer(dim, n_head, dim_head, dim_ff, grid, window_size,
+                                                       shift=k % 2 == 0, drop_ff=drop_ff, drop_attn=drop_attn)
+                                      for k in range(depth)))
 
     def forward(self, input):
         with VF.weight_scope(self, input), drop_path_scope(self, input.shape[0], input.device):   # one cast, one mask draw
             out = self.patch_embedding.forward_nchw(input)   # permute(0,2,3,1) + patchify folded into the gather
-            out = self.block1(out)
-            out = self.block2(out)
-            out = self.block3(out)
-            out = self.block4(out)
+            for stage in self.stages():
+                out = stage(out)
             norm = self.final_linear[0]
             out = VF.LayerNormFn.apply(out, norm.weight, norm.bias, norm.eps)
             out = VF.TokenMeanFn.apply(out)                   # AdaptiveAvgPool2d(1) + Flatten(1) on NHWC

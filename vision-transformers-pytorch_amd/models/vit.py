@@ -8,7 +8,6 @@ multi-resolution crops) and state_dict keys / shapes / dtypes (SURVEY.md section
   VisionTransformer      reference models/vit.py:79-203
   DINOHead / dino        reference models/vit.py:206-307
 """
-import math
 from typing import Tuple, Union
 
 import torch
@@ -28,9 +27,10 @@ except Exception:  # pragma: no cover
 
 from vtx import functional as VF
 from vtx.nn import LayerNorm as _LayerNorm
-from vtx.nn import Linear, drop_path_scale, drop_path_scope
+from vtx.nn import (Linear, drop_path_scale, drop_path_scope, pair, projection_mlp, reset_transformer_parameters,
+                    resize_position_grid, same_resolution_runs, stochastic_depth_rates)
 
-from .layer import DropPath, PositionwiseFeedForward, tuple2
+from .layer import DropPath, PositionwiseFeedForward
 
 LayerNorm = lambda x: _LayerNorm(x, eps=1e-6)
 
@@ -106,83 +106,47 @@ class VisionTransformer(nn.Module):
     def __init__(self, head, image_size, window_size, depth, dim, n_head, dim_ff, dropout, drop_attn, drop_ff,
                  drop_path):
         super().__init__()
-        image_size = tuple2(image_size)
-        n_patch = (image_size[0] // window_size) * (image_size[1] // window_size)
-
+        rows, cols = (side // window_size for side in pair(image_size))
+        self.depth = depth
         self.patch_embedding = PatchEmbedding(3, dim, window_size)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
-        self.pos_embed = nn.Parameter(torch.zeros(1, n_patch + 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, rows * cols + 1, dim))
         self.pos_drop = nn.Dropout(dropout)
-
-        drop_path_rate = torch.linspace(0, drop_path, depth).tolist()
-        self.layers = nn.ModuleList(
-            [TransformerLayer(dim, n_head, dim_ff, dropout, drop_attn, drop_ff, dpr) for dpr in drop_path_rate])
+        self.layers = nn.ModuleList(TransformerLayer(dim, n_head, dim_ff, dropout, drop_attn, drop_ff, rate)
+                                    for rate in stochastic_depth_rates(drop_path, depth, endpoint=True))
         self.norm = LayerNorm(dim)
-
         self.apply(self.init_weights)
-        nn.init.normal_(self.pos_embed, std=0.02)
-        nn.init.normal_(self.cls_token, std=0.02)
+        for table in (self.pos_embed, self.cls_token):
+            nn.init.normal_(table, std=0.02)
+        self.head = head                                     # registered last (state_dict order), not re-initialised
 
-        self.head = head
-        self.depth = depth
+    init_weights = staticmethod(reset_transformer_parameters)
 
     def set_drop_path(self, drop_path):
-        drop_path_rate = torch.linspace(0, drop_path, self.depth).tolist()
-        for layer, p in zip(self.layers, drop_path_rate):
-            layer.set_drop_path(p)
-
-    def init_weights(self, module):
-        if isinstance(module, nn.Linear):
-            nn.init.normal_(module.weight, std=0.02)
-            if module.bias is not None:
-                nn.init.zeros_(module.bias)
-        elif isinstance(module, nn.LayerNorm):
-            nn.init.ones_(module.weight)
-            nn.init.zeros_(module.bias)
+        for layer, rate in zip(self.layers, stochastic_depth_rates(drop_path, self.depth, endpoint=True)):
+            layer.set_drop_path(rate)
 
     def forward_feature(self, input):
         if self.training and self.pos_drop.p > 0:
             raise NotImplementedError("vtx: positional dropout > 0 is not supported by the fused HIP path")
-        out = self.patch_embedding(input)
-        pos_embed = self.interpolate_pos_embedding(out.shape[1], out.shape[-1], self.pos_embed)
-        out = VF.VitAssembleFn.apply(out, self.cls_token, pos_embed)
-        with drop_path_scope(self, out.shape[0], out.device):    # one mask draw per crop group
+        tokens = self.patch_embedding(input)
+        tokens = VF.VitAssembleFn.apply(tokens, self.cls_token, resize_position_grid(self.pos_embed, tokens.shape[1]))
+        with drop_path_scope(self, tokens.shape[0], tokens.device):    # one mask draw per crop group
             for layer in self.layers:
-                out = layer(out)
+                tokens = layer(tokens)
         # reference: norm(out)[:, 0]; LayerNorm is per token, so normalising only the cls rows is identical
-        return self.norm(out[:, 0])
+        return self.norm(tokens[:, 0])
 
-    def interpolate_pos_embedding(self, n_patch, dim, pos_embed):
-        """Bicubic resize of the patch position grid for non-default crop sizes (reference vit.py:153-175);
-        host-side glue on fp32 parameters (a (1, n, dim) tensor), differentiable through torch."""
-        if not isinstance(n_patch, int):   # reference call style: (input, pos_embed)
-            n_patch, dim, pos_embed = n_patch.shape[1] - 1, n_patch.shape[-1], dim
-        n_pos = pos_embed.shape[1] - 1
-        if n_patch == n_pos:
-            return pos_embed
-        cls_embed = pos_embed[:, 0]
-        grid = pos_embed[:, 1:]
-        side = int(math.sqrt(n_pos))
-        grid = F.interpolate(grid.reshape(1, side, side, dim).permute(0, 3, 1, 2),
-                             scale_factor=math.sqrt(n_patch / n_pos), mode="bicubic", align_corners=False,
-                             recompute_scale_factor=False)
-        grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
-        return torch.cat((cls_embed.unsqueeze(0), grid), 1)
+    def interpolate_pos_embedding(self, input, pos_embed):
+        """Reference call style (vit.py:153-175): ``input`` is the (batch, 1 + n_patch, dim) token tensor."""
+        return resize_position_grid(pos_embed, input.shape[1] - 1)
 
     def forward(self, input):
-        if not isinstance(input, (list, tuple)):
-            input = [input]
-        crops = torch.cumsum(
-            torch.unique_consecutive(torch.tensor([i.shape[-1] for i in input]), return_counts=True)[1], 0)
-        start = 0
-        with VF.weight_scope(self, input[0]):                # bf16: one multi-tensor cast of all weights per forward
-            for end in crops:
-                out = self.forward_feature(torch.cat(input[start:end]))
-                output = out if start == 0 else torch.cat((output, out))
-                start = end
-            if self.head is not None:
-                output = self.head(output)
-        return output
+        crops = list(input) if isinstance(input, (list, tuple)) else [input]
+        with VF.weight_scope(self, crops[0]):                # bf16: one multi-tensor cast of all weights per forward
+            feats = [self.forward_feature(torch.cat(crops[a:b])) for a, b in same_resolution_runs(crops)]
+            output = feats[0] if len(feats) == 1 else torch.cat(feats)
+            return output if self.head is None else self.head(output)
 
 
 class DINOHead(nn.Module):
@@ -191,31 +155,14 @@ class DINOHead(nn.Module):
     def __init__(self, in_dim, out_dim, use_bn=False, norm_last_layer=True, depth=3, dim_ff=2048,
                  dim_bottleneck=256):
         super().__init__()
-        if depth == 1:
-            self.mlp = Linear(in_dim, dim_bottleneck)
-        else:
-            layers = [Linear(in_dim, dim_ff)]
-            if use_bn:
-                layers.append(nn.BatchNorm1d(dim_ff))
-            layers.append(nn.GELU())
-            for _ in range(depth - 2):
-                layers.append(Linear(dim_ff, dim_ff))
-                if use_bn:
-                    layers.append(nn.BatchNorm1d(dim_ff))
-                layers.append(nn.GELU())
-            layers.append(Linear(dim_ff, dim_bottleneck))
-            self.mlp = nn.Sequential(*layers)
+        self.mlp = projection_mlp([in_dim] + [dim_ff] * (depth - 1) + [dim_bottleneck], use_bn)
         self.apply(self.init_weights)
+        # weight-normalised output layer with unit gain, trainable only when norm_last_layer is off (vit.py:238-241)
         self.last = nn.utils.weight_norm(Linear(dim_bottleneck, out_dim, bias=False))
-        self.last.weight_g.detach().fill_(1)
-        if norm_last_layer:
-            self.last.weight_g.requires_grad = False
+        self.last.weight_g.data.fill_(1)
+        self.last.weight_g.requires_grad_(not norm_last_layer)
 
-    def init_weights(self, module):
-        if isinstance(module, nn.Linear):
-            nn.init.normal_(module.weight, std=0.02)
-            if module.bias is not None:
-                nn.init.zeros_(module.bias)
+    init_weights = staticmethod(reset_transformer_parameters)     # no LayerNorm inside: Linear rule only
 
     def forward(self, input):
         linears = [self.mlp] if isinstance(self.mlp, nn.Linear) else list(self.mlp)

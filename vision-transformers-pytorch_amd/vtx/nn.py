@@ -79,3 +79,75 @@ def drop_path_scale(module_p, training, batch, device):
     keep = 1.0 - module_p
     mask = torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
     return mask / keep
+
+
+# ------------------------------------------------------------------------------- host-side pieces shared by the families
+# One implementation each of the small host-side rules the transformer families have in common (the reference spells
+# them out per model file: vit.py:108-128 / 153-203 / 215-248, swin_transformer.py:15-22 / 307-332, pvt.py:230-262).
+
+def reset_transformer_parameters(module, std=0.02):
+    """Initialisation rule of all three families, to be used with ``Module.apply``: Linear weights ~ N(0, std),
+    Linear biases 0, LayerNorm affine (1, 0); every other module keeps its torch default."""
+    if isinstance(module, nn.LayerNorm):
+        nn.init.constant_(module.weight, 1.0)
+        nn.init.constant_(module.bias, 0.0)
+    elif isinstance(module, nn.Linear):
+        module.weight.data.normal_(mean=0.0, std=std)
+        if module.bias is not None:
+            module.bias.data.zero_()
+
+
+def pair(value):
+    """``v -> (v, v)``; a 2-sequence passes through; any other length is an error."""
+    if isinstance(value, (str, bytes)) or not hasattr(value, "__iter__"):
+        return (value, value)
+    if hasattr(value, "__len__") and len(value) != 2:
+        raise ValueError(f"length of {value} (length: {len(value)}) does not match the expected length 2")
+    return value
+
+
+def stochastic_depth_rates(top, n_layer, endpoint):
+    """Per-layer drop-path probabilities rising linearly from 0: ``endpoint`` -> the last layer gets ``top`` (ViT, PVT:
+    linspace), otherwise layer i gets top * i / n (Swin)."""
+    if endpoint:
+        return torch.linspace(0, top, n_layer).tolist()
+    return [top * float(i) / n_layer for i in range(n_layer)]
+
+
+def same_resolution_runs(images):
+    """[(start, end)) index runs of consecutive entries with equal width -- DINO multi-crop batching: every run is
+    concatenated and sent through the backbone once."""
+    runs, start = [], 0
+    for i in range(1, len(images) + 1):
+        if i == len(images) or images[i].shape[-1] != images[start].shape[-1]:
+            runs.append((start, i))
+            start = i
+    return runs
+
+
+def resize_position_grid(pos_embed, n_patch):
+    """(1, 1 + n, dim) class + patch position table -> (1, 1 + n_patch, dim): the square patch grid is resampled
+    bicubically by sqrt(n_patch / n) (align_corners False, scale not recomputed), the class row is kept."""
+    n_grid = pos_embed.shape[1] - 1
+    if n_grid == n_patch:
+        return pos_embed
+    dim, side = pos_embed.shape[-1], int(n_grid ** 0.5)
+    grid = pos_embed[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2)
+    grid = nn.functional.interpolate(grid, scale_factor=(n_patch / n_grid) ** 0.5, mode="bicubic", align_corners=False,
+                                     recompute_scale_factor=False)
+    return torch.cat((pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), 1)
+
+
+def projection_mlp(widths, batch_norm):
+    """Linear(widths[0], widths[1]) [BatchNorm1d] GELU ... Linear(widths[-2], widths[-1]) as an nn.Sequential (a single
+    Linear for two widths), index layout as in the reference's DINO head so that state_dict keys agree."""
+    if len(widths) == 2:
+        return Linear(widths[0], widths[1])
+    seq = []
+    for k, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
+        seq.append(Linear(a, b))
+        if k < len(widths) - 2:
+            if batch_norm:
+                seq.append(nn.BatchNorm1d(b))
+            seq.append(nn.GELU())
+    return nn.Sequential(*seq)
