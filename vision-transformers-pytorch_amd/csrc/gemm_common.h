@@ -147,7 +147,7 @@ int gemm_glds_launch(const GemmArgs& a, hipStream_t st);
 bool gemm_glds_enabled();
 bool gemm_glds_ok(int N, int K);
 
-// LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N % 128 == 0, Kin % 128 == 0,
+// LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N and Kin multiples of 8 and >= 64,
 // rowscale values restricted to {0, scale_const}
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const);
 int wgrad_glds_resident();
