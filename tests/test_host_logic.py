@@ -206,3 +206,47 @@ def test_drop_path_scope_hands_out_one_row_per_draw():
     m.eval()
     with vnn.drop_path_scope(m, 64, torch.device("cpu")):
         assert getattr(vnn._dp, "rows", None) is None                         # eval: nothing drawn
+
+
+# ------------------------------------------------------------------ host-side rules shared by the families (vtx/nn.py)
+def test_position_grid_resize_matches_the_reference_output():
+    """vtx.nn.resize_position_grid on the golden ViT position table -> the reference's own interpolated table (G5)."""
+    from oracle.formula import check_summary, fill_state_dict
+    from vtx.nn import resize_position_grid
+    g = Golden("g5_multicrop")
+    pos = fill_state_dict({"pos_embed": torch.zeros(1, 197, 384)})["pos_embed"]
+    check_summary(resize_position_grid(pos, 36), g.rec("multicrop.pos36"), 1e-6, "pos36 (product)")
+    assert resize_position_grid(pos, 196) is pos                      # native resolution: the parameter itself
+
+
+def test_crop_runs_rates_and_pairs():
+    from vtx.nn import pair, same_resolution_runs, stochastic_depth_rates
+    crops = [torch.zeros(2, 3, s, s) for s in (224, 224, 96, 96, 96, 224)]
+    assert same_resolution_runs(crops) == [(0, 2), (2, 5), (5, 6)]
+    assert same_resolution_runs(crops[:1]) == [(0, 1)]
+    assert stochastic_depth_rates(0.3, 4, endpoint=True) == pytest.approx([0.0, 0.1, 0.2, 0.3])     # ViT / PVT
+    assert stochastic_depth_rates(0.3, 4, endpoint=False) == pytest.approx([0.0, 0.075, 0.15, 0.225])  # Swin
+    assert pair(7) == (7, 7) and pair((4, 8)) == (4, 8) and pair([3, 5]) == [3, 5]
+    with pytest.raises(ValueError):
+        pair((1, 2, 3))
+    from models.layer import ensure_tuple, tuple2
+    assert ensure_tuple(2, 3) == (2, 2, 2) and tuple2(5) == (5, 5)
+    with pytest.raises(ValueError):
+        ensure_tuple((1, 2), 3)
+
+
+@pytest.mark.parametrize("depth,use_bn", [(1, False), (2, False), (3, False), (3, True), (4, True)])
+def test_projection_mlp_layout_is_the_references(depth, use_bn):
+    """state_dict keys of the DINO head's MLP: Linear at Sequential index 0, then every (2 or 3) entries."""
+    from models.vit import DINOHead
+    h = DINOHead(32, 64, use_bn=use_bn, depth=depth, dim_ff=48, dim_bottleneck=16)
+    keys = [k for k in h.state_dict() if k.startswith("mlp") and k.endswith("weight") and "running" not in k]
+    if depth == 1:
+        assert keys == ["mlp.weight"] and tuple(h.mlp.weight.shape) == (16, 32)
+        return
+    step = 3 if use_bn else 2
+    lin = [f"mlp.{i * step}.weight" for i in range(depth)]
+    assert [k for k in keys if h.state_dict()[k].dim() == 2] == lin
+    assert tuple(h.state_dict()[lin[0]].shape) == (48, 32) and tuple(h.state_dict()[lin[-1]].shape) == (16, 48)
+    assert ("mlp.1.running_mean" in h.state_dict()) == use_bn
+    assert tuple(h.last.weight_v.shape) == (64, 16) and float(h.last.weight_g.min()) == 1.0
