@@ -349,3 +349,35 @@ def test_training_overfits_a_fixed_batch(family):
     losses = [train_step(model, crit, opt, data, clip_grad_norm=5.0).item() for _ in range(60)]
     assert losses[0] > 2.0 and all(np.isfinite(losses))
     assert report(f"{family}: loss after 60 bf16 steps on a fixed batch (start {losses[0]:.2f})", min(losses[-5:]), 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["swin", "vit", "pvt", "dino"])
+def test_no_grad_forward_is_bitwise_the_training_graph_forward(family):
+    """Under torch.no_grad() (evaluation, the DINO teacher) the layer functions skip what only a backward would read
+    (the pre-activation z of the MLP): the outputs must not change by a bit."""
+    torch.manual_seed(0)
+    if family == "swin":
+        from models import SwinTransformer
+        model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32,
+                                n_heads=(1, 2, 4, 8), dim_ffs=(128, 256, 512, 1024), window_size=7, drop_path=0.0)
+    elif family == "vit":
+        from models import VisionTransformer
+        from vtx.nn import Linear
+        model = VisionTransformer(Linear(128, 16), 224, 16, 3, 128, 2, 512, 0.0, 0.0, 0.0, 0.0)
+    elif family == "pvt":
+        from models.pvt import PyramidVisionTransformer
+        model = PyramidVisionTransformer(224, 16, 3, (1, 1, 2, 1), (64, 128, 320, 512), (1, 2, 5, 8), (256, 512, 640, 1024),
+                                         (8, 4, 2, 1), drop_path=0.0)
+    else:
+        from models.vit import dino
+        model = dino(224, 16, 2, 128, 2, 512, 0.0, 0.0, 0.0, 0.0, 1024, depth_head=3, dim_head_ff=256, dim_head_bottleneck=64)
+    model.to(dev()).eval()
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(dev())
+    for ac in (None, torch.bfloat16):
+        with torch.autocast("cuda", dtype=ac, enabled=ac is not None):
+            ref = model(x)
+            with torch.no_grad():
+                out = model(x)
+        assert ref.requires_grad and not out.requires_grad
+        assert torch.equal(ref.detach(), out), f"{family} {ac}: no-grad forward differs from the training-graph forward"

@@ -214,6 +214,14 @@ class LinearFn(Function):
         return dx, dW.view_as(weight), db
 
 
+def _act_gemm(ctx, a, w, bias, act):
+    """GEMM + fused activation; the pre-activation z is written only when a backward will read it (under
+    ``torch.no_grad()`` -- the DINO teacher, evaluation -- nothing needs gradients and that HBM write is skipped)."""
+    if any(ctx.needs_input_grad):
+        return ops.gemm(a, w, 0, bias=bias, act=act, want_aux=True)
+    return ops.gemm(a, w, 0, bias=bias, act=act), None
+
+
 class FeedForwardFn(Function):
     """PositionwiseFeedForward (reference models/layer.py:186-196): Linear -> SiLU -> Linear, SiLU fused
     into the first GEMM's epilogue, silu' into the second GEMM's dgrad epilogue."""
@@ -223,7 +231,7 @@ class FeedForwardFn(Function):
         x = _c(x)
         T = x.dtype
         ctx.wp = (wcast(w1, T), wcast(w2, T))
-        h, z = ops.gemm(x, ctx.wp[0][0], 0, bias=b1.detach(), act=ACT_SILU, want_aux=True)
+        h, z = _act_gemm(ctx, x, ctx.wp[0][0], b1.detach(), ACT_SILU)
         y = ops.gemm(h, ctx.wp[1][0], 0, bias=b2.detach())
         ctx.save_for_backward(x, w1, w2, z, h)
         return y
@@ -255,7 +263,7 @@ class MlpChainFn(Function):
         for i in range(n):
             b = None if wb[2 * i + 1] is None else wb[2 * i + 1].detach()
             if i < n - 1:
-                h, z = ops.gemm(h, wps[i][0], 0, bias=b, act=act, want_aux=True)
+                h, z = _act_gemm(ctx, h, wps[i][0], b, act)
                 hs.append(h); zs.append(z)
             else:
                 h = ops.gemm(h, wps[i][0], 0, bias=b)
@@ -372,7 +380,7 @@ class TransformerLayerFn(Function):
         o, lse, bias = _attn_forward(qkv, rel_pos, meta)
         x1 = ops.gemm(o, wo[0], 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), meta.eps)
-        h, z = ops.gemm(ln2, w1[0], 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
+        h, z = _act_gemm(ctx, ln2, w1[0], fc1_b.detach(), ACT_SILU)
         y = ops.gemm(h, w2[0], 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
                               mean2, rstd2, ln2, z, h, bias, s1, s2, rel_pos)
@@ -551,7 +559,7 @@ class PvtLayerFn(Function):
         o, lse = ops.srattn_fwd(q, kv, B, L, Lk, m.n_head)
         x1 = ops.gemm(o, wo[0], 0, bias=proj_b.detach(), resid=x, rowscale=s1, rows_per_scale=rps)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, ln2_w.detach(), ln2_b.detach(), m.eps)
-        h, z = ops.gemm(ln2, w1[0], 0, bias=fc1_b.detach(), act=ACT_SILU, want_aux=True)
+        h, z = _act_gemm(ctx, ln2, w1[0], fc1_b.detach(), ACT_SILU)
         y = ops.gemm(h, w2[0], 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, ln2_w, srn_w, mean1, rstd1, ln1, q, kv, o, lse, x1, mean2, rstd2, ln2, z, h,
                               patches, red, means, rstds, kvin if r > 1 else None, s1, s2)
