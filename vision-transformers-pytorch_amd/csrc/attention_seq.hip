@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
 
   sa_stage<LP>(im0, qb + g.hd, ld, g.L, wave, lane);
   sa_stage<LP>(im1, qb + 2 * g.hd, ld, g.L, wave, lane);
-  for (int i = threadIdx.x; i < LP; i += 256) lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] : 0.f;
+  // lse * log2 e, +inf for padded query rows: exp2(. - inf) = 0 masks them in both phases without a select
+  for (int i = threadIdx.x; i < LP; i += 256) lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] * 1.4426950408889634f : INFINITY;
+  const float sl = g.scale * 1.4426950408889634f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
       s += shfl_xor_f(s, 16);
       s += shfl_xor_f(s, 32);
       dsum[t] = s;
-      lq[t] = lse_s[qq];
+      lq[t] = lse_s[q];                             // log2 domain; +inf on padded rows (q < LP always)
       if (g_ == 0) dq_s[q] = qv[t] ? s : 0.f;       // q < LP always
     }
     f32x4 dqacc[2][4];
@@ -274,12 +276,14 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
 #pragma unroll
           for (int t = 0; t < 2; ++t) { mma16(kf, qf[t][ds], pt[t]); mma16(vf, dof[t][ds], dpt[t]); }
         }
+        // padded keys have zero K / V rows (their dS only has to stay finite): masked in the straddling tile only
+        const bool edge = kt * 16 + 16 > g.L;           // uniform
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = qv[t] && (kt * 16 + g_ * 4 + r) < g.L;
-            const float p = ok ? __expf(pt[t][r] * g.scale - lq[t]) : 0.f;
+            float p = __builtin_amdgcn_exp2f(fmaf(pt[t][r], sl, -lq[t]));
+            if (edge && (kt * 16 + g_ * 4 + r) >= g.L) p = 0.f;
             dsv[t][half][r] = p * (dpt[t][r] - dsum[t]);
           }
       }
@@ -350,8 +354,9 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = kv[t] && (q0 + r) < g.L;
-            const float p = ok ? __expf(s[t][r] * g.scale - ls[r]) : 0.f;
+            // padded query rows: ls = +inf -> p = 0; padded key columns (zero K / V fragments) only feed their own,
+            // never stored, dK / dV columns
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sl, -ls[r]));
             pp[t][half][r] = p;
             dss[t][half][r] = p * (dp[t][r] - dd[r]);
           }
