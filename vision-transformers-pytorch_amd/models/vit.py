@@ -144,7 +144,8 @@ class VisionTransformer(nn.Module):
     def forward(self, input):
         crops = list(input) if isinstance(input, (list, tuple)) else [input]
         with VF.weight_scope(self, crops[0]):                # bf16: one multi-tensor cast of all weights per forward
-            feats = [self.forward_feature(torch.cat(crops[a:b])) for a, b in same_resolution_runs(crops)]
+            feats = [self.forward_feature(crops[a] if b - a == 1 else torch.cat(crops[a:b]))   # no copy of a lone batch
+                     for a, b in same_resolution_runs(crops)]
             output = feats[0] if len(feats) == 1 else torch.cat(feats)
             return output if self.head is None else self.head(output)
 
