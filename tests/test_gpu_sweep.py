@@ -1,0 +1,187 @@
+"""-m gpu: seeded random sweep of shapes / epilogue combinations through the C ABI vs the CPU oracle.
+
+The fixed cases of test_gpu_kernels.py are the model shapes; this sweep walks the supported range around them: ragged
+row counts, widths that are only multiples of 8, every epilogue combination, window sizes 2..8 with and without shift,
+sequence lengths 1..224, split-K slices cut at arbitrary sample boundaries."""
+import random
+
+import pytest
+import torch
+
+from gpu_util import TOL, check, dev
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _mk(shape, gen, dtype, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+def _cases(seed, n):
+    rng = random.Random(seed)
+    return [rng.randrange(1 << 30) for _ in range(n)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", _cases(101, 14))
+def test_sweep_gemm_epilogues(dtype, case):
+    from vtx import ops
+    rng = random.Random(case)
+    g = torch.Generator().manual_seed(case)
+    d = dev()
+    T = rng.choice([1, 3, 49, 64, 197])
+    B = rng.randint(1, 5)
+    M = B * T
+    N = 8 * rng.randint(1, 96)
+    K = 8 * rng.randint(1, 96)
+    mode = rng.choice([0, 0, 1])
+    a = _mk((M, K), g, dtype)
+    w = _mk((N, K) if mode == 0 else (K, N), g, dtype, 0.1)
+    kw, ref = {}, a.double() @ (w.double().t() if mode == 0 else w.double())
+    if rng.random() < 0.7:
+        bias = _mk((N,), g, torch.float32, 0.3)
+        kw["bias"] = bias.to(d); ref = ref + bias.double()
+    act = rng.choice([None, "silu", "gelu", "dsilu", "dgelu"])
+    z = None
+    if act in ("dsilu", "dgelu"):
+        z = _mk((M, N), g, dtype)
+        zd = z.double()
+        if act == "dsilu":
+            s = torch.sigmoid(zd); der = s * (1 + zd * (1 - s))
+        else:
+            der = 0.5 * (1 + torch.erf(zd / 2 ** 0.5)) + zd * torch.exp(-0.5 * zd * zd) / (2 * torch.pi) ** 0.5
+        kw.update(act=ops.ACT_DSILU if act == "dsilu" else ops.ACT_DGELU, aux_in=z.to(d)); ref = ref * der
+    if rng.random() < 0.5 and act not in ("silu", "gelu"):     # DropPath scale rides on the residual GEMMs / dgrads only
+        sc = (torch.rand(B, generator=g) > 0.3).float() / 0.7
+        kw.update(rowscale=sc.to(d), rows_per_scale=T); ref = ref * sc.double().repeat_interleave(T)[:, None]
+    if rng.random() < 0.5 and act not in ("silu", "gelu"):
+        res = _mk((M, N), g, dtype)
+        kw["resid"] = res.to(d); ref = ref + res.double()
+    tag = f"sweep gemm {dtype} {M}x{N}x{K} mode{mode} {act} {sorted(k for k in kw if k not in ('act', 'aux_in'))}"
+    if act in ("silu", "gelu"):
+        h, zz = ops.gemm(a.to(d), w.to(d), mode, act=ops.ACT_SILU if act == "silu" else ops.ACT_GELU, want_aux=True, **kw)
+        check(tag + " z", zz, ref, TOL[dtype]["out"])
+        zq = zz.cpu().double()
+        check(tag + " h", h, R.silu(zq) if act == "silu" else 0.5 * zq * (1 + torch.erf(zq / 2 ** 0.5)), TOL[dtype]["out"])
+    else:
+        check(tag, ops.gemm(a.to(d), w.to(d), mode, **kw), ref, TOL[dtype]["out"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", _cases(202, 12))
+def test_sweep_wgrad(dtype, case):
+    from vtx import ops
+    rng = random.Random(case)
+    g = torch.Generator().manual_seed(case)
+    d = dev()
+    T = rng.choice([1, 5, 49, 196, 197])
+    B = rng.randint(1, 40)
+    N, K = 8 * rng.randint(1, 64), 8 * rng.randint(1, 64)
+    dy, x = _mk((B * T, N), g, dtype), _mk((B * T, K), g, dtype)
+    kind = rng.choice(["none", "const", "free"])
+    kw, rowf = {}, torch.ones(B * T, 1, dtype=torch.float64)
+    if kind == "const":
+        c = 1 / (1 - 0.25)
+        sc = (torch.rand(B, generator=g) > 0.25).float() * c
+        kw = dict(rowscale=sc.to(d), rows_per_scale=T, scale_const=c)
+        rowf = sc.double().repeat_interleave(T)[:, None]
+    elif kind == "free":
+        sc = torch.rand(B, generator=g) * 2
+        kw = dict(rowscale=sc.to(d), rows_per_scale=T)
+    want_bias = rng.random() < 0.7
+    dW, db = ops.wgrad(dy.to(d), x.to(d), want_bias=want_bias, **kw)
+    sd = dy.double() * rowf if kind != "free" else (sc.double().repeat_interleave(T)[:, None] * dy.double()).to(dtype).double()
+    tol = 2e-5 if dtype == torch.float32 else (3e-3 if kind == "free" else 1e-4)
+    check(f"sweep wgrad {dtype} {B}x{T} {N}x{K} {kind}", dW, sd.t() @ x.double(), tol)
+    if want_bias:
+        check(f"sweep wgrad bias {dtype} {B}x{T} {N} {kind}", db, sd.sum(0), tol)
+    else:
+        assert db is None
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", _cases(303, 10))
+def test_sweep_layernorm(dtype, case):
+    from vtx import ops
+    rng = random.Random(case)
+    g = torch.Generator().manual_seed(case)
+    d = dev()
+    rows, C = rng.randint(1, 3000), 8 * rng.randint(2, 192)
+    x = _mk((rows, C), g, dtype, 2.0) + 0.3
+    dy, dres = _mk((rows, C), g, dtype), _mk((rows, C), g, dtype)
+    gm, bt = 1 + 0.1 * _mk((C,), g, torch.float32), 0.1 * _mk((C,), g, torch.float32)
+    eps = rng.choice([1e-5, 1e-6])
+    y, mean, rstd = ops.layernorm_fwd(x.to(d), gm.to(d), bt.to(d), eps)
+    use_res = rng.random() < 0.5
+    dx, dg, db = ops.layernorm_bwd(dy.to(d), x.to(d), mean, rstd, gm.to(d), dres=dres.to(d) if use_res else None)
+    xr, gr, br = x.double().requires_grad_(True), gm.double().requires_grad_(True), bt.double().requires_grad_(True)
+    yr = R.layer_norm(xr, gr, br, eps)
+    dxr, dgr, dbr = torch.autograd.grad(yr, [xr, gr, br], dy.double())
+    t = TOL[dtype]
+    check(f"sweep ln fwd {dtype} {rows}x{C}", y, yr, t["out"])
+    check(f"sweep ln dx {dtype} {rows}x{C}", dx, dxr + (dres.double() if use_res else 0), t["out"])
+    check(f"sweep ln dgamma {dtype} {rows}x{C}", dg, dgr, 1e-5 if dtype == torch.float32 else 3e-4)
+    check(f"sweep ln dbeta {dtype} {rows}x{C}", db, dbr, 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", _cases(404, 10))
+def test_sweep_global_attention(dtype, case):
+    from vtx import ops
+    rng = random.Random(case)
+    g = torch.Generator().manual_seed(case)
+    d = dev()
+    B, L, nH, D = rng.randint(1, 5), rng.choice([1, 2, 15, 16, 17, 37, 63, 64, 65, 128, 129, 197, 223, 224]), rng.randint(1, 6), 64
+    qkv, do = _mk((B, L, 3 * nH * D), g, dtype), _mk((B, L, nH * D), g, dtype)
+    if rng.random() < 0.3:
+        qkv = qkv * 4                                  # sharp softmax rows
+    o, lse = ops.attention_fwd(qkv.to(d), B, L, nH, D)
+    dqkv, _ = ops.attention_bwd(qkv.to(d), o, do.to(d), lse, B, L, nH, D)
+    qr = qkv.double().requires_grad_(True)
+    orf = R.global_attention_core(qr, nH)
+    (dqr,) = torch.autograd.grad(orf, [qr], do.double())
+    check(f"sweep attn fwd {dtype} B{B} L{L} h{nH}", o, orf, TOL[dtype]["out"] * 1.5)
+    check(f"sweep attn dqkv {dtype} B{B} L{L} h{nH}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1.2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", _cases(505, 10))
+def test_sweep_window_attention(dtype, case):
+    from oracle import tables
+    from vtx import ops
+    from vtx.tables import mask_regions
+    rng = random.Random(case)
+    g = torch.Generator().manual_seed(case)
+    d = dev()
+    win = rng.randint(2, 8)
+    H, W = win * rng.randint(1, 4), win * rng.randint(1, 4)
+    B, nH, D, shift = rng.randint(1, 4), rng.randint(1, 7), 32, rng.random() < 0.6
+    L, ntab = win * win, (2 * win - 1) ** 2
+    qkv, do = _mk((B, H, W, 3 * nH * D), g, dtype), _mk((B, H, W, nH * D), g, dtype)
+    rel = _mk((ntab, nH), g, torch.float32, 0.5)
+    pos_np, mask_np = tables.make_pos_mask((H, W), win, shift)
+    pos = torch.from_numpy(pos_np).to(d)
+    mask = torch.from_numpy(mask_np).to(d) if shift else None
+    swin = (H, W, win, shift)
+    if ops.wattn_supported(D, win):                    # one-wave-per-window kernels (window <= 7), as the module dispatches
+        region = None
+        if shift:
+            region, ok = mask_regions(mask)
+            assert ok
+        o, lse = ops.wattn_fwd(qkv.to(d), rel.to(d), pos, region, B, L, nH, swin)
+        dqkv, drel = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, rel.to(d), pos, region, B, L, nH, swin, ntab)
+    else:                                              # window 8: generic masked kernels
+        csr = tuple(t.to(d) for t in ops.pos_csr(torch.from_numpy(pos_np), ntab))
+        bias = ops.relpos_bias(rel.to(d), pos, nH)
+        o, lse = ops.attention_fwd(qkv.to(d), B, L, nH, D, swin=swin, bias=bias, mask=mask)
+        dqkv, drel = ops.attention_bwd(qkv.to(d), o, do.to(d), lse, B, L, nH, D, swin=swin, bias=bias, mask=mask, csr=csr,
+                                       ntab=ntab)
+    qr, rr = qkv.double().requires_grad_(True), rel.double().requires_grad_(True)
+    orf = R.window_attention_core(qr, rr, nH, D, win, shift)
+    dqr, drr = torch.autograd.grad(orf, [qr, rr], do.double())
+    tag = f"{dtype} {H}x{W} w{win} h{nH} s{int(shift)} B{B}"
+    check(f"sweep wattn fwd {tag}", o, orf, TOL[dtype]["out"] * 1.5)
+    check(f"sweep wattn dqkv {tag}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+    check(f"sweep wattn drel_pos {tag}", drel, drr, 2e-5 if dtype == torch.float32 else 1e-2)

@@ -61,11 +61,10 @@ def mask_regions(local_mask):
     """
     keep = ~local_mask.bool()
     nW, L, _ = keep.shape
-    if L > 63:
+    if L > 64:
         return None, False
     region = keep.to(torch.uint8).argmax(-1)                         # first attended key of every query
     ok = bool(torch.equal(region[:, :, None] == region[:, None, :], keep))
     out = torch.zeros((nW, 64), dtype=torch.uint8, device=local_mask.device)
     out[:, :L] = region.to(torch.uint8)
-    out[:, 63] = local_mask.bool().flatten(1).any(1).to(torch.uint8)   # "this window has masked pairs" (L <= 49 < 64)
     return out.contiguous(), ok
