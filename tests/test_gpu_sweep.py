@@ -208,3 +208,69 @@ def test_sweep_sr_attention(dtype, case):
     check(f"sweep srattn fwd {tag}", o, orf, TOL[dtype]["out"] * 1.5)
     check(f"sweep srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"sweep srattn dkv {tag}", dkv, dkvr, 2e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+# ------------------------------------------------------------------ whole modules on random small configurations (fp32)
+def _model_vs_oracle_fp32(model, oracle_fwd, x, what):
+    """fp32 parity mode of the drop-in module vs the fp32 CPU oracle on the same seeded weights: logits and the
+    relative L2 of ALL parameter gradients taken together."""
+    from test_gpu_models import _seeded_init
+    sd = _seeded_init(model, 5)
+    model.to(dev()).train()
+    out = model(x.to(dev()))
+    P = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    ref = oracle_fwd(P, x.double())
+    check(f"{what} logits vs oracle", out, ref, 2e-4)
+    cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(7))
+    (out * cot.to(dev())).sum().backward()
+    names = [n for n, _ in model.named_parameters()]
+    rg = torch.autograd.grad((ref * cot.double()).sum(), [P[n] for n in names])
+    num = den = 0.0
+    for n, r in zip(names, rg):
+        gp = dict(model.named_parameters())[n].grad.double().cpu()
+        num += (gp - r).norm().item() ** 2
+        den += r.norm().item() ** 2
+    from gpu_util import report
+    assert report(f"{what} all-parameter gradient rel-L2 vs oracle", (num / den) ** 0.5, 5e-4)
+
+
+@pytest.mark.parametrize("case", _cases(707, 5))
+def test_sweep_swin_configurations(case):
+    from models import SwinTransformer
+    from oracle import ref_models as M
+    rng = random.Random(case)
+    win = rng.choice([2, 4, 7])
+    # every stage's grid (H/4 ... H/32) must split into windows: sides are multiples of 32 * win
+    ka, kb = rng.randint(1, 2), rng.randint(1, 2)
+    if 32 * win * ka * 32 * win * kb > 224 * 448:
+        kb = 1
+    size = (32 * win * ka, 32 * win * kb)
+    heads = tuple(rng.randint(1, 3) for _ in range(4))
+    cfg = dict(image_size=size, n_class=8 * rng.randint(1, 4), depths=tuple(rng.randint(1, 2) for _ in range(4)),
+               dims=tuple(32 * h for h in heads), dim_head=32, n_heads=heads, dim_ffs=tuple(8 * rng.randint(4, 16) for _ in range(4)),
+               window_size=win)
+    torch.manual_seed(case)
+    model = SwinTransformer(**cfg, drop_path=0.0)
+    x = torch.randn(rng.randint(1, 3), 3, *size, generator=torch.Generator().manual_seed(case))
+    _model_vs_oracle_fp32(model, lambda P, xx: M.swin_forward(P, xx, cfg), x, f"sweep swin {size} w{win} h{heads} d{cfg['depths']}")
+
+
+@pytest.mark.parametrize("case", _cases(808, 4))
+def test_sweep_vit_configurations(case):
+    from models import VisionTransformer
+    from oracle import ref_models as M
+    from vtx.nn import Linear
+    rng = random.Random(case)
+    patch = rng.choice([8, 16, 32])
+    side = patch * rng.randint(2, min(14, 224 // patch))
+    n_head = rng.randint(1, 4)
+    cfg = dict(image_size=side, window_size=patch, depth=rng.randint(1, 3), dim=64 * n_head, n_head=n_head, dim_ff=8 * rng.randint(8, 48))
+    n_class = 8 * rng.randint(1, 8)
+    torch.manual_seed(case)
+    model = VisionTransformer(Linear(cfg["dim"], n_class), side, patch, cfg["depth"], cfg["dim"], n_head, cfg["dim_ff"], 0.0, 0.0, 0.0, 0.0)
+    x = torch.randn(rng.randint(1, 4), 3, side, side, generator=torch.Generator().manual_seed(case))
+
+    def oracle(P, xx):
+        feat = M.vit_forward(P, xx, cfg)
+        return feat @ P["head.weight"].t() + P["head.bias"]
+    _model_vs_oracle_fp32(model, oracle, x, f"sweep vit {side}/{patch} h{n_head} depth{cfg['depth']}")
