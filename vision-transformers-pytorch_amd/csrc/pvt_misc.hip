@@ -59,26 +59,38 @@ __global__ void add_pos_fwd_kernel(const T* __restrict__ x, const float* __restr
   store8<T>(out + bt * C + v * 8, o);
 }
 
-// dx[b, t] = dout[b, s + t]; dpos[t'] = sum_b dout[b, t'] (fixed order over b); dcls = sum_b dout[b, 0]
+// dx[b, t] = dout[b, s + t]; dpos[t'] = sum_b dout[b, t'] (fixed order over b); dcls = sum_b dout[b, 0].
+// 16 column vectors x 16 batch lanes per workgroup, partial sums added in lane order through LDS (misc.hip has the twin).
 template <typename T>
-__global__ void add_pos_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, float* __restrict__ dcls,
-                                   float* __restrict__ dpos, int B, int T_, int C, int s) {
+__global__ __launch_bounds__(256) void add_pos_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx,
+                                                         float* __restrict__ dcls, float* __restrict__ dpos, int B, int T_,
+                                                         int C, int s) {
+  __shared__ float red[16][16][9];
   const int cv = C >> 3;
   const int L = T_ + s;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= L * cv) return;
-  const int t = idx / cv, v = idx - t * cv;
+  const int vl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + vl;
+  const bool live = idx < L * cv;
+  const int t = live ? idx / cv : 0, v = live ? idx - t * cv : 0;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < B; ++b) {
-    Vec8<T> a = load8<T>(dout + ((int64_t)b * L + t) * C + v * 8);
+  if (live)
+    for (int b = bl; b < B; b += 16) {
+      Vec8<T> a = load8<T>(dout + ((int64_t)b * L + t) * C + v * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += a.get(e);
-    if (t >= s) store8<T>(dx + ((int64_t)b * T_ + (t - s)) * C + v * 8, a);
-  }
+      for (int e = 0; e < 8; ++e) acc[e] += a.get(e);
+      if (t >= s) store8<T>(dx + ((int64_t)b * T_ + (t - s)) * C + v * 8, a);
+    }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    dpos[(int64_t)t * C + v * 8 + e] = acc[e];
-    if (s && t == 0) dcls[v * 8 + e] = acc[e];
+  for (int e = 0; e < 8; ++e) red[bl][vl][e] = acc[e];
+  __syncthreads();
+  if (bl == 0 && live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float sum = 0.f;
+      for (int j = 0; j < 16; ++j) sum += red[j][vl][e];
+      dpos[(int64_t)t * C + v * 8 + e] = sum;
+      if (s && t == 0) dcls[v * 8 + e] = sum;
+    }
   }
 }
 
@@ -140,12 +152,12 @@ int vtx_add_pos_bwd(const void* dout, void* dx, float* dcls, float* dpos, int B,
   if (C & 7) return VTX_ERR_ALIGN;
   const int s = dcls ? 1 : 0;
   const int n = (T + s) * (C >> 3);
-  dim3 grid((n + 63) / 64);
+  dim3 grid((n + 15) / 16);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VTX_BF16)
-    hipLaunchKernelGGL((add_pos_bwd_kernel<bf16>), grid, dim3(64), 0, st, (const bf16*)dout, (bf16*)dx, dcls, dpos, B, T, C, s);
+    hipLaunchKernelGGL((add_pos_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, dcls, dpos, B, T, C, s);
   else if (dtype == VTX_F32)
-    hipLaunchKernelGGL((add_pos_bwd_kernel<float>), grid, dim3(64), 0, st, (const float*)dout, (float*)dx, dcls, dpos, B, T, C, s);
+    hipLaunchKernelGGL((add_pos_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, dcls, dpos, B, T, C, s);
   else return VTX_ERR_DTYPE;
   return vtx_check_launch();
 }
