@@ -18,6 +18,7 @@ case "$1" in
     timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_bench.log
     timeout 300 python tools/bench_input.py 2>&1 | grep -v amdgpu.ids > gpurun_out/input_bench.log
     timeout 120 python tools/probe/hbm_floor.py 2>&1 | grep MB > gpurun_out/hbm_floor.log
+    [ -x tools/probe/store_pattern.bin ] || hipcc --offload-arch=gfx950 -O3 -o tools/probe/store_pattern.bin tools/probe/store_pattern.hip > /dev/null 2>&1
     timeout 120 tools/probe/store_pattern.bin > gpurun_out/store_pattern.log 2>&1 ;;
   bench)
     timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | grep '"metric"' > gpurun_out/bench_swin_s.log
