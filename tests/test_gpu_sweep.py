@@ -101,6 +101,22 @@ def test_sweep_wgrad(dtype, case):
         assert db is None
 
 
+def test_wgrad_droppath_many_samples_per_slice():
+    """One-token sequences: a split-K slice spans more samples than the LDS-DMA kernel's liveness table holds -> the
+    register-staged kernel takes over (same results)."""
+    from vtx import ops
+    d = dev()
+    g = torch.Generator().manual_seed(9)
+    B, T, N, K = 20000, 1, 128, 128
+    dy, x = _mk((B * T, N), g, torch.bfloat16), _mk((B * T, K), g, torch.bfloat16)
+    c = 1 / 0.8
+    sc = (torch.rand(B, generator=g) > 0.2).float() * c
+    dW, db = ops.wgrad(dy.to(d), x.to(d), rowscale=sc.to(d), rows_per_scale=T, scale_const=c)
+    keep = (sc > 0).double()[:, None]
+    check("wgrad mask, 20000 one-token samples", dW, c * (keep * dy.double()).t() @ x.double(), 1e-4)
+    check("wgrad mask bias, 20000 one-token samples", db, c * (keep * dy.double()).sum(0), 1e-4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", _cases(303, 10))
 def test_sweep_layernorm(dtype, case):

@@ -329,7 +329,9 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   a.ksum_out = dbias ? (nz == 1 ? dbias : bias_part) : nullptr;
   int rc = gemm_validate(a, 2);
   if (rc) return rc;
-  if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const))
+  // (the LDS-DMA kernel keeps the DropPath liveness of a slice's samples in a 512-entry table: slices spanning more
+  //  samples -- sequences of one or two tokens -- take the register-staged kernel)
+  if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const) && (rowscale == nullptr || a.kchunk / a.k_per_scale + 2 <= 512))
     rc = wgrad_glds_launch(dy, x, (float*)a.C, a.ksum_out, mtok, N, Kin, ld_dy, ld_x, rowscale, a.k_per_scale,
                            scale_const, nz, a.kchunk, st);
   else if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
