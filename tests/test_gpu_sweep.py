@@ -290,3 +290,13 @@ def test_sweep_vit_configurations(case):
         feat = M.vit_forward(P, xx, cfg)
         return feat @ P["head.weight"].t() + P["head.bias"]
     _model_vs_oracle_fp32(model, oracle, x, f"sweep vit {side}/{patch} h{n_head} depth{cfg['depth']}")
+
+
+def test_empty_batch_is_refused_loudly():
+    """A batch of zero images is not a supported input: the first op says so (VtxError), nothing is launched on NULL."""
+    from models import VisionTransformer
+    from vtx._lib import VtxError
+    from vtx.nn import Linear
+    model = VisionTransformer(Linear(128, 16), 64, 16, 2, 128, 2, 256, 0.0, 0.0, 0.0, 0.0).to(dev()).train()
+    with pytest.raises(VtxError, match="empty tensor"):
+        model(torch.zeros(0, 3, 64, 64, device=dev()))

@@ -30,6 +30,8 @@ def _dev(*ts):
                            "move the module / inputs to 'cuda'")
         if not t.is_contiguous():
             raise VtxError("vtx: tensor must be contiguous")
+        if t.numel() == 0:
+            raise VtxError("vtx: empty tensor (batch of zero samples?) -- the HIP kernels take at least one row")
 
 
 def _p(t):
