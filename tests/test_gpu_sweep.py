@@ -300,3 +300,29 @@ def test_empty_batch_is_refused_loudly():
     model = VisionTransformer(Linear(128, 16), 64, 16, 2, 128, 2, 256, 0.0, 0.0, 0.0, 0.0).to(dev()).train()
     with pytest.raises(VtxError, match="empty tensor"):
         model(torch.zeros(0, 3, 64, 64, device=dev()))
+
+
+def test_tensors_beyond_2g_elements():
+    """64-bit addressing: 6 M rows x 384 bf16 (2.3 G elements, 4.6 GB) through LayerNorm, the LDS-DMA GEMM (output rows
+    past element 2^31) and the split-K weight gradient (contraction over all 6 M rows)."""
+    from vtx import ops
+    d = dev()
+    rows, C = 6_000_000, 384
+    gen = torch.Generator(device=d).manual_seed(3)
+    x = torch.randn(rows, C, device=d, dtype=torch.bfloat16, generator=gen)
+    g, b = torch.ones(C, device=d), torch.zeros(C, device=d)
+    y, _, _ = ops.layernorm_fwd(x, g, b, 1e-6)
+    for r in (0, 3_000_000, rows - 1):
+        ref = torch.nn.functional.layer_norm(x[r].float(), (C,), eps=1e-6)
+        check(f"big LN row {r}", y[r], ref, 4e-3)
+    del y
+    w = (torch.randn(C, 64, device=d, generator=gen) * 0.1).bfloat16()
+    a = torch.randn(rows, 64, device=d, dtype=torch.bfloat16, generator=gen)
+    c = ops.gemm(a, w, 0)
+    for r in (0, 2_999_999, 5_592_406, rows - 1):                     # 5 592 406 * 384 > 2^31
+        check(f"big GEMM row {r}", c[r], a[r].float() @ w.float().t(), 4e-3)
+    dW, _ = ops.wgrad(c, a)
+    ref = torch.zeros(C, 64, device=d, dtype=torch.float64)
+    for i in range(0, rows, 500_000):
+        ref += (c[i:i + 500_000].float().t() @ a[i:i + 500_000].float()).double()
+    check("big wgrad", dW, ref, 1e-5)
