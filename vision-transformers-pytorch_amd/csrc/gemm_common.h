@@ -29,29 +29,31 @@ struct GemmArgs {
 // 81 us of a 139 us launch with the main loop AND the stores switched off.
 //   bias: per lane the WN columns of its accumulator tiles (added while staging);  z (act') or the residual: one
 //   16-byte vector per store iteration, both passes (never both on the hot path: a residual next to act' is loaded late)
-template <typename T, int BM, int BN> struct EpiOperands {
-  static constexpr int WN = BN / 32;
+// NWN = waves along N (2: 2 x 2 waves, 4: 2 x 4 waves); the workgroup has 128 * NWN threads
+template <typename T, int BM, int BN, int NWN = 2> struct EpiOperands {
+  static constexpr int NT = 128 * NWN;
+  static constexpr int WN = BN / (16 * NWN);
   static constexpr int VROW = BN / 8;                       // 8-element vectors per staged row
   static constexpr int NVEC = (BM / 2) * VROW;              // vectors per pass
-  static constexpr int NIT = (NVEC + 255) / 256;            // iterations per pass
+  static constexpr int NIT = (NVEC + NT - 1) / NT;          // iterations per pass
   float bcol[WN];
   float rsc[2 * NIT];
   Vec8<T> ein[2 * NIT];
 
   // (row, col) of the 8-vector this thread stores in iteration it of a pass; false when it has none
   static __device__ __forceinline__ bool where(const GemmArgs& p, int m0, int n0, int pass, int it, int& row, int& col) {
-    const int v = threadIdx.x + 256 * it;
+    const int v = threadIdx.x + NT * it;
     const int lr = v / VROW, cv = v - lr * VROW;
     const int w2 = lr / (BM / 4), rem = lr - w2 * (BM / 4);
     row = m0 + w2 * (BM / 2) + pass * (BM / 4) + rem;
     col = n0 + cv * 8;
-    return (NVEC % 256 == 0 || v < NVEC) && row < p.M && col < p.N;
+    return (NVEC % NT == 0 || v < NVEC) && row < p.M && col < p.N;
   }
 
   __device__ __forceinline__ void load(const GemmArgs& p, int m0, int n0, int wn, int c_) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 16 + c_;
+      const int col = n0 + wn * (BN / NWN) + j * 16 + c_;
       bcol[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
     }
     const bool act_bwd = p.act == 2 || p.act == 4;
@@ -73,13 +75,14 @@ template <typename T, int BM, int BN> struct EpiOperands {
 // acc[i][j][r] = C[m0 + wm*(BM/2) + 16 i + 4 g + r][n0 + wn*(BN/2) + 16 j + c]; lds_raw: >= (BM/2)*(BN+4)*4 bytes,
 // no longer read by anybody when this is called (callers barrier after their last operand read).
 // The tile goes through LDS in two passes of BM/2 rows so that every lane stores 16 contiguous bytes.
-template <typename T, typename TO, int BM, int BN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* lds_raw,
+template <typename T, typename TO, int BM, int BN, int NWN = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM / 32][BN / (16 * NWN)], unsigned char* lds_raw,
                                               int m0, int n0, int tz, int wm, int wn, int c_, int g_,
-                                              const EpiOperands<T, BM, BN>& eo) {
-  constexpr int WM = BM / 32, WN = BN / 32;
+                                              const EpiOperands<T, BM, BN, NWN>& eo) {
+  constexpr int WM = BM / 32, WN = BN / (16 * NWN);
+  constexpr int NT = 128 * NWN;
   constexpr int CSTR = BN + 4;                // fp32 C-staging row stride (floats)
-  using EO = EpiOperands<T, BM, BN>;
+  using EO = EpiOperands<T, BM, BN, NWN>;
   constexpr int VROW = EO::VROW, NIT = EO::NIT;
   TO* __restrict__ Cout = (TO*)p.C + (int64_t)tz * p.M * p.ldc;
   const T* __restrict__ resid = (const T*)p.resid;
@@ -96,7 +99,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / 2) + j * 16 + c_] = acc[i][j][r] + eo.bcol[j];
+          cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / NWN) + j * 16 + c_] = acc[i][j][r] + eo.bcol[j];
     }
     __syncthreads();
 #pragma unroll
@@ -105,7 +108,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       int row, col;
       if (!EO::where(p, m0, n0, pass, it, row, col)) continue;
       const int64_t off = (int64_t)row * p.ldc + col;
-      const int v = threadIdx.x + 256 * it;
+      const int v = threadIdx.x + NT * it;
       const int lr = v / VROW, cv = v - lr * VROW;
       const float* cp = cbuf + lr * CSTR + cv * 8;
       f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);

@@ -27,20 +27,23 @@ template <int BK> __device__ __forceinline__ int glds_swz(int r) {
 // NS-stage LDS ring: the DMA of k-tile kt+NS-1 is issued while tile kt is multiplied; a counted
 // s_waitcnt vmcnt(N) + raw s_barrier (never __syncthreads, which would drain the DMA queue) lets NS-2
 // tiles stay in flight across the barrier.
-template <int BM, int BN, int BK, int NS>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
+// NWN waves along N: 2 (2 x 2 waves, 256 threads) or 4 (2 x 4 waves of BM/2 x BN/4, 512 threads: half the DMA requests and
+// MFMAs per wave and k-tile, twice the waves per SIMD to interleave them; 64 x 128 x 64 tiles only).
+template <int BM, int BN, int BK, int NS, int NWN = 2>
+__global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
   constexpr int ROWB = BK * 2;                           // bytes per LDS row
   constexpr int CPR = BK / 8;                            // 16-byte chunks per row
   constexpr int PR = 1024 / ROWB;                        // rows per DMA instruction (1 KB per wave-instruction)
   constexpr int KS = BK / 32;                            // mma16 k-steps per tile
-  constexpr int WM = BM / 32, WN = BN / 32;
+  constexpr int NWV = 2 * NWN;                           // waves
+  constexpr int WM = BM / 32, WN = BN / (16 * NWN);      // 16 x 16 tiles per wave along M / N
   constexpr int STAGE = (BM + BN) * ROWB;                // bytes per pipeline stage
   static_assert(NS * STAGE >= (BM / 2) * (BN + 4) * 4, "C staging must fit");
   extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];   // [NS][STAGE]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int c_ = lane & 15, g_ = lane >> 4;
 
   const int ntn = gridDim.x, ntm = gridDim.y;
@@ -55,31 +58,32 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
-  EpiOperands<bf16, BM, BN> eo;               // bias / residual / z / DropPath scale: requested before the first DMA
+  EpiOperands<bf16, BM, BN, NWN> eo;               // bias / residual / z / DropPath scale: requested before the first DMA
   eo.load(p, m0, n0, wn, c_);
 
   // per-lane source pointers of this wave's DMA pieces (PR rows x ROWB bytes per instruction)
   const int lr = lane / CPR, slot = lane % CPR;
-  constexpr int APW = BM / (4 * PR), BPW = BN / (4 * PR);     // pieces per wave for A / B
+  constexpr int APW = BM / (NWV * PR), BPW = BN / (NWV * PR);   // pieces per wave for A / B
+  static_assert(APW * NWV * PR == BM && BPW * NWV * PR == BN, "whole DMA pieces per wave");
   constexpr int LPT = APW + BPW;                               // DMA instructions per wave per k-tile
   const bf16* asrc[APW];
   const bf16* bsrc[BPW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
-    const int r = wave * (BM / 4) + j * PR + lr;
+    const int r = wave * (BM / NWV) + j * PR + lr;
     const int row = min(m0 + r, p.M - 1);                // rows past M are never stored: any valid address will do
     asrc[j] = A + (int64_t)row * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
-    const int r = wave * (BN / 4) + j * PR + lr;
+    const int r = wave * (BN / NWV) + j * PR + lr;
     const int row = min(n0 + r, p.N - 1);
     bsrc[j] = B + (int64_t)row * p.ldb + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 
   auto issue = [&](int kt, int buf) {
-    unsigned char* sa = glds_smem + buf * STAGE + wave * (BM / 4) * ROWB;
-    unsigned char* sb = glds_smem + buf * STAGE + BM * ROWB + wave * (BN / 4) * ROWB;
+    unsigned char* sa = glds_smem + buf * STAGE + wave * (BM / NWV) * ROWB;
+    unsigned char* sb = glds_smem + buf * STAGE + BM * ROWB + wave * (BN / NWV) * ROWB;
 #pragma unroll
     for (int j = 0; j < APW; ++j)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + kt * BK), (lds_void_t*)(sa + j * PR * ROWB), 16, 0, 0);
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int r = wn * (BN / 2) + j * 16 + c_;
+        const int r = wn * (BN / NWN) + j * 16 + c_;
         fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ glds_swz<BK>(r)) << 4)));
       }
 #pragma unroll
@@ -133,17 +137,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
-  gemm_epilogue<bf16, bf16, BM, BN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_, eo);
+  gemm_epilogue<bf16, bf16, BM, BN, NWN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_, eo);
 }
 
-template <int BM, int BN, int BK, int NS> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int BK, int NS, int NWN = 2> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {
   constexpr size_t smem = (size_t)NS * (BM + BN) * BK * 2;
-  auto kern = gemm_glds_kernel<BM, BN, BK, NS>;
+  auto kern = gemm_glds_kernel<BM, BN, BK, NS, NWN>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(128 * NWN), smem, st, a);
   return vtx_check_launch();
 }
 
@@ -158,6 +162,13 @@ template <int BM, int BN, int BK, int NS> static int glds_launch_cfg(const GemmA
 template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_t st) {
   if constexpr (BN == 128) {
     if (a.K % 64 != 0) return glds_launch_cfg<BM, BN, 32, 3>(a, st);
+  }
+  if constexpr (BM == 64 && BN == 128) {
+    static int nw = -1;
+    // 2 x 4 waves: fwd 3.95 -> 3.78, dgrad 3.66 -> 3.55 ms per step on the Swin stage-2..4 shapes, ViT-S/16 4.64 -> 4.38 /
+    // 4.14 -> 4.07 (the activation epilogues gain most); VTX_GLDS_WAVES=4 keeps the 2 x 2 variant for comparison
+    if (nw < 0) { const char* e = getenv("VTX_GLDS_WAVES"); nw = e ? atoi(e) : 8; }
+    if (nw != 4) return glds_launch_cfg<BM, BN, 64, 2, 4>(a, st);
   }
   return glds_launch_cfg<BM, BN, 64, 2>(a, st);
 }
