@@ -163,7 +163,7 @@ template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_
   if constexpr (BN == 128) {
     if (a.K % 64 != 0) return glds_launch_cfg<BM, BN, 32, 3>(a, st);
   }
-  if constexpr (BM == 64 && BN == 128) {
+  if constexpr (BN == 128) {
     static int nw = -1;
     // 2 x 4 waves: fwd 3.95 -> 3.78, dgrad 3.66 -> 3.55 ms per step on the Swin stage-2..4 shapes, ViT-S/16 4.64 -> 4.38 /
     // 4.14 -> 4.07 (the activation epilogues gain most); VTX_GLDS_WAVES=4 keeps the 2 x 2 variant for comparison
@@ -175,18 +175,20 @@ template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_
 
 bool gemm_glds_ok(int N, int K) { return (K % 64) == 0 || ((K % 32) == 0 && (N % 128) == 0); }
 
-// Tile height: 64 rows.  With the epilogue's global reads requested up front (gemm_common.h) these GEMMs are bound by
-// how many independent tiles a CU keeps in flight, not by operand reuse: a 64x128 tile needs 48 KB of LDS and
-// 119 registers -> 3 resident workgroups per CU instead of 2.  Measured over the 32 Swin-S fwd / dgrad shapes
-// (tools/bench_gemm.py, same box): 64-row tiles 4.62 + 4.14 ms per step, 128-row tiles 4.99 + 4.59 ms, the former
-// grid-quantisation rule (128 unless the last round of workgroups is mostly empty) 4.91 + 4.46 ms; 64x64 tiles
-// 5.18 + 4.84 ms, 32-deep k-tiles x 3 stages 5.04 + 4.74 ms and a 3-stage ring of 64-deep tiles (2 workgroups per CU)
-// 5.25 + 4.66 ms are worse again; 64x96 tiles (4 per CU) are equal.  VTX_GLDS_BM=128 forces the tall tile
-// (within 3-7 % on the four widest stage-4 shapes, slower everywhere else).
-static int glds_pick_bm(const GemmArgs&, int) {
+// Tile height.  64-row tiles (48 KB of LDS, 3 workgroups per CU) win wherever a launch has few tiles: the per-tile
+// prologue / epilogue is hidden by the other resident workgroups.  With 2 x 4 waves per tile the 128 x 128 tile (64 KB,
+// 2 workgroups = 16 waves per CU, 2/3 of the operand bytes per FLOP) wins once a launch has >= ~1.6 rounds of them:
+// per shape (tools/bench_gemm.py, same box, 128 rows / 64 rows) ViT-S/16 0.80-0.95 on all eight GEMMs, Swin stage 4
+// 0.87-0.96 on the wide ones, stage 3 0.92-0.99 (N >= 1152) but 1.05-1.10 on the N = 384 GEMMs (588 tiles), stage 2
+// 0.93-0.96 (N = 768).  In the models: ViT-S/16 +4.9 %, Swin-S -0.9 % with 128 rows everywhere -> chosen per launch.
+// VTX_GLDS_BM = 64 | 128 forces one.
+static int glds_pick_bm(const GemmArgs& a, int bn) {
   static int force = -1;
   if (force < 0) { const char* e = getenv("VTX_GLDS_BM"); force = e ? atoi(e) : 0; }
-  return force == 128 ? 128 : 64;
+  if (force == 64 || force == 128) return force;
+  if (bn != 128 || a.K % 64 != 0) return 64;                 // the 2 x 4-wave tiles exist for 128 columns, 64-deep k-tiles
+  const long tiles128 = (long)((a.N + 127) / 128) * ((a.M + 127) / 128);
+  return tiles128 >= 800 ? 128 : 64;
 }
 
 template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {

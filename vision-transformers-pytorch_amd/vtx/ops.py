@@ -157,10 +157,16 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
     to = "float" if out_f32 else t
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
-        bm = 128 if os.environ.get("VTX_GLDS_BM") == "128" else 64       # mirrors glds_pick_bm in gemm_glds.hip
+        force = os.environ.get("VTX_GLDS_BM")                              # mirrors glds_pick_bm in gemm_glds.hip
+        if force in ("64", "128"):
+            bm = int(force)
+        elif bn != 128 or K % 64 != 0:
+            bm = 64
+        else:
+            bm = 128 if ((N + 127) // 128) * ((M + 127) // 128) >= 800 else 64
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
-        nwn = 4 if (bm == 64 and bn == 128 and os.environ.get("VTX_GLDS_WAVES") != "4") else 2   # mirrors glds_launch_t
+        nwn = 4 if (bn == 128 and os.environ.get("VTX_GLDS_WAVES") != "4") else 2   # mirrors glds_launch_t
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2, {nwn}>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
     return f"gemm_kernel<{t}, {to}, 128, {bn}, {ta}, {tb}>"
