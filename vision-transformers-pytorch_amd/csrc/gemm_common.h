@@ -72,7 +72,7 @@ template <typename T, int BM, int BN, int NWN = 2> struct EpiOperands {
   }
 };
 
-// acc[i][j][r] = C[m0 + wm*(BM/2) + 16 i + 4 g + r][n0 + wn*(BN/2) + 16 j + c]; lds_raw: >= (BM/2)*(BN+4)*4 bytes,
+// acc[i][j][r] = C[m0 + wm*(BM/2) + 16 i + 4 g + r][n0 + wn*(BN/NWN) + 16 j + c]; lds_raw: >= (BM/2)*(BN+4)*4 bytes,
 // no longer read by anybody when this is called (callers barrier after their last operand read).
 // The tile goes through LDS in two passes of BM/2 rows so that every lane stores 16 contiguous bytes.
 template <typename T, typename TO, int BM, int BN, int NWN = 2>
