@@ -299,7 +299,8 @@ int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, 
   a.scale_const = scale_const; a.kchunk = kchunk;
   if (rowscale != nullptr && kchunk / rows_per_scale + 2 > WG_MAXSAMPLES) return VTX_ERR_SHAPE;
   // 8 waves per workgroup: every shape of Swin-S / ViT-S 9-11 % faster than with 4 (stage-2..4 weight gradients 5.20 ->
-  // 4.72 ms, ViT-S/16 4.66 -> 4.16 ms per step); VTX_WG_WAVES=4 keeps the 2 x 2 variant for comparison
+  // 4.72 ms, ViT-S/16 4.66 -> 4.16 ms per step); 16 waves (one workgroup per CU: 73 registers) 5.6 vs 4.25 ms.
+  // VTX_WG_WAVES=4 keeps the 2 x 2 variant for comparison
   static int nw = -1;
   if (nw < 0) { const char* e = getenv("VTX_WG_WAVES"); nw = e ? atoi(e) : 8; }
   if (nw == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, nz, st);
