@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// HBM-bound row kernels want every CU full of waves (8 blocks of 256 threads per CU): the forward takes up to
-// 4096 blocks; the backward is capped at 1024 because every block writes one row of dgamma/dbeta partials.
+// HBM-bound row kernels: up to 1024 blocks of 256 threads, grid-stride over the rows.  The backward's cap is structural
+// (every block writes one row of dgamma/dbeta partials, the workspace is sized for 1024); sizing the forward for one
+// sweep over 2048 resident blocks measured no better (13.4 -> 14.1 us at 25 088 x 384).
 static int ln_grid(int64_t rows, int gpb, int cap) {
   int64_t nb = (rows + gpb - 1) / gpb;
   if (nb > cap) nb = cap;
