@@ -10,8 +10,9 @@
  *   - return 0 on success, a negative VTX_ERR_* code otherwise (vtx_strerror); never throw, never exit
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator), including
  *     workspaces whose size comes from the matching vtx_*_workspace(); no ownership transfer
- *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise and keep
- *     no global mutable state: re-entrant across streams / threads (autograd's backward thread)
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise; re-entrant across
+ *     streams / threads (autograd's backward thread).  The only process-global mutable state is the table of
+ *     dispatch switches behind vtx_set_option (atomic ints, read once per call)
  *   - dtype: VTX_F32 (parity mode, exact-fp32 MFMA) or VTX_BF16 (training mode: bf16 storage,
  *     fp32 accumulation / statistics); parameters, their gradients and all statistics are fp32
  *   - activations are row-major [rows, C] (tokens x channels) = NHWC / (B, L, C)
@@ -40,6 +41,17 @@ extern "C" {
 const char* vtx_strerror(int code);
 /* ABI version of the library (bumped on any signature change). */
 int vtx_abi_version(void);
+
+/* ---- Dispatch switches (csrc/options.h).  Which kernel variant an entry point launches -- LDS-DMA vs register-staged
+ * GEMM, tile height, waves per workgroup, split-K target, fused vs separate split-K reduction, persistent-grid sizes --
+ * is a table of ints, initialised from the environment variable of the same name (vtx_option_name: "VTX_GLDS_BM", ...)
+ * at library load and changeable in-process: every variant computes the same function (most of them bit-identically,
+ * tests/test_gpu_dispatch.py), the switches exist for measurement and for parity tests at a forced dispatch.
+ * (The reference has no counterpart: its dispatch is torch's.) */
+int vtx_option_count(void);
+const char* vtx_option_name(int id);
+int vtx_get_option(int id);              /* -1 for an unknown id */
+int vtx_set_option(int id, int value);   /* VTX_ERR_SHAPE for an unknown id */
 
 /* ---- LayerNorm (reference: nn.LayerNorm at models/vit.py:13, models/swin_transformer.py:12,
  * 206, 221, 277).  y = (x - mean) * rstd * gamma + beta over the last dim, biased variance.
@@ -72,10 +84,28 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
  * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that
  * every rowscale value is either 0 or scale_const (DropPath: mask / (1 - p)), which lets the LDS-DMA kernel
  * skip dropped samples' rows instead of scaling; pass 0 for arbitrary scales.
- * Deterministic (split-K slabs + fixed-order reduce). */
+ * Deterministic: split-K over tokens into fp32 slabs, summed in slice order -- inside the launch by each output tile's
+ * last-arriving workgroup when `tickets` is given (int32 [vtx_wgrad_tickets()], ZERO on entry, re-armed to zero by the
+ * kernel; launches sharing a ticket buffer must be ordered, i.e. one buffer per stream), else (tickets NULL, option
+ * WGRAD_FUSED_REDUCE 0, or the register-staged kernels) by separate reduce launches: bitwise the same result. */
+int vtx_wgrad_tickets(void);
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
               int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
-              void* workspace, size_t ws_bytes, void* stream);
+              void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream);
+/* Grouped form: the weight gradients of nprob <= vtx_wgrad_group_max() linears over the SAME mtok tokens in ONE launch
+ * -- the four of a transformer layer's backward (fc2, fc1, proj, qkv: models/vit.py:59-63, swin_transformer.py:193-197,
+ * layer.py:191-196).  Split-K only exists to fill the chip, so four problems together need a quarter of the slices (and
+ * of the fp32 slab traffic) of one.  bf16, every (N[i], Kin[i]) a multiple of 8 and >= 64 (vtx_wgrad_group_ok tells;
+ * otherwise call vtx_wgrad per problem).  Arrays are HOST arrays of nprob entries; dbias / rowscale may be NULL or hold
+ * NULL entries; rowscale values in {0, scale_const} (scale_const > 0) as for vtx_wgrad; same determinism contract. */
+int vtx_wgrad_group_max(void);
+int vtx_wgrad_group_ok(int dtype, int nprob, const int* N, const int* Kin, int64_t mtok, int has_rowscale,
+                       int rows_per_scale, float scale_const);
+size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_t mtok);
+int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                    float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                    const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
+                    void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream);
 
 /* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order
  * [q|k|v][head][d] (models/vit.py:30-34, models/swin_transformer.py:128); o is [rows, nH*D].

@@ -16,6 +16,7 @@
 // fp32 (parity mode) and other head dims use the generic kernels in attention.hip.
 #include <stdlib.h>
 
+#include "options.h"
 #include "vtx_common.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -388,9 +389,7 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
 }
 
 bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("VTX_SATTN"); on = e ? atoi(e) : 1; }
-  return on && dtype == VTX_BF16 && D == 64 && !swin && bias == nullptr && L >= 1 && L <= 224;
+  return vtx_opt(VTX_OPT_SATTN) && dtype == VTX_BF16 && D == 64 && !swin && bias == nullptr && L >= 1 && L <= 224;
 }
 
 template <int NKT> static int sattn_fwd_t(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {

@@ -20,6 +20,7 @@
 // Templated on T in {bf16, float} (float = parity mode on the exact fp32 MFMA).
 #include <stdlib.h>
 
+#include "options.h"
 #include "vtx_common.h"
 
 #define SR_D 64
@@ -340,8 +341,8 @@ static int sr_geom(SrGeom& g, int Lq, int Lk, int nH, int B) {
   g.Lq = Lq; g.Lk = Lk; g.nH = nH; g.hd = nH * SR_D;
   g.nsub = (Lq + SR_QB - 1) / SR_QB;
   // sub-chunks per workgroup: enough workgroups to fill the chip (~2048), as few partial slabs as possible
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("VTX_SRATTN_WGS"); target = e ? atoi(e) : 2048; }
+  int target = vtx_opt(VTX_OPT_SRATTN_WGS);
+  if (target <= 0) target = 2048;
   int64_t per_bh = target / ((int64_t)B * nH);
   if (per_bh < 1) per_bh = 1;
   g.qc = (int)((g.nsub + per_bh - 1) / per_bh);

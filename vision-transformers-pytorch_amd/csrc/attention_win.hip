@@ -21,6 +21,7 @@
 //     program order => deterministic), then reduced over waves in fixed order.
 #include <stdlib.h>
 
+#include "options.h"
 #include "vtx_common.h"
 
 #define WA_D 32
@@ -414,19 +415,13 @@ static int wattn_blocks(int nbn, int nH, int cap) {
   const int waves = (nbn + ppw - 1) / ppw;
   return (waves + WA_WAVES - 1) / WA_WAVES;
 }
-static int wattn_cap(const char* env, int dflt) {
-  const char* e = getenv(env);
-  return e ? atoi(e) : dflt;
-}
 static int wattn_fwd_blocks(int nbn, int nH) {
-  static int cap = -1;
-  if (cap < 0) cap = wattn_cap("VTX_WATTN_FWD_WAVES", 4096);
-  return wattn_blocks(nbn, nH, cap);
+  const int cap = vtx_opt(VTX_OPT_WATTN_FWD_WAVES);
+  return wattn_blocks(nbn, nH, cap > 0 ? cap : 4096);
 }
 static int wattn_bwd_blocks(int nbn, int nH) {
-  static int cap = -1;
-  if (cap < 0) cap = wattn_cap("VTX_WATTN_WAVES", 2048);
-  return wattn_blocks(nbn, nH, cap);
+  const int cap = vtx_opt(VTX_OPT_WATTN_BWD_WAVES);
+  return wattn_blocks(nbn, nH, cap > 0 ? cap : 2048);
 }
 
 template <typename K> static int wa_smem_attr(K kern, int bytes) {

@@ -1,7 +1,41 @@
 // Library-level C ABI entry points (include/vtx.h): error strings and ABI version.
+#include <atomic>
+#include <stdlib.h>
+
+#include "options.h"
 #include "vtx_common.h"
 
+namespace {
+struct OptDef { const char* env; int dflt; };
+const OptDef kOptDefs[VTX_OPT_COUNT] = {
+    {"VTX_GEMM_GLDS", 1},   {"VTX_GLDS_BM", 0},          {"VTX_GLDS_WAVES", 8},   {"VTX_WGRAD_GLDS", 1},
+    {"VTX_WG_WAVES", 8},    {"VTX_WGRAD_BLOCKS", 512},   {"VTX_SATTN", 1},        {"VTX_WATTN_FWD_WAVES", 4096},
+    {"VTX_WATTN_WAVES", 2048}, {"VTX_SRATTN_WGS", 2048}, {"VTX_WGRAD_FUSED_REDUCE", 1},
+};
+struct OptTable {
+  std::atomic<int> v[VTX_OPT_COUNT];
+  OptTable() {
+    for (int i = 0; i < VTX_OPT_COUNT; ++i) {
+      const char* e = getenv(kOptDefs[i].env);
+      v[i].store(e ? atoi(e) : kOptDefs[i].dflt, std::memory_order_relaxed);
+    }
+  }
+};
+OptTable& opt_table() { static OptTable t; return t; }   // initialised on first use (thread-safe static)
+}  // namespace
+
+int vtx_opt(int id) { return opt_table().v[id].load(std::memory_order_relaxed); }
+
 extern "C" {
+
+int vtx_option_count(void) { return VTX_OPT_COUNT; }
+const char* vtx_option_name(int id) { return (id >= 0 && id < VTX_OPT_COUNT) ? kOptDefs[id].env : nullptr; }
+int vtx_get_option(int id) { return (id >= 0 && id < VTX_OPT_COUNT) ? vtx_opt(id) : -1; }
+int vtx_set_option(int id, int value) {
+  if (id < 0 || id >= VTX_OPT_COUNT) return VTX_ERR_SHAPE;
+  opt_table().v[id].store(value, std::memory_order_relaxed);
+  return VTX_OK;
+}
 
 const char* vtx_strerror(int code) {
   switch (code) {
@@ -16,6 +50,6 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 5; }
+int vtx_abi_version(void) { return 6; }
 
 }  // extern "C"

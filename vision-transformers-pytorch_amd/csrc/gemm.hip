@@ -20,6 +20,7 @@
 // is repeated per N-tile and serialises with the staging; writing h once from fc1's epilogue is cheaper.)
 // Workgroup ids are remapped so that tiles sharing an operand panel run on the same XCD (private L2).
 #include "gemm_common.h"
+#include "options.h"
 
 template <typename T> struct GemmGeom {
   static constexpr int BK = 128 / (int)sizeof(T);      // elements per LDS k-tile row
@@ -287,19 +288,14 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   return VTX_ERR_DTYPE;
 }
 
-// Number of contraction slices (split-K over tokens) of the wgrad kernels: tiles x slices should just fill a whole
-// number of resident block rounds (256 CUs x 2 blocks) -- a partly filled round leaves CUs idle for the whole
-// kernel because every block runs the same long k-loop.
-static int wgrad_slices(int64_t mtok, int N, int Kin) {
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("VTX_WGRAD_BLOCKS"); target = e ? atoi(e) : wgrad_glds_resident(); }
-  const int tiles = ((N + 127) / 128) * ((Kin + 127) / 128);
-  int nz = target / tiles;
-  const int64_t maxz = (mtok + 255) / 256;
-  if (nz > maxz) nz = (int)maxz;
-  if (nz < 1) nz = 1;
-  if (nz > 256) nz = 256;
-  return nz;
+// Number of contraction slices (split-K over tokens) of the register-staged wgrad kernels: tiles x slices should just
+// fill a whole number of resident block rounds (256 CUs x 2 blocks) -- a partly filled round leaves CUs idle for the
+// whole kernel because every block runs the same long k-loop.  (The LDS-DMA kernel: wgrad_glds_slices.)
+static int wgrad_slices(int64_t mtok, int N, int Kin) { return wgrad_glds_slices(mtok, wgrad_glds_tiles(N, Kin)); }
+
+static int64_t chunk_of(int64_t mtok, int nz) {
+  int64_t chunk = (mtok + nz - 1) / nz;
+  return ((chunk + 127) / 128) * 128;
 }
 
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
@@ -307,10 +303,22 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
   return ((size_t)nz * (size_t)N * (size_t)Kin + (size_t)nz * (size_t)N) * sizeof(float);
 }
 
+int vtx_wgrad_tickets(void) { return 4096; }
+
+static int reduce_slabs(const float* slabs, const float* bias_part, float* dW, float* dbias, int N, int Kin, int nz,
+                        hipStream_t st) {
+  const int64_t n = (int64_t)N * Kin;
+  hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(n), dim3(256), 0, st, slabs, dW, n, nz);
+  int rc = vtx_check_launch();
+  if (rc || !dbias) return rc;
+  hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(N), dim3(256), 0, st, bias_part, dbias, (int64_t)N, nz);
+  return vtx_check_launch();
+}
+
 // dW[N,Kin] = sum_m s[m] * dy[m,N]^T x[m,Kin]  (fp32 out);  dbias[N] = sum_m s[m] * dy[m,:] (same kernel)
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
               int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
-              void* workspace, size_t ws_bytes, void* stream) {
+              void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream) {
   if (!dy || !x || !dW || !workspace) return VTX_ERR_NULL;
   if (mtok <= 0 || mtok > 0x7fffffff) return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_wgrad_workspace(mtok, N, Kin)) return VTX_ERR_WORKSPACE;
@@ -322,33 +330,90 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   a.bias = nullptr; a.resid = nullptr; a.rowscale = nullptr; a.rows_per_scale = 1;
   a.aux_out = nullptr; a.aux_in = nullptr; a.act = 0;
   a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.kscale_const = scale_const;
-  int64_t chunk = (mtok + nz - 1) / nz;
-  chunk = ((chunk + 127) / 128) * 128;
-  a.kchunk = (int)chunk;
+  a.kchunk = (int)chunk_of(mtok, nz);
   float* bias_part = (float*)workspace + (size_t)nz * N * Kin;
   a.ksum_out = dbias ? (nz == 1 ? dbias : bias_part) : nullptr;
   int rc = gemm_validate(a, 2);
   if (rc) return rc;
   // (the LDS-DMA kernel keeps the DropPath liveness of a slice's samples in a 512-entry table: slices spanning more
   //  samples -- sequences of one or two tokens -- take the register-staged kernel)
-  if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const) && (rowscale == nullptr || a.kchunk / a.k_per_scale + 2 <= 512))
-    rc = wgrad_glds_launch(dy, x, (float*)a.C, a.ksum_out, mtok, N, Kin, ld_dy, ld_x, rowscale, a.k_per_scale,
-                           scale_const, nz, a.kchunk, st);
-  else if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
+  if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const) && (rowscale == nullptr || a.kchunk / a.k_per_scale + 2 <= 512)) {
+    WgradProbHost hp;
+    hp.dy = dy; hp.x = x; hp.slab = (float*)workspace; hp.out = dW; hp.ksum_part = bias_part; hp.ksum_out = dbias;
+    hp.rowscale = rowscale; hp.ld_dy = ld_dy; hp.ld_x = ld_x; hp.N = N; hp.Kin = Kin;
+    const bool fused = tickets != nullptr && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE) && wgrad_glds_tiles(N, Kin) <= vtx_wgrad_tickets();
+    rc = wgrad_glds_group_launch(1, &hp, mtok, a.k_per_scale, scale_const, nz, a.kchunk, fused ? tickets : nullptr, st);
+    if (rc || nz == 1 || fused) return rc;
+    return reduce_slabs((const float*)workspace, bias_part, dW, dbias, N, Kin, nz, st);
+  }
+  if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
   else if (dtype == VTX_F32) rc = gemm_pick_bn<float, float, true, true>(a, nz, st);
   else return VTX_ERR_DTYPE;
-  if (rc) return rc;
-  if (nz > 1) {
-    const int64_t n = (int64_t)N * Kin;
-    hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(n), dim3(256), 0, st, (const float*)workspace, dW, n, nz);
-    rc = vtx_check_launch();
-    if (rc) return rc;
-    if (dbias) {
-      hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(N), dim3(256), 0, st, (const float*)bias_part, dbias,
-                         (int64_t)N, nz);
-      rc = vtx_check_launch();
-    }
+  if (rc || nz == 1) return rc;
+  return reduce_slabs((const float*)workspace, bias_part, dW, dbias, N, Kin, nz, st);
+}
+
+// ---- grouped weight gradients (bf16, every problem eligible for the LDS-DMA kernel: vtx_wgrad_group_ok)
+int vtx_wgrad_group_max(void) { return wgrad_glds_max_problems(); }
+
+int vtx_wgrad_group_ok(int dtype, int nprob, const int* N, const int* Kin, int64_t mtok, int has_rowscale,
+                       int rows_per_scale, float scale_const) {
+  if (nprob < 1 || nprob > wgrad_glds_max_problems() || mtok <= 0 || mtok > 0x7fffffff) return 0;
+  int tiles = 0;
+  static const float one = 1.f;
+  const float* rs = has_rowscale ? &one : nullptr;
+  for (int i = 0; i < nprob; ++i) {
+    if (!wgrad_glds_ok(dtype, N[i], Kin[i], rs, scale_const)) return 0;
+    tiles += wgrad_glds_tiles(N[i], Kin[i]);
   }
+  if (tiles > vtx_wgrad_tickets()) return 0;
+  const int nz = wgrad_glds_slices(mtok, tiles);
+  if (has_rowscale && chunk_of(mtok, nz) / (rows_per_scale > 0 ? rows_per_scale : 1) + 2 > 512) return 0;
+  return 1;
+}
+
+static int group_tiles(int nprob, const int* N, const int* Kin) {
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) tiles += wgrad_glds_tiles(N[i], Kin[i]);
+  return tiles;
+}
+
+size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_t mtok) {
+  const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  size_t fl = 0;
+  for (int i = 0; i < nprob; ++i) fl += (size_t)nz * ((size_t)N[i] * Kin[i] + (size_t)N[i]);
+  return (fl + 4) * sizeof(float);
+}
+
+int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                    float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                    const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
+                    void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream) {
+  if (!dy || !x || !dW || !N || !Kin || !ld_dy || !ld_x || !workspace) return VTX_ERR_NULL;
+  bool any_scale = false;
+  if (nprob >= 1 && nprob <= wgrad_glds_max_problems())
+    for (int i = 0; i < nprob; ++i) any_scale = any_scale || (rowscale && rowscale[i]);
+  if (!vtx_wgrad_group_ok(dtype, nprob, N, Kin, mtok, any_scale, rows_per_scale, scale_const)) return VTX_ERR_SHAPE;
+  if (ws_bytes < vtx_wgrad_group_workspace(nprob, N, Kin, mtok)) return VTX_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  const int kchunk = (int)chunk_of(mtok, nz);
+  WgradProbHost hp[8];
+  float* w = (float*)workspace;
+  for (int i = 0; i < nprob; ++i) {
+    if (!dy[i] || !x[i] || !dW[i]) return VTX_ERR_NULL;
+    if ((N[i] & 7) || (Kin[i] & 7) || (ld_dy[i] & 7) || (ld_x[i] & 7)) return VTX_ERR_ALIGN;
+    hp[i].dy = dy[i]; hp[i].x = x[i]; hp[i].out = dW[i]; hp[i].ksum_out = dbias ? dbias[i] : nullptr;
+    hp[i].rowscale = rowscale ? rowscale[i] : nullptr; hp[i].ld_dy = ld_dy[i]; hp[i].ld_x = ld_x[i];
+    hp[i].N = N[i]; hp[i].Kin = Kin[i];
+    hp[i].slab = w; w += (size_t)nz * N[i] * Kin[i];
+    hp[i].ksum_part = w; w += (size_t)nz * N[i];
+  }
+  const bool fused = tickets != nullptr && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE);
+  int rc = wgrad_glds_group_launch(nprob, hp, mtok, rows_per_scale, scale_const, nz, kchunk, fused ? tickets : nullptr, st);
+  if (rc || nz == 1 || fused) return rc;
+  for (int i = 0; i < nprob && !rc; ++i)
+    rc = reduce_slabs(hp[i].slab, hp[i].ksum_part, hp[i].out, hp[i].ksum_out, N[i], Kin[i], nz, st);
   return rc;
 }
 

@@ -151,9 +151,19 @@ bool gemm_glds_enabled();
 bool gemm_glds_ok(int N, int K);
 
 // LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N and Kin multiples of 8 and >= 64,
-// rowscale values restricted to {0, scale_const}
+// rowscale values restricted to {0, scale_const}.  Grouped: up to wgrad_glds_max_problems() weight gradients over the
+// same tokens in one launch, split-K partials summed in-launch by each tile's last arriver (tickets) or left as slabs.
+struct WgradProbHost {
+  const void* dy; const void* x;
+  float* slab; float* out; float* ksum_part; float* ksum_out;
+  const float* rowscale;
+  int64_t ld_dy, ld_x;
+  int N, Kin;
+};
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const);
 int wgrad_glds_resident();
-int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, int64_t mtok, int N, int Kin,
-                      int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
-                      int nz, int kchunk, hipStream_t st);
+int wgrad_glds_max_problems();
+int wgrad_glds_tiles(int N, int Kin);
+int wgrad_glds_slices(int64_t mtok, int ntiles);
+int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
+                            int nz, int kchunk, unsigned int* tickets, hipStream_t st);

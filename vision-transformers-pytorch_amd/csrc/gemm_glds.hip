@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "gemm_common.h"
+#include "options.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -164,11 +165,9 @@ template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_
     if (a.K % 64 != 0) return glds_launch_cfg<BM, BN, 32, 3>(a, st);
   }
   if constexpr (BN == 128) {
-    static int nw = -1;
     // 2 x 4 waves: fwd 3.95 -> 3.78, dgrad 3.66 -> 3.55 ms per step on the Swin stage-2..4 shapes, ViT-S/16 4.64 -> 4.38 /
-    // 4.14 -> 4.07 (the activation epilogues gain most); VTX_GLDS_WAVES=4 keeps the 2 x 2 variant for comparison
-    if (nw < 0) { const char* e = getenv("VTX_GLDS_WAVES"); nw = e ? atoi(e) : 8; }
-    if (nw != 4) return glds_launch_cfg<BM, BN, 64, 2, 4>(a, st);
+    // 4.14 -> 4.07 (the activation epilogues gain most); option GLDS_WAVES = 4 keeps the 2 x 2 variant for comparison
+    if (vtx_opt(VTX_OPT_GLDS_WAVES) != 4) return glds_launch_cfg<BM, BN, 64, 2, 4>(a, st);
   }
   return glds_launch_cfg<BM, BN, 64, 2>(a, st);
 }
@@ -181,10 +180,9 @@ bool gemm_glds_ok(int N, int K) { return (K % 64) == 0 || ((K % 32) == 0 && (N %
 // per shape (tools/bench_gemm.py, same box, 128 rows / 64 rows) ViT-S/16 0.80-0.95 on all eight GEMMs, Swin stage 4
 // 0.87-0.96 on the wide ones, stage 3 0.92-0.99 (N >= 1152) but 1.05-1.10 on the N = 384 GEMMs (588 tiles), stage 2
 // 0.93-0.96 (N = 768).  In the models: ViT-S/16 +4.9 %, Swin-S -0.9 % with 128 rows everywhere -> chosen per launch.
-// VTX_GLDS_BM = 64 | 128 forces one.
+// Option GLDS_BM = 64 | 128 forces one.
 static int glds_pick_bm(const GemmArgs& a, int bn) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("VTX_GLDS_BM"); force = e ? atoi(e) : 0; }
+  const int force = vtx_opt(VTX_OPT_GLDS_BM);
   if (force == 64 || force == 128) return force;
   if (bn != 128 || a.K % 64 != 0) return 64;                 // the 2 x 4-wave tiles exist for 128 columns, 64-deep k-tiles
   const long tiles128 = (long)((a.N + 127) / 128) * ((a.M + 127) / 128);
@@ -196,9 +194,7 @@ template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {
 }
 
 bool gemm_glds_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("VTX_GEMM_GLDS"); on = e ? atoi(e) : 1; }
-  return on != 0;
+  return vtx_opt(VTX_OPT_GEMM_GLDS) != 0;
 }
 
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st) {

@@ -15,6 +15,7 @@
 //   * bias gradient = column sums of the dy tile, accumulated from LDS with 16-byte reads by the blocks
 //     of the first Kin tile; split-K over tokens into fp32 slabs + fixed-order reduce (deterministic).
 #include "gemm_common.h"
+#include "options.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -23,13 +24,32 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __attribute__((aligned(256))) unsigned int vtx_zero_row[128];   // 512 zero bytes
 
-struct WgradArgs {
-  const bf16* dy; const bf16* x; float* C; float* ksum_out;
-  int M;            // tokens
-  int N, Kin;       // dW is [N][Kin]
+constexpr int WG_MAXPROB = 8;        // weight gradients per grouped launch
+constexpr int WG_MAXSAMPLES = 512;   // DropPath liveness table entries (samples one split-K slice may span)
+
+// One weight gradient of a grouped launch: dW[N][Kin] = c * sum_m keep[m] dy[m,:]^T x[m,:]
+struct WgradProb {
+  const bf16* dy; const bf16* x;
+  float* slab;        // [nz][N][Kin] fp32 partials (nz > 1) -- unused when nz == 1
+  float* out;         // final dW [N][Kin]
+  float* ksum_part;   // [nz][N] bias-gradient partials (nz > 1) or null
+  float* ksum_out;    // final dbias [N] or null
+  const float* rowscale;   // [samples] in {0, scale_const} or null (DropPath)
   int64_t ld_dy, ld_x;
-  const float* rowscale; int rows_per_scale; float scale_const;   // rowscale[sample] in {0, scale_const} or null
-  int kchunk;       // tokens per grid.z slice (multiple of 64)
+  int N, Kin;
+  int ntk;            // Kin tiles (128 wide); N tiles = ceil(N / 128)
+  int tile0;          // first tile id of this problem inside a slice
+};
+
+struct WgradArgs {
+  WgradProb pr[WG_MAXPROB];
+  int nprob;
+  int M;              // tokens (shared by all problems of the launch)
+  int rows_per_scale; float scale_const;
+  int kchunk;         // tokens per split-K slice (multiple of 64)
+  int nz;             // slices
+  int ntiles;         // tiles per slice over all problems; grid = ntiles * nz workgroups
+  unsigned int* tickets;   // [ntiles] zero on entry, zero again on exit: fused in-launch reduction; null: slabs only
 };
 
 __device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
@@ -54,12 +74,28 @@ __device__ __forceinline__ Vec8<bf16> wg_frag(const unsigned char* tile, int tok
   return f;
 }
 
+// 16-byte write-through (sc1) store: a split-K slab is read by another workgroup of the SAME launch (the tile's last
+// arriver), possibly on another XCD whose L2 is not coherent with ours -- write-through + vmcnt(0) + ticket publishes
+// it without a release fence (cdna guide, Guideline 16 R1; 64 KB per workgroup: 3.0 vs 8.2 us for fence-published
+// plain stores).  hipcc does not count an asm store: the caller drains with its own s_waitcnt vmcnt(0).
+__device__ __forceinline__ void store16_sc1(float* dst, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+
 // BKT tokens per k-tile, NS-stage LDS ring.  The operands are streamed from HBM (activations, read once per XCD
 // through its L2), so a k-tile costs an HBM-miss latency: what matters is how many bytes each CU keeps in flight.
 // NS-1 tiles are always requested ahead (counted s_waitcnt vmcnt + raw s_barrier, never a draining __syncthreads);
 // nothing but the DMA uses vmcnt inside the loop: DropPath liveness comes from a per-workgroup LDS table.
-constexpr int WG_MAXSAMPLES = 512;
-
+//
+// GROUPED: one launch computes up to WG_MAXPROB weight gradients over the same tokens (the four of a transformer
+// layer's backward: fc2, fc1, proj, qkv).  Split-K exists only to fill the chip (512 resident workgroups); a single
+// Swin stage-3 weight gradient has 9-36 output tiles and needs 14-57 slices -- 512 fp32 slab tiles of 64 KB written and
+// re-read per launch -- while the layer's four together have 108 tiles and need 4: a quarter of the slab traffic and
+// of the launches, and a 4x longer k-loop per workgroup to amortise its prologue / epilogue.
+//
+// FUSED REDUCTION (tickets != null, nz > 1): every workgroup writes its slab tile write-through, takes a ticket of its
+// tile; the workgroup that draws nz - 1 acquires and sums the tile's nz slabs in slice order (the same fixed order as
+// slab_reduce_kernel: bitwise identical, deterministic) into dW, the bias partials likewise, and re-arms the ticket.
 // NW waves per workgroup: 4 (2 x 2 waves of 64 x 64) or 8 (4 x 2 waves of 32 x 64 -- half the DMA requests and MFMAs per
 // wave and k-tile, twice the waves per SIMD to interleave them).
 template <int BKT, int NS, int NW>
@@ -71,33 +107,49 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   constexpr int RPW = BKT / NW;                            // tile rows per wave
   constexpr int IPW = RPW / 4;                             // DMA instructions per wave and operand (4 rows x 256 B each)
   constexpr int LPT = 2 * IPW;                             // DMA instructions per wave and k-tile
-  static_assert(NS * STAGE >= 64 * (BT + 4) * 4, "C staging must fit");
-  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];   // [NS][A | B]
-  __shared__ unsigned char live_tab[WG_MAXSAMPLES];
+  constexpr int RING = NS * STAGE;
+  static_assert(RING >= 64 * (BT + 4) * 4, "C staging must fit");
+  // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before the first ds_read of every k-step):
+  // [NS][A | B] ring, then the DropPath liveness table, then the "I am the last arriver" word
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+  unsigned char* live_tab = wg_smem + RING;
+  unsigned int* last_flag = reinterpret_cast<unsigned int*>(wg_smem + RING + WG_MAXSAMPLES);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;                  // wm: 0..NW/2-1 (rows wm * 16 WMT ..), wn: column half
   const int c_ = lane & 15, g_ = lane >> 4;
 
-  const int ntk = gridDim.x, ntn = gridDim.y;
-  const int nblk = ntk * ntn * gridDim.z;
-  const int did = (blockIdx.z * ntn + blockIdx.y) * ntk + blockIdx.x;
+  // workgroup -> (slice, problem, tile): XCD-contiguous remap, then slice-major so that the tiles of one slice (which
+  // stream the same token rows) sit on the same XCD
+  const int nblk = gridDim.x;
+  const int did = blockIdx.x;
   const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
   const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
-  const int tk = lid % ntk;                 // Kin tile
-  const int tnn = (lid / ntk) % ntn;        // N (feature) tile
-  const int tz = lid / (ntk * ntn);
+  const int tz = lid / p.ntiles;
+  const int tile = lid - tz * p.ntiles;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXPROB; ++i)
+    if (i < p.nprob && tile >= p.pr[i].tile0) pi = i;
+  const WgradProb& q = p.pr[pi];
+  const int lt = tile - q.tile0;
+  const int tk = lt % q.ntk, tnn = lt / q.ntk;
   const int n0 = tnn * BT, k0 = tk * BT;
+  const int N = q.N, Kin = q.Kin;
+  const bf16* __restrict__ gdy = q.dy;
+  const bf16* __restrict__ gx = q.x;
+  const int64_t ld_dy = q.ld_dy, ld_x = q.ld_x;
+  const float* rowscale = q.rowscale;
   const int mbeg = tz * p.kchunk;
   const int mend = min(p.M, mbeg + p.kchunk);
-  const int nkt = (mend - mbeg + BKT - 1) / BKT;
+  const int nkt = mend > mbeg ? (mend - mbeg + BKT - 1) / BKT : 0;
 
   // DropPath liveness of the samples this slice touches (host guarantees they fit the table)
   const int s0 = mbeg / p.rows_per_scale;
-  if (p.rowscale != nullptr && nkt > 0) {
+  if (rowscale != nullptr && nkt > 0) {
     const int ns = (mend - 1) / p.rows_per_scale - s0 + 1;
-    for (int i = threadIdx.x; i < ns; i += NT) live_tab[i] = p.rowscale[s0 + i] != 0.f;
+    for (int i = threadIdx.x; i < ns; i += NT) live_tab[i] = rowscale[s0 + i] != 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -119,9 +171,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   bool cok_a[IPW], cok_b[IPW];
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
-    const int q = pslot ^ wg_swz(wave * RPW + j * 4 + prow);
-    cok_a[j] = n0 + (q << 3) < p.N;
-    cok_b[j] = k0 + (q << 3) < p.Kin;
+    const int qq = pslot ^ wg_swz(wave * RPW + j * 4 + prow);
+    cok_a[j] = n0 + (qq << 3) < N;
+    cok_b[j] = k0 + (qq << 3) < Kin;
   }
 
   auto issue = [&](int kt, int buf) {          // called with kt = 0, 1, 2, ... in order
@@ -131,14 +183,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     for (int j = 0; j < IPW; ++j) {
       const int r = wave * RPW + j * 4 + prow;
       const int tok = mbeg + kt * BKT + r;
-      const int q = pslot ^ wg_swz(r);
+      const int qq = pslot ^ wg_swz(r);
       bool live = tok < mend;
-      const bf16* srcb = (live && cok_b[j]) ? p.x + (int64_t)tok * p.ld_x + k0 + (q << 3) : zero + (q << 3);
-      if (live && p.rowscale != nullptr) live = live_tab[smp[j]] != 0;
-      const bf16* srca = (live && cok_a[j]) ? p.dy + (int64_t)tok * p.ld_dy + n0 + (q << 3) : zero + (q << 3);
+      const bf16* srcb = (live && cok_b[j]) ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : zero + (qq << 3);
+      if (live && rowscale != nullptr) live = live_tab[smp[j]] != 0;
+      const bf16* srca = (live && cok_a[j]) ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : zero + (qq << 3);
       __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
-      if (p.rowscale != nullptr) {
+      if (rowscale != nullptr) {
         rem[j] += BKT;
         while (rem[j] >= p.rows_per_scale) { rem[j] -= p.rows_per_scale; ++smp[j]; }
       }
@@ -152,7 +204,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // bias gradient partials: thread (chunk = tid & 15, row group = tid >> 4) sums 8 columns over rows rg, rg+16, ...
-  const bool do_ksum = p.ksum_out != nullptr && tk == 0;
+  const bool have_ksum = q.ksum_out != nullptr && tk == 0;
   float ks8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
@@ -168,7 +220,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     if (refill) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
     const unsigned char* la = wg_smem + buf * STAGE;
     const unsigned char* lb = la + OPB;
-    if (do_ksum) {
+    if (have_ksum) {
       const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
 #pragma unroll
       for (int rr = 0; rr < BKT / (NT / 16); ++rr) {
@@ -198,8 +250,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
-  const float sc = p.rowscale != nullptr ? p.scale_const : 1.f;
-  if (do_ksum) {
+  const float sc = rowscale != nullptr ? p.scale_const : 1.f;
+  const bool split = p.nz > 1;                                // wave-uniform (kernel argument)
+  if (have_ksum) {
     float* red = reinterpret_cast<float*>(wg_smem);         // [NT / 16 row groups][128 cols]
     const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
 #pragma unroll
@@ -208,8 +261,12 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     if (threadIdx.x < 128) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < NT / 16; ++q) s += red[q * 128 + threadIdx.x];
-      if (n0 + (int)threadIdx.x < p.N) p.ksum_out[(int64_t)tz * p.N + n0 + threadIdx.x] = s * sc;
+      for (int qd = 0; qd < NT / 16; ++qd) s += red[qd * 128 + threadIdx.x];
+      if (n0 + (int)threadIdx.x < N) {
+        if (split) __hip_atomic_store(q.ksum_part + (int64_t)tz * N + n0 + threadIdx.x, s * sc, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);                       // 4-byte sc1 store
+        else q.ksum_out[n0 + threadIdx.x] = s * sc;
+      }
     }
     __syncthreads();
   }
@@ -219,46 +276,83 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
   }
-  if constexpr (NW == 4) {
-    GemmArgs e;
-    e.C = p.C; e.M = p.N; e.N = p.Kin; e.ldc = p.Kin;
-    e.bias = nullptr; e.resid = nullptr; e.rowscale = nullptr; e.rows_per_scale = 1; e.aux_out = nullptr;
-    e.aux_in = nullptr; e.act = 0;
-    EpiOperands<bf16, 128, 128> eo;
-    eo.load(e, n0, k0, wn, c_);               // no epilogue operands here: compiles to constants
-    gemm_epilogue<bf16, float, 128, 128>(e, acc, wg_smem, n0, k0, tz, wm, wn, c_, g_, eo);
-  } else {
-    // fp32 slab tile through LDS in two passes of 64 rows (waves wm = 2 pass, 2 pass + 1 own them), 32-byte row pieces out:
-    // acc[i][j][r] = C[n0 + 32 wm + 16 i + 4 g + r][k0 + 64 wn + 16 j + c]
-    constexpr int CSTR = BT + 4;
-    float* cbuf = reinterpret_cast<float*>(wg_smem);
-    float* Cout = p.C + (int64_t)tz * p.N * p.Kin;
+  // fp32 tile through LDS in two passes of 64 rows, 32-byte row pieces out:
+  // acc[i][j][r] = C[n0 + 16 WMT wm + 16 i + 4 g + r][k0 + 64 wn + 16 j + c]
+  constexpr int CSTR = BT + 4;
+  constexpr int RW = 16 * WMT;                    // rows per wave row: 64 (NW 4) | 32 (NW 8)
+  constexpr int WPP = 64 / RW;                    // wave rows per pass
+  float* cbuf = reinterpret_cast<float*>(wg_smem);
+  float* Cout = split ? q.slab + (int64_t)tz * N * Kin : q.out;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if ((wm >> 1) == pass) {
+  for (int pass = 0; pass < 2; ++pass) {
+    if (wm / WPP == pass) {
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
+      for (int i = 0; i < WMT; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              cbuf[((wm & 1) * 32 + i * 16 + g_ * 4 + r) * CSTR + wn * 64 + j * 16 + c_] = acc[i][j][r];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < (64 * 16) / NT; ++it) {
-        const int v = threadIdx.x + NT * it;
-        const int lr = v >> 4, cv = v & 15;
-        const int row = n0 + 64 * pass + lr, col = k0 + cv * 8;
-        if (row < p.N && col < p.Kin) {
-          const float* cp = cbuf + lr * CSTR + cv * 8;
-          float* dst = Cout + (int64_t)row * p.Kin + col;
-          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(cp);
-          *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(cp + 4);
-        }
-      }
-      if (pass == 0) __syncthreads();
+          for (int r = 0; r < 4; ++r)
+            cbuf[((wm % WPP) * RW + i * 16 + g_ * 4 + r) * CSTR + wn * 64 + j * 16 + c_] = acc[i][j][r];
     }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (64 * 16) / NT; ++it) {
+      const int v = threadIdx.x + NT * it;
+      const int lr = v >> 4, cv = v & 15;
+      const int row = n0 + 64 * pass + lr, col = k0 + cv * 8;
+      if (row < N && col < Kin) {
+        const float* cp = cbuf + lr * CSTR + cv * 8;
+        float* dst = Cout + (int64_t)row * Kin + col;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
+        if (split) { store16_sc1(dst, lo); store16_sc1(dst + 4, hi); }
+        else { *reinterpret_cast<f32x4*>(dst) = lo; *reinterpret_cast<f32x4*>(dst + 4) = hi; }
+      }
+    }
+    if (pass == 0) __syncthreads();
+  }
+  if (!split || p.tickets == nullptr) return;
+
+  // ---- fused split-K reduction: publish (every storing wave drains, then ONE ticket), last arriver sums
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int last = old == (unsigned int)(p.nz - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale L1 lines of the slabs
+      __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    }
+    *last_flag = last;
+  }
+  __syncthreads();
+  if (*last_flag == 0u) return;
+  const int64_t nk = (int64_t)N * Kin;
+  for (int v = threadIdx.x; v < 128 * 16; v += NT) {          // 128 rows x 16 eight-float pieces
+    const int lr = v >> 4, cv = v & 15;
+    const int row = n0 + lr, col = k0 + cv * 8;
+    if (row >= N || col >= Kin) continue;
+    const float* src = q.slab + (int64_t)row * Kin + col;
+    f32x4 s_lo = {0.f, 0.f, 0.f, 0.f}, s_hi = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= p.nz; z += 4) {                           // 8 loads in flight, summed in slice order
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk), a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk + 4);
+      f32x4 b0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 1) * nk), b1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 1) * nk + 4);
+      f32x4 c0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2) * nk), c1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2) * nk + 4);
+      f32x4 d0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3) * nk), d1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3) * nk + 4);
+      s_lo += a0; s_hi += a1; s_lo += b0; s_hi += b1; s_lo += c0; s_hi += c1; s_lo += d0; s_hi += d1;
+    }
+    for (; z < p.nz; ++z) {
+      s_lo += *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk);
+      s_hi += *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk + 4);
+    }
+    float* dst = q.out + (int64_t)row * Kin + col;
+    *reinterpret_cast<f32x4*>(dst) = s_lo;
+    *reinterpret_cast<f32x4*>(dst + 4) = s_hi;
+  }
+  if (have_ksum && threadIdx.x < 128 && n0 + (int)threadIdx.x < N) {
+    float s = 0.f;
+    for (int z = 0; z < p.nz; ++z) s += q.ksum_part[(int64_t)z * N + n0 + threadIdx.x];
+    q.ksum_out[n0 + threadIdx.x] = s;
   }
 }
 
@@ -268,10 +362,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
 // 7.22 ms -- twice the barriers per token cost more than the deeper prefetch returns; the next tile's requests spread
 // between the MFMA rows (with or without scheduling barriers) 5.11 vs 4.60 ms -- the pieces issued late land late.
 int wgrad_glds_resident() { return 512; }
+int wgrad_glds_max_problems() { return WG_MAXPROB; }
 
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const) {
-  static int on = -1;
-  if (on < 0) { const char* ev = getenv("VTX_WGRAD_GLDS"); on = ev ? atoi(ev) : 1; }
+  const int on = vtx_opt(VTX_OPT_WGRAD_GLDS);
   // any N, Kin that are multiples of 8 (16-byte DMA chunks) and at least half a tile wide: edge tiles are zero-filled.
   // Against the register-staged kernel on the ragged shapes (Swin-S stage 1/2, PVT-Small stage 1/3, through DropPath):
   // 5-20 % faster on every one, 1 365 -> 1 238 us summed (tools/probe/wgrad_shapes.py).
@@ -279,30 +373,55 @@ bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale
   return on && dtype == VTX_BF16 && shape_ok && (rowscale == nullptr || scale_const > 0.f);
 }
 
-template <int BKT, int NS, int NW> static int wgrad_glds_launch_cfg(const WgradArgs& a, int nz, hipStream_t st) {
-  constexpr int smem = NS * 2 * BKT * 256;
+template <int BKT, int NS, int NW> static int wgrad_glds_launch_cfg(const WgradArgs& a, hipStream_t st) {
+  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES + 16;
   auto kern = wgrad_glds_kernel<BKT, NS, NW>;
-  if (smem + WG_MAXSAMPLES > 64 * 1024 &&
+  if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
-  dim3 grid((a.Kin + 127) / 128, (a.N + 127) / 128, nz);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nz), dim3(64 * NW), smem, st, a);
   return vtx_check_launch();
 }
 
-int wgrad_glds_launch(const void* dy, const void* x, float* C, float* ksum_out, int64_t mtok, int N, int Kin,
-                      int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
-                      int nz, int kchunk, hipStream_t st) {
+// Split-K slices of a (grouped) launch: tiles x slices should just fill ONE round of resident workgroups -- a partly
+// filled second round leaves CUs idle for the whole kernel because every workgroup runs the same long k-loop.
+int wgrad_glds_slices(int64_t mtok, int ntiles) {
+  int target = vtx_opt(VTX_OPT_WGRAD_BLOCKS);
+  if (target <= 0) target = wgrad_glds_resident();
+  int nz = target / ntiles;
+  const int64_t maxz = (mtok + 255) / 256;
+  if (nz > maxz) nz = (int)maxz;
+  if (nz < 1) nz = 1;
+  if (nz > 256) nz = 256;
+  return nz;
+}
+
+int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) / 128); }
+
+// slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)
+int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
+                            int nz, int kchunk, unsigned int* tickets, hipStream_t st) {
+  if (nprob < 1 || nprob > WG_MAXPROB) return VTX_ERR_SHAPE;
   WgradArgs a;
-  a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.C = C; a.ksum_out = ksum_out; a.M = (int)mtok; a.N = N; a.Kin = Kin;
-  a.ld_dy = ld_dy; a.ld_x = ld_x; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale;
-  a.scale_const = scale_const; a.kchunk = kchunk;
-  if (rowscale != nullptr && kchunk / rows_per_scale + 2 > WG_MAXSAMPLES) return VTX_ERR_SHAPE;
+  int t0 = 0;
+  bool any_scale = false;
+  for (int i = 0; i < nprob; ++i) {
+    WgradProb& q = a.pr[i];
+    q.dy = (const bf16*)hp[i].dy; q.x = (const bf16*)hp[i].x; q.slab = hp[i].slab; q.out = hp[i].out;
+    q.ksum_part = hp[i].ksum_part; q.ksum_out = hp[i].ksum_out; q.rowscale = hp[i].rowscale;
+    q.ld_dy = hp[i].ld_dy; q.ld_x = hp[i].ld_x; q.N = hp[i].N; q.Kin = hp[i].Kin;
+    q.ntk = (hp[i].Kin + 127) / 128; q.tile0 = t0;
+    t0 += wgrad_glds_tiles(hp[i].N, hp[i].Kin);
+    any_scale = any_scale || hp[i].rowscale != nullptr;
+  }
+  for (int i = nprob; i < WG_MAXPROB; ++i) a.pr[i] = a.pr[0];
+  a.nprob = nprob; a.M = (int)mtok; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+  a.scale_const = scale_const; a.kchunk = kchunk; a.nz = nz; a.ntiles = t0;
+  a.tickets = (nz > 1 && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE)) ? tickets : nullptr;
+  if (any_scale && kchunk / a.rows_per_scale + 2 > WG_MAXSAMPLES) return VTX_ERR_SHAPE;
   // 8 waves per workgroup: every shape of Swin-S / ViT-S 9-11 % faster than with 4 (stage-2..4 weight gradients 5.20 ->
   // 4.72 ms, ViT-S/16 4.66 -> 4.16 ms per step); 16 waves (one workgroup per CU: 73 registers) 5.6 vs 4.25 ms.
-  // VTX_WG_WAVES=4 keeps the 2 x 2 variant for comparison
-  static int nw = -1;
-  if (nw < 0) { const char* e = getenv("VTX_WG_WAVES"); nw = e ? atoi(e) : 8; }
-  if (nw == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, nz, st);
-  return wgrad_glds_launch_cfg<64, 2, 8>(a, nz, st);
+  // option WG_WAVES = 4 keeps the 2 x 2 variant for comparison
+  if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
+  return wgrad_glds_launch_cfg<64, 2, 8>(a, st);
 }

@@ -1,0 +1,24 @@
+// Dispatch switches of libvtx.so (include/vtx.h: vtx_set_option / vtx_get_option).
+//
+// The ONLY process-global mutable state of the library: a table of atomic ints, read once per entry-point call with
+// a relaxed load (no getenv caches frozen at first use -- a test flips a switch in-process and compares the kernel
+// variants bit for bit).  Initial values come from the VTX_* environment variables of the same name at library load.
+#pragma once
+
+enum VtxOptionId {
+  VTX_OPT_GEMM_GLDS = 0,        // 1: bf16 forward-layout GEMMs take the LDS-DMA kernel (gemm_glds.hip); 0: register-staged
+  VTX_OPT_GLDS_BM = 1,          // 0: tile height per launch (glds_pick_bm) | 64 | 128
+  VTX_OPT_GLDS_WAVES = 2,       // 8: 2 x 4 waves per 128-column tile | 4: 2 x 2 waves
+  VTX_OPT_WGRAD_GLDS = 3,       // 1: LDS-DMA + transpose-read weight-gradient kernel; 0: register-staged
+  VTX_OPT_WG_WAVES = 4,         // 8 | 4 waves per weight-gradient workgroup
+  VTX_OPT_WGRAD_BLOCKS = 5,     // split-K target: workgroups per weight-gradient launch (512 = one resident round)
+  VTX_OPT_SATTN = 6,            // 1: ViT fast path sattn_* (D = 64, L <= 224); 0: generic attn_*
+  VTX_OPT_WATTN_FWD_WAVES = 7,  // persistent window-attention forward: resident waves (4096)
+  VTX_OPT_WATTN_BWD_WAVES = 8,  // ... backward (2048)
+  VTX_OPT_SRATTN_WGS = 9,       // PVT spatial-reduction attention: target workgroups (2048)
+  VTX_OPT_WGRAD_FUSED_REDUCE = 10,  // 1: the split-K slabs are summed inside the weight-gradient launch by each tile's
+                                    //    last-arriving workgroup (ticket counter); 0: separate slab_reduce launches
+  VTX_OPT_COUNT = 11
+};
+
+int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip

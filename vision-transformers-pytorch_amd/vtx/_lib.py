@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvtx.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class VtxError(RuntimeError):
@@ -21,6 +21,10 @@ class VtxError(RuntimeError):
 _SIGNATURES = {
     "vtx_strerror": (c_char_p, [c_int]),
     "vtx_abi_version": (c_int, []),
+    "vtx_option_count": (c_int, []),
+    "vtx_option_name": (c_char_p, [c_int]),
+    "vtx_get_option": (c_int, [c_int]),
+    "vtx_set_option": (c_int, [c_int, c_int]),
     "vtx_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                   c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_layernorm_bwd_workspace": (c_size_t, [c_int64, c_int]),
@@ -30,8 +34,14 @@ _SIGNATURES = {
     "vtx_gemm": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                          c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vtx_wgrad_workspace": (c_size_t, [c_int64, c_int, c_int]),
+    "vtx_wgrad_tickets": (c_int, []),
     "vtx_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64,
-                          c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+                          c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "vtx_wgrad_group_max": (c_int, []),
+    "vtx_wgrad_group_ok": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_float]),
+    "vtx_wgrad_group_workspace": (c_size_t, [c_int, c_void_p, c_void_p, c_int64]),
+    "vtx_wgrad_group": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_int, c_float, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "vtx_relpos_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vtx_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -91,7 +91,9 @@ def weight_scope(module, x):
         yield
         return
     plan = module.__dict__.get("_vtx_weight_plan")
-    ids = [id(m) for m in module.modules()]
+    # keyed by the module objects AND their current weight Parameters (load_state_dict(assign=True) / a later
+    # weight_norm replace Parameters without touching the module tree)
+    ids = [(id(m), id(m._parameters.get("weight"))) for m in module.modules()]
     if plan is None or plan[0] != ids:
         plan = (ids, WeightPlan(module))
         module.__dict__["_vtx_weight_plan"] = plan
@@ -132,35 +134,83 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# ------------------------------------------------------------------------------------------- weight gradients off the critical path
-# Consecutive kernels of one HIP stream run strictly one after the other: every launch pays its ramp-up and its
-# partially filled last round (~6 us per GEMM launch here, ~600 launches per step).  The weight-gradient GEMMs of a
-# layer's backward feed nothing downstream in that backward, so they go to a second stream: they fill the CUs the
-# activation-gradient chain leaves idle.  fork = the side stream waits for everything enqueued so far (its operands);
-# join (once per layer, before the gradients are handed back to autograd) = the main stream waits for the side stream.
-_side_streams = {}
-# Off by default: per-kernel durations (bench.py's roofline, rocprofv3) are no longer attributable when two GEMM kernels
-# share the chip -- the dominant kernel's measured TFLOP/s drops by ~28 % while the step gets 1.6 % faster.
-_SIDE = os.environ.get("VTX_SIDE_WGRAD", "0") != "0"
+# ------------------------------------------------------------------------------------------- a layer's weight gradients
+# The weight-gradient GEMMs of a layer's backward feed nothing downstream in that backward.  Two things follow:
+#   * GROUPING: the four of a transformer layer (fc2, fc1, proj, qkv) run as ONE launch (ops.wgrad_group): split-K is
+#     only there to fill the chip, and four problems together need a quarter of the slices of one -- a quarter of the
+#     fp32 slab traffic, and the slab sum happens inside the launch (ticket counters) instead of in 8 more launches;
+#   * SIDE STREAM (opt-in per backward pass: ``deferred_wgrad()``): the grouped launch goes to a second HIP stream and
+#     fills the CUs the activation-gradient chain of the NEXT layers leaves idle (consecutive kernels of one stream run
+#     strictly one after the other: every launch pays its ramp-up and its partly filled last round).  fork = the side
+#     stream waits for everything enqueued so far (its operands); join = ``side_join()`` ONCE, after backward.
+#     That is only correct when nothing on the main stream touches the returned gradients before the join: every
+#     parameter must receive exactly one gradient per backward (no accumulation into an existing .grad, no parameter
+#     shared by two graph nodes) -- vtx.train_step's supervised step guarantees it and opts in; GradAllReduce joins
+#     before it reduces a bucket.  Operands are kept alive until the join (the caching allocator would otherwise hand
+#     their memory to the main stream while the side stream still reads it).  Bitwise identical either way.
+_SIDE_ENABLED = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
+_deferred = False
 
 
-def side_wgrad(dy, x, **kw):
-    if not _SIDE or not dy.is_cuda:
-        return ops.wgrad(dy, x, **kw)
-    dev = dy.device
-    side = _side_streams.get(dev)
-    if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        return ops.wgrad(dy, x, **kw)
+class _SideState:
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.pending = False
+        self.keep = []
 
 
-def side_join(t):
-    if _SIDE and t.is_cuda:
-        side = _side_streams.get(t.device)
-        if side is not None:
-            torch.cuda.current_stream(t.device).wait_stream(side)
+_side_states = {}
+
+
+@contextlib.contextmanager
+def deferred_wgrad(enabled=True):
+    """Within this context (wrap ``loss.backward()``) the layers' grouped weight-gradient launches run on a side stream
+    and are joined once, on exit.  Caller's promise: every parameter gets exactly ONE gradient in this backward and has
+    ``.grad is None`` on entry (see the section comment above)."""
+    global _deferred
+    prev, _deferred = _deferred, bool(enabled) and _SIDE_ENABLED
+    try:
+        yield
+    finally:
+        _deferred = prev
+        side_join()
+
+
+def side_join():
+    """The current stream of every device with outstanding side-stream weight gradients waits for them."""
+    for dev, st in _side_states.items():
+        if st.pending:
+            torch.cuda.current_stream(dev).wait_stream(st.stream)
+            st.pending = False
+            st.keep.clear()
+
+
+def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None):
+    """Weight (and bias) gradients of several linears over the same tokens: jobs = [(dy, x, want_bias, rowscale)].
+    -> [(dW, db)] (+ ``post(result)`` evaluated on the same stream).  One grouped launch when every problem is eligible
+    (bf16, LDS-DMA shapes), else one launch each."""
+    def run():
+        if len(jobs) > 1 and ops.wgrad_group_ok(jobs, rows_per_scale, scale_const):
+            res = ops.wgrad_group(jobs, rows_per_scale, scale_const)
+        else:
+            res = [ops.wgrad(dy, x, want_bias=wb, rowscale=rs, rows_per_scale=rows_per_scale,
+                             scale_const=scale_const if rs is not None else 0.0) for dy, x, wb, rs in jobs]
+        return post(res) if post is not None else res
+
+    dev = jobs[0][0].device
+    # (bench.py's event-sampled steps stay single-stream: with two kernels sharing the chip per-kernel durations are
+    #  not attributable)
+    if not (_deferred and dev.type == "cuda" and not ops.timing()):
+        return run()
+    st = _side_states.get(dev)
+    if st is None:
+        st = _side_states[dev] = _SideState(dev)
+    st.stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(st.stream):
+        res = run()
+    st.keep.append(jobs)
+    st.pending = True
+    return res
 
 
 class LayerNormFn(Function):
@@ -397,19 +447,17 @@ class TransformerLayerFn(Function):
         dy = _c(dy)
         B = x.shape[0]
         # ---- MLP branch
-        dW2, db2 = side_wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
         dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
-        dW1, db1 = side_wgrad(dz, ln2)
         dln2 = dgrad(dz, w1, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
-        dWo, dbo = side_wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
         do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
         dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m, rel_pos)
-        dWq, dbq = side_wgrad(dqkv, ln1)
         dln1 = dgrad(dqkv, wq, T)
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
-        side_join(dx)
+        # ---- the four weight gradients: one grouped launch (dropped samples' rows are skipped, 1/(1-p) on the accumulators)
+        (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, dbq) = layer_wgrads(
+            [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c)
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
 
@@ -578,34 +626,35 @@ class PvtLayerFn(Function):
         r = m.reduction
         dy = _c(dy)
         # ---- MLP branch
-        dW2, db2 = side_wgrad(dy, h, rowscale=s2, rows_per_scale=rps, scale_const=dp_c)
         dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
-        dW1, db1 = side_wgrad(dz, ln2)
         dln2 = dgrad(dz, w1, T)
         dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
-        dWo, dbo = side_wgrad(dx1, o, rowscale=s1, rows_per_scale=rps, scale_const=dp_c)
         do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
         dq, dkv = ops.srattn_bwd(q, kv, o, do, lse, B, L, Lk, m.n_head)
-        dWq, _ = side_wgrad(dq, ln1, want_bias=False)
         dWsr = dbsr = dgs = dbs = None
+        jobs = [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dq, ln1, False, None)]
         if r > 1:
-            dWkv, _ = side_wgrad(dkv, kvin, want_bias=False)
             dkvin = dgrad(dkv, wkv, T)
             dred, dgs, dbs = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach())
-            dWsr, dbsr = side_wgrad(dred, patches)
             dpatches = dgrad(dred, wsr, T)
             dln1 = dgrad(dq, wq, T)
             ops.patchify_bwd(dpatches, dln1, B, m.height, m.width, C, r, m.skip, accumulate=True)
+            co, _, pp, _ = ctx.sr_shape
+
+            def unpermute(res):                                        # (py, px, c) columns back to (c, py, px)
+                (a, _), (b, bb) = res
+                return a, b.view(co, pp, pp, C).permute(0, 3, 1, 2).contiguous(), bb
+            dWkv, dWsr, dbsr = layer_wgrads([(dkv, kvin, False, None), (dred, patches, True, None)], post=unpermute)
         else:
-            dWkv, _ = side_wgrad(dkv, ln1, want_bias=False)
+            jobs.append((dkv, ln1, False, None))
             dkvin = dgrad(dkv, wkv, T)
             dln1 = dgrad(dq, wq, T, resid=dkvin)                       # both consumers of LN1's output
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
-        side_join(dx)
-        if r > 1:                                                      # (after the join: dWsr comes from the side stream)
-            co, _, p, _ = ctx.sr_shape
-            dWsr = dWsr.view(co, p, p, C).permute(0, 3, 1, 2).contiguous()   # (py, px, c) columns back to (c, py, px)
+        res = layer_wgrads(jobs, rps, dp_c)
+        (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, _) = res[:4]
+        if r == 1:
+            dWkv = res[4][0]
         return (dx.view(B, L, C), dg1, dbe1, dWq, dWkv, dWsr, dbsr, dgs, dbs, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2,
                 None, None, None, None)
 

@@ -69,9 +69,11 @@ def plan_batch(n, height, width, mixup, cutmix, erase=None, rng=None, indices=No
         index = k if indices is None else indices[k]
         apply_mixup, apply_cutmix = mixup > 0, cutmix > 0
         partner, mode, wgt, box, label_ratio = k, 0, 1.0, (0, 0, 0, 0), 1
+        if n == 1:                      # a one-image batch has no partner inside the batch (the reference draws its
+            apply_mixup = apply_cutmix = False   # partner from the whole dataset, mix_dataset.py:43-47): leave it unmixed
         if apply_mixup or apply_cutmix:
             partner = k
-            while partner == k:
+            while partner == k:         # partners come from WITHIN the batch
                 partner = rng.randrange(n)
         if apply_mixup and apply_cutmix:
             if index % 2 == 0:

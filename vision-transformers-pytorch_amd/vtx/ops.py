@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, options
 from ._lib import BF16, F32, VtxError, check
 
 
@@ -69,8 +69,9 @@ def layernorm_fwd(x, gamma, beta, eps, merge_hw=None):
         raise VtxError("vtx: layernorm weight/bias size mismatch")
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib.vtx_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
-                                _dt(x), merge, H, W, _stream()), "vtx_layernorm_fwd")
+    with _timed("ln_fwd_kernel", 0.0, 2.0 * rows * C * x.element_size() + 8.0 * rows):
+        check(lib.vtx_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, float(eps),
+                                    _dt(x), merge, H, W, _stream()), "vtx_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -89,9 +90,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, merge_hw=None):
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     wsb = lib.vtx_layernorm_bwd_workspace(rows, C)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    check(lib.vtx_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
-                                _p(dbeta), _p(ws), wsb, rows, C, _dt(x), merge, H, W, _stream()),
-          "vtx_layernorm_bwd")
+    with _timed("ln_bwd_kernel (+colreduce)", 0.0, (3.0 + (dres is not None)) * rows * C * x.element_size() + 8.0 * rows):
+        check(lib.vtx_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
+                                    _p(dbeta), _p(ws), wsb, rows, C, _dt(x), merge, H, W, _stream()),
+              "vtx_layernorm_bwd")
     return dx, dgamma, dbeta
 
 
@@ -128,6 +130,40 @@ class KernelTimer:
 _timer = None
 
 
+class _Timed:
+    """``with _timed(name, flops, bytes):`` -- HIP events around the launches inside, on torch's CURRENT stream (= the
+    stream the kernels are enqueued on), when a KernelTimer is installed; free otherwise."""
+    __slots__ = ("ev",)
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def __enter__(self):
+        if self.ev is not None:
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+        return False
+
+
+_NOT_TIMED = _Timed(None)
+
+
+def _timed(name, flops=0.0, nbytes=0.0):
+    if _timer is None:
+        return _NOT_TIMED
+    return _Timed(_timer.bracket(name, float(flops), float(nbytes)))
+
+
+def timing():
+    """True while a KernelTimer is installed (bench.py's sampled steps run single-stream so that per-kernel durations
+    stay attributable, see functional.side_wgrad)."""
+    return _timer is not None
+
+
 def _attn_bracket(name, nprob, L, D, rows, hd, es, bwd):
     """HIP-event bracket of an attention launch: algorithmic FLOPs 2*2*L^2*D per problem forward (QK^T, PV), 5 products
     backward (S, dP, dV, dQ, dK); algorithmic bytes q,k,v read + o written (forward) / q,k,v,o,do read + dq,dk,dv
@@ -157,16 +193,16 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
     to = "float" if out_f32 else t
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
-        force = os.environ.get("VTX_GLDS_BM")                              # mirrors glds_pick_bm in gemm_glds.hip
-        if force in ("64", "128"):
-            bm = int(force)
+        force = options.get("GLDS_BM")                                     # mirrors glds_pick_bm in gemm_glds.hip
+        if force in (64, 128):
+            bm = force
         elif bn != 128 or K % 64 != 0:
             bm = 64
         else:
             bm = 128 if ((N + 127) // 128) * ((M + 127) // 128) >= 800 else 64
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
-        nwn = 4 if (bn == 128 and os.environ.get("VTX_GLDS_WAVES") != "4") else 2   # mirrors glds_launch_t
+        nwn = 4 if (bn == 128 and options.get("GLDS_WAVES") != 4) else 2   # mirrors glds_launch_t
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2, {nwn}>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
     return f"gemm_kernel<{t}, {to}, 128, {bn}, {ta}, {tb}>"
@@ -208,22 +244,101 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     return (c, aux) if want_aux else c
 
 
-def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.0):
+_tickets = {}
+
+
+def _ticket_buffer(device):
+    """Per (device, stream) int32 ticket counters of the fused split-K reduction (vtx.h: zero on entry, re-armed to zero
+    by the kernel): launches of ONE stream run in order, so they can share a buffer; two streams must not."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(_lib.load().vtx_wgrad_tickets(), dtype=torch.int32, device=device)
+    return t
+
+
+def wgrad_kernel_name(dtype, N, Kin, glds):
+    if glds:
+        return f"wgrad_glds_kernel<64, 2, {4 if options.get('WG_WAVES') == 4 else 8}>"
+    t = "__bf16" if dtype == torch.bfloat16 else "float"
+    bn = 128 if Kin % 128 == 0 else (96 if Kin % 96 == 0 else (64 if Kin <= 64 else 128))
+    return f"gemm_kernel<{t}, float, 128, {bn}, true, true>"
+
+
+def _wgrad_glds_shape(dtype, N, Kin, rowscale, scale_const):
+    return (dtype == torch.bfloat16 and options.get("WGRAD_GLDS") and N % 8 == 0 and Kin % 8 == 0 and N >= 64 and
+            Kin >= 64 and (rowscale is None or scale_const > 0))
+
+
+def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.0, out=None):
     """dW[N,Kin] (fp32), dbias[N] (fp32 or None) from dy[M,N], x[M,Kin].  scale_const > 0: every rowscale value
-    is 0 or scale_const (DropPath), see vtx.h."""
+    is 0 or scale_const (DropPath), see vtx.h.  ``out``: fp32 [N, Kin] destination (e.g. a gradient-bucket view)."""
     _dev(dy, x, rowscale)
     lib = _lib.load()
     N, Kin = dy.shape[-1], x.shape[-1]
     M = dy.numel() // N
     if x.numel() // Kin != M:
         raise VtxError("vtx: wgrad token-count mismatch")
-    dW = torch.empty((N, Kin), dtype=torch.float32, device=x.device)
+    dW = out if out is not None else torch.empty((N, Kin), dtype=torch.float32, device=x.device)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
     wsb = lib.vtx_wgrad_workspace(M, N, Kin)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
-                        int(rows_per_scale), float(scale_const), _p(ws), wsb, _stream()), "vtx_wgrad")
+    glds = _wgrad_glds_shape(x.dtype, N, Kin, rowscale, scale_const)
+    with _timed(wgrad_kernel_name(x.dtype, N, Kin, glds) + " (+split-K reduce)", 2.0 * M * N * Kin,
+                x.element_size() * M * (N + Kin) + 4.0 * N * Kin):
+        check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
+                            int(rows_per_scale), float(scale_const), _p(ws), wsb, _p(_ticket_buffer(x.device)), _stream()),
+              "vtx_wgrad")
     return dW, db
+
+
+def wgrad_group_ok(jobs, rows_per_scale=1, scale_const=0.0):
+    """True when ``jobs`` = [(dy, x, want_bias, rowscale), ...] can run as ONE grouped LDS-DMA weight-gradient launch
+    (bf16, same token count, every shape eligible; mirrors vtx_wgrad_group_ok)."""
+    lib = _lib.load()
+    n = len(jobs)
+    if n < 1 or n > lib.vtx_wgrad_group_max():
+        return False
+    dy0, x0 = jobs[0][0], jobs[0][1]
+    M = dy0.numel() // dy0.shape[-1]
+    for dy, x, _, _ in jobs:
+        if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.numel() // dy.shape[-1] != M or \
+                x.numel() // x.shape[-1] != M:
+            return False
+    Ns = (ctypes.c_int * n)(*[j[0].shape[-1] for j in jobs])
+    Ks = (ctypes.c_int * n)(*[j[1].shape[-1] for j in jobs])
+    has_rs = int(any(j[3] is not None for j in jobs))
+    return bool(lib.vtx_wgrad_group_ok(BF16, n, Ns, Ks, M, has_rs, int(rows_per_scale), float(scale_const)))
+
+
+def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None):
+    """The weight gradients of several linears over the SAME tokens in one launch (csrc/gemm_wgrad_glds.hip):
+    jobs = [(dy [M, N_i], x [M, Kin_i], want_bias, rowscale or None), ...] -> [(dW_i fp32 [N_i, Kin_i], db_i or None)].
+    Split-K partials are summed inside the launch (ticket counters) -- deterministic, fixed slice order."""
+    lib = _lib.load()
+    n = len(jobs)
+    for dy, x, _, rs in jobs:
+        _dev(dy, x, rs)
+    dev = jobs[0][1].device
+    M = jobs[0][0].numel() // jobs[0][0].shape[-1]
+    Nl = [j[0].shape[-1] for j in jobs]
+    Kl = [j[1].shape[-1] for j in jobs]
+    dWs = [outs[i] if outs is not None and outs[i] is not None else
+           torch.empty((Nl[i], Kl[i]), dtype=torch.float32, device=dev) for i in range(n)]
+    dbs = [torch.empty(Nl[i], dtype=torch.float32, device=dev) if jobs[i][2] else None for i in range(n)]
+    Ns, Ks = (ctypes.c_int * n)(*Nl), (ctypes.c_int * n)(*Kl)
+    lds = (ctypes.c_int64 * n)(*Nl)
+    ldx = (ctypes.c_int64 * n)(*Kl)
+    vp = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    wsb = lib.vtx_wgrad_group_workspace(n, Ns, Ks, M)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    flops = sum(2.0 * M * a * b for a, b in zip(Nl, Kl))
+    nbytes = sum(2.0 * M * (a + b) + 4.0 * a * b for a, b in zip(Nl, Kl))
+    with _timed(wgrad_kernel_name(torch.bfloat16, 0, 0, True) + " (+split-K reduce)", flops, nbytes):
+        check(lib.vtx_wgrad_group(BF16, n, vp([j[0] for j in jobs]), vp([j[1] for j in jobs]), vp(dWs), vp(dbs), Ns, Ks,
+                                  lds, ldx, vp([j[3] for j in jobs]), int(rows_per_scale), float(scale_const), M, _p(ws),
+                                  wsb, _p(_ticket_buffer(dev)), _stream()), "vtx_wgrad_group")
+    return list(zip(dWs, dbs))
 
 
 # ------------------------------------------------------------------------------- PVT: spatial-reduction attention
@@ -324,7 +439,8 @@ def grad_sqnorm(grads):
     dev = grads[0].device
     partial = torch.empty(max(nchunks, 1), dtype=torch.float32, device=dev)
     out = torch.empty(2, dtype=torch.float32, device=dev)
-    check(lib.vtx_grad_sqnorm(len(grads), _ptr_array(grads), numel, _p(partial), _p(out), _stream()), "vtx_grad_sqnorm")
+    with _timed("grad_sqnorm_*_kernel", 0.0, 4.0 * sum(g.numel() for g in grads)):
+        check(lib.vtx_grad_sqnorm(len(grads), _ptr_array(grads), numel, _p(partial), _p(out), _stream()), "vtx_grad_sqnorm")
     return out
 
 
@@ -333,10 +449,11 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, lrs, wds, norm, max_norm, bet
     _dev(*params, *grads, *exp_avg, *exp_avg_sq, norm)
     n = len(params)
     numel = (ctypes.c_int64 * n)(*[p.numel() for p in params])
-    check(_lib.load().vtx_adamw_step(n, _ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg),
-                                     _ptr_array(exp_avg_sq), numel, (ctypes.c_float * n)(*lrs),
-                                     (ctypes.c_float * n)(*wds), _p(norm), float(max_norm), float(beta1), float(beta2),
-                                     float(eps), int(t), _stream()), "vtx_adamw_step")
+    with _timed("adamw_step_kernel", 0.0, 28.0 * sum(p.numel() for p in params)):     # p, g, m, v read; p, m, v written
+        check(_lib.load().vtx_adamw_step(n, _ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg),
+                                         _ptr_array(exp_avg_sq), numel, (ctypes.c_float * n)(*lrs),
+                                         (ctypes.c_float * n)(*wds), _p(norm), float(max_norm), float(beta1), float(beta2),
+                                         float(eps), int(t), _stream()), "vtx_adamw_step")
 
 
 def ema_update(targets, sources, momentum):
@@ -345,6 +462,12 @@ def ema_update(targets, sources, momentum):
     n = len(targets)
     if n == 0:
         return
+    if len(sources) != n:
+        raise VtxError("vtx: ema_update needs as many sources as targets")
+    for t, s in zip(targets, sources):
+        if t.dtype != torch.float32 or s.dtype != torch.float32 or t.numel() != s.numel():
+            raise VtxError("vtx: ema_update needs fp32 tensor pairs of equal size "
+                           f"(got {t.dtype} {tuple(t.shape)} / {s.dtype} {tuple(s.shape)})")
     numel = (ctypes.c_int64 * n)(*[t.numel() for t in targets])
     check(_lib.load().vtx_ema_update(n, _ptr_array(targets), _ptr_array(sources), numel, float(momentum), _stream()),
           "vtx_ema_update")
@@ -434,7 +557,8 @@ def cast_desc_bytes():
 def cast_weights(desc, nmat, ntiles, flat, flat_t):
     """Multi-tensor fp32 -> bf16 weight cast (plain + transposed copies), one launch (csrc/cast.hip)."""
     _dev(desc, flat, flat_t)
-    check(_lib.load().vtx_cast_weights(_p(desc), nmat, ntiles, _p(flat), _p(flat_t), _stream()), "vtx_cast_weights")
+    with _timed("cast_weights_kernel", 0.0, 8.0 * flat.numel()):
+        check(_lib.load().vtx_cast_weights(_p(desc), nmat, ntiles, _p(flat), _p(flat_t), _stream()), "vtx_cast_weights")
 
 
 def patch_gather(x_nchw, patch, order, dtype, kp=None):

@@ -49,19 +49,23 @@ class FusedAdamW(torch.optim.Optimizer):
         tensors = self._tensors()
         if not tensors:
             return loss
-        groups = {(g["betas"], g["eps"]) for _, _, _, g in tensors}
-        steps = {float(st["step"]) for _, _, st, _ in tensors}
-        if len(groups) != 1 or len(steps) != 1:
-            raise ops.VtxError("FusedAdamW: all param groups must share betas / eps and the step count")
-        (betas, eps), t = next(iter(groups)), int(next(iter(steps))) + 1
         ps = [p for p, _, _, _ in tensors]
         gs = [g for _, g, _, _ in tensors]
         norm = None
         if max_grad_norm and max_grad_norm > 0:
-            norm = ops.grad_sqnorm(gs)
-        ops.adamw_step(ps, gs, [st["exp_avg"] for _, _, st, _ in tensors], [st["exp_avg_sq"] for _, _, st, _ in tensors],
-                       [float(g["lr"]) for _, _, _, g in tensors], [float(g["weight_decay"]) for _, _, _, g in tensors],
-                       norm, float(max_grad_norm or 0.0), betas[0], betas[1], eps, t)
+            norm = ops.grad_sqnorm(gs)                       # over ALL gradients, whatever their step counts
+        # torch.optim.AdamW keeps a step count PER PARAMETER (a parameter that gets its first gradient late -- DINO's
+        # last layer is frozen during epoch 0, train_dino.py:250 -- starts at step 1 then): one multi-tensor launch per
+        # distinct (betas, eps, step) -- a single one in the steady state
+        by_key = {}
+        for i, (_, _, st, g) in enumerate(tensors):
+            by_key.setdefault((g["betas"], g["eps"], int(st["step"])), []).append(i)
+        for (betas, eps, t0), idx in by_key.items():
+            sel = [tensors[i] for i in idx]
+            ops.adamw_step([ps[i] for i in idx], [gs[i] for i in idx], [st["exp_avg"] for _, _, st, _ in sel],
+                           [st["exp_avg_sq"] for _, _, st, _ in sel], [float(g["lr"]) for _, _, _, g in sel],
+                           [float(g["weight_decay"]) for _, _, _, g in sel], norm, float(max_grad_norm or 0.0),
+                           betas[0], betas[1], eps, t0 + 1)
         for _, _, st, _ in tensors:
             st["step"] += 1
         return norm[1] if norm is not None else loss

@@ -4,12 +4,13 @@ The reference's train.py never ships; this is the harness the benchmark and the 
 Same op order: autocast forward -> MixLoss / grad_accum -> backward (DDP all-reduce overlapped) ->
 clip_grad_norm_ -> optimizer step -> zero_grad(set_to_none).  With ``vtx.optim.FusedAdamW`` clipping + AdamW run as
 two multi-tensor HIP kernels; any torch optimizer works too (clip_grad_norm_ + step()).
-MixLoss is O(B x classes) PyTorch device ops.
+MixLoss is one fused HIP kernel (value + gradient); there is no torch-composed fallback.
 """
 import torch
 from torch import nn
-from torch.nn import functional as F
 
+from . import functional as VF
+from .ops import VtxError
 from .optim import FusedAdamW
 
 
@@ -26,7 +27,7 @@ class _MixLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl.mul_(g.to(dl.dtype)), None, None, None, None
+        return dl * g.to(dl.dtype), None, None, None, None      # (not in place: a second backward must see dl unscaled)
 
 
 class MixLoss(nn.Module):
@@ -38,23 +39,11 @@ class MixLoss(nn.Module):
         self.reduction = reduction
 
     def forward(self, output, target1, target2, interpolation):
-        if output.is_cuda and self.reduction == "mean" and output.dim() == 2 and \
-                output.dtype in (torch.float32, torch.bfloat16):
-            return _MixLossFn.apply(output, target1, target2, interpolation, float(self.eps))   # one HIP kernel
-        n_class = output.shape[-1]
-        output = F.log_softmax(output.float(), -1)
-        true_dist = torch.full_like(output, self.eps / n_class)
-        on = 1 - self.eps + self.eps / n_class
-        true1 = true_dist.scatter(1, target1.unsqueeze(1), on)
-        true2 = true_dist.scatter(1, target2.unsqueeze(1), on)
-        inter = torch.as_tensor(interpolation, device=output.device).unsqueeze(-1)
-        true_dist = inter * true1 + (1 - inter) * true2
-        loss = F.kl_div(output, true_dist.detach(), reduction="sum" if self.reduction != "none" else "none")
-        if self.reduction == "none":
-            return loss.sum(1)
-        if self.reduction == "mean":
-            loss = loss / target1.shape[0]
-        return loss
+        if self.reduction != "mean":
+            raise NotImplementedError("vtx: MixLoss supports reduction='mean' (the reference's train.py setting)")
+        if not output.is_cuda or output.dim() != 2 or output.dtype not in (torch.float32, torch.bfloat16):
+            raise VtxError("vtx: MixLoss needs (B, classes) fp32 / bf16 logits on the GPU (no CPU fallback)")
+        return _MixLossFn.apply(output, target1, target2, interpolation, float(self.eps))   # one HIP kernel
 
 
 def wd_skip(skip_type):
@@ -84,8 +73,10 @@ def make_param_groups(named_parameters, weight_decay, skip_type="vit"):
 
 
 def train_step(model, criterion, optimizer, batch, clip_grad_norm=5.0, autocast_dtype=torch.bfloat16,
-               grad_accum=1, ddp=None):
-    """One micro-step (+ optimizer step).  ``batch`` = (input NCHW fp32, label1, label2, ratio) on the device.
+               grad_accum=1, ddp=None, micro_step=0):
+    """One micro-batch of the reference's loop body (train.py:273-299).  ``batch`` = (input NCHW fp32, label1, label2,
+    ratio) on the device.  Like the reference, clip + optimizer step + zero_grad run only on accumulation boundaries:
+    ``(micro_step + 1) % grad_accum == 0`` (``micro_step`` = the loader index ``i``); in between, gradients accumulate.
 
     ``ddp`` (vtx.ddp.GradAllReduce) overlaps the gradient all-reduce with backward; its ``finish()`` is the
     only synchronisation point before clipping.  Returns the (unsynchronised) loss tensor.
@@ -94,7 +85,13 @@ def train_step(model, criterion, optimizer, batch, clip_grad_norm=5.0, autocast_
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
         out = model(x)
         loss = criterion(out, l1, l2, ratio) / grad_accum
-    loss.backward()
+    # Side-stream weight gradients (functional.deferred_wgrad) need "one gradient per parameter, .grad None on entry":
+    # true for the first micro-batch after zero_grad(set_to_none) of these single-pass models, not while accumulating.
+    fresh = grad_accum == 1 or micro_step % grad_accum == 0
+    with VF.deferred_wgrad(fresh):
+        loss.backward()
+    if (micro_step + 1) % grad_accum != 0:
+        return loss
     if ddp is not None:
         ddp.finish()
     if isinstance(optimizer, FusedAdamW):       # clip + AdamW in two multi-tensor HIP kernels (csrc/optim.hip)
