@@ -7,13 +7,19 @@ of Swin-S 224x224, bf16 autocast, batch 128 per GPU, synthetic data (BASELINE.js
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU; RCCL gradient all-reduce (vtx.ddp) overlapped with backward; weak scaling (per-GPU batch
-fixed).  Rank 0 prints ONE JSON line.  `roofline` = the dominant HIP kernel (MFMA GEMM family) timed with HIP
-events on its launch stream inside the timed region; `cpu_baseline` = the CPU oracle (a port of the reference's
-path, parity-checked against the reference's own outputs) timed on this box's host cores on a bounded sample.
+fixed).  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself
+(re-exec through torch.distributed.run on 127.0.0.1, like the reference's ``dist.launch(main, conf.n_gpu, ...)``,
+train.py:389-396).  Rank 0 prints ONE JSON line.  `roofline` = the HIP kernel with the largest share of the step
+(every launch class is bracketed with HIP events on its launch stream, in every --event-every-th step of the timed
+region; those sampled steps run single-stream so that durations are attributable) + the per-kernel table;
+`cpu_baseline` = the CPU oracle (a port of the reference's path, parity-checked against the reference's own outputs)
+timed on this box's host cores as BASELINE.md section 3 prescribes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,17 +50,21 @@ PEAK_F32_TFLOPS = 157.3                                         # dense fp32 MFM
 def pmc_traffic(model, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (tools/pmc_traffic.sh: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes) -- PMC collection cannot
-    run inside the timed process, so the figure comes from profiles/; None when no summary is committed."""
-    path = os.path.join(REPO, "profiles", f"round1_pmc_traffic_{model}.json")
-    try:
-        tab = json.load(open(path))
-    except OSError:
-        return None, None
-    key = kernel.replace(" ", "")
-    for k, v in tab.items():
-        if k.replace(" ", "") == key:
-            return v["fetch_x2_bytes"] + v["write_bytes"], os.path.relpath(path, REPO)
-    return None, None
+    run inside the timed process, so the figure comes from profiles/ (newest round first) together with the commit
+    the profile was taken at (`_meta.commit` in the file; the kernels may have changed since: compare with HEAD);
+    None when no summary is committed or the kernel is not in it."""
+    for rnd in (2, 1):
+        path = os.path.join(REPO, "profiles", f"round{rnd}_pmc_traffic_{model}.json")
+        try:
+            tab = json.load(open(path))
+        except OSError:
+            continue
+        key = kernel.split(" (+")[0].replace(" ", "")
+        for k, v in tab.items():
+            if k != "_meta" and k.replace(" ", "") == key:
+                return (v["fetch_x2_bytes"] + v["write_bytes"], os.path.relpath(path, REPO),
+                        tab.get("_meta", {}).get("commit"))
+    return None, None, None
 
 
 def build_model(name, drop_path):
@@ -113,41 +123,95 @@ def _cpu_baseline_dino(batch, steps, cores):
                        f"after 1 warm-up ({dt:.1f} s)")
 
 
+def host_cpu():
+    """(physical cores, model name) of this box's host CPU."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    return int(cores or 1), model
+
+
 def cpu_baseline(name, batch, steps):
-    """Reference path restated on the CPU (oracle/, kind 'port'), fp32, fwd + bwd + AdamW, bounded sample."""
+    """the reference path restated on the CPU (oracle/, kind 'port'), fp32, train mode,
+    torch.set_num_threads(physical cores); torch.manual_seed(0); x = randn(batch = 32, 3, 224, 224); 1 warm-up + 3 timed
+    ``model(x).sum().backward()`` iterations (forward + backward, no optimizer)."""
     from oracle import ref_models as M
     from oracle import ref_ops as R
+    cores, cpu_model = host_cpu()
+    torch.set_num_threads(cores)
+    if name == "dino":
+        return cpu_baseline_dino(min(batch, 4), max(1, steps - 1), cores)
     torch.manual_seed(0)
-    cores = torch.get_num_threads()
     model = build_model(name, 0.0)                                      # parameter container only (CPU, never run)
     P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
          if torch.is_floating_point(v)}
-    if name == "dino":
-        return cpu_baseline_dino(batch, steps, cores)
     if name == "swin_s":
         fwd = lambda x: M.swin_forward(P, x, M.SWIN_S)
     elif name == "pvt_small":
         fwd = lambda x: M.pvt_forward(P, x, M.PVT_SMALL)
     else:
         fwd = lambda x: M.vit_forward(P, x, M.VIT_S16, head=lambda f: R.linear(f, P["head.weight"], P["head.bias"]))
-    opt = torch.optim.AdamW(list(P.values()), lr=1e-3, weight_decay=0.05)
+    torch.manual_seed(0)
     x = torch.randn(batch, 3, 224, 224)
-    l1 = torch.randint(0, 1000, (batch,)); l2 = l1.roll(1); ratio = torch.rand(batch)
 
-    def step():
-        loss = R.mix_loss(fwd(x), l1, l2, ratio, 0.1)
-        loss.backward()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
+    def it():
+        t = time.perf_counter()
+        fwd(x).sum().backward()
+        for p in P.values():
+            p.grad = None
+        return time.perf_counter() - t
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, kind="port",
-                sample=f"{name} fwd+bwd+AdamW fp32 on CPU oracle, batch {batch}, {steps} timed steps after 1 warm-up "
-                       f"({dt:.1f} s)")
+    warm = it()
+    if warm > 75.0:                      # bound the sample: one timed iteration when a single one already takes > 75 s
+        steps = 1
+    ts = [it() for _ in range(steps)]
+    dt = sum(ts)
+    return dict(value=round(batch * steps / dt, 3), unit="images/sec", cores=cores, cpu_model=cpu_model, kind="port",
+                sample=f"{name} model(x).sum().backward() fp32 on the CPU oracle, x = randn({batch}, 3, 224, 224), "
+                       f"{steps} timed iterations after 1 warm-up ({warm:.1f} s warm-up, {dt:.1f} s timed), "
+                       f"torch.set_num_threads({cores})")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks through torch.distributed.run on
+    127.0.0.1 (one process per GPU) and pass this process's arguments through -- what the reference's
+    dist.launch(main, conf.n_gpu, ...) (train.py:389-396) does with spawn."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def selftest_launch(rank, world):
+    """--selftest-launch: the launcher / rendezvous plumbing only (gloo, CPU): every rank contributes rank + 1 to an
+    all-reduce; rank 0 prints the observed world size and the sum.  Used by tests/test_ddp_gloo.py."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        t, seen = torch.tensor([1.0]), 1
+    if rank == 0:
+        print(json.dumps({"selftest_launch": True, "world_size_observed": seen, "sum": t.item()}))
 
 
 def main():
@@ -161,24 +225,32 @@ def main():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--event-every", type=int, default=8,
-                    help="HIP-event brackets around the GEMM / attention launches in every N-th timed step (each bracket "
-                         "costs ~2 us of stream time: on all ~1000 launches of a step that is ~8 %% of the step)")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="HIP-event brackets around every kernel launch in every N-th timed step; 0 (default): only in the "
+                         "first timed step.  A sampled step runs single-stream and each bracket costs ~2 us of stream "
+                         "time (~600 launches: the sampled step is ~15 %% slower than the others; it is inside the timed "
+                         "region and counted in `value`)")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--selftest-launch", action="store_true", help="launcher plumbing only (gloo on CPU, no model)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                     # never returns
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if args.selftest_launch:
+        return selftest_launch(rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from vtx import functional as VF
     from vtx import ops
     from vtx.ddp import GradAllReduce
     from vtx.train_step import MixLoss, make_param_groups, train_step
@@ -194,6 +266,7 @@ def main():
     ddp = GradAllReduce(model)
     ac = torch.bfloat16 if args.dtype == "bf16" else None
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    torch.manual_seed(4242 + rank)             # DropPath masks differ per rank from here on (the model is already built)
 
     def make_opt(groups, lr):
         if args.optimizer == "fused":
@@ -242,13 +315,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_events = []
     for i in range(args.steps):
-        sampled = timer is not None and i % max(1, args.event_every) == 0
+        sampled = timer is not None and (i % args.event_every == 0 if args.event_every > 0 else i == 0)
         if sampled:                                   # inside the timed region, on the launch stream
             ops.set_kernel_timer(timer)
             nsampled += 1
+            step_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            step_events[-1][0].record()
         loss = step()
         if sampled:
+            step_events[-1][1].record()
             ops.set_kernel_timer(None)
     torch.cuda.synchronize()
     if world > 1:
@@ -267,31 +344,42 @@ def main():
         roof = None
         if timer is not None:
             allk = timer.summary()
-            attn = {k: v for k, v in allk.items() if "attn" in k}
-            summ = {k: v for k, v in allk.items() if "attn" not in k}
-            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
             peak = PEAK_BF16_TFLOPS if ac else PEAK_F32_TFLOPS
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic(args.model, name)
-            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 4), traffic=traffic, traffic_source=tsrc,
+            sampled_ms = sum(a.elapsed_time(b) for a, b in step_events) / nsampled
+
+            def row(k, v):
+                sec = v["ms"] * 1e-3
+                r = dict(launches_per_step=round(v["launches"] / nsampled, 1), ms_per_step=round(v["ms"] / nsampled, 3),
+                         avg_launch_us=round(1e3 * v["ms"] / v["launches"], 2),
+                         hbm_gbps_algorithmic=round(v["bytes"] / sec / 1e9, 1),
+                         frac_hbm=round(v["bytes"] / sec / 1e12 / PEAK_HBM_TBPS, 4))
+                if v["flops"] > 0:
+                    r.update(tflops=round(v["flops"] / sec / 1e12, 1), frac_mfma=round(v["flops"] / sec / 1e12 / peak, 4),
+                             # what the kernel's own algorithmic intensity (FLOP per HBM byte, scores on chip) allows
+                             hbm_bound_tflops=round(v["flops"] / v["bytes"] * PEAK_HBM_TBPS, 1))
+                return r
+
+            table = {k: row(k, v) for k, v in sorted(allk.items(), key=lambda kv: -kv[1]["ms"])}
+            name, d = max(allk.items(), key=lambda kv: kv[1]["ms"])
+            traffic, tsrc, tcommit = pmc_traffic(args.model, name)
+            # MFMA-bound when the kernel's algorithmic intensity exceeds the machine balance (2.5 PF / 8 TB/s = 312 FLOP/B)
+            mfma = d["flops"] > 0 and ("attn" not in name) and d["flops"] / d["bytes"] >= 0.5 * peak / PEAK_HBM_TBPS
+            if mfma:
+                ach, unit, pk = d["flops"] / (d["ms"] * 1e-3) / 1e12, "TFLOP/s", peak
+            else:
+                ach, unit, pk = d["bytes"] / (d["ms"] * 1e-3) / 1e9, "GB/s", PEAK_HBM_TBPS * 1e3
+            roof = dict(bound="mfma" if mfma else "hbm", kernel=name, achieved=round(ach, 2), peak=pk, unit=unit,
+                        frac=round(ach / pk, 4), traffic=traffic, traffic_source=tsrc, traffic_profile_commit=tcommit,
                         algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
                         algorithmic_flops_per_launch=round(d["flops"] / d["launches"]),
-                        launches_per_step=d["launches"] // nsampled, event_sampled_steps=nsampled,
+                        launches_per_step=round(d["launches"] / nsampled, 1), event_sampled_steps=nsampled,
                         avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
-                        hbm_gbps_algorithmic=round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
-                        gemm_family={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                                             ms_per_step=round(v["ms"] / nsampled, 3)) for k, v in summ.items()},
                         end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[args.model] / 1e3 / peak, 4),
-                        # the north star's attention sub-figure: these kernels keep the scores on chip, so their
-                        # algorithmic intensity (FLOP per HBM byte of q,k,v,o) caps them at hbm_bound_tflops, far
-                        # below the MFMA peak -- frac_of_hbm_bound is the meaningful fraction
-                        attention={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                                           frac_mfma=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 4),
-                                           hbm_gbps_algorithmic=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                           hbm_bound_tflops=round(v["flops"] / v["bytes"] * PEAK_HBM_TBPS, 1),
-                                           frac_of_hbm_bound=round(v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
-                                           ms_per_step=round(v["ms"] / nsampled, 3)) for k, v in attn.items()})
+                        # every launch class of the step (HIP events on the launch stream, sampled steps are
+                        # single-stream): coverage = sum of the table / GPU time of the sampled steps
+                        sampled_step_ms=round(sampled_ms, 3),
+                        kernels_coverage=round(sum(v["ms"] for v in allk.values()) / nsampled / sampled_ms, 4),
+                        kernels=table)
         line = {
             "metric": "images/sec training (fwd+bwd+step)", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -299,6 +387,9 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if ac else "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": batch * world, "parallelism": f"dp{world}"},
+            "world_size_observed": dist.get_world_size() if world > 1 else 1,
+            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 else None,
+            "side_stream_wgrad": bool(VF._SIDE_ENABLED),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -125,3 +125,25 @@ def test_bucket_assignment_sizes():
     assert b[0].numel * 4 <= 100 or len(b[0].params) == 1
     for bb in b[1:]:
         assert bb.numel * 4 <= 10_000 or len(bb.params) == 1
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher must start 2 ranks itself (re-exec through torch.distributed.run
+    on 127.0.0.1, like the reference's dist.launch(main, conf.n_gpu, ...), train.py:389-396) -- the command the
+    round-end driver uses.  --selftest-launch runs the rendezvous plumbing only (gloo on CPU, no model)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--selftest-launch"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world_size_observed"] == 2 and out["sum"] == 3.0
+    # launcher and flag disagreeing is an error, not a silent 1-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                        capture_output=True, text=True, timeout=120, env=env2)
+    assert r2.returncode != 0 and "disagree" in (r2.stderr + r2.stdout)

@@ -135,3 +135,91 @@ def test_dino_step_gradients_and_train_step():
     s_last = dict(student.named_parameters())["head.last.weight_v"]
     assert torch.equal(s_last, dict(s2.named_parameters())["head.last.weight_v"]), \
         "epoch < freeze_last_layer: the last layer must not move (cancel_last_layer_grad, train_util.py:25-31)"
+
+
+def test_dino_freeze_boundary_with_fused_adamw():
+    """epoch 0 -> 1 with freeze_last_layer = 1: the last layer's weight_v gets its first gradient one epoch late, i.e.
+    enters the optimizer at step 1 while every other parameter is at step 3 (torch.optim.AdamW keeps per-parameter
+    step counts; FusedAdamW must too) -- compared with the same steps driven by torch.optim.AdamW."""
+    from models.vit import dino
+    from vtx.dino import DINOLoss, dino_train_step
+    from vtx.optim import FusedAdamW
+    d = dev()
+    kw = dict(image_size=224, window_size=16, depth=1, dim=384, n_head=6, dim_ff=768, dropout=0.0, drop_attn=0.0,
+              drop_ff=0.0, drop_path=0.0, dim_head_out=1024, norm_last_layer=False)
+    gen = torch.Generator().manual_seed(3)
+    crops = [torch.randn(2, 3, 224, 224, generator=gen).to(d) for _ in range(2)] + \
+            [torch.randn(2, 3, 96, 96, generator=gen).to(d) for _ in range(2)]
+
+    def run(fused):
+        torch.manual_seed(4)
+        student = dino(**kw).to(d).train()
+        teacher = dino(**kw).to(d).train()
+        teacher.load_state_dict(student.state_dict())
+        for p in teacher.parameters():
+            p.requires_grad = False
+        crit = DINOLoss(1024, 4, 0.04, 0.07, 30, 100).to(d)
+        opt = (FusedAdamW if fused else torch.optim.AdamW)(student.parameters(), lr=1e-4, weight_decay=0.04)
+        for epoch in (0, 0, 1, 1):
+            loss = dino_train_step(student, teacher, crit, opt, crops, epoch=epoch, momentum=0.99, clip_grad_norm=3.0,
+                                   freeze_last_layer=1, autocast_dtype=None)
+        assert torch.isfinite(loss).item()
+        steps = {n: int(opt.state[p]["step"]) for n, p in student.named_parameters()}
+        return steps, {n: p.detach().clone() for n, p in student.named_parameters()}
+
+    steps_f, pf = run(True)
+    steps_t, pt = run(False)
+    assert steps_f == steps_t and steps_f["head.last.weight_v"] == 2 and max(steps_f.values()) == 4
+    num = den = 0.0
+    for n in pf:
+        num += (pf[n].double() - pt[n].double()).norm().item() ** 2
+        den += pt[n].double().norm().item() ** 2
+    assert report("dino freeze boundary: parameters after 4 steps, fused vs torch AdamW", (num / den) ** 0.5, 1e-5)
+
+
+def test_dino_bf16_step_at_the_configured_shape_vs_fp32_oracle():
+    """config/dino_deit-s-16.conf:1-19 as configured (DeiT-S/16 depth 12, head 384-2048-2048-256-65536, 2 x 224^2 + 8 x
+    96^2 crops) at B = 1 under bf16 autocast, against the fp32 CPU oracle on the same seeded weights and crops: student
+    logits, loss and the all-parameter student gradient.  Tolerances = 2 x the bf16 whole-model band measured for ViT-S/16
+    (logits 1e-2, gradients 1.1e-2)."""
+    from models.vit import dino
+    from oracle import ref_models as M
+    from vtx.dino import DINOLoss
+    d = dev()
+    torch.manual_seed(6)
+    student = dino(image_size=224, window_size=16, depth=12, dim=384, n_head=6, dim_ff=1536, dropout=0.0, drop_attn=0.0,
+                   drop_ff=0.0, drop_path=0.0, dim_head_out=65536, use_bn=False, norm_last_layer=False, depth_head=3,
+                   dim_head_ff=2048, dim_head_bottleneck=256)
+    sd = {k: v.detach().clone() for k, v in student.state_dict().items() if torch.is_floating_point(v)}
+    student.to(d).train()
+    gen = torch.Generator().manual_seed(7)
+    crops = [torch.randn(1, 3, 224, 224, generator=gen) for _ in range(2)] + \
+            [torch.randn(1, 3, 96, 96, generator=gen) for _ in range(8)]
+    center = torch.randn(1, 65536, generator=gen) * 0.1
+    crit = DINOLoss(65536, 10, 0.04, 0.07, 30, 300).to(d)
+    crit.center.copy_(center)
+    dcrops = [c.to(d) for c in crops]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad():
+            tout = student(dcrops[:2])                 # teacher = the same weights (what train_dino.py starts from)
+        sout = student(dcrops)
+        loss = crit(sout, tout, 1)
+    loss.backward()
+    # fp32 oracle
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hp = lambda D: {k[len("head."):]: v for k, v in D.items() if k.startswith("head.")}
+    fwd = lambda D, cs: M.vit_forward(D, cs, M.VIT_S16, head=lambda f: R.dino_head(f, hp(D)))
+    with torch.no_grad():
+        rt = fwd(P, crops[:2])
+    rs = fwd(P, crops)
+    rl = R.dino_loss(rs, rt, center, 10, 0.1, crit.teacher_temperature_schedule[1])
+    names = [n for n, _ in student.named_parameters()]
+    rg = torch.autograd.grad(rl, [P[n] for n in names])
+    check("dino cfg-5 bf16 student logits vs fp32 oracle", sout.float(), rs, 2e-2)
+    assert report("dino cfg-5 bf16 loss vs fp32 oracle", abs(loss.item() - rl.item()) / abs(rl.item()), 1e-2)
+    num = den = 0.0
+    for n, r in zip(names, rg):
+        gp = dict(student.named_parameters())[n].grad.double().cpu()
+        num += (gp - r.double()).norm().item() ** 2
+        den += r.double().norm().item() ** 2
+    assert report("dino cfg-5 bf16 all-parameter student gradient rel-L2 vs fp32 oracle", (num / den) ** 0.5, 2.5e-2)

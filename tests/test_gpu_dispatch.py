@@ -1,0 +1,266 @@
+"""-m gpu: parity AT THE BENCHMARK'S OWN DISPATCH.
+
+The small-shape kernel tests never reach the kernel variants the headline numbers run on: ``glds_pick_bm`` chooses the
+128 x 128 x 64 2 x 4-wave LDS-DMA GEMM only for launches with >= 800 such tiles, the grouped weight-gradient launch
+only splits 4-ways at the real token counts, the persistent window-attention loop runs > 1 round per wave only with
+thousands of windows per head.  Here the exact launches of bench.py (Swin-S B = 128 / ViT-S/16 B = 256, bf16) are
+compared with the fp64 CPU oracle, and every dispatch switch (vtx.options) is flipped in-process to check that the
+variants agree BIT FOR BIT where they must (same summation order per output element).
+
+Tolerances as in gpu_util.TOL: bf16-stored outputs 4e-3 (one bf16 rounding of an fp64-exact value), fp32 gradient
+outputs 2e-5.
+"""
+import pytest
+import torch
+
+from gpu_util import TOL, check, dev
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _mk(shape, seed, dtype, scale=1.0, device="cpu"):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=device) * scale).to(dtype)
+
+
+def _mm64(a, b_t):
+    """a [M, K] @ b_t [N, K]^T in fp64 on the CPU (the oracle of every GEMM here)."""
+    return a.double() @ b_t.double().t()
+
+
+BIG128 = "gemm_glds_kernel<128, 128, 64, 2, 4>"
+
+
+# ------------------------------------------------------------------ the 128-row LDS-DMA GEMM with every fused epilogue
+@pytest.mark.parametrize("M,N,K,T", [(25088, 1536, 384, 196),      # Swin-S stage-3 fc1 / fc2-dgrad, B = 128
+                                     (50432, 1536, 384, 197),      # ViT-S/16 fc1 / fc2-dgrad, B = 256
+                                     (100352, 768, 192, 784)])     # Swin-S stage-2 fc1 / fc2-dgrad
+def test_glds128_silu_and_dsilu_epilogues_vs_oracle(M, N, K, T):
+    from vtx import ops
+    d = dev()
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128, "this shape must dispatch to the benchmark's kernel"
+    x = _mk((M, K), 101, BF)
+    w1 = _mk((N, K), 102, BF, 0.05)
+    b1 = _mk((N,), 103, torch.float32, 0.1)
+    # forward: z = x W1^T + b1 (saved), h = silu(rounded z)
+    h, z = ops.gemm(x.to(d), w1.to(d), 0, bias=b1.to(d), act=ops.ACT_SILU, want_aux=True)
+    zr = _mm64(x, w1) + b1.double()
+    check(f"glds128 fc1 z {M}x{N}x{K}", z, zr, TOL[BF]["out"])
+    zq = z.cpu().double()
+    check(f"glds128 fc1 silu(z) {M}x{N}x{K}", h, R.silu(zq), TOL[BF]["out"])
+    del zr
+    # backward of fc2 through DropPath and SiLU: dz = s[row] * (dy W2) * silu'(z)  -- N, K as above (the transposed problem)
+    B = M // T
+    keep = (torch.rand(B, generator=torch.Generator().manual_seed(104)) < 0.8).float() / 0.8
+    dy = _mk((M, K), 105, BF)
+    w2t = _mk((N, K), 106, BF, 0.05)              # the transposed weight copy [in = N][out = K] the dgrad kernel reads
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    dz = ops.gemm(dy.to(d), w2t.to(d), 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep.to(d), rows_per_scale=T)
+    s = torch.sigmoid(zq)
+    dzr = keep.double().repeat_interleave(T)[:, None] * _mm64(dy, w2t) * (s * (1 + zq * (1 - s)))
+    check(f"glds128 fc2-dgrad dsilu+droppath {M}x{N}x{K}", dz, dzr, TOL[BF]["out"])
+
+
+@pytest.mark.parametrize("M,N,K,T", [(50432, 384, 1536, 197),      # ViT-S/16 fc2 + DropPath + residual, B = 256
+                                     (50432, 384, 384, 197)])      # ViT-S/16 attention projection
+def test_glds128_droppath_residual_epilogue_vs_oracle(M, N, K, T):
+    from vtx import ops
+    d = dev()
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    hh = _mk((M, K), 111, BF)
+    w = _mk((N, K), 112, BF, 0.05)
+    b = _mk((N,), 113, torch.float32, 0.1)
+    res = _mk((M, N), 114, BF)
+    keep = (torch.rand(M // T, generator=torch.Generator().manual_seed(115)) < 0.9).float() / 0.9
+    y = ops.gemm(hh.to(d), w.to(d), 0, bias=b.to(d), resid=res.to(d), rowscale=keep.to(d), rows_per_scale=T)
+    yr = res.double() + keep.double().repeat_interleave(T)[:, None] * (_mm64(hh, w) + b.double())
+    check(f"glds128 bias+droppath+residual {M}x{N}x{K}", y, yr, TOL[BF]["out"])
+
+
+def test_glds_tile_and_wave_variants_are_bitwise_identical():
+    """64- vs 128-row tiles and 2 x 2 vs 2 x 4 waves only change which wave owns an output element, not the order its
+    products are summed in: the three epilogues must agree bit for bit."""
+    from vtx import ops, options
+    d = dev()
+    M, N, K, T = 25088, 1536, 384, 196
+    x, w, b = _mk((M, K), 121, BF, device=d), _mk((N, K), 122, BF, 0.05, device=d), _mk((N,), 123, torch.float32, 0.1, device=d)
+    dy, res = _mk((M, K), 124, BF, device=d), _mk((M, N), 125, BF, device=d)
+    keep = ((torch.rand(M // T, device=d) < 0.8).float() / 0.8)
+
+    def run():
+        h, z = ops.gemm(x, w, 0, bias=b, act=ops.ACT_SILU, want_aux=True)
+        dz = ops.gemm(dy, w, 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep, rows_per_scale=T)
+        y = ops.gemm(x, w, 0, bias=b, resid=res, rowscale=keep, rows_per_scale=T)
+        return h, z, dz, y
+
+    base = run()
+    for kw in (dict(GLDS_BM=64), dict(GLDS_BM=128), dict(GLDS_BM=128, GLDS_WAVES=4), dict(GLDS_BM=64, GLDS_WAVES=4)):
+        with options.override(**kw):
+            assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) != BIG128 or kw == dict(GLDS_BM=128)
+            got = run()
+        for a, g, name in zip(base, got, ("h", "z", "dz", "y")):
+            assert torch.equal(a, g), f"{name} differs under {kw}"
+
+
+# ------------------------------------------------------------------ weight gradients at the real token counts
+def _wgrad_ref(dy, x, keep, T, c):
+    m = None if keep is None else (keep > 0).double().repeat_interleave(T)[:, None]
+    dyd = dy.double() if m is None else m * dy.double()
+    sc = 1.0 if keep is None else c
+    return sc * (dyd.t() @ x.double()), sc * dyd.sum(0)
+
+
+@pytest.mark.parametrize("B,T,N,Kin", [(128, 3136, 96, 384),       # Swin-S stage-1 fc2: 401 408 tokens
+                                       (128, 196, 384, 1536),      # stage-3 fc2: 25 088 tokens
+                                       (128, 196, 1536, 384)])     # stage-3 fc1 (no DropPath on its dy)
+def test_wgrad_through_droppath_at_benchmark_size(B, T, N, Kin):
+    from vtx import ops
+    d = dev()
+    M = B * T
+    dy, x = _mk((M, N), 131, BF), _mk((M, Kin), 132, BF)
+    c = 1.0 / 0.7
+    keep = (torch.rand(B, generator=torch.Generator().manual_seed(133)) < 0.7).float() * c
+    use = None if N == 1536 else keep
+    assert ops.wgrad_kernel_name(BF, N, Kin, True) == "wgrad_glds_kernel<64, 2, 8>"
+    dW, db = ops.wgrad(dy.to(d), x.to(d), rowscale=None if use is None else use.to(d), rows_per_scale=T,
+                       scale_const=c if use is not None else 0.0)
+    rW, rb = _wgrad_ref(dy, x, use, T, c)
+    check(f"wgrad dW {M}x{N}x{Kin}", dW, rW, 2e-5)
+    check(f"wgrad db {M}x{N}x{Kin}", db, rb, 2e-5)
+
+
+def _layer_jobs(B, T, C, ff, d, seed=140):
+    M = B * T
+    c = 1.0 / 0.7
+    g = torch.Generator().manual_seed(seed)
+    s1 = ((torch.rand(B, generator=g) < 0.7).float() * c)
+    s2 = ((torch.rand(B, generator=g) < 0.7).float() * c)
+    mk = lambda n, k: _mk((M, n), seed + k, BF)
+    dy, h, dz, ln2, dx1, o, dqkv, ln1 = mk(C, 1), mk(ff, 2), mk(ff, 3), mk(C, 4), mk(C, 5), mk(C, 6), mk(3 * C, 7), mk(C, 8)
+    cpu = [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)]
+    gpu = [(a.to(d), b.to(d), wb, None if s is None else s.to(d)) for a, b, wb, s in cpu]
+    return cpu, gpu, c
+
+
+@pytest.mark.parametrize("B,T,C,ff", [(128, 196, 384, 1536),       # Swin-S stage 3 (18 of the 24 layers): 108 tiles x 4 slices
+                                      (128, 3136, 96, 384),        # stage 1: ragged 96-wide tiles, 51 slices
+                                      (256, 197, 384, 1536)])      # ViT-S/16 B = 256
+def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
+    """The grouped launch of a layer's four weight gradients (fc2 and proj through DropPath) vs fp64; fused in-launch
+    split-K reduction vs separate reduce launches: bit-identical; 8 vs 4 waves: dW bit-identical; rerun: bit-identical
+    (deterministic), including the re-armed ticket counters."""
+    from vtx import ops, options
+    d = dev()
+    cpu, gpu, c = _layer_jobs(B, T, C, ff, d)
+    assert ops.wgrad_group_ok(gpu, T, c)
+    res = ops.wgrad_group(gpu, T, c)
+    for (dy, x, _, s), (dW, db), name in zip(cpu, res, ("fc2", "fc1", "proj", "qkv")):
+        rW, rb = _wgrad_ref(dy, x, s, T, c)
+        check(f"grouped wgrad dW {name} B{B} T{T} C{C}", dW, rW, 2e-5)
+        check(f"grouped wgrad db {name} B{B} T{T} C{C}", db, rb, 2e-5)
+    again = ops.wgrad_group(gpu, T, c)
+    with options.override(WGRAD_FUSED_REDUCE=0):
+        sep = ops.wgrad_group(gpu, T, c)
+    with options.override(WG_WAVES=4):
+        w4 = ops.wgrad_group(gpu, T, c)
+    for other, what in ((again, "rerun"), (sep, "separate reduce launches")):
+        for (a, ab), (g, gb) in zip(res, other):
+            assert torch.equal(a, g) and torch.equal(ab, gb), f"grouped wgrad differs: {what}"
+    # 4 waves: every dW element is summed in the same order (bit-identical); the bias gradient's row groups are
+    # 16 instead of 32 per workgroup, i.e. a different (still fixed) summation order
+    for (a, ab), (g, gb) in zip(res, w4):
+        assert torch.equal(a, g), "grouped wgrad dW differs with 4 waves"
+        check("grouped wgrad db, 4 vs 8 waves", gb, ab, 2e-6)
+    assert int(ops._ticket_buffer(d).abs().sum().item()) == 0, "ticket counters must be re-armed to zero"
+
+
+def test_single_wgrad_fused_reduce_is_bitwise_the_separate_reduce():
+    from vtx import ops, options
+    d = dev()
+    dy, x = _mk((25088, 1152), 151, BF, device=d), _mk((25088, 384), 152, BF, device=d)
+    a = ops.wgrad(dy, x)
+    with options.override(WGRAD_FUSED_REDUCE=0):
+        b = ops.wgrad(dy, x)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------ persistent window attention at B = 128
+@pytest.mark.parametrize("H,nH,shift", [(56, 3, True), (56, 3, False), (14, 12, True)])
+def test_window_attention_at_benchmark_batch(H, nH, shift):
+    """B = 128: 8 192 (image, window) pairs per head at stage 1 (> 1 problem per persistent wave, several rounds), 512 at
+    stage 3 -- forward, dqkv and the rel_pos gradient vs the fp64 oracle."""
+    from oracle import tables
+    from vtx import ops
+    from vtx.tables import mask_regions
+    d = dev()
+    B, D, win = 128, 32, 7
+    L, ntab = win * win, (2 * win - 1) ** 2
+    qkv = _mk((B, H, H, 3 * nH * D), 161, BF)
+    do = _mk((B, H, H, nH * D), 162, BF)
+    rel = _mk((ntab, nH), 163, torch.float32, 0.5)
+    pos_np, mask_np = tables.make_pos_mask((H, H), win, shift)
+    pos = torch.from_numpy(pos_np).to(d)
+    region = None
+    if shift:
+        region, ok = mask_regions(torch.from_numpy(mask_np).to(d))
+        assert ok
+    swin = (H, H, win, shift)
+    qd, dod, reld = qkv.to(d), do.to(d), rel.to(d)
+    o, lse = ops.wattn_fwd(qd, reld, pos, region, B, L, nH, swin)
+    dqkv, drel = ops.wattn_bwd(qd, o, dod, lse, reld, pos, region, B, L, nH, swin, ntab)
+    dqkv2, drel2 = ops.wattn_bwd(qd, o, dod, lse, reld, pos, region, B, L, nH, swin, ntab)
+    assert torch.equal(drel, drel2) and torch.equal(dqkv, dqkv2), "not deterministic"
+    # oracle in chunks of 16 images (fp64 autograd over the full batch would hold ~10 GB of scores at stage 1)
+    orf, dqr = [], []
+    drr = torch.zeros(ntab, nH, dtype=torch.float64)
+    for i in range(0, B, 16):
+        qr = qkv[i:i + 16].double().requires_grad_(True)
+        rr = rel.double().requires_grad_(True)
+        oo = R.window_attention_core(qr, rr, nH, D, win, shift)
+        gq, gr = torch.autograd.grad(oo, [qr, rr], do[i:i + 16].double())
+        orf.append(oo.detach()); dqr.append(gq); drr += gr
+    tag = f"B128 {H}x{H} h{nH} s{int(shift)}"
+    check(f"wattn fwd {tag}", o, torch.cat(orf), TOL[BF]["out"] * 1.5)
+    check(f"wattn dqkv {tag}", dqkv, torch.cat(dqr), 1e-2)
+    check(f"wattn drel_pos {tag}", drel, drr, 1e-2)
+
+
+# ------------------------------------------------------------------ side-stream (deferred) weight gradients
+def test_train_step_side_stream_wgrads_are_bitwise_the_single_stream_step():
+    """vtx.train_step runs the layers' grouped weight gradients on a second HIP stream, joined once after backward; the
+    parameters after two steps must equal those of the single-stream run bit for bit (every kernel is deterministic,
+    the event graph fixes all cross-stream orderings)."""
+    from models import SwinTransformer
+    from vtx import functional as VF
+    from vtx.optim import FusedAdamW
+    from vtx.train_step import MixLoss, make_param_groups, train_step
+    d = dev()
+    cfg = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 2, 2), dims=(96, 192, 384, 768), dim_head=32,
+               n_heads=(3, 6, 12, 24), dim_ffs=(384, 768, 1536, 3072), window_size=7, drop_path=0.2)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 3, 224, 224, generator=gen).to(d)
+    l1 = torch.randint(0, 1000, (16,), generator=gen).to(d)
+    batch = (x, l1, l1.roll(1), torch.rand(16, generator=gen).to(d))
+
+    def run(side):
+        torch.manual_seed(0)
+        model = SwinTransformer(**cfg).to(d).train()
+        opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3)
+        old = VF._SIDE_ENABLED
+        VF._SIDE_ENABLED = side
+        try:
+            torch.manual_seed(1)                      # DropPath masks
+            for _ in range(2):
+                loss = train_step(model, MixLoss(0.1), opt, batch, clip_grad_norm=5.0)
+        finally:
+            VF._SIDE_ENABLED = old
+        torch.cuda.synchronize()
+        return loss, [p.detach().clone() for p in model.parameters()]
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert torch.equal(la, lb)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a, b), f"parameter {i} differs between the side-stream and the single-stream step"

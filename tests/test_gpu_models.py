@@ -4,8 +4,8 @@ Tolerances (relative L2 unless noted):
   fp32 mode  logits 1e-4, sampled grads / per-parameter grad norms 2e-3  (north_star: 1e-3 on logits/grads;
              the reference's OWN fp32-vs-fp64 noise on the deepest gradients is ~6e-4, see
              tests/test_oracle_models.py, so grads are compared against the fp64 reference run)
-  bf16 mode  checked against the fp32 CPU oracle on a seeded default-init model (logits 3e-2, gradients 6e-2,
-             see _bf16_vs_oracle).  The formula-weight goldens are NOT used for bf16: that network is
+  bf16 mode  checked against the fp32 CPU oracle on a seeded default-init model (logits 1.5e-2, gradients 2e-2 =
+             at most 2 x what is measured, see _bf16_vs_oracle).  The formula-weight goldens are NOT used for bf16: that network is
              deliberately ill-conditioned and the reference's own CPU bf16-autocast run is 21-30 % off on its
              logits (measured in the authoring container), so it pins nothing at bf16 precision
 """
@@ -96,9 +96,10 @@ def _seeded_init(model, seed):
 def _bf16_vs_oracle(model, oracle_fwd, sd, x, what):
     """HIP path under bf16 autocast vs the fp32 CPU oracle on the SAME seeded weights / inputs.
 
-    Whole-model bf16 tolerances: logits 3e-2 (the reference's own bf16-autocast-vs-fp64 band on a
-    default-init model is 8e-3..9.5e-3); gradients: relative L2 of the concatenation of all
-    parameter gradients <= 6e-2 and median per-parameter relative L2 <= 6e-2.
+    Whole-model bf16 tolerances: logits 1.5e-2 (measured 6.7e-3 Swin-S / 9.4e-3 ViT-S/16; the reference's own
+    bf16-autocast-vs-fp64 band on a default-init model is 8e-3..9.5e-3); gradients: relative L2 of the
+    concatenation of all parameter gradients <= 2e-2 (measured 7.7e-3 / 1.1e-2) and median per-parameter relative
+    L2 <= 2e-2 -- a regression that doubles the bf16 error fails.
     """
     model.to(dev()).train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -106,7 +107,7 @@ def _bf16_vs_oracle(model, oracle_fwd, sd, x, what):
     assert out.dtype == torch.bfloat16
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = oracle_fwd(P, x)
-    check(f"{what} bf16 logits vs fp32 oracle", out.float(), ref, 3e-2)
+    check(f"{what} bf16 logits vs fp32 oracle", out.float(), ref, 1.5e-2)
     cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(7))
     (out.float() * cot.to(dev())).sum().backward()
     names = [n for n, _ in model.named_parameters()]
@@ -119,8 +120,8 @@ def _bf16_vs_oracle(model, oracle_fwd, sd, x, what):
         num += d * d
         den += r.double().norm().item() ** 2
         per.append(d / max(r.double().norm().item(), 1e-30))
-    assert report(f"{what} bf16 all-parameter gradient rel-L2 vs oracle", (num / den) ** 0.5, 6e-2)
-    assert report(f"{what} bf16 median per-parameter gradient rel-L2", float(np.median(per)), 6e-2)
+    assert report(f"{what} bf16 all-parameter gradient rel-L2 vs oracle", (num / den) ** 0.5, 2e-2)
+    assert report(f"{what} bf16 median per-parameter gradient rel-L2", float(np.median(per)), 2e-2)
     report(f"{what} bf16 worst per-parameter gradient rel-L2 (informational)", float(np.max(per)), float("inf"))
 
 

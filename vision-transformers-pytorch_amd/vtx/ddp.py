@@ -122,6 +122,9 @@ class GradAllReduce:
         return hook
 
     def _launch(self, b):
+        if b.params[0].is_cuda:
+            from . import functional as VF
+            VF.side_join()              # weight gradients computed on the side stream (functional.deferred_wgrad)
         grads = [p.grad for p in b.params]
         torch._foreach_copy_(b.views, grads)          # one multi-tensor copy into the flat bucket
         if self._avg is not None:
