@@ -181,16 +181,22 @@ int vtx_l2norm_fwd(const void* x, void* y, float* nrm, int64_t rows, int C, floa
 int vtx_l2norm_bwd(const void* dy, const void* y, const float* nrm, void* dx, int64_t rows, int C, int dtype, void* stream);
 
 /* ---- Device-side input pipeline (csrc/input.hip): per-sample mixup / cutmix
- * (reference mix_dataset.py:36-90) + Normalize + constant-mode RandomErasing (reference transforms.py:321-418) of a
- * device-resident batch in one pass.  The random plan is drawn on the host in the reference's order
- * (vtx.input_pipeline.plan_batch): device array of N records
+ * (reference mix_dataset.py:36-90) + Normalize + RandomErasing in its three colour modes (reference transforms.py:309-418;
+ * factory.py:177-181 configures mode "pixel") of a device-resident batch in one pass.  The random plan is drawn on the
+ * host in the reference's order (vtx.input_pipeline.plan_batch): device array of N records
  *   {int partner, mode (0 none | 1 mixup | 2 cutmix); float ratio; int x1, y1, x2, y2, nrect, top[4], left[4];
- *    short eh[4], ew[4]}   (vtx_mix_plan_bytes() = 80 bytes each; at most vtx_mix_max_rects() rectangles).
- * x [N, C, H, W] uint8 (in_u8: scaled by 1/255 like ToTensor) or fp32, out [N, C, H, W] fp32, W % 4 == 0. */
+ *    short eh[4], ew[4]; int fmode (0 const | 1 rand | 2 pixel), foff[4]}
+ *   (vtx_mix_plan_bytes() = 100 bytes each; at most vtx_mix_max_rects() rectangles);
+ * fills: fp32 table of the host-drawn normal values (Tensor.normal_ with the reference's shapes), rectangle r of a sample
+ *   reads [C] (rand) or [C][eh][ew] (pixel) floats at foff[r]; may be NULL when every fmode is 0.
+ * x [N, C, H, W] uint8 (in_u8: scaled by 1/255 like ToTensor) or fp32, W % 4 == 0;
+ * out: [N, C, H, W] fp32 (out_nhwc_bf16 == 0: the reference's model input) or [N, H, W, C] bf16 (C in {1, 3, 4}) -- the
+ *   layout vtx_patch_gather_nhwc consumes, so the patch-embedding input is written once, in place of train.py:267's
+ *   fp32 NCHW batch + the permute / patchify copies of swin_transformer.py:371, 15-22. */
 size_t vtx_mix_plan_bytes(void);
 int vtx_mix_max_rects(void);
-int vtx_mix_normalize_erase(const void* x, int in_u8, const void* plan, const float* mean, const float* stdv, float* out,
-                            int N, int C, int H, int W, void* stream);
+int vtx_mix_normalize_erase(const void* x, int in_u8, const void* plan, const float* mean, const float* stdv,
+                            const float* fills, void* out, int out_nhwc_bf16, int N, int C, int H, int W, void* stream);
 
 /* ---- Fused optimizer tail (csrc/optim.hip): nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of the reference's
  * train step (train.py:285-299) as two multi-tensor passes.  Tensors are given as HOST arrays of n device pointers
@@ -242,6 +248,9 @@ int vtx_cast_weights(const void* desc, int nmat, int ntiles, void* dst, void* ds
  *   order 1: column (c, py, px)  -- ViT: Conv2d(3, C, p, stride=p) as an im2col GEMM (models/vit.py:73, 76) */
 int vtx_patch_gather(const float* x, void* out, int B, int Cin, int H, int W, int p, int Kp, int order, int dtype,
                      void* stream);
+/* Same patch matrix from a bf16 NHWC image [B, H, W, Cin] (vtx_mix_normalize_erase's out_nhwc_bf16 output), W % 8 == 0. */
+int vtx_patch_gather_nhwc(const void* x, void* out, int B, int Cin, int H, int W, int p, int Kp, int order, int dtype,
+                          void* stream);
 /* ---- Token mean over Tn tokens: AdaptiveAvgPool2d(1)+Flatten of the Swin classifier
  * (models/swin_transformer.py:281, 376-377) on NHWC features. */
 int vtx_token_mean_fwd(const void* x, void* y, int B, int Tn, int C, int dtype, void* stream);

@@ -322,9 +322,20 @@ def rand_bbox(size, ratio, rng):
     return x1, y1, x2, y2
 
 
+def erase_pixels(mode, chan, h, w, tgen=None):
+    """transforms._get_pixels (transforms.py:309-318): the colour block a rectangle is overwritten with -- per-pixel normal
+    draws ('pixel'), one per channel ('rand') or zeros ('const'); tgen = torch CPU generator (None: the global one)."""
+    if mode == "pixel":
+        return torch.empty((chan, h, w), dtype=torch.float32).normal_(generator=tgen)
+    if mode == "rand":
+        return torch.empty((chan, 1, 1), dtype=torch.float32).normal_(generator=tgen)
+    return torch.zeros((chan, 1, 1), dtype=torch.float32)
+
+
 def random_erasing_const(img, rng, p=0.5, min_area=0.02, max_area=1 / 3, min_aspect=0.3, max_aspect=None, min_count=1,
-                         max_count=None):
-    """transforms.RandomErasing._erase on one (C, H, W) tensor, mode 'const' (zeros) -- transforms.py:381-409."""
+                         max_count=None, mode="const", tgen=None):
+    """transforms.RandomErasing._erase on one (C, H, W) tensor -- transforms.py:381-409; mode 'const' (zeros), 'rand' or
+    'pixel' (normal draws from the torch generator tgen, transforms.py:309-318)."""
     max_aspect = max_aspect or 1 / min_aspect
     la = (math.log(min_aspect), math.log(max_aspect))
     max_count = max_count or min_count
@@ -342,7 +353,7 @@ def random_erasing_const(img, rng, p=0.5, min_area=0.02, max_area=1 / 3, min_asp
             if w < img_w and h < img_h:
                 top = rng.randint(0, img_h - h)
                 left = rng.randint(0, img_w - w)
-                img[:, top:top + h, left:left + w] = 0
+                img[:, top:top + h, left:left + w] = erase_pixels(mode, chan, h, w, tgen)
                 break
     return img
 

@@ -49,8 +49,47 @@ def test_host_planner_draws_like_the_reference():
                 x1, y1, x2, y2 = p["box"]
                 a[:, y1:y2, x1:x2] = b[:, y1:y2, x1:x2]
             a = (a - MEAN) / STD
-            for top, left, eh, ew in p["rects"]:
+            for top, left, eh, ew, _colour in p["rects"]:
                 a[:, top:top + eh, left:left + ew] = 0
             assert np.array_equal(a.numpy(), g.arr(f"{tag}.images")[i]), f"{tag} image {i}"
             assert labels[p["partner"]] == int(g.arr(f"{tag}.label2")[i])
             assert float(p["label_ratio"]) == float(g.arr(f"{tag}.ratio")[i])
+
+
+MODE_CASES = (("pixel", 0.2, 1, 8, "pixel"), ("rand", 0.2, 1, 9, "rand"), ("pixel_only", 0.0, 0, 10, "pixel"))
+
+
+def test_oracle_reproduces_reference_erase_colour_modes():
+    """RandomErasing 'pixel' (the mode factory.py:177-181 configures) and 'rand': the colour draws come from torch's CPU
+    generator, interleaved with the python `random` draws of the rectangles -- golden G9b (reference outputs)."""
+    g = Golden("g9b_erase_modes")
+    images, labels = dataset()
+    for tag, mixup, cutmix, seed, mode in MODE_CASES:
+        rng = random.Random(seed)
+        tgen = torch.Generator().manual_seed(1000 + seed)
+        tf = lambda img: R.random_erasing_const((img - MEAN) / STD, rng, p=0.8, max_count=2, mode=mode, tgen=tgen)
+        for i in range(N):
+            img, l1, l2, r = R.mix_dataset_item(images, labels, i, mixup, cutmix, tf, rng)
+            assert np.array_equal(img.numpy(), g.arr(f"{tag}.images")[i]), f"{tag} image {i}"
+            assert l2 == int(g.arr(f"{tag}.label2")[i]) and float(r) == float(g.arr(f"{tag}.ratio")[i])
+
+
+def test_host_planner_draws_erase_colours_like_the_reference():
+    from vtx.input_pipeline import ErasePlan, plan_batch
+    g = Golden("g9b_erase_modes")
+    images, labels = dataset()
+    for tag, mixup, cutmix, seed, mode in MODE_CASES:
+        erase = ErasePlan(p=0.8, max_count=2, mode=mode, generator=torch.Generator().manual_seed(1000 + seed))
+        plans = plan_batch(N, H, W, mixup, cutmix, erase, random.Random(seed))
+        assert any(p["rects"] for p in plans)
+        for i, p in enumerate(plans):
+            a, b = images[i].clone(), images[p["partner"]]
+            if p["mode"] == 1:
+                a = a.mul(p["ratio"]).add_(b, alpha=1 - p["ratio"])
+            elif p["mode"] == 2:
+                x1, y1, x2, y2 = p["box"]
+                a[:, y1:y2, x1:x2] = b[:, y1:y2, x1:x2]
+            a = (a - MEAN) / STD
+            for top, left, eh, ew, colour in p["rects"]:
+                a[:, top:top + eh, left:left + ew] = colour
+            assert np.array_equal(a.numpy(), g.arr(f"{tag}.images")[i]), f"{tag} image {i}"

@@ -349,6 +349,29 @@ def gen_input_pipeline():
         rec[f"{tag}.label2"] = np.array(l2)
         rec[f"{tag}.ratio"] = np.array(ratio, dtype=np.float64)
     save("g9_input_pipeline", rec)
+    # G9b: the 'pixel' (what factory.py:177-181 configures) and 'rand' colour modes -- normal draws from torch's global
+    # CPU generator, interleaved with the python `random` draws of the rectangles
+    rec = {}
+    for tag, mixup, cutmix, seed, mode in (("pixel", 0.2, 1, 8, "pixel"), ("rand", 0.2, 1, 9, "rand"),
+                                           ("pixel_only", 0.0, 0, 10, "pixel")):
+        erase = ref_tf.RandomErasing(p=0.8, max_count=2, mode=mode, device="cpu")
+        class Fresh2:
+            def __len__(self):
+                return n
+
+            def __getitem__(self, i):
+                return images[i].clone(), labels[i]
+        md = ref_mix.MixDataset(Fresh2(), lambda img: erase((img - mean) / std), mixup=mixup, cutmix=cutmix)
+        random.seed(seed)
+        torch.manual_seed(1000 + seed)
+        outs, l2, ratio = [], [], []
+        for i in range(n):
+            img, a, b, r = md[i]
+            outs.append(img.numpy()); l2.append(b); ratio.append(float(r))
+        rec[f"{tag}.images"] = np.stack(outs)
+        rec[f"{tag}.label2"] = np.array(l2)
+        rec[f"{tag}.ratio"] = np.array(ratio, dtype=np.float64)
+    save("g9b_erase_modes", rec)
 
 
 def gen_train_step():

@@ -21,10 +21,11 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 rows = {}
 for e in prof.events():
-    if e.name.startswith("aten::") and e.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::zeros", "aten::empty_strided",
-                                                  "aten::to", "aten::_to_copy", "aten::add_", "aten::mul", "aten::div", "aten::lt", "aten::rand", "aten::sum", "aten::contiguous", "aten::clone", "aten::cat"):
-        st = [f for f in (e.stack or []) if "vision-transformers" in f or "bench.py" in f or "autograd" in f][:3]
-        key = (e.name, " <- ".join(s.split("/")[-1] for s in st))
+    n = e.name
+    if ("fill" in n.lower() or "zero" in n.lower() or "copy" in n.lower() or "Memcpy" in n or "Memset" in n) and not n.startswith("void") :
+        st = [f for f in (e.stack or [])][:6]
+        key = (n[:40], " <- ".join(s.split("/")[-1][:60] for s in st))
         rows[key] = rows.get(key, 0) + 1
-for (n, st), c in sorted(rows.items(), key=lambda kv: -kv[1])[:40]:
-    print(f"{c:5d} {n:22s} {st[:200]}")
+for (n, st), c in sorted(rows.items(), key=lambda kv: -kv[1])[:30]:
+    print(f"{c:5d} {n:40s} {st[:400]}")
+print(prof.key_averages().table(sort_by="count", row_limit=45, max_name_column_width=70))

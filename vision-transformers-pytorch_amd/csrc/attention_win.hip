@@ -128,29 +128,49 @@ template <typename T> struct WaSmem {
   static constexpr int kBwd = kBias + WA_WAVES * kBwdWave;
 };
 
+// Workgroup -> (block of the head's persistent grid, head), 1-D grid of nblk * nH workgroups.  Head dim 32 in bf16 is
+// 64 bytes: TWO heads share every 128-byte line of q / k / v / o / dO.  With the head as the slow grid dimension the two
+// workgroups that need a line run far apart in time and on unrelated XCDs, and the line is fetched from HBM twice (PMC:
+// backward 1.43x its algorithmic bytes).  `xcd_major` (nblk % 8 == 0): workgroup b runs on XCD b % 8 (observed dispatch
+// rule, speed only), so give each XCD the sequence slot = b / 8 -> head = slot % nH fastest, block = 8 (slot / nH) + XCD:
+// all heads of the same (image, window) pairs are dispatched back to back on ONE XCD and share its L2 lines.
+__device__ __forceinline__ void wa_block_map(int nblk, int nH, int xcd_major, int& blk, int& h) {
+  const int b = blockIdx.x;
+  if (xcd_major) {
+    const int xcd = b & 7, slot = b >> 3;
+    h = slot % nH;
+    blk = (slot / nH) * 8 + xcd;
+  } else {
+    blk = b % nblk;                 // head-major (round-1 order): all blocks of head 0, then head 1, ...
+    h = b / nblk;
+  }
+}
+
 // --------------------------------------------------------------------------------------------- forward
-// grid = (nblk, nH); wave w of block x serves the (image, window) pairs 4 x + w, 4 x + w + 4 nblk, ... of head y
+// grid = nblk * nH workgroups (wa_block_map -> block x, head y); wave w of block x serves the (image, window) pairs
+// 4 x + w, 4 x + w + 4 nblk, ... of head y
 template <typename T, bool MASKED>
 __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                                   float* __restrict__ lse,
                                                                   const float* __restrict__ rel_pos,
                                                                   const int64_t* __restrict__ pos,
                                                                   const uint8_t* __restrict__ region, int nbn,
-                                                                  WinGeom g) {
+                                                                  int nblk, int xcd_major, WinGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
   float* bias_s = reinterpret_cast<float*>(wa_smem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* wbase = wa_smem + WaSmem<T>::kBias + wave * WaSmem<T>::kFwdWave;
   T* vt = reinterpret_cast<T*>(wbase);
   uint8_t* reg_s = wbase + WaSmem<T>::kImg;
-  const int h = blockIdx.y;
+  int blk, h;
+  wa_block_map(nblk, g.nH, xcd_major, blk, h);
   const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
   const int64_t ld = 3 * (int64_t)g.hd;
   wa_build_bias(bias_s, reinterpret_cast<float*>(wa_smem + WaSmem<T>::kBias), rel_pos, pos, g.L, g.nH, h,
                 (2 * g.win - 1) * (2 * g.win - 1));
   __syncthreads();                                    // table complete; the relh scratch (wave 0's region) is free again
 
-  for (int bn = blockIdx.x * WA_WAVES + wave; bn < nbn; bn += gridDim.x * WA_WAVES) {
+  for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
     const int n = bn % g.nW, b = bn / g.nW;
     const int prob = bn * g.nH + h;
     int64_t row[4];
@@ -226,7 +246,7 @@ template <typename T, bool MASKED>
 __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ oin, const T* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ rel_pos, const int64_t* __restrict__ pos, const uint8_t* __restrict__ region,
-    T* __restrict__ dqkv, float* __restrict__ bins_part, int nbn, WinGeom g) {
+    T* __restrict__ dqkv, float* __restrict__ bins_part, int nbn, int nblk, int xcd_major, WinGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
   float* bias_s = reinterpret_cast<float*>(wa_smem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,7 +258,8 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
   float* lse_s = dq_s + WA_LP;
   float* bins = lse_s + WA_LP;
   uint8_t* reg_s = reinterpret_cast<uint8_t*>(bins + WA_NBIN);
-  const int h = blockIdx.y;
+  int blk, h;
+  wa_block_map(nblk, g.nH, xcd_major, blk, h);
   const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
   const int64_t ld = 3 * (int64_t)g.hd;
   wa_build_bias(bias_s, reinterpret_cast<float*>(wa_smem + WaSmem<T>::kBias), rel_pos, pos, g.L, g.nH, h,
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) dsacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int bn = blockIdx.x * WA_WAVES + wave; bn < nbn; bn += gridDim.x * WA_WAVES) {
+  for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
     const int n = bn % g.nW, b = bn / g.nW;
     const int prob = bn * g.nH + h;
 
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
   }
   wa_wave_sync();
   // partial layout [wave][bin][head]: the fixed-order column reduce then yields drel_pos[(bin, head)] directly
-  float* out = bins_part + ((int64_t)blockIdx.x * WA_WAVES + wave) * WA_NBIN * g.nH + h;
+  float* out = bins_part + ((int64_t)blk * WA_WAVES + wave) * WA_NBIN * g.nH + h;
   for (int i = lane; i < WA_NBIN; i += 64) out[(int64_t)i * g.nH] = bins[i];
 }
 
@@ -413,8 +434,13 @@ static int wattn_blocks(int nbn, int nH, int cap) {
   if (per_head < WA_WAVES) per_head = WA_WAVES;
   const int ppw = (nbn + per_head - 1) / per_head;            // problems per wave
   const int waves = (nbn + ppw - 1) / ppw;
-  return (waves + WA_WAVES - 1) / WA_WAVES;
+  int blocks = (waves + WA_WAVES - 1) / WA_WAVES;
+  // a multiple of 8 blocks per head makes the XCD-major head-fastest mapping (wa_block_map) a bijection; the few extra
+  // workgroups find no work past nbn
+  if (blocks >= 8 && vtx_opt(VTX_OPT_WATTN_XCD_MAJOR)) blocks = (blocks + 7) / 8 * 8;
+  return blocks;
 }
+static int wattn_xcd_major(int nblk) { return (nblk % 8 == 0 && vtx_opt(VTX_OPT_WATTN_XCD_MAJOR)) ? 1 : 0; }
 static int wattn_fwd_blocks(int nbn, int nH) {
   const int cap = vtx_opt(VTX_OPT_WATTN_FWD_WAVES);
   return wattn_blocks(nbn, nH, cap > 0 ? cap : 4096);
@@ -437,8 +463,9 @@ static int wattn_fwd_launch(const void* qkv, void* o, float* lse, const float* r
   auto kern = wattn_fwd_kernel<T, MASKED>;
   int rc = wa_smem_attr(kern, WaSmem<T>::kFwd);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(wattn_fwd_blocks(nbn, g.nH), g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kFwd, st,
-                     (const T*)qkv, (T*)o, lse, rel_pos, pos, region, nbn, g);
+  const int nblk = wattn_fwd_blocks(nbn, g.nH);
+  hipLaunchKernelGGL(kern, dim3(nblk * g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kFwd, st,
+                     (const T*)qkv, (T*)o, lse, rel_pos, pos, region, nbn, nblk, wattn_xcd_major(nblk), g);
   return vtx_check_launch();
 }
 
@@ -449,8 +476,10 @@ static int wattn_bwd_launch(const void* qkv, const void* o, const void* dout, co
   auto kern = wattn_bwd_kernel<T, MASKED>;
   int rc = wa_smem_attr(kern, WaSmem<T>::kBwd);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(wattn_bwd_blocks(nbn, g.nH), g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kBwd, st,
-                     (const T*)qkv, (const T*)o, (const T*)dout, lse, rel_pos, pos, region, (T*)dqkv, part, nbn, g);
+  const int nblk = wattn_bwd_blocks(nbn, g.nH);
+  hipLaunchKernelGGL(kern, dim3(nblk * g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kBwd, st,
+                     (const T*)qkv, (const T*)o, (const T*)dout, lse, rel_pos, pos, region, (T*)dqkv, part, nbn, nblk,
+                     wattn_xcd_major(nblk), g);
   return vtx_check_launch();
 }
 

@@ -48,6 +48,41 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
   }
 }
 
+// Same gather from a bf16 NHWC image [B, H, W, Cin] (the device input pipeline's output, csrc/input.hip): the p image
+// rows of a patch row are p contiguous runs of W * Cin elements -- coalesced 16-byte loads into LDS, 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void patch_gather_nhwc_kernel(const bf16* __restrict__ x, T* __restrict__ out, int Cin,
+                                                               int H, int W, int p, int K, int Kp, int order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pgn_smem_raw[];   // [p][W][Cin] bf16
+  bf16* sm = reinterpret_cast<bf16*>(pgn_smem_raw);
+  const int gh = H / p, gw = W / p;
+  const int b = blockIdx.x / gh, i = blockIdx.x % gh;
+  const int rowlen = W * Cin;                                  // elements per image row (a multiple of 8: W % 8 == 0)
+  const bf16* src = x + ((int64_t)b * H + (int64_t)i * p) * rowlen;   // p consecutive rows = one contiguous run
+  for (int v = threadIdx.x; v < (p * rowlen) >> 3; v += blockDim.x)
+    *reinterpret_cast<bf16x8*>(sm + v * 8) = *reinterpret_cast<const bf16x8*>(src + (int64_t)v * 8);
+  __syncthreads();
+  const int kvec = Kp >> 3;
+  T* obase = out + ((int64_t)b * gh + i) * gw * (int64_t)Kp;
+  for (int idx = threadIdx.x; idx < gw * kvec; idx += blockDim.x) {
+    const int j = idx / kvec, kv = idx - j * kvec;
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = kv * 8 + e;
+      float val = 0.f;
+      if (col < K) {
+        int c, py, px;
+        if (order == 0) { c = col % Cin; const int t = col / Cin; px = t % p; py = t / p; }
+        else { px = col % p; const int t = col / p; py = t % p; c = t / p; }
+        val = (float)sm[(py * W + j * p + px) * Cin + c];
+      }
+      o.set(e, val);
+    }
+    store8<T>(obase + (int64_t)j * Kp + kv * 8, o);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Token mean: y[b][c] = mean_t x[b][t][c]   (AdaptiveAvgPool2d(1)+Flatten, swin_transformer.py:281)
 template <typename T>
@@ -165,6 +200,20 @@ int vtx_patch_gather(const float* x, void* out, int B, int Cin, int H, int W, in
   MISC_BY_DTYPE(
       hipLaunchKernelGGL((patch_gather_kernel<bf16>), grid, dim3(256), smem, st, x, (bf16*)out, Cin, H, W, p, K, Kp, order),
       hipLaunchKernelGGL((patch_gather_kernel<float>), grid, dim3(256), smem, st, x, (float*)out, Cin, H, W, p, K, Kp, order));
+}
+
+int vtx_patch_gather_nhwc(const void* x, void* out, int B, int Cin, int H, int W, int p, int Kp, int order, int dtype,
+                          void* stream) {
+  if (!x || !out) return VTX_ERR_NULL;
+  const int K = Cin * p * p;
+  if (p <= 0 || H % p || W % p || (W & 7) || (Kp & 7) || Kp < K) return VTX_ERR_SHAPE;
+  const size_t smem = (size_t)Cin * p * W * sizeof(bf16);
+  if (smem > 64 * 1024) return VTX_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(B * (H / p));
+  MISC_BY_DTYPE(
+      hipLaunchKernelGGL((patch_gather_nhwc_kernel<bf16>), grid, dim3(256), smem, st, (const bf16*)x, (bf16*)out, Cin, H, W, p, K, Kp, order),
+      hipLaunchKernelGGL((patch_gather_nhwc_kernel<float>), grid, dim3(256), smem, st, (const bf16*)x, (float*)out, Cin, H, W, p, K, Kp, order));
 }
 
 int vtx_token_mean_fwd(const void* x, void* y, int B, int Tn, int C, int dtype, void* stream) {

@@ -18,7 +18,9 @@ enum VtxOptionId {
   VTX_OPT_SRATTN_WGS = 9,       // PVT spatial-reduction attention: target workgroups (2048)
   VTX_OPT_WGRAD_FUSED_REDUCE = 10,  // 1: the split-K slabs are summed inside the weight-gradient launch by each tile's
                                     //    last-arriving workgroup (ticket counter); 0: separate slab_reduce launches
-  VTX_OPT_COUNT = 11
+  VTX_OPT_WATTN_XCD_MAJOR = 11,     // 1: window-attention workgroups ordered head-fastest per XCD (the heads sharing a
+                                    //    128-byte line run back to back on one L2); 0: all blocks of head 0, then head 1, ...
+  VTX_OPT_COUNT = 12
 };
 
 int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip

@@ -70,8 +70,8 @@ _SIGNATURES = {
     "vtx_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vtx_mix_plan_bytes": (c_size_t, []),
     "vtx_mix_max_rects": (c_int, []),
-    "vtx_mix_normalize_erase": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                        c_int, c_void_p]),
+    "vtx_mix_normalize_erase": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_int, c_void_p]),
     "vtx_ema_update": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "vtx_dino_loss_workspace": (c_size_t, [c_int, c_int]),
     "vtx_dino_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
@@ -82,6 +82,8 @@ _SIGNATURES = {
     "vtx_cast_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vtx_patch_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p]),
+    "vtx_patch_gather_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
     "vtx_token_mean_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_token_mean_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_vit_assemble_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

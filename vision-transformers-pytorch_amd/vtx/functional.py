@@ -134,6 +134,11 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _img(x):
+    """Image batch as the patch gathers take it: bf16 channels-last (device input pipeline) as is, else contiguous NCHW."""
+    return x if ops.is_nhwc_bf16(x) else _c(x)
+
+
 # ------------------------------------------------------------------------------------------- a layer's weight gradients
 # The weight-gradient GEMMs of a layer's backward feed nothing downstream in that backward.  Two things follow:
 #   * GROUPING: the four of a transformer layer (fc2, fc1, proj, qkv) run as ONE launch (ops.wgrad_group): split-K is
@@ -491,7 +496,7 @@ class SwinPatchEmbedFn(Function):
 
     @staticmethod
     def forward(ctx, x_nchw, w, b, ln_w, ln_b, patch, eps, dtype):
-        patches = ops.patch_gather(_c(x_nchw), patch, 0, dtype)
+        patches = ops.patch_gather(_img(x_nchw), patch, 0, dtype)
         t = ops.gemm(patches, wcast(w, dtype)[0], 0, bias=b.detach())
         y, mean, rstd = ops.layernorm_fwd(t, ln_w.detach(), ln_b.detach(), eps)
         ctx.save_for_backward(patches, t, mean, rstd, ln_w)
@@ -512,7 +517,7 @@ class VitPatchEmbedFn(Function):
     @staticmethod
     def forward(ctx, x_nchw, w, b, dtype):
         C, Cin, p, _ = w.shape
-        patches = ops.patch_gather(_c(x_nchw), p, 1, dtype)
+        patches = ops.patch_gather(_img(x_nchw), p, 1, dtype)
         B, gh, gw, K = patches.shape
         y = ops.gemm(patches.view(B, gh * gw, K), wcast(w, dtype)[0].view(C, K), 0, bias=b.detach())
         ctx.save_for_backward(patches)
@@ -671,7 +676,7 @@ class PvtPatchEmbedFn(Function):
         if x.dim() == 4:                                               # NCHW image
             B = x.shape[0]
             H, W = x.shape[2] // patch, x.shape[3] // patch
-            patches = ops.patch_gather(_c(x), patch, 1, T).view(B * H * W, -1)
+            patches = ops.patch_gather(_img(x), patch, 1, T).view(B * H * W, -1)
             wp = (wcast(w, T)[0].view(out_ch, -1), None)
             ctx.tok = None
         else:

@@ -1,12 +1,14 @@
 """Device-side input pipeline: per-sample mixup / cutmix (reference
-mix_dataset.py:27-90), Normalize and constant-mode RandomErasing (reference transforms.py:321-418) applied to a batch
-that is already resident on the GPU, in one HIP kernel (csrc/input.hip).
+mix_dataset.py:27-90), Normalize and RandomErasing (reference transforms.py:321-418; all three colour modes: 'const',
+'rand' and the 'pixel' mode factory.py:177-181 configures) applied to a batch that is already resident on the GPU, in
+one HIP kernel (csrc/input.hip); output fp32 NCHW (the reference's contract) or bf16 NHWC for the models' patch gathers.
 
 The reference runs these per sample on the CPU inside the Dataset; here every random decision is drawn on the host
 with the SAME generator calls in the SAME order (``plan_batch``: partner ``randrange`` loop, mixup for even / cutmix for
 odd indices, ``betavariate`` / ``uniform`` ratio, ``rand_bbox``, then RandomErasing's ``random`` / ``uniform`` /
-``randint`` sequence), so a seeded ``random.Random`` reproduces the reference's outputs; only the pixel work moves to
-the device.  The "dataset" a partner is drawn from is the batch.
+``randint`` sequence; the erase colours of the 'rand' / 'pixel' modes with ``Tensor.normal_()`` of the same shapes from a
+torch CPU generator), so a seeded ``random.Random`` (+ ``torch.Generator``) reproduces the reference's outputs; only the
+pixel work moves to the device.  The "dataset" a partner is drawn from is the batch.
 """
 import math
 import random as _random
@@ -30,18 +32,33 @@ def rand_bbox(size, ratio, rng):
 
 
 class ErasePlan:
-    """Parameters of transforms.RandomErasing (mode 'const'); draws rectangles in the reference's order."""
+    """Parameters of transforms.RandomErasing; draws rectangles -- and, for the 'rand' / 'pixel' modes, their colours --
+    in the reference's order.  ``generator``: torch CPU generator of the colour draws (None = torch's global one, which is
+    what the reference's ``torch.empty(...).normal_()`` consumes, transforms.py:309-318)."""
+
+    MODES = {"const": 0, "": 0, None: 0, "rand": 1, "pixel": 2}
 
     def __init__(self, p=0.5, min_area=0.02, max_area=1 / 3, min_aspect=0.3, max_aspect=None, min_count=1,
-                 max_count=None, mode="const"):
-        if mode not in ("const", "", None):
-            raise NotImplementedError("vtx: RandomErasing modes 'rand' / 'pixel' are not implemented on the device")
+                 max_count=None, mode="const", generator=None):
+        mode = mode.lower() if isinstance(mode, str) else mode
+        if mode not in self.MODES:
+            raise ValueError(f"RandomErasing mode {mode!r} (const | rand | pixel)")
         max_aspect = max_aspect or 1 / min_aspect
         self.p, self.min_area, self.max_area = p, min_area, max_area
         self.log_aspect = (math.log(min_aspect), math.log(max_aspect))
         self.min_count, self.max_count = min_count, max_count or min_count
+        self.fmode, self.generator = self.MODES[mode], generator
 
-    def draw(self, img_h, img_w, rng):
+    def colour(self, chan, h, w):
+        """_get_pixels (transforms.py:309-318): (chan, h, w) normal draws per pixel, (chan, 1, 1) per block, or zeros."""
+        if self.fmode == 2:
+            return torch.empty((chan, h, w), dtype=torch.float32).normal_(generator=self.generator)
+        if self.fmode == 1:
+            return torch.empty((chan, 1, 1), dtype=torch.float32).normal_(generator=self.generator)
+        return None
+
+    def draw(self, img_h, img_w, rng, chan=3):
+        """-> [(top, left, h, w, colour tensor or None)]"""
         rects = []
         if rng.random() > self.p:
             return rects
@@ -54,15 +71,16 @@ class ErasePlan:
                 h = int(round(math.sqrt(target_area * aspect)))
                 w = int(round(math.sqrt(target_area / aspect)))
                 if w < img_w and h < img_h:
-                    rects.append((rng.randint(0, img_h - h), rng.randint(0, img_w - w), h, w))
+                    top, left = rng.randint(0, img_h - h), rng.randint(0, img_w - w)
+                    rects.append((top, left, h, w, self.colour(chan, h, w)))
                     break
         return rects
 
 
-def plan_batch(n, height, width, mixup, cutmix, erase=None, rng=None, indices=None):
-    """Per-sample plans for a batch of n images: list of dicts (partner, mode, ratio (mixup weight), box, rects,
-    label_ratio).  ``indices``: the dataset index of every sample (decides mixup vs cutmix by parity like the
-    reference); default 0..n-1."""
+def plan_batch(n, height, width, mixup, cutmix, erase=None, rng=None, indices=None, chan=3):
+    """Per-sample plans for a batch of n images: list of dicts (partner, mode, ratio (mixup weight), box, rects =
+    [(top, left, h, w, colour)], label_ratio).  ``indices``: the dataset index of every sample (decides mixup vs cutmix
+    by parity like the reference); default 0..n-1."""
     rng = rng or _random
     plans = []
     for k in range(n):
@@ -88,61 +106,79 @@ def plan_batch(n, height, width, mixup, cutmix, erase=None, rng=None, indices=No
             x1, y1, x2, y2 = rand_bbox((height, width), r, rng)
             mode, box = 2, (x1, y1, x2, y2)
             label_ratio = 1 - ((x2 - x1) * (y2 - y1) / (height * width))
-        rects = erase.draw(height, width, rng) if erase is not None else []
+        rects = erase.draw(height, width, rng, chan) if erase is not None else []
         plans.append(dict(partner=partner, mode=mode, ratio=wgt, box=box, rects=rects, label_ratio=label_ratio))
     return plans
 
 
 class DeviceMixPipeline:
-    """batch (N, C, H, W) uint8 or fp32 on the GPU + labels (N,)  ->  (fp32 normalised batch, label1, label2, ratio):
-    the tuple the reference's train step consumes (train.py:270-272)."""
+    """batch (N, C, H, W) uint8 or fp32 on the GPU + labels (N,)  ->  (normalised batch, label1, label2, ratio): the tuple
+    the reference's train step consumes (train.py:270-272).  ``output``: "nchw_fp32" (the reference's model input) or
+    "nhwc_bf16" -- a bf16 tensor of shape (N, C, H, W) in channels-last memory that the HIP models' patch gathers read
+    directly (same patch values bit for bit under bf16 autocast: the one rounding happens here instead of there)."""
 
-    def __init__(self, mixup=0.2, cutmix=1, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), erase=None, seed=None):
-        self.mixup, self.cutmix, self.erase = mixup, cutmix, erase
+    def __init__(self, mixup=0.2, cutmix=1, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), erase=None, seed=None,
+                 output="nchw_fp32"):
+        if output not in ("nchw_fp32", "nhwc_bf16"):
+            raise ValueError(output)
+        self.mixup, self.cutmix, self.erase, self.output = mixup, cutmix, erase, output
         self.mean, self.std = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)
         self.rng = _random.Random(seed) if seed is not None else _random
-        self._ring, self._slot = [], 0            # pinned staging buffers for the plan table (asynchronous upload)
+        self._ring, self._slot = {}, {}           # pinned staging buffers (asynchronous uploads), per table kind
 
     def pack(self, plans):
+        """-> (plan table uint8 [N * vtx_mix_plan_bytes()], fill table fp32 or None)"""
         maxr = ops.mix_max_rects()
-        recs = []
+        fmode = self.erase.fmode if self.erase is not None else 0
+        recs, fills, foff = [], [], 0
         for p in plans:
             rects = p["rects"]
             if len(rects) > maxr:
                 raise ops.VtxError(f"vtx: at most {maxr} erase rectangles per image")
-            pad = [(0, 0, 0, 0)] * (maxr - len(rects))
-            rr = list(rects) + pad
+            rr = [r[:4] for r in rects] + [(0, 0, 0, 0)] * (maxr - len(rects))
+            offs = [0] * maxr
+            for i, r in enumerate(rects):
+                if fmode and r[4] is not None:
+                    offs[i] = foff
+                    fills.append(r[4].reshape(-1))
+                    foff += r[4].numel()
             x1, y1, x2, y2 = p["box"]
-            recs.append(struct.pack("<iifiiiii4i4i4h4h", p["partner"], p["mode"], p["ratio"], x1, y1, x2, y2, len(rects),
-                                    *[r[0] for r in rr], *[r[1] for r in rr], *[r[2] for r in rr], *[r[3] for r in rr]))
+            recs.append(struct.pack("<iifiiiii4i4i4h4hi4i", p["partner"], p["mode"], p["ratio"], x1, y1, x2, y2, len(rects),
+                                    *[r[0] for r in rr], *[r[1] for r in rr], *[r[2] for r in rr], *[r[3] for r in rr],
+                                    fmode, *offs))
         assert len(recs[0]) == ops.mix_plan_bytes()
-        return torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
+        table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
+        return table, (torch.cat(fills) if fills else None)
 
-    def upload(self, host_plan, dev):
-        """Plan table -> device without stalling the host: a pageable host-to-device copy would serialise the host with
+    def upload(self, host, dev, kind="plan"):
+        """Host table -> device without stalling the host: a pageable host-to-device copy would serialise the host with
         the GPU stream every step; a ring of 4 pinned buffers (each guarded by an event) keeps the copy asynchronous."""
-        n = host_plan.numel()
-        if not self._ring or self._ring[0][0].numel() < n:
-            self._ring = [(torch.empty(n, dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(4)]
-            self._slot = 0
-            for _, ev in self._ring:
+        n = host.numel()
+        ring = self._ring.get(kind)
+        if not ring or ring[0][0].numel() < n or ring[0][0].dtype != host.dtype:
+            cap = max(n, 2 * (ring[0][0].numel() if ring else 0))
+            ring = self._ring[kind] = [(torch.empty(cap, dtype=host.dtype).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._slot[kind] = 0
+            for _, ev in ring:
                 ev.record()
-        buf, ev = self._ring[self._slot]
-        self._slot = (self._slot + 1) % len(self._ring)
+        buf, ev = ring[self._slot[kind]]
+        self._slot[kind] = (self._slot[kind] + 1) % len(ring)
         ev.synchronize()                          # the copy issued 4 calls ago has long finished
-        buf[:n].copy_(host_plan)
+        buf[:n].copy_(host)
         out = buf[:n].to(dev, non_blocking=True)
         ev.record()
         return out
 
     def __call__(self, images, labels, indices=None):
         n, c, h, w = images.shape
-        plans = plan_batch(n, h, w, self.mixup, self.cutmix, self.erase, self.rng, indices)
+        plans = plan_batch(n, h, w, self.mixup, self.cutmix, self.erase, self.rng, indices, chan=c)
         dev = images.device
-        plan = self.upload(self.pack(plans), dev)
+        table, fills = self.pack(plans)
+        plan = self.upload(table, dev)
+        fills = self.upload(fills, dev, "fills") if fills is not None else None
         if self.mean.device != dev:
             self.mean, self.std = self.mean.to(dev), self.std.to(dev)
-        out = ops.mix_normalize_erase(images, plan, self.mean, self.std)
+        out = ops.mix_normalize_erase(images, plan, self.mean, self.std, fills, nhwc_bf16=self.output == "nhwc_bf16")
         partner = torch.tensor([p["partner"] for p in plans], device=labels.device)
         ratio = torch.tensor([p["label_ratio"] for p in plans], dtype=torch.float32, device=dev)
         return out, labels, labels[partner], ratio

@@ -502,16 +502,22 @@ def mix_max_rects():
     return _lib.load().vtx_mix_max_rects()
 
 
-def mix_normalize_erase(images, plan, mean, std):
-    """One pass over a device batch: mixup / cutmix with the partner image, normalise, zero the erase rectangles."""
-    _dev(images, plan, mean, std)
+def mix_normalize_erase(images, plan, mean, std, fills=None, nhwc_bf16=False):
+    """One pass over a device batch: mixup / cutmix with the partner image, normalise, RandomErasing (zeros, or the
+    host-drawn normal values in ``fills`` for the 'rand' / 'pixel' modes).  -> fp32 (N, C, H, W), or with ``nhwc_bf16``
+    a bf16 tensor of SHAPE (N, C, H, W) in torch.channels_last memory (physically [N, H, W, C]) -- the layout the
+    patch-embedding gather of the models reads directly."""
+    _dev(images, plan, mean, std, fills)
     if images.dtype not in (torch.uint8, torch.float32):
         raise VtxError("vtx: input images must be uint8 or float32")
     x = images if images.is_contiguous() else images.contiguous()
     n, c, h, w = x.shape
-    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
-    check(_lib.load().vtx_mix_normalize_erase(_p(x), int(x.dtype == torch.uint8), _p(plan), _p(mean), _p(std), _p(out), n, c,
-                                              h, w, _stream()), "vtx_mix_normalize_erase")
+    if nhwc_bf16:
+        out = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    else:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().vtx_mix_normalize_erase(_p(x), int(x.dtype == torch.uint8), _p(plan), _p(mean), _p(std), _p(fills),
+                                              _p(out), int(nhwc_bf16), n, c, h, w, _stream()), "vtx_mix_normalize_erase")
     return out
 
 
@@ -561,8 +567,26 @@ def cast_weights(desc, nmat, ntiles, flat, flat_t):
         check(_lib.load().vtx_cast_weights(_p(desc), nmat, ntiles, _p(flat), _p(flat_t), _stream()), "vtx_cast_weights")
 
 
+def is_nhwc_bf16(x):
+    """A (B, C, H, W) bf16 tensor stored channels-last (physically [B, H, W, C]) -- what DeviceMixPipeline(output=
+    "nhwc_bf16") hands to the models."""
+    return (x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] > 1 and
+            x.is_contiguous(memory_format=torch.channels_last))
+
+
 def patch_gather(x_nchw, patch, order, dtype, kp=None):
-    """NCHW fp32 image -> [B, H/p, W/p, Kp] patch matrix of `dtype` (order 0: Swin (py,px,c); 1: ViT (c,py,px))."""
+    """Image batch -> [B, H/p, W/p, Kp] patch matrix of `dtype` (order 0: Swin (py,px,c); 1: ViT (c,py,px)).  The image
+    is (B, C, H, W) fp32 contiguous (the reference's input contract) or bf16 channels-last (is_nhwc_bf16: the device
+    input pipeline's output, read without a layout pass)."""
+    if is_nhwc_bf16(x_nchw):
+        B, Cin, H, W = x_nchw.shape
+        K = Cin * patch * patch
+        kp = K if kp is None else kp
+        out = torch.empty((B, H // patch, W // patch, kp), dtype=dtype, device=x_nchw.device)
+        with _timed("patch_gather_nhwc_kernel", 0.0, x_nchw.numel() * 2.0 + out.numel() * out.element_size()):
+            check(_lib.load().vtx_patch_gather_nhwc(x_nchw.data_ptr(), _p(out), B, Cin, H, W, patch, kp, order, _dt(out),
+                                                    _stream()), "vtx_patch_gather_nhwc")
+        return out
     _dev(x_nchw)
     if x_nchw.dtype != torch.float32:
         x_nchw = x_nchw.float()
@@ -570,8 +594,9 @@ def patch_gather(x_nchw, patch, order, dtype, kp=None):
     K = Cin * patch * patch
     kp = K if kp is None else kp
     out = torch.empty((B, H // patch, W // patch, kp), dtype=dtype, device=x_nchw.device)
-    check(_lib.load().vtx_patch_gather(_p(x_nchw), _p(out), B, Cin, H, W, patch, kp, order, _dt(out), _stream()),
-          "vtx_patch_gather")
+    with _timed("patch_gather_kernel", 0.0, x_nchw.numel() * 4.0 + out.numel() * out.element_size()):
+        check(_lib.load().vtx_patch_gather(_p(x_nchw), _p(out), B, Cin, H, W, patch, kp, order, _dt(out), _stream()),
+              "vtx_patch_gather")
     return out
 
 

@@ -19,6 +19,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._steps = {}
 
     def _tensors(self):
         out = []
@@ -36,6 +37,17 @@ class FusedAdamW(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 out.append((p, g, st, group))
         return out
+
+    def _step_of(self, st):
+        """Step count of one parameter as a Python int.  state["step"] stays a tensor (torch.optim.AdamW's format, so
+        optimizer checkpoints are interchangeable); reading ~330 of them with .item() and bumping each with a tensor add
+        costs ~2 ms of host time per step, so the ints are mirrored here and re-read only when the tensor object changes
+        (load_state_dict)."""
+        t = st["step"]
+        ent = self._steps.get(id(st))
+        if ent is None or ent[0] is not t:
+            ent = self._steps[id(st)] = [t, int(t)]
+        return ent[1]
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=0.0):
@@ -59,13 +71,14 @@ class FusedAdamW(torch.optim.Optimizer):
         # distinct (betas, eps, step) -- a single one in the steady state
         by_key = {}
         for i, (_, _, st, g) in enumerate(tensors):
-            by_key.setdefault((g["betas"], g["eps"], int(st["step"])), []).append(i)
+            by_key.setdefault((g["betas"], g["eps"], self._step_of(st)), []).append(i)
         for (betas, eps, t0), idx in by_key.items():
             sel = [tensors[i] for i in idx]
             ops.adamw_step([ps[i] for i in idx], [gs[i] for i in idx], [st["exp_avg"] for _, _, st, _ in sel],
                            [st["exp_avg_sq"] for _, _, st, _ in sel], [float(g["lr"]) for _, _, _, g in sel],
                            [float(g["weight_decay"]) for _, _, _, g in sel], norm, float(max_grad_norm or 0.0),
                            betas[0], betas[1], eps, t0 + 1)
+        torch._foreach_add_([st["step"] for _, _, st, _ in tensors], 1)        # one call for all step tensors
         for _, _, st, _ in tensors:
-            st["step"] += 1
+            self._steps[id(st)][1] += 1
         return norm[1] if norm is not None else loss
