@@ -41,6 +41,8 @@ for what in "$@"; do
          python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_${tag}/run.log 2>&1)
       grep '"metric"' gpurun_out/prof_${tag}/run.log | cut -c1-220
       python tools/rocpd_stats.py gpurun_out/prof_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/prof_${tag}/kernel_stats.md
+      python tools/rocpd_stats.py gpurun_out/prof_${tag}/trace_results.db --neighbours FillFunctor > gpurun_out/prof_${tag}/fill_neighbours.txt
+      python tools/rocpd_stats.py gpurun_out/prof_${tag}/trace_results.db --neighbours copyBuffer > gpurun_out/prof_${tag}/copy_neighbours.txt
       rm -f gpurun_out/prof_${tag}/trace_results.db
       head -24 gpurun_out/prof_${tag}/kernel_stats.md | cut -c1-170 ;;
   esac

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--steps", type=int, default=0, help="divide totals by this many steps")
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--neighbours", default="", help="kernel-name substring: print which kernels run right before / after it")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -44,6 +45,18 @@ def main():
     rows = c.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
                      f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name").fetchall()
     dm = demangle([r[0] for r in rows])
+    if a.neighbours:
+        seq = c.execute(f"select s.kernel_name, d.start from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
+        names = [short(dm[n]) for n, _ in seq]
+        from collections import Counter
+        cnt = Counter()
+        for i, n in enumerate(names):
+            if a.neighbours in n:
+                cnt[(names[i - 1][:70] if i else "-", names[i + 1][:70] if i + 1 < len(names) else "-")] += 1
+        print(f"## neighbours of *{a.neighbours}*: count | previous kernel | next kernel")
+        for (p, q), k in cnt.most_common(25):
+            print(f"{k:6d} | {p} | {q}")
+        return
     tot = sum(r[2] for r in rows)
     rows.sort(key=lambda r: -r[2])
     div = a.steps if a.steps else 1

@@ -423,5 +423,11 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
   // 4.72 ms, ViT-S/16 4.66 -> 4.16 ms per step); 16 waves (one workgroup per CU: 73 registers) 5.6 vs 4.25 ms.
   // option WG_WAVES = 4 keeps the 2 x 2 variant for comparison
   if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
+  switch (vtx_opt(VTX_OPT_WG_RING)) {            // experimental ring geometries: 10 * tokens per k-tile + stages
+    case 643: return wgrad_glds_launch_cfg<64, 3, 8>(a, st);      // 96 KB: one workgroup per CU, two tiles ahead
+    case 324: return wgrad_glds_launch_cfg<32, 4, 8>(a, st);      // 64 KB: three half-tiles ahead
+    case 323: return wgrad_glds_launch_cfg<32, 3, 8>(a, st);      // 48 KB: three workgroups per CU
+    default: break;
+  }
   return wgrad_glds_launch_cfg<64, 2, 8>(a, st);
 }
