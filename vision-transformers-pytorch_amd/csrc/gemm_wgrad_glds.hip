@@ -74,6 +74,53 @@ __device__ __forceinline__ Vec8<bf16> wg_frag(const unsigned char* tile, int tok
   return f;
 }
 
+// The same fragment through INLINE-ASM transpose reads.  hipcc gives the ds_read_tr builtin no memory operand, so its
+// waitcnt pass must assume the read may touch LDS that an in-flight LDS-DMA is still writing and puts `s_waitcnt
+// vmcnt(0)` in front of the first fragment read of every k-tile: the DMA of tile kt + 1, requested a few instructions
+// earlier, is drained before tile kt is multiplied -- no overlap inside a workgroup, an iteration costs the DMA latency
+// PLUS the compute (found in the ISA in round 2; the plain ds_read_b128 of gemm_glds.hip are not affected).  An asm
+// read is invisible to that pass; the price is doing its lgkmcnt bookkeeping by hand (wg_wait: the wait statement names
+// every destination "+v", so no consumer is scheduled above it and the registers stay allocated until the data landed).
+// lane_off = byte offset of the lane's 4-column piece in row (p >> 2) + 8 g of a tile (swizzle included: it depends on
+// (r & 3, (r >> 3) & 1) = (p >> 2, g & 1) only, not on the k-step or the half); OFF = operand base + 8 KB k-step + 1 KB half.
+__device__ __forceinline__ unsigned wg_lane_off(int col0, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int n = col0 + ((p & 3) << 2);
+  const int r = g * 8 + (p >> 2);
+  return (unsigned)(r * 256 + ((((n >> 3) ^ wg_swz(r))) << 4) + ((n & 7) << 1));
+}
+template <int OFF> __device__ __forceinline__ void wg_tr2(s16x4& lo, s16x4& hi, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(OFF + 1024));
+}
+__device__ __forceinline__ Vec8<bf16> wg_join(const s16x4& lo, const s16x4& hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  Vec8<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, w);
+  return f;
+}
+// the 12 fragment halves (2 A + 4 B fragments) of k-step KS of the tile at LDS byte offset tb
+template <int KS, int OPB_>
+__device__ __forceinline__ void wg_read12(s16x4 (&r)[12], const unsigned (&fa)[2], const unsigned (&fb)[4], unsigned tb) {
+  wg_tr2<KS * 8192>(r[0], r[1], fa[0] + tb);            wg_tr2<KS * 8192>(r[2], r[3], fa[1] + tb);
+  wg_tr2<OPB_ + KS * 8192>(r[4], r[5], fb[0] + tb);     wg_tr2<OPB_ + KS * 8192>(r[6], r[7], fb[1] + tb);
+  wg_tr2<OPB_ + KS * 8192>(r[8], r[9], fb[2] + tb);     wg_tr2<OPB_ + KS * 8192>(r[10], r[11], fb[3] + tb);
+}
+// wait until at most N LDS operations of this wave are outstanding; the 12 fragment halves of one k-step become defined
+template <int N> __device__ __forceinline__ void wg_wait(s16x4 (&a)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                 "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
+               : "i"(N));
+}
+__device__ __forceinline__ void wg_mma12(const s16x4 (&r)[12], f32x4 (&acc)[2][4]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mma16(wg_join(r[2 * i], r[2 * i + 1]), wg_join(r[4 + 2 * j], r[5 + 2 * j]), acc[i][j]);
+}
+
 // 16-byte write-through (sc1) store: a split-K slab is read by another workgroup of the SAME launch (the tile's last
 // arriver), possibly on another XCD whose L2 is not coherent with ours -- write-through + vmcnt(0) + ticket publishes
 // it without a release fence (cdna guide, Guideline 16 R1; 64 KB per workgroup: 3.0 vs 8.2 us for fence-published
@@ -214,6 +261,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  // LDS byte addresses of this lane's fragment pieces in ring stage 0, k-step 0, half 0 (asm transpose reads, NW 8)
+  const unsigned smem0 = (unsigned)(uintptr_t)(lds_void_t*)wg_smem;
+  unsigned fa_off[2], fb_off[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa_off[i] = smem0 + wg_lane_off(wm * 32 + i * 16, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb_off[j] = smem0 + wg_lane_off(wn * 64 + j * 16, lane);
+
   int buf = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     const bool refill = kt + NS - 1 < nkt;
@@ -230,17 +285,36 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
         for (int e = 0; e < 8; ++e) ks8[e] += t.get(e);
       }
     }
+    if constexpr (NW == 8) {
+      // fragment reads issued up front (asm, see wg_tr2); the MFMAs of k-step 0 start once its 12 reads have returned
+      // (LDS returns in order: the 12 younger ones of k-step 1 may still be outstanding)
+      const unsigned tb = (unsigned)(buf * STAGE);
+      s16x4 r0[12];
+      wg_read12<0, OPB>(r0, fa_off, fb_off, tb);
+      if constexpr (BKT == 64) {
+        s16x4 r1[12];
+        wg_read12<1, OPB>(r1, fa_off, fb_off, tb);
+        wg_wait<12>(r0);
+        wg_mma12(r0, reinterpret_cast<f32x4 (&)[2][4]>(acc));
+        wg_wait<0>(r1);
+        wg_mma12(r1, reinterpret_cast<f32x4 (&)[2][4]>(acc));
+      } else {
+        wg_wait<0>(r0);
+        wg_mma12(r0, reinterpret_cast<f32x4 (&)[2][4]>(acc));
+      }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < BKT / 32; ++ks) {
-      Vec8<bf16> fa[WMT], fb[4];
+      for (int ks = 0; ks < BKT / 32; ++ks) {
+        Vec8<bf16> fa[WMT], fb[4];
 #pragma unroll
-      for (int i = 0; i < WMT; ++i) fa[i] = wg_frag(la, ks * 32, wm * (16 * WMT) + i * 16, lane);
+        for (int i = 0; i < WMT; ++i) fa[i] = wg_frag(la, ks * 32, wm * (16 * WMT) + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = wg_frag(lb, ks * 32, wn * 64 + j * 16, lane);
+        for (int j = 0; j < 4; ++j) fb[j] = wg_frag(lb, ks * 32, wn * 64 + j * 16, lane);
 #pragma unroll
-      for (int i = 0; i < WMT; ++i)
+        for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
+      }
     }
     // tile kt+1 must have landed; up to NS-2 younger tiles stay in flight (vmcnt retires in order)
     if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
@@ -427,6 +501,7 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
     case 643: return wgrad_glds_launch_cfg<64, 3, 8>(a, st);      // 96 KB: one workgroup per CU, two tiles ahead
     case 324: return wgrad_glds_launch_cfg<32, 4, 8>(a, st);      // 64 KB: three half-tiles ahead
     case 323: return wgrad_glds_launch_cfg<32, 3, 8>(a, st);      // 48 KB: three workgroups per CU
+    case 325: return wgrad_glds_launch_cfg<32, 5, 8>(a, st);      // 80 KB: two workgroups per CU, four half-tiles ahead
     default: break;
   }
   return wgrad_glds_launch_cfg<64, 2, 8>(a, st);
