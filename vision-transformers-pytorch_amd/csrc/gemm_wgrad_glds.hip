@@ -201,45 +201,81 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     __syncthreads();
   }
 
-  // DMA piece geometry: one instruction = 4 rows x 256 B; wave w owns rows RPW w .. RPW w + RPW - 1 of each operand tile
+  // DMA piece geometry: one instruction = 4 rows x 256 B; wave w owns rows RPW w .. RPW w + RPW - 1 of each operand tile.
+  //
+  // The issue path runs once per k-tile in EVERY wave, next to 16 MFMAs: its instruction count is what bounds the loop
+  // (profiles/round2_wgrad_phase_ablation.txt: 108 of 160 us with ~150 instructions per k-tile -- 64-bit address
+  // products, column / slice-end / DropPath selects, two LDS round trips for the liveness bytes).  So everything that
+  // does not change from tile to tile is decided ONCE per lane: the source pointers of the FULL tiles advance by a
+  // per-lane constant stride (0 for lanes whose 16-byte chunk lies past the operand's last column: they stay on the
+  // zero row, so the excess rows / columns of the accumulator tile are exact zeros and are never stored); the DropPath
+  // liveness byte of the next tile's rows is fetched from the LDS table one tile ahead; only the slice's partial last
+  // tile (rows past `mend` come from the zero row) takes the general code.
   const int prow = lane >> 4, pslot = lane & 15;
   const bf16* zero = reinterpret_cast<const bf16*>(vtx_zero_row);
-  // (sample - s0, token within the sample) of this lane's rows in the NEXT tile to be requested; advanced per issue
-  int smp[IPW], rem[IPW];
+  const int rps = p.rows_per_scale;
+  const bool has_rs = rowscale != nullptr;                  // wave-uniform
+  const int nfull = (mend - mbeg) / BKT;                    // k-tiles that lie completely inside the slice
+  const bf16* pa[IPW];                                      // next full tile's source of this lane, dy / x
+  const bf16* pb[IPW];
+  const bf16* pz[IPW];                                      // the lane's chunk of the zero row
+  unsigned inca[IPW], incb[IPW];                            // byte stride per k-tile (0: parked on the zero row)
+  int smp[IPW], rem[IPW];                                   // (sample - s0, token within the sample) of the next tile's row
+  int nlive[IPW];                                           // its DropPath liveness (read one tile ahead)
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
-    const int tok = mbeg + wave * RPW + j * 4 + prow;
-    smp[j] = tok / p.rows_per_scale - s0;
-    rem[j] = tok % p.rows_per_scale;
+    const int r = wave * RPW + j * 4 + prow;
+    const int qq = pslot ^ wg_swz(r);
+    const int tok = mbeg + r;
+    const bool ca = n0 + (qq << 3) < N, cb = k0 + (qq << 3) < Kin;
+    pz[j] = zero + (qq << 3);
+    pa[j] = ca ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : pz[j];
+    pb[j] = cb ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
+    inca[j] = ca ? (unsigned)(BKT * ld_dy * 2) : 0u;
+    incb[j] = cb ? (unsigned)(BKT * ld_x * 2) : 0u;
+    smp[j] = tok / rps - s0;
+    rem[j] = tok % rps;
+    nlive[j] = has_rs ? live_tab[smp[j]] : 1;
   }
 
-  // ragged N / Kin (multiples of 8): 16-byte chunks past the operand's last column come from the zero row, so the
-  // excess rows / columns of the accumulator tile are exact zeros (and are never stored)
-  bool cok_a[IPW], cok_b[IPW];
-#pragma unroll
-  for (int j = 0; j < IPW; ++j) {
-    const int qq = pslot ^ wg_swz(wave * RPW + j * 4 + prow);
-    cok_a[j] = n0 + (qq << 3) < N;
-    cok_b[j] = k0 + (qq << 3) < Kin;
-  }
-
-  auto issue = [&](int kt, int buf) {          // called with kt = 0, 1, 2, ... in order
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {          // called with kt = 0, 1, 2, ... in order
     unsigned char* sa = wg_smem + buf * STAGE + wave * RPW * ROWB;
     unsigned char* sb = sa + OPB;
+    if (kt < nfull) {
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int r = wave * RPW + j * 4 + prow;
-      const int tok = mbeg + kt * BKT + r;
-      const int qq = pslot ^ wg_swz(r);
-      bool live = tok < mend;
-      const bf16* srcb = (live && cok_b[j]) ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : zero + (qq << 3);
-      if (live && rowscale != nullptr) live = live_tab[smp[j]] != 0;
-      const bf16* srca = (live && cok_a[j]) ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : zero + (qq << 3);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
-      if (rowscale != nullptr) {
-        rem[j] += BKT;
-        while (rem[j] >= p.rows_per_scale) { rem[j] -= p.rows_per_scale; ++smp[j]; }
+      for (int j = 0; j < IPW; ++j) {
+        const bf16* srca = nlive[j] ? pa[j] : pz[j];
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)pb[j], (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+        pa[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pa[j]) + inca[j]);
+        pb[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pb[j]) + incb[j]);
+      }
+      if (has_rs) {
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+          rem[j] += BKT;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {                       // branch-free for samples of >= BKT / 2 tokens
+            const bool w = rem[j] >= rps;
+            rem[j] -= w ? rps : 0;
+            smp[j] += w ? 1 : 0;
+          }
+          if (rps * 2 < BKT) { while (rem[j] >= rps) { rem[j] -= rps; ++smp[j]; } }   // (wave-uniform condition)
+          nlive[j] = live_tab[smp[j]];                        // consumed by the NEXT call: the LDS latency is off the path
+        }
+      }
+    } else {                                                  // the slice's partial last tile
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) {
+        const int r = wave * RPW + j * 4 + prow;
+        const int tok = mbeg + kt * BKT + r;
+        const int qq = pslot ^ wg_swz(r);
+        bool live = tok < mend;
+        const bf16* srcb = (live && k0 + (qq << 3) < Kin) ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
+        if (live && has_rs) live = live_tab[tok / rps - s0] != 0;
+        const bf16* srca = (live && n0 + (qq << 3) < N) ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : pz[j];
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
       }
     }
   };
