@@ -153,6 +153,9 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
  * The backward writes dq and dkv fully; key-side partials are summed in fixed order (deterministic). */
 int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int dtype,
                    void* stream);
+/* score [B, nH, Lq, Lk] = q k^T / sqrt(64) before the softmax: the second value pvt.MultiHeadedAttention.forward returns
+ * (models/pvt.py:53, 69; the PVT layers discard it).  Inference-side helper: no backward. */
+int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int dtype, void* stream);
 size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH);
 int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
                    void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int dtype, void* stream);

@@ -147,3 +147,77 @@ def test_bench_self_launches_its_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--selftest-launch"],
                         capture_output=True, text=True, timeout=120, env=env2)
     assert r2.returncode != 0 and "disagree" in (r2.stderr + r2.stdout)
+
+
+def _sink_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vtx import functional as VF
+        from vtx.ddp import GradAllReduce
+
+        class SinkLinear(torch.autograd.Function):
+            """Stand-in for the HIP layer functions: its backward writes dW into functional.grad_sink(weight) when there
+            is one and returns that tensor (what ops.wgrad_group(outs=...) does on the GPU)."""
+
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x, w)
+                return x @ w.t()
+
+            @staticmethod
+            def backward(ctx, dy):
+                x, w = ctx.saved_tensors
+                out = VF.grad_sink(w)
+                dW = dy.t() @ x
+                if out is not None:
+                    out.copy_(dW)
+                    dW = out
+                return dy @ w, dW
+
+        torch.manual_seed(0)
+        lin = nn.Linear(16, 8, bias=True)
+        model = nn.Sequential(lin, nn.SiLU(), nn.Linear(8, 4))
+        ddp = GradAllReduce(model, bucket_bytes=1 << 20, first_bucket_bytes=1 << 20)
+        for step in range(2):                         # second step: the grads were reset to None -> the sink is used again
+            torch.manual_seed(10 + rank + 7 * step)
+            x = torch.randn(5, 16)
+            h = SinkLinear.apply(x, lin.weight) + lin.bias
+            model[2](torch.nn.functional.silu(h)).square().sum().backward()
+            b, off = ddp._slot[id(lin.weight)]
+            assert lin.weight.grad.data_ptr() == b.flat.data_ptr() + 4 * off, "weight grad must live in the bucket (no copy)"
+            ddp.finish()
+            # reference: mean over ranks of the plain-autograd gradient
+            exp = 0
+            for r in range(world):
+                torch.manual_seed(0)
+                ref = nn.Sequential(nn.Linear(16, 8), nn.SiLU(), nn.Linear(8, 4))
+                ref.load_state_dict(model.state_dict())
+                torch.manual_seed(10 + r + 7 * step)
+                ref(torch.randn(5, 16)).square().sum().backward()
+                exp = exp + ref[0].weight.grad / world
+            assert torch.allclose(lin.weight.grad, exp, rtol=1e-5, atol=1e-6), f"rank {rank} step {step}"
+            model.zero_grad(set_to_none=True)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_gradients_land_in_the_bucket_without_a_copy():
+    """Persistent bucket views: a backward that writes its weight gradient into functional.grad_sink(param) makes
+    autograd adopt the bucket view as .grad (no per-step packing copy), and the all-reduced result equals plain DDP."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

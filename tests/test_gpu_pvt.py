@@ -153,3 +153,43 @@ def test_pvt_small_drop_path_runs_and_is_deterministic_given_masks(monkeypatch):
     P = {k: v.clone() for k, v in sd.items()}
     ref = M.pvt_forward(P, x, M.PVT_SMALL, drop_masks=masks, drop_path=0.2)
     check("pvt-small fp32 drop-path logits vs oracle", out, ref, 1e-4)
+
+
+@pytest.mark.parametrize("reduction,height,width,n_head", [(4, 28, 28, 2), (1, 7, 7, 8), (2, 14, 14, 5)])
+def test_pvt_attention_standalone_forward_returns_out_and_score(reduction, height, width, n_head):
+    """models.pvt.MultiHeadedAttention.forward(input, height, width) -> (out, score) as in the reference (pvt.py:31-69):
+    out and the parameter / input gradients vs the oracle's pvt_attention, score vs q k^T / sqrt(d) (fp32 parity mode)."""
+    from models.pvt import MultiHeadedAttention
+    d = dev()
+    dim = n_head * 64
+    torch.manual_seed(3)
+    attn = MultiHeadedAttention(dim, n_head, reduction=reduction)
+    sd = {k: v.detach().clone() for k, v in attn.state_dict().items()}
+    attn.to(d).train()
+    gen = torch.Generator().manual_seed(4)
+    B, L = 2, height * width
+    x = torch.randn(B, L, dim, generator=gen)
+    cot = torch.randn(B, L, dim, generator=gen)
+    xg = x.to(d).requires_grad_(True)
+    out, score = attn(xg, height, width)
+    (out * cot.to(d)).sum().backward()
+    P = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    xr = x.double().requires_grad_(True)
+    ref = R.pvt_attention(xr, height, width, P, n_head, reduction)
+    names = list(P.keys())
+    grads = torch.autograd.grad((ref * cot.double()).sum(), [xr] + [P[n] for n in names])
+    check(f"pvt attn standalone out r{reduction}", out, ref, 2e-5)
+    check(f"pvt attn standalone dx r{reduction}", xg.grad, grads[0], 5e-5)
+    got = dict(attn.named_parameters())
+    for n, g in zip(names, grads[1:]):
+        check(f"pvt attn standalone grad {n} r{reduction}", got[n].grad, g, 1e-4)
+    # score = (B, heads, L, Lk) pre-softmax
+    q = R.linear(xr, P["linear_q.weight"], None)
+    kvin = xr if reduction == 1 else R.pvt_reduce(xr, height, width, P["reduce_conv.weight"], P["reduce_conv.bias"],
+                                                  P["reduce_norm.weight"], P["reduce_norm.bias"], reduction)
+    k = R.linear(kvin, P["linear_kv.weight"], None)[..., :dim]
+    sref = torch.einsum("bihd,bjhd->bhij", q.view(B, L, n_head, 64), k.view(B, -1, n_head, 64)) / 8.0
+    assert score.shape == sref.shape
+    check(f"pvt attn standalone score r{reduction}", score, sref, 2e-5)
+    with pytest.raises(NotImplementedError):
+        attn(xg, height, width, prev=score)

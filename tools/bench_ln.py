@@ -6,7 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vision-transformers-pytorch_amd"))
 import torch
 
-from vtx import ops
+from vtx import ops, options
 
 dev = torch.device("cuda")
 
@@ -24,6 +24,9 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+if len(sys.argv) > 1:
+    options.set("LN_FIT", int(sys.argv[1]))
+    print("LN_FIT =", sys.argv[1])
 for rows, C in ((401408, 96), (100352, 192), (25088, 384), (6272, 768), (50432, 384), (401408, 64)):
     x = torch.randn(rows, C, device=dev).bfloat16()
     dy = torch.randn(rows, C, device=dev).bfloat16()

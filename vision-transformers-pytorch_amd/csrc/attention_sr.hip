@@ -352,7 +352,48 @@ static int sr_geom(SrGeom& g, int Lq, int Lk, int nH, int B) {
 }
 static int sr_wgs(const SrGeom& g) { return (g.nsub + g.qc - 1) / g.qc; }
 
+// score[b][h][i][j] = <q[b, i, h, :], k[b, j, h, :]> / sqrt(64): the pre-softmax scores the reference's
+// MultiHeadedAttention.forward RETURNS next to its output (models/pvt.py:53, 69).  Not on the training path (the PVT
+// layers discard it), so a plain kernel: one workgroup per (image, head, 64 queries), K in LDS, fp32 accumulation.
+template <typename T>
+__global__ __launch_bounds__(256) void srattn_score_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                           T* __restrict__ score, int Lq, int Lk, int nH) {
+  __shared__ float ks[SR_LK][SR_D + 1];
+  const int bh = blockIdx.y, b = bh / nH, h = bh - b * nH;
+  const int hd = nH * SR_D;
+  for (int i = threadIdx.x; i < Lk * SR_D; i += 256) {
+    const int j = i / SR_D, d = i - j * SR_D;
+    ks[j][d] = to_f32<T>(kv[((int64_t)b * Lk + j) * 2 * hd + h * SR_D + d]);
+  }
+  __syncthreads();
+  const int q0 = blockIdx.x * 64;
+  for (int idx = threadIdx.x; idx < 64 * Lk; idx += 256) {
+    const int qi = q0 + idx / Lk, j = idx % Lk;
+    if (qi >= Lq) continue;
+    const T* qp = q + ((int64_t)b * Lq + qi) * hd + h * SR_D;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < SR_D; ++d) s += to_f32<T>(qp[d]) * ks[j][d];
+    score[(((int64_t)b * nH + h) * Lq + qi) * Lk + j] = from_f32<T>(s * 0.125f);
+  }
+}
+
 extern "C" {
+
+/* Pre-softmax scores q k^T / sqrt(64) [B, nH, Lq, Lk] of the same operands as vtx_srattn_fwd (reference models/pvt.py:53):
+ * the second return value of pvt.MultiHeadedAttention.forward (models/pvt.py:69); no gradient flows through it here. */
+int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int dtype, void* stream) {
+  if (!q || !kv || !score) return VTX_ERR_NULL;
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0) return VTX_ERR_SHAPE;
+  dim3 grid((Lq + 63) / 64, B * nH);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16)
+    hipLaunchKernelGGL((srattn_score_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)kv, (bf16*)score, Lq, Lk, nH);
+  else if (dtype == VTX_F32)
+    hipLaunchKernelGGL((srattn_score_kernel<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)score, Lq, Lk, nH);
+  else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
 
 /* Spatial-reduction attention of PVT (reference models/pvt.py:38-66), head dim 64, Lk <= 64 keys:
  * q [B*Lq, nH*64], kv [B*Lk, 2*nH*64] (k | v halves, head-major inside each), o [B*Lq, nH*64], lse [B*nH*Lq] fp32. */

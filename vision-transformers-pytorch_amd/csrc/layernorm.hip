@@ -7,6 +7,7 @@
 // register passes (biased variance, fp32 statistics) and sub-wave __shfl_xor reductions.
 // "merge" addressing folds PatchMerge's 2x2 patchify gather (swin_transformer.py:15-22,224) into
 // the row load (forward) and the dx scatter (backward): the 4C-wide row never exists in HBM.
+#include "options.h"
 #include "vtx_common.h"
 
 struct LnAddr {
@@ -228,9 +229,15 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
   return vtx_check_launch();
 }
 
-#define LN_DISPATCH(FN, T, ...)                                          \
+// EXACT-FIT groups (option LN_FIT bit FITBIT): C = 384 = 16 lanes x 3 vectors, C = 768 = 32 x 3 -- every lane of the group
+// holds data (48 of 64 lanes with <64, 1>), four / two rows per wavefront, and the 16-lane sums stay inside DPP rows
+#define LN_DISPATCH(FN, T, FITBIT, ...)                                  \
   do {                                                                   \
     const int nvec = C >> 3;                                             \
+    if (vtx_opt(VTX_OPT_LN_FIT) & (FITBIT)) {                            \
+      if (nvec == 48) return FN<T, 16, 3>(__VA_ARGS__);                  \
+      if (nvec == 96) return FN<T, 32, 3>(__VA_ARGS__);                  \
+    }                                                                    \
     if (nvec <= 16) return FN<T, 16, 1>(__VA_ARGS__);                    \
     if (nvec <= 32) return FN<T, 32, 1>(__VA_ARGS__);                    \
     if (nvec <= 64) return FN<T, 64, 1>(__VA_ARGS__);                    \
@@ -260,8 +267,8 @@ int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
   int rc = ln_make_addr(a, rows, C, merge, H, W);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VTX_BF16) LN_DISPATCH(ln_fwd_launch, bf16, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
-  if (dtype == VTX_F32) LN_DISPATCH(ln_fwd_launch, float, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
+  if (dtype == VTX_BF16) LN_DISPATCH(ln_fwd_launch, bf16, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
+  if (dtype == VTX_F32) LN_DISPATCH(ln_fwd_launch, float, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
   return VTX_ERR_DTYPE;
 }
 
@@ -283,9 +290,9 @@ int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
   float* ws = (float*)workspace;
   if (rows <= 0) return VTX_OK;
   if (dtype == VTX_BF16)
-    LN_DISPATCH(ln_bwd_launch, bf16, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
+    LN_DISPATCH(ln_bwd_launch, bf16, 2, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
   if (dtype == VTX_F32)
-    LN_DISPATCH(ln_bwd_launch, float, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
+    LN_DISPATCH(ln_bwd_launch, float, 2, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
   return VTX_ERR_DTYPE;
 }
 

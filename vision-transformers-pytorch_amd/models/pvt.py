@@ -39,6 +39,39 @@ class MultiHeadedAttention(nn.Module):
             self.reduce_conv = nn.Conv2d(dim, dim, self.reduction, stride=self.reduction)
             self.reduce_norm = LayerNorm(dim)
 
+    def forward(self, input, height, width, prev=None):
+        """The reference's standalone contract (models/pvt.py:31-69): input (B, L, dim) with the last height * width tokens
+        on the grid (leading tokens -- a cls token -- attend but are not reduced); returns ``(out, score)`` with score =
+        q k^T / sqrt(d) of shape (B, heads, L, Lk) before the softmax.  The PVT layers do not come through here (they run
+        the fused PvtLayerFn and discard the score like the reference's TransformerLayer, pvt.py:100); every op is a HIP
+        kernel.  ``prev`` (never passed inside the reference) is not supported; no gradient flows through ``score``."""
+        self.check()
+        if prev is not None:
+            raise NotImplementedError("vtx: pvt.MultiHeadedAttention.forward(prev=...) is not supported")
+        T = VF.compute_dtype(input)
+        x = input.to(T)
+        B, L, C = x.shape
+        r, skip = self.reduction, L - height * width
+        if skip < 0 or (r > 1 and (height % r or width % r)):
+            raise ValueError("pvt.MultiHeadedAttention: tokens do not match the (height, width) grid / reduction")
+        q = VF.LinearFn.apply(x, self.linear_q.weight, None)
+        if r > 1:
+            patches = VF.PatchifyFn.apply(x, height, width, r, skip)
+            w_rows = self.reduce_conv.weight.permute(0, 2, 3, 1).reshape(C, -1)       # conv weight as (py, px, c) columns
+            red = VF.LinearFn.apply(patches, w_rows, self.reduce_conv.bias)
+            kvin = self.reduce_norm(red)
+            Lk = (height // r) * (width // r)
+        else:
+            kvin, Lk = x, L
+        kv = VF.LinearFn.apply(kvin.reshape(B * Lk, C), self.linear_kv.weight, None)
+        q2 = q.reshape(B * L, C)
+        out = VF.SrAttentionFn.apply(q2, kv, B, L, Lk, self.n_head)
+        out = VF.LinearFn.apply(out.view(B, L, C), self.linear.weight, self.linear.bias)
+        from vtx import ops
+        with torch.no_grad():
+            score = ops.srattn_scores(q2.detach().contiguous(), kv.detach().contiguous(), B, L, Lk, self.n_head)
+        return out, score
+
     def check(self):
         if self.dim_head != 64:
             raise NotImplementedError("vtx: the PVT attention kernel is built for head dim 64 (all PVT configurations)")

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "vtx_wattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_srattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_srattn_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_srattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vtx_srattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -92,16 +92,21 @@ class GradAllReduce:
             self.broadcast_state()
         self.buckets = assign_buckets(named, bucket_bytes, first_bucket_bytes, last_bucket_bytes)
         self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else None
+        self._slot = {}
         for b in self.buckets:
             dev = b.params[0].device
             b.flat = torch.zeros(b.numel, dtype=torch.float32, device=dev)
             off = 0
             for p in b.params:
                 b.views.append(b.flat[off:off + p.numel()].view_as(p))
+                self._slot[id(p)] = (b, off)
                 off += p.numel()
             b.pending = len(b.params)
             for p in b.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+        if self.active:
+            from . import functional as VF
+            VF.register_grad_sink_provider(self)
 
     # -- construction-time sync (DDP broadcasts parameters and buffers from rank 0, train.py:102-107)
     @torch.no_grad()
@@ -114,6 +119,15 @@ class GradAllReduce:
             else:
                 dist.broadcast(t.data, 0, group=self.group)
 
+    def grad_sink(self, p):
+        """A FRESH view of ``p``'s slot in its bucket (functional.grad_sink): a kernel that writes the gradient there and
+        returns this tensor from backward makes autograd adopt it as ``p.grad`` -- no packing copy before the all-reduce."""
+        ent = self._slot.get(id(p)) if self.active else None
+        if ent is None:
+            return None
+        b, off = ent
+        return b.flat[off:off + p.numel()].view_as(p)
+
     def _make_hook(self, bucket):
         def hook(param):
             bucket.pending -= 1
@@ -125,8 +139,14 @@ class GradAllReduce:
         if b.params[0].is_cuda:
             from . import functional as VF
             VF.side_join()              # weight gradients computed on the side stream (functional.deferred_wgrad)
-        grads = [p.grad for p in b.params]
-        torch._foreach_copy_(b.views, grads)          # one multi-tensor copy into the flat bucket
+        dst, src = [], []
+        for p, v in zip(b.params, b.views):           # gradients that already live in the bucket need no packing
+            g = p.grad
+            if g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                dst.append(v)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)            # one multi-tensor copy of the rest into the flat bucket
         if self._avg is not None:
             b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
         else:

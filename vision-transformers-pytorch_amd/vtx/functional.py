@@ -190,16 +190,50 @@ def side_join():
             st.keep.clear()
 
 
-def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None):
+_grad_sink_providers = []      # weak references to objects with .grad_sink(param) (vtx.ddp.GradAllReduce)
+
+
+def register_grad_sink_provider(obj):
+    import weakref
+    _grad_sink_providers.append(weakref.ref(obj))
+
+
+def grad_sink(param):
+    """Destination the weight-gradient kernel should write ``param``'s gradient to, or None.  A data-parallel gradient
+    bucket (vtx.ddp) hands out a fresh view of the parameter's slot in its flat buffer: the kernel's final sum lands in
+    the bucket, autograd adopts the returned tensor as ``param.grad`` without a copy, and the all-reduce needs no packing
+    pass.  Only for the first gradient of a step (``param.grad is None``): later ones accumulate into .grad as usual."""
+    if not _grad_sink_providers or param is None or param.grad is not None:
+        return None
+    for ref in list(_grad_sink_providers):
+        obj = ref()
+        if obj is None:
+            _grad_sink_providers.remove(ref)
+            continue
+        v = obj.grad_sink(param)
+        if v is not None:
+            return v
+    return None
+
+
+def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None):
     """Weight (and bias) gradients of several linears over the same tokens: jobs = [(dy, x, want_bias, rowscale)].
     -> [(dW, db)] (+ ``post(result)`` evaluated on the same stream).  One grouped launch when every problem is eligible
-    (bf16, LDS-DMA shapes), else one launch each."""
+    (bf16, LDS-DMA shapes), else one launch each.  ``params``: the weight Parameters, so that gradients can be written
+    straight into a gradient bucket (grad_sink)."""
+    outs = None
+    if params is not None and _grad_sink_providers:
+        outs = [grad_sink(p) for p in params]
+        if not any(o is not None for o in outs):
+            outs = None
+
     def run():
         if len(jobs) > 1 and ops.wgrad_group_ok(jobs, rows_per_scale, scale_const):
-            res = ops.wgrad_group(jobs, rows_per_scale, scale_const)
+            res = ops.wgrad_group(jobs, rows_per_scale, scale_const, outs=outs)
         else:
             res = [ops.wgrad(dy, x, want_bias=wb, rowscale=rs, rows_per_scale=rows_per_scale,
-                             scale_const=scale_const if rs is not None else 0.0) for dy, x, wb, rs in jobs]
+                             scale_const=scale_const if rs is not None else 0.0,
+                             out=None if outs is None else outs[i]) for i, (dy, x, wb, rs) in enumerate(jobs)]
         return post(res) if post is not None else res
 
     dev = jobs[0][0].device
@@ -462,7 +496,8 @@ class TransformerLayerFn(Function):
         dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
         # ---- the four weight gradients: one grouped launch (dropped samples' rows are skipped, 1/(1-p) on the accumulators)
         (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, dbq) = layer_wgrads(
-            [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c)
+            [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c,
+            params=(fc2_w, fc1_w, proj_w, qkv_w))
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
 
@@ -578,6 +613,44 @@ class PvtMeta:
 
     def __init__(self, n_head, height, width, reduction, skip, eps=1e-6):
         self.n_head, self.height, self.width, self.reduction, self.skip, self.eps = n_head, height, width, reduction, skip, eps
+
+
+class PatchifyFn(Function):
+    """Token-major features (B, skip + H*W, C) -> patch matrix (B*(H/p)*(W/p), p*p*C), columns (py, px, c): the im2col of a
+    stride = kernel convolution (PVT's spatial-reduction conv, pvt.py:44-46); backward = the inverse scatter."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, p, skip):
+        x = _c(x)
+        B, _, C = x.shape
+        ctx.geom = (x.shape, H, W, p, skip)
+        return ops.patchify_fwd(x, B, H, W, C, p, skip)
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, H, W, p, skip = ctx.geom
+        dx = torch.zeros(shape, dtype=dout.dtype, device=dout.device) if skip else \
+            torch.empty(shape, dtype=dout.dtype, device=dout.device)
+        ops.patchify_bwd(_c(dout), dx, shape[0], H, W, shape[2], p, skip)
+        return dx, None, None, None, None
+
+
+class SrAttentionFn(Function):
+    """softmax(q k^T / 8) v for PVT's (reduced-key) attention on the q / kv projection outputs (pvt.py:51-63)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, Lq, Lk, n_head):
+        q, kv = _c(q), _c(kv)
+        o, lse = ops.srattn_fwd(q, kv, B, Lq, Lk, n_head)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.geom = (B, Lq, Lk, n_head)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        dq, dkv = ops.srattn_bwd(q, kv, o, _c(do), lse, *ctx.geom)
+        return dq, dkv, None, None, None, None
 
 
 class PvtLayerFn(Function):

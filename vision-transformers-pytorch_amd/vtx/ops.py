@@ -364,6 +364,14 @@ def srattn_fwd(q, kv, B, Lq, Lk, n_head):
     return o, lse
 
 
+def srattn_scores(q, kv, B, Lq, Lk, n_head):
+    """Pre-softmax scores q k^T / 8 as (B, n_head, Lq, Lk) -- what pvt.MultiHeadedAttention.forward returns second."""
+    _dev(q, kv)
+    score = torch.empty((B, n_head, Lq, Lk), dtype=q.dtype, device=q.device)
+    check(_lib.load().vtx_srattn_scores(_p(q), _p(kv), _p(score), B, Lq, Lk, n_head, _dt(q), _stream()), "vtx_srattn_scores")
+    return score
+
+
 def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head):
     """dq, dkv (deterministic)."""
     _dev(q, kv, o, dout, lse)
