@@ -47,21 +47,14 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
   const int wm = wave / NWN, wn = wave % NWN;
   const int c_ = lane & 15, g_ = lane >> 4;
 
-  // PERSISTENT tiles: the grid is 1-D with at most as many workgroups as the chip keeps resident (a multiple of 8), and
-  // workgroup b walks the tiles b, b + G, b + 2 G, ...  A workgroup that exits holds its wave slots and LDS until its
-  // epilogue stores have drained, and every resident workgroup reaches its epilogue at about the same time -- the chip
-  // alternates between a phase where everybody multiplies and a phase where everybody waits for HBM writes (phase
-  // ablation, profiles/round2_gemm_phase_ablation.txt: the parts of a launch ADD).  A persistent workgroup issues its
-  // stores and moves on: the next tile's operand requests and first k-tiles run while they drain.
-  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntn = gridDim.x, ntm = gridDim.y;
   const int nblk = ntn * ntm;
-  const int nk = p.K / BK;
-  const int xq = nblk >> 3, xr = nblk & 7;
-  for (int did = blockIdx.x; did < nblk; did += gridDim.x) {
-  const int xcd = did & 7;
+  const int did = blockIdx.y * ntn + blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
   const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
   const int tn = lid % ntn, tm = lid / ntn;
   const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K / BK;
 
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
@@ -146,11 +139,6 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
   }
 
   gemm_epilogue<bf16, bf16, BM, BN, NWN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_, eo);
-  // the staging buffer (= ring stage 0) is read by every thread in the epilogue's last pass: all of them must be through
-  // before the next tile's DMA lands there.  Raw barrier + LDS-only wait: the stores stay in flight.
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  }
 }
 
 template <int BM, int BN, int BK, int NS, int NWN = 2> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -159,16 +147,7 @@ template <int BM, int BN, int BK, int NS, int NWN = 2> static int glds_launch_cf
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
-  const long tiles = (long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
-  // resident workgroups: 160 KB of LDS per CU / ring size, at most 32 waves per CU; x 256 CUs (a multiple of 8 XCDs)
-  int per_cu = (int)(160 * 1024 / (smem + 1024));
-  if (per_cu * 2 * NWN > 32) per_cu = 32 / (2 * NWN);
-  if (per_cu < 1) per_cu = 1;
-  const int persist = vtx_opt(VTX_OPT_GLDS_PERSIST);
-  long g = persist > 0 ? (long)256 * per_cu * persist / 100 : tiles;
-  g = (g + 7) / 8 * 8;
-  if (g > tiles) g = tiles;
-  dim3 grid((unsigned)g, 1, 1);
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
   hipLaunchKernelGGL(kern, grid, dim3(128 * NWN), smem, st, a);
   return vtx_check_launch();
 }

@@ -21,8 +21,7 @@ enum VtxOptionId {
   VTX_OPT_WATTN_XCD_MAJOR = 11,     // 1: window-attention workgroups ordered head-fastest per XCD (the heads sharing a
                                     //    128-byte line run back to back on one L2); 0: all blocks of head 0, then head 1, ...
   VTX_OPT_WG_RING = 12,             // weight-gradient LDS ring: 0 / 642 = 64-token k-tiles x 2 stages (default) | 643 | 324 | 323
-  VTX_OPT_GLDS_PERSIST = 13,        // LDS-DMA GEMM grid: 0 one workgroup per tile | P > 0: P % of the resident workgroups,
-                                    //    each walking several tiles (100 = exactly one resident round)
+  VTX_OPT_RESERVED13 = 13,          // (unused: a persistent-tile variant of the LDS-DMA GEMM was measured and removed)
   VTX_OPT_LN_FIT = 14,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
   VTX_OPT_COUNT = 15
 };
