@@ -9,7 +9,7 @@ case "$1" in
     TAG=${2:-r1}
     tools/gpu_check.sh tests prof:$TAG profvit:$TAG profpvt:$TAG
     mkdir -p gpurun_out/profdino_$TAG
-    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profdino_$TAG -o trace -- \
+    (cd /tmp && VTX_SIDE_WGRAD=0 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profdino_$TAG -o trace -- \
        python $R/bench.py --model dino --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/profdino_$TAG/run.log 2>&1)
     python tools/rocpd_stats.py gpurun_out/profdino_$TAG/trace_results.db --steps 5 --top 70 > gpurun_out/profdino_$TAG/kernel_stats.md
     rm -f gpurun_out/profdino_$TAG/trace_results.db

@@ -16,7 +16,7 @@ for what in "$@"; do
       tag=${what#profpvt:}
       mkdir -p gpurun_out/profpvt_${tag}
       export TMPDIR=/tmp
-      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profpvt_${tag} -o trace -- \
+      (cd /tmp && VTX_SIDE_WGRAD=0 timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profpvt_${tag} -o trace -- \
          python $R/bench.py --model pvt_small --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/profpvt_${tag}/run.log 2>&1)
       grep '"metric"' gpurun_out/profpvt_${tag}/run.log | cut -c1-220
       python tools/rocpd_stats.py gpurun_out/profpvt_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/profpvt_${tag}/kernel_stats.md
@@ -26,7 +26,7 @@ for what in "$@"; do
       tag=${what#profvit:}
       mkdir -p gpurun_out/profvit_${tag}
       export TMPDIR=/tmp
-      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profvit_${tag} -o trace -- \
+      (cd /tmp && VTX_SIDE_WGRAD=0 timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/profvit_${tag} -o trace -- \
          python $R/bench.py --model vit_s16 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/profvit_${tag}/run.log 2>&1)
       grep '"metric"' gpurun_out/profvit_${tag}/run.log | cut -c1-220
       python tools/rocpd_stats.py gpurun_out/profvit_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/profvit_${tag}/kernel_stats.md
