@@ -114,7 +114,10 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
  *     windows (L = win*win), shift != 0 selects the rolled partition (roll by -win/2 and back are
  *     folded into addressing); bias = [nH][L][L] fp32 from vtx_relpos_bias; mask = local_mask
  *     buffer [nW][L][L] bytes (True = -inf) or NULL.
- * lse [B*nW*nH*L] fp32 (log-sum-exp per query row) is saved for the backward. */
+ * lse [B*nW*nH*L] fp32 (log-sum-exp per query row) is saved for the backward.
+ * Global attention (swin == 0, no bias / mask) runs at ANY L: up to 224 tokens on the register-resident kernels, beyond
+ * (e.g. 577 = ViT-S/16 at 384 x 384, models/vit.py:153-175) on key-block / online-softmax kernels (csrc/attention_long.hip);
+ * their backward needs vtx_attention_bwd_workspace() bytes of workspace (B*nH*L floats). */
 int vtx_relpos_bias(const float* rel_pos, const int64_t* pos, float* bias, int L, int nH, void* stream);
 int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
                       int nH, int D, int swin, int H, int W, int win, int shift, int dtype, void* stream);

@@ -154,7 +154,9 @@ def test_wgrad_droppath_scale(dtype):
 
 # ------------------------------------------------------------------ attention cores
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,L,nH,D", [(2, 197, 6, 64), (3, 37, 6, 64), (1, 49, 2, 32), (2, 64, 1, 64), (2, 101, 3, 64), (1, 128, 2, 64), (2, 224, 1, 64), (1, 5, 2, 64)])
+@pytest.mark.parametrize("B,L,nH,D", [(2, 197, 6, 64), (3, 37, 6, 64), (1, 49, 2, 32), (2, 64, 1, 64), (2, 101, 3, 64), (1, 128, 2, 64), (2, 224, 1, 64), (1, 5, 2, 64),
+                                      # beyond 224 tokens: the key-block / online-softmax kernels (attention_long.hip): 577 = ViT-S/16 at 384^2
+                                      (2, 577, 6, 64), (1, 225, 2, 64), (1, 1025, 1, 64), (2, 300, 3, 32), (1, 256, 2, 64)])
 def test_global_attention_core(dtype, B, L, nH, D):
     from vtx import ops
     d = dev()

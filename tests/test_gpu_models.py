@@ -382,3 +382,31 @@ def test_no_grad_forward_is_bitwise_the_training_graph_forward(family):
                 out = model(x)
         assert ref.requires_grad and not out.requires_grad
         assert torch.equal(ref.detach(), out), f"{family} {ac}: no-grad forward differs from the training-graph forward"
+
+
+def test_vit_at_384_runs_beyond_224_tokens_vs_oracle():
+    """ViT-S/16 at 384 x 384 (577 tokens: the fine-tuning resolution of reference vit.py:153-175 -- bicubic position
+    resize + attention over more tokens than the register-resident kernels hold): fp32 features and gradients vs the
+    oracle, bf16 features within the whole-model band."""
+    from models import VisionTransformer
+    torch.manual_seed(11)
+    vit = VisionTransformer(None, 224, 16, 2, 384, 6, 1536, 0.0, 0.0, 0.0, 0.0)
+    sd = {k: v.detach().clone() for k, v in vit.state_dict().items()}
+    vit.to(dev()).train()
+    x = torch.randn(2, 3, 384, 384, generator=torch.Generator().manual_seed(12))
+    cot = torch.randn(2, 384, generator=torch.Generator().manual_seed(13))
+    f = vit(x.to(dev()))
+    (f * cot.to(dev())).sum().backward()
+    P = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = M.vit_forward(P, x.double(), dict(M.VIT_S16, depth=2))
+    names = [n for n, _ in vit.named_parameters()]
+    rg = torch.autograd.grad((ref * cot.double()).sum(), [P[n] for n in names])
+    check("vit 384^2 (577 tokens) fp32 features", f, ref, 1e-4)
+    num = den = 0.0
+    for (n, p), r in zip(vit.named_parameters(), rg):
+        num += (p.grad.double().cpu() - r).norm().item() ** 2
+        den += r.norm().item() ** 2
+    assert report("vit 384^2 fp32 all-parameter gradient rel-L2", (num / den) ** 0.5, 1e-3)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        fb = vit(x.to(dev()))
+    check("vit 384^2 bf16 features", fb.float(), ref, 1.5e-2)

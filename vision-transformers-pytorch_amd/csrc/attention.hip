@@ -504,6 +504,16 @@ int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH,
 int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int L, int nH,
                      hipStream_t st);
 
+// global attention of any length (attention_long.hip): blocks of 64 keys, online softmax
+bool lattn_ok(int dtype, int D);
+size_t lattn_bwd_workspace(int B, int L, int nH);
+int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st);
+int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
+                     int L, int nH, int D, int dtype, hipStream_t st);
+static bool attn_is_long(int L, int swin, const void* bias, const void* mask) {
+  return !swin && bias == nullptr && mask == nullptr && L > 224;
+}
+
 extern "C" {
 
 int vtx_relpos_bias(const float* rel_pos, const int64_t* pos, float* bias, int L, int nH, void* stream) {
@@ -523,10 +533,12 @@ int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, c
   if (B <= 0) return VTX_OK;
   hipStream_t st = (hipStream_t)stream;
   if (sattn_ok(dtype, L, D, swin, bias)) return sattn_fwd_launch(qkv, o, lse, B, L, nH, st);
+  if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) return lattn_fwd_launch(qkv, o, lse, B, L, nH, D, dtype, st);
   ATTN_DISPATCH(attn_fwd_launch, qkv, o, lse, bias, mask, B, g, st);
 }
 
 size_t vtx_attention_bwd_workspace(int B, int L, int nH, int swin, int H, int W, int win) {
+  if (!swin && L > 224) return lattn_bwd_workspace(B, L, nH);        // Dq = rowsum(dO o O) per query (no bias there)
   const int nW = swin ? (H / win) * (W / win) : 1;
   const int nblk = attn_bwd_blocks(B * nW, nH);
   const size_t slab = ((size_t)nH * L * L + 3) & ~(size_t)3;
@@ -546,6 +558,11 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
   if (B <= 0) return VTX_OK;
   hipStream_t st = (hipStream_t)stream;
   if (sattn_ok(dtype, L, D, swin, bias)) return sattn_bwd_launch(qkv, o, dout, lse, dqkv, B, L, nH, st);
+  if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) {
+    if (!workspace) return VTX_ERR_NULL;
+    if (ws_bytes < lattn_bwd_workspace(B, L, nH)) return VTX_ERR_WORKSPACE;
+    return lattn_bwd_launch(qkv, o, dout, lse, dqkv, (float*)workspace, B, L, nH, D, dtype, st);
+  }
   const int nblk = attn_bwd_blocks(B * g.nW, nH);
   float* part = (float*)workspace;
   if (bias) {

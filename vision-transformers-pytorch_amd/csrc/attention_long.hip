@@ -1,0 +1,355 @@
+// Global attention for ANY sequence length (head dim 64 or 32): the ViT path beyond the 224 tokens the register-resident
+// kernels of attention.hip / attention_seq.hip hold -- e.g. ViT-S/16 at 384 x 384 = 577 tokens, the fine-tuning resolution
+// whose position-embedding interpolation the reference implements at models/vit.py:153-175.
+//
+// Same math as vit.MultiHeadedAttention.forward (models/vit.py:30-42: (q k^T) / sqrt(d), softmax over keys, @ v) on the
+// QKV-projection output [B*L, 3*h*D] (channel order [q|k|v][head][d]), with the keys walked in blocks of 64 and an
+// online softmax (running row maximum m and denominator l; the output accumulators are rescaled by exp(m_old - m_new)
+// when the maximum moves), so nothing of size L x L exists anywhere.  The backward recomputes P from the saved
+// log-sum-exp in two launches: dQ per query tile over all key blocks, dK / dV per key tile over all query blocks
+// (every output element is owned by exactly one wave: deterministic, no atomics).
+//
+// Tiling as in attention.hip (16 x 16 MFMA tiles via mma16): forward and dQ use the swapped product S^T = K Q^T so that
+// a lane holds, for ONE query, 4 keys of every key tile (softmax statistics are lane-local + two shuffles) and the
+// score tiles are directly the A operand of P V / dS K; operands contracted over tokens (V, K for dQ; Q, dO for dK / dV)
+// are staged transposed in LDS one 64-token block at a time.
+#include "vtx_common.h"
+
+#define LA_KB 64                 // tokens per block (4 tiles of 16)
+#define LA_STR (LA_KB + 8)       // transposed LDS row stride
+
+struct LongGeom {
+  int L, nH, hd;
+  float scale;
+};
+
+template <typename T> __device__ __forceinline__ Vec8<T> la_load(const T* p, bool valid) {
+  return valid ? load8<T>(p) : vec8_zero<T>();
+}
+template <typename T> __device__ __forceinline__ Vec8<T> la_frag_acc(const f32x4& lo, const f32x4& hi) {
+  Vec8<T> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.set(j, lo[j]); f.set(4 + j, hi[j]); }
+  return f;
+}
+template <typename T> __device__ __forceinline__ Vec8<T> la_frag_t(const T* p, int g) {   // p -> Xt[d][32 * ks]
+  Vec8<T> f;
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p + 4 * g);
+    bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 16 + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  } else {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * g);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 16 + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = a[j]; f.v[4 + j] = b[j]; }
+  }
+  return f;
+}
+// X[tok0 .. tok0 + 64)[0..D) of image b (row stride ld) -> Xt[d][LA_STR], tokens >= L as zeros
+template <typename T, int D>
+__device__ __forceinline__ void la_stage_t(T* __restrict__ xt, const T* __restrict__ src, int64_t ld, int64_t row0,
+                                           int tok0, int L) {
+  constexpr int DV = D / 8;
+  for (int idx = threadIdx.x; idx < LA_KB * DV; idx += blockDim.x) {
+    const int t = idx / DV, dv = idx - t * DV;
+    Vec8<T> v = vec8_zero<T>();
+    if (tok0 + t < L) v = load8<T>(src + (row0 + tok0 + t) * ld + dv * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xt[(dv * 8 + e) * LA_STR + t] = v.v[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- forward
+// grid = (ceil(L / 64), B * nH); wave w of a block owns query tile 4 blockIdx.x + w
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                       float* __restrict__ lse, LongGeom g) {
+  constexpr int DS = D / 32, DT = D / 16;
+  __shared__ __attribute__((aligned(16))) T vt[D * LA_STR];
+  const int bh = blockIdx.y, b = bh / g.nH, h = bh - b * g.nH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c_ = lane & 15, g_ = lane >> 4;
+  const int64_t ld = 3 * (int64_t)g.hd, row0 = (int64_t)b * g.L;
+  const T* qb = qkv + h * D;
+  const T* kb = qkv + g.hd + h * D;
+  const T* vb = qkv + 2 * g.hd + h * D;
+  const int qt = blockIdx.x * 4 + wave;
+  const int q = qt * 16 + c_;
+  const bool qv = q < g.L;
+  Vec8<T> qf[DS];
+#pragma unroll
+  for (int ds = 0; ds < DS; ++ds) qf[ds] = la_load<T>(qb + (row0 + (qv ? q : 0)) * ld + ds * 32 + g_ * 8, qv);
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < g.L; k0 += LA_KB) {
+    __syncthreads();                                           // the previous block's Vt readers are done
+    la_stage_t<T, D>(vt, vb, ld, row0, k0, g.L);
+    __syncthreads();
+    f32x4 st[4];
+    float mb = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int key = k0 + kt * 16 + c_;
+      const bool kv = key < g.L;
+      const T* kp = kb + (row0 + (kv ? key : 0)) * ld + g_ * 8;
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) mma16(la_load<T>(kp + ds * 32, kv), qf[ds], st[kt]);   // S^T[key][q = c_]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + kt * 16 + g_ * 4 + r;
+        st[kt][r] = kk < g.L ? st[kt][r] * g.scale : -INFINITY;
+        mb = fmaxf(mb, st[kt][r]);
+      }
+    }
+    mb = fmaxf(mb, shfl_xor_f(mb, 16));
+    mb = fmaxf(mb, shfl_xor_f(mb, 32));
+    const float m_new = fmaxf(m_run, mb);                      // finite: every block holds at least one real key
+    const float alpha = __expf(m_run - m_new);                 // exp(-inf) = 0 on the first block
+    float lb = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[kt][r] - m_new);
+        st[kt][r] = p;
+        lb += p;
+      }
+    lb += shfl_xor_f(lb, 16);
+    lb += shfl_xor_f(lb, 32);
+    l_run = l_run * alpha + lb;
+    m_run = m_new;
+    // the accumulators hold queries 4 g_ + r (not c_): fetch their rescale factors from the lanes that own them
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = __shfl(alpha, 4 * g_ + r, 64);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) oacc[dt][r] *= a;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Vec8<T> pf = la_frag_acc<T>(st[2 * ks], st[2 * ks + 1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) mma16(pf, la_frag_t<T>(vt + (dt * 16 + c_) * LA_STR + ks * 32, g_), oacc[dt]);
+    }
+  }
+  if (qv && g_ == 0) lse[(int64_t)bh * g.L + q] = m_run + __logf(l_run);
+  const float inv = 1.f / l_run;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float iv = __shfl(inv, 4 * g_ + r, 64);
+    const int qo = qt * 16 + g_ * 4 + r;
+    if (qo < g.L) {
+      T* op = o + (row0 + qo) * (int64_t)g.hd + h * D + c_;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) op[dt * 16] = from_f32<T>(oacc[dt][r] * iv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward: dQ
+// grid = (ceil(L / 64), B * nH); wave <-> query tile; also writes Dq[q] = rowsum(dO o O) for the dK / dV launch
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ oin,
+                                                          const T* __restrict__ dout, const float* __restrict__ lse,
+                                                          T* __restrict__ dqkv, float* __restrict__ dsum_out, LongGeom g) {
+  constexpr int DS = D / 32, DT = D / 16;
+  __shared__ __attribute__((aligned(16))) T kt_s[D * LA_STR];
+  const int bh = blockIdx.y, b = bh / g.nH, h = bh - b * g.nH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c_ = lane & 15, g_ = lane >> 4;
+  const int64_t ld = 3 * (int64_t)g.hd, row0 = (int64_t)b * g.L;
+  const T* qb = qkv + h * D;
+  const T* kb = qkv + g.hd + h * D;
+  const T* vb = qkv + 2 * g.hd + h * D;
+  const int qt = blockIdx.x * 4 + wave;
+  const int q = qt * 16 + c_;
+  const bool qv = q < g.L;
+  const int64_t qrow = row0 + (qv ? q : 0);
+  Vec8<T> qf[DS], dof[DS];
+  float dsum = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < DS; ++ds) {
+    qf[ds] = la_load<T>(qb + qrow * ld + ds * 32 + g_ * 8, qv);
+    dof[ds] = la_load<T>(dout + qrow * g.hd + h * D + ds * 32 + g_ * 8, qv);
+    Vec8<T> of = la_load<T>(oin + qrow * g.hd + h * D + ds * 32 + g_ * 8, qv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsum += of.get(e) * dof[ds].get(e);
+  }
+  dsum += shfl_xor_f(dsum, 16);
+  dsum += shfl_xor_f(dsum, 32);
+  const float lq = qv ? lse[(int64_t)bh * g.L + q] : INFINITY;          // padded query rows: exp(. - inf) = 0
+  if (qv && g_ == 0) dsum_out[(int64_t)bh * g.L + q] = dsum;
+  f32x4 dqacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < g.L; k0 += LA_KB) {
+    __syncthreads();
+    la_stage_t<T, D>(kt_s, kb, ld, row0, k0, g.L);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 dsv[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kt = 2 * ks + half;
+        f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int key = k0 + kt * 16 + c_;
+        const bool kv = key < g.L;
+        const int64_t krow = row0 + (kv ? key : 0);
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+          mma16(la_load<T>(kb + krow * ld + ds * 32 + g_ * 8, kv), qf[ds], pt);      // S^T [key][q = c_]
+          mma16(la_load<T>(vb + krow * ld + ds * 32 + g_ * 8, kv), dof[ds], dpt);    // dP^T
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = k0 + kt * 16 + g_ * 4 + r;
+          const float p = kk < g.L ? __expf(pt[r] * g.scale - lq) : 0.f;
+          dsv[half][r] = p * (dpt[r] - dsum);
+        }
+      }
+      Vec8<T> dsf = la_frag_acc<T>(dsv[0], dsv[1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) mma16(dsf, la_frag_t<T>(kt_s + (dt * 16 + c_) * LA_STR + ks * 32, g_), dqacc[dt]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qo = qt * 16 + g_ * 4 + r;
+    if (qo < g.L) {
+      T* p = dqkv + (row0 + qo) * ld + h * D + c_;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) p[dt * 16] = from_f32<T>(dqacc[dt][r] * g.scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward: dK, dV
+// grid = (ceil(L / 64), B * nH); wave <-> key tile; walks the queries in blocks of 64 (Qt, dOt staged transposed)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum_in,
+                                                           T* __restrict__ dqkv, LongGeom g) {
+  constexpr int DS = D / 32, DT = D / 16;
+  __shared__ __attribute__((aligned(16))) T qt_s[D * LA_STR];
+  __shared__ __attribute__((aligned(16))) T dot_s[D * LA_STR];
+  __shared__ float lse_s[LA_KB], dsum_s[LA_KB];
+  const int bh = blockIdx.y, b = bh / g.nH, h = bh - b * g.nH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c_ = lane & 15, g_ = lane >> 4;
+  const int64_t ld = 3 * (int64_t)g.hd, row0 = (int64_t)b * g.L;
+  const T* qb = qkv + h * D;
+  const T* kb = qkv + g.hd + h * D;
+  const T* vb = qkv + 2 * g.hd + h * D;
+  const T* dob = dout + h * D;
+  const int kt = blockIdx.x * 4 + wave;
+  const int key = kt * 16 + c_;
+  const bool kv = key < g.L;
+  const int64_t krow = row0 + (kv ? key : 0);
+  Vec8<T> kf[DS], vf[DS];
+#pragma unroll
+  for (int ds = 0; ds < DS; ++ds) {
+    kf[ds] = la_load<T>(kb + krow * ld + ds * 32 + g_ * 8, kv);
+    vf[ds] = la_load<T>(vb + krow * ld + ds * 32 + g_ * 8, kv);
+  }
+  f32x4 dkacc[DT], dvacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < g.L; q0 += LA_KB) {
+    __syncthreads();
+    la_stage_t<T, D>(qt_s, qb, ld, row0, q0, g.L);
+    la_stage_t<T, D>(dot_s, dob, (int64_t)g.hd, row0, q0, g.L);
+    if (threadIdx.x < LA_KB) {
+      const int qq = q0 + threadIdx.x;
+      lse_s[threadIdx.x] = qq < g.L ? lse[(int64_t)bh * g.L + qq] : INFINITY;      // padded queries: p = 0
+      dsum_s[threadIdx.x] = qq < g.L ? dsum_in[(int64_t)bh * g.L + qq] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x4 pp[2], dss[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qtl = 2 * qs + half;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int q = q0 + qtl * 16 + c_;
+        const bool qv = q < g.L;
+        const int64_t qrow = row0 + (qv ? q : 0);
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+          mma16(la_load<T>(qb + qrow * ld + ds * 32 + g_ * 8, qv), kf[ds], s);           // S [q][key = c_]
+          mma16(la_load<T>(dob + qrow * g.hd + ds * 32 + g_ * 8, qv), vf[ds], dp);       // dP
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qtl * 16 + g_ * 4 + r;
+          const float p = kv ? __expf(s[r] * g.scale - lse_s[ql]) : 0.f;
+          pp[half][r] = p;
+          dss[half][r] = p * (dp[r] - dsum_s[ql]);
+        }
+      }
+      Vec8<T> pf = la_frag_acc<T>(pp[0], pp[1]);
+      Vec8<T> dsf = la_frag_acc<T>(dss[0], dss[1]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        mma16(pf, la_frag_t<T>(dot_s + (dt * 16 + c_) * LA_STR + qs * 32, g_), dvacc[dt]);
+        mma16(dsf, la_frag_t<T>(qt_s + (dt * 16 + c_) * LA_STR + qs * 32, g_), dkacc[dt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ko = kt * 16 + g_ * 4 + r;
+    if (ko < g.L) {
+      T* p = dqkv + (row0 + ko) * ld + h * D + c_;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        p[g.hd + dt * 16] = from_f32<T>(dkacc[dt][r] * g.scale);
+        p[2 * g.hd + dt * 16] = from_f32<T>(dvacc[dt][r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host
+bool lattn_ok(int dtype, int D) { return (dtype == VTX_BF16 || dtype == VTX_F32) && (D == 64 || D == 32); }
+size_t lattn_bwd_workspace(int B, int L, int nH) { return (size_t)B * nH * L * sizeof(float); }
+
+template <typename T, int D>
+static int lattn_fwd_t(const void* qkv, void* o, float* lse, int B, const LongGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL((lattn_fwd_kernel<T, D>), dim3((g.L + 63) / 64, B * g.nH), dim3(256), 0, st, (const T*)qkv, (T*)o, lse, g);
+  return vtx_check_launch();
+}
+template <typename T, int D>
+static int lattn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
+                       const LongGeom& g, hipStream_t st) {
+  dim3 grid((g.L + 63) / 64, B * g.nH);
+  hipLaunchKernelGGL((lattn_bwd_dq_kernel<T, D>), grid, dim3(256), 0, st, (const T*)qkv, (const T*)o, (const T*)dout, lse,
+                     (T*)dqkv, ws, g);
+  int rc = vtx_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL((lattn_bwd_dkv_kernel<T, D>), grid, dim3(256), 0, st, (const T*)qkv, (const T*)dout, lse,
+                     (const float*)ws, (T*)dqkv, g);
+  return vtx_check_launch();
+}
+
+int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st) {
+  LongGeom g{L, nH, nH * D, 1.0f / sqrtf((float)D)};
+  if (dtype == VTX_BF16) return D == 64 ? lattn_fwd_t<bf16, 64>(qkv, o, lse, B, g, st) : lattn_fwd_t<bf16, 32>(qkv, o, lse, B, g, st);
+  return D == 64 ? lattn_fwd_t<float, 64>(qkv, o, lse, B, g, st) : lattn_fwd_t<float, 32>(qkv, o, lse, B, g, st);
+}
+int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
+                     int L, int nH, int D, int dtype, hipStream_t st) {
+  LongGeom g{L, nH, nH * D, 1.0f / sqrtf((float)D)};
+  if (dtype == VTX_BF16)
+    return D == 64 ? lattn_bwd_t<bf16, 64>(qkv, o, dout, lse, dqkv, ws, B, g, st) : lattn_bwd_t<bf16, 32>(qkv, o, dout, lse, dqkv, ws, B, g, st);
+  return D == 64 ? lattn_bwd_t<float, 64>(qkv, o, dout, lse, dqkv, ws, B, g, st) : lattn_bwd_t<float, 32>(qkv, o, dout, lse, dqkv, ws, B, g, st);
+}

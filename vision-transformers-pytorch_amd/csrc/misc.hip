@@ -194,7 +194,12 @@ int vtx_patch_gather(const float* x, void* out, int B, int Cin, int H, int W, in
   const int K = Cin * p * p;
   if (p <= 0 || H % p || W % p || (W & 3) || (Kp & 7) || Kp < K) return VTX_ERR_SHAPE;
   const size_t smem = (size_t)Cin * p * W * sizeof(float);
-  if (smem > 64 * 1024) return VTX_ERR_SHAPE;
+  if (smem > 160 * 1024) return VTX_ERR_SHAPE;
+  if (smem > 64 * 1024) {                                 // e.g. ViT-S/16 at 384 x 384: 3 x 16 rows x 384 floats = 72 KB
+    if (hipFuncSetAttribute((const void*)patch_gather_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)patch_gather_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return VTX_ERR_LAUNCH;
+  }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(B * (H / p));
   MISC_BY_DTYPE(

@@ -678,8 +678,9 @@ def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
     lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
     fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224      # mirrors sattn_ok
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
-    ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}>" if fast else "attn_fwd_kernel", B * nW * n_head, L, D, rows, n_head * D,
-                       qkv.element_size(), False)
+    long_ = swin is None and bias is None and mask is None and L > 224
+    ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
+                       B * nW * n_head, L, D, rows, n_head * D, qkv.element_size(), False)
     check(_lib.load().vtx_attention_fwd(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
                                         int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), _stream()),
           "vtx_attention_fwd")
@@ -699,13 +700,15 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
         order, offsets = csr
         _dev(order, offsets)
         drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
+    if bias is not None or (swin is None and L > 224):          # bias-gradient slabs / the long kernels' Dq vector
         wsb = lib.vtx_attention_bwd_workspace(B, L, n_head, int(swin is not None), H, W, max(win, 1))
         ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
     rows = qkv.numel() // (3 * n_head * D)
     fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
-    ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}>" if fast else "attn_bwd_kernel", rows // L * n_head, L, D, rows,
-                       n_head * D, qkv.element_size(), True)
+    long_ = swin is None and bias is None and mask is None and L > 224
+    ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
+                       rows // L * n_head, L, D, rows, n_head * D, qkv.element_size(), True)
     check(lib.vtx_attention_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
                                 _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
                                 H, W, win, int(bool(shift)), _dt(qkv), _stream()), "vtx_attention_bwd")
