@@ -104,6 +104,29 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
             assert torch.equal(a, g), f"{name} differs under {kw}"
 
 
+def test_wave_specialised_persistent_gemm_is_bitwise_the_shipped_kernel():
+    """csrc/gemm_ws.hip (option GEMM_WS, off by default: measured slower): producer / consumer waves, persistent tiles --
+    the same summation order per output element, so every fused epilogue must give the shipped kernel's bits."""
+    from vtx import ops, options
+    d = dev()
+    for M, N, K, T in ((25088, 1536, 384, 196), (50432, 384, 1536, 197), (16500, 1280, 64, 100)):
+        x, w = _mk((M, K), 171, BF, device=d), _mk((N, K), 172, BF, 0.05, device=d)
+        b, res = _mk((N,), 173, torch.float32, 0.1, device=d), _mk((M, N), 174, BF, device=d)
+        keep = (torch.rand(M // T, device=d) < 0.8).float() / 0.8
+
+        def run():
+            h, z = ops.gemm(x, w, 0, bias=b, act=ops.ACT_SILU, want_aux=True)
+            dz = ops.gemm(x, w, 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep, rows_per_scale=T)
+            y = ops.gemm(x, w, 0, bias=b, resid=res, rowscale=keep, rows_per_scale=T)
+            return h, z, dz, y
+
+        base = run()
+        with options.override(GEMM_WS=1):
+            got = run()
+        for a, g, name in zip(base, got, ("h", "z", "dz", "y")):
+            assert torch.equal(a, g), f"{name} differs ({M}x{N}x{K})"
+
+
 # ------------------------------------------------------------------ weight gradients at the real token counts
 def _wgrad_ref(dy, x, keep, T, c):
     m = None if keep is None else (keep > 0).double().repeat_interleave(T)[:, None]

@@ -280,7 +280,10 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   int rc = gemm_validate(a, mode);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VTX_BF16 && mode == 0 && gemm_glds_ok(N, K) && gemm_glds_enabled()) return gemm_glds_launch(a, st);
+  if (dtype == VTX_BF16 && mode == 0 && gemm_glds_ok(N, K) && gemm_glds_enabled()) {
+    if (gemm_ws_ok(a)) return gemm_ws_launch(a, st);
+    return gemm_glds_launch(a, st);
+  }
   if (dtype == VTX_BF16)
     return mode == 0 ? gemm_pick_bn<bf16, bf16, false, false>(a, 1, st) : gemm_pick_bn<bf16, bf16, false, true>(a, 1, st);
   if (dtype == VTX_F32)

@@ -149,6 +149,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st);
 bool gemm_glds_enabled();
 bool gemm_glds_ok(int N, int K);
+// persistent wave-specialised variant (gemm_ws.hip; option GEMM_WS)
+bool gemm_ws_ok(const GemmArgs& a);
+int gemm_ws_launch(const GemmArgs& a, hipStream_t st);
 
 // LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N and Kin multiples of 8 and >= 64,
 // rowscale values restricted to {0, scale_const}.  Grouped: up to wgrad_glds_max_problems() weight gradients over the

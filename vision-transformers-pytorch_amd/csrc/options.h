@@ -21,7 +21,7 @@ enum VtxOptionId {
   VTX_OPT_WATTN_XCD_MAJOR = 11,     // 1: window-attention workgroups ordered head-fastest per XCD (the heads sharing a
                                     //    128-byte line run back to back on one L2); 0: all blocks of head 0, then head 1, ...
   VTX_OPT_WG_RING = 12,             // weight-gradient LDS ring: 0 / 642 = 64-token k-tiles x 2 stages (default) | 643 | 324 | 323
-  VTX_OPT_RESERVED13 = 13,          // (unused: a persistent-tile variant of the LDS-DMA GEMM was measured and removed)
+  VTX_OPT_GEMM_WS = 13,             // 1: persistent wave-specialised GEMM (gemm_ws.hip) for launches with >= 1024 128 x 128 tiles (experimental)
   VTX_OPT_LN_FIT = 14,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
   VTX_OPT_COUNT = 15
 };
