@@ -61,7 +61,13 @@ int vtx_set_option(int id, int value);   /* VTX_ERR_SHAPE for an unknown id */
 int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int C, float eps, int dtype, int merge, int H, int W, void* stream);
 size_t vtx_layernorm_bwd_workspace(int64_t rows, int C);
-/* dx = dres + LN'(dy)  (dres optional, plain layout only), dgamma / dbeta fp32 [C] (overwritten). */
+/* dx = dres + LN'(dy)  (dres optional, plain layout only), dgamma / dbeta fp32 [C] (overwritten).
+ * dgamma == dbeta == NULL defers the final column reduce: the per-block partials stay in the workspace as
+ * [vtx_layernorm_bwd_blocks(rows, C)][2 C] fp32 and the caller sums them -- together with the layer's other small
+ * reductions -- in one vtx_colreduce_multi launch (same summation order, same bits). */
+int vtx_layernorm_bwd_blocks(int64_t rows, int C);
+int vtx_colreduce_multi(int n, const float* const* part, float* const* out0, float* const* out1, const int* nb,
+                        const int* C, const int* ld, void* stream);
 int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
                       int64_t rows, int C, int dtype, int merge, int H, int W, void* stream);
@@ -145,6 +151,10 @@ int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const float* rel_pos, co
                   const uint8_t* region, int B, int L, int nH, int H, int W, int win, int shift, int dtype,
                   void* stream);
 size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win);
+/* drel_pos == NULL defers the rel_pos-gradient reduce: vtx_wattn_bwd_parts() partial rows of stride vtx_wattn_bwd_part_ld(nH)
+ * stay in the workspace (columns (2 win - 1)^2 * nH) for vtx_colreduce_multi. */
+int vtx_wattn_bwd_parts(int B, int nH, int H, int W, int win);
+int vtx_wattn_bwd_part_ld(int nH);
 int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
                   size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream);

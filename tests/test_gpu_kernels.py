@@ -417,3 +417,36 @@ def test_mix_loss_kernel(dtype, B, K, eps):
     (gr,) = torch.autograd.grad(lr * 0.5, [xr])
     check(f"mix loss {dtype} B{B} K{K}", loss, lr, 2e-6)
     check(f"mix loss d logits {dtype} B{B} K{K}", x.grad, gr, 2e-5 if dtype == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_deferred_column_reductions_match_the_kernels_own_bit_for_bit(dtype):
+    """LayerNorm dgamma / dbeta and the window-attention rel_pos gradient, reduced later by ONE colreduce_multi launch
+    (what TransformerLayerFn.backward does per layer) vs the reductions the kernels run themselves."""
+    from oracle import tables
+    from vtx import ops
+    from vtx.tables import mask_regions
+    d = dev()
+    rows, C = 2 * 14 * 14, 384
+    x, dy, res = _mk((rows, C), 501, dtype).to(d), _mk((rows, C), 502, dtype).to(d), _mk((rows, C), 503, dtype).to(d)
+    g, b = (1 + 0.1 * _mk((C,), 504, torch.float32)).to(d), _mk((C,), 505, torch.float32, 0.1).to(d)
+    _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    dx_a, dg_a, db_a = ops.layernorm_bwd(dy, x, mean, rstd, g, dres=res)
+    dx_b, part_ln = ops.layernorm_bwd(dy, x, mean, rstd, g, dres=res, defer=True)
+    B, H, nH, win = 2, 14, 12, 7
+    L, ntab = win * win, (2 * win - 1) ** 2
+    qkv, do = _mk((B, H, H, 3 * nH * 32), 506, dtype).to(d), _mk((B, H, H, nH * 32), 507, dtype).to(d)
+    rel = _mk((ntab, nH), 508, torch.float32, 0.5).to(d)
+    pos_np, mask_np = tables.make_pos_mask((H, H), win, True)
+    pos = torch.from_numpy(pos_np).to(d)
+    region, ok = mask_regions(torch.from_numpy(mask_np).to(d))
+    assert ok
+    swin = (H, H, win, True)
+    o, lse = ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin)
+    dq_a, drel_a = ops.wattn_bwd(qkv, o, do, lse, rel, pos, region, B, L, nH, swin, ntab)
+    dq_b, part_rel = ops.wattn_bwd(qkv, o, do, lse, rel, pos, region, B, L, nH, swin, ntab, defer=True)
+    (dg_b, db_b), (dg_c, db_c), (drel_b, none) = ops.colreduce_multi([part_ln, part_ln, part_rel])
+    assert none is None
+    assert torch.equal(dx_a, dx_b) and torch.equal(dq_a, dq_b)
+    assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b) and torch.equal(dg_a, dg_c) and torch.equal(db_a, db_c)
+    assert torch.equal(drel_a, drel_b.view(ntab, nH))

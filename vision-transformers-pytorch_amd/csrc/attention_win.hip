@@ -508,6 +508,14 @@ int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const float* rel_pos, co
   return VTX_ERR_DTYPE;
 }
 
+/* partial rows ([rows][172 * nH] fp32, the first (2 win - 1)^2 * nH columns used) vtx_wattn_bwd leaves in its workspace when
+ * drel_pos == NULL (the caller reduces them with vtx_colreduce_multi: C = (2 win - 1)^2 * nH, ld = 172 * nH) */
+int vtx_wattn_bwd_parts(int B, int nH, int H, int W, int win) {
+  if (win <= 0 || H % win || W % win) return 0;
+  return wattn_bwd_blocks(B * (H / win) * (W / win), nH) * WA_WAVES;
+}
+int vtx_wattn_bwd_part_ld(int nH) { return WA_NBIN * nH; }
+
 size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win) {
   const int nbn = B * (H / win) * (W / win);
   return (size_t)wattn_bwd_blocks(nbn, nH) * WA_WAVES * nH * WA_NBIN * sizeof(float);
@@ -516,7 +524,7 @@ size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win) {
 int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
                   size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream) {
-  if (!qkv || !o || !dout || !lse || !rel_pos || !pos || !dqkv || !drel_pos || !workspace) return VTX_ERR_NULL;
+  if (!qkv || !o || !dout || !lse || !rel_pos || !pos || !dqkv || !workspace) return VTX_ERR_NULL;   // drel_pos NULL: deferred reduce
   WinGeom g;
   int rc = win_geom(g, L, nH, H, W, win, shift);
   if (rc) return rc;
@@ -532,7 +540,7 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
     rc = region ? wattn_bwd_launch<float, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st)
                 : wattn_bwd_launch<float, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st);
   else return VTX_ERR_DTYPE;
-  if (rc) return rc;
+  if (rc || drel_pos == nullptr) return rc;              // deferred: partials stay in the workspace
   const int ntab = (2 * win - 1) * (2 * win - 1);
   const int nwaves = wattn_bwd_blocks(nbn, nH) * WA_WAVES;
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(ntab * nH), dim3(1024), 0, st, (const float*)part, drel_pos,

@@ -224,7 +224,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
   hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
                      gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
   int rc = vtx_check_launch();
-  if (rc) return rc;
+  if (rc || dgamma == nullptr) return rc;                // deferred: the partials stay in ws ([nb][2C]), see vtx_colreduce_multi
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(2 * C), dim3(1024), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
   return vtx_check_launch();
 }
@@ -272,6 +272,16 @@ int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
   return VTX_ERR_DTYPE;
 }
 
+/* number of partial rows ([blocks][2C] fp32) vtx_layernorm_bwd leaves in its workspace when dgamma == dbeta == NULL */
+int vtx_layernorm_bwd_blocks(int64_t rows, int C) {
+  const int nvec = C >> 3;
+  const int G = nvec <= 16 ? 16 : (nvec <= 32 ? 32 : 64);
+  int g2 = G;
+  if ((vtx_opt(VTX_OPT_LN_FIT) & 2) && nvec == 48) g2 = 16;
+  if ((vtx_opt(VTX_OPT_LN_FIT) & 2) && nvec == 96) g2 = 32;
+  return ln_grid(rows, 256 / g2, 1024);
+}
+
 size_t vtx_layernorm_bwd_workspace(int64_t rows, int C) {
   (void)rows;
   return (size_t)1024 * 2 * (size_t)C * sizeof(float);
@@ -280,7 +290,8 @@ size_t vtx_layernorm_bwd_workspace(int64_t rows, int C) {
 int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
                       int64_t rows, int C, int dtype, int merge, int H, int W, void* stream) {
-  if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return VTX_ERR_NULL;
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !workspace) return VTX_ERR_NULL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return VTX_ERR_NULL;      // both (reduce now) or neither (deferred)
   if (ws_bytes < vtx_layernorm_bwd_workspace(rows, C)) return VTX_ERR_WORKSPACE;
   LnAddr a;
   int rc = ln_make_addr(a, rows, C, merge, H, W);
@@ -294,6 +305,30 @@ int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
   if (dtype == VTX_F32)
     LN_DISPATCH(ln_bwd_launch, float, 2, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
   return VTX_ERR_DTYPE;
+}
+
+/* Several fixed-order column reductions in one launch: out0[i][c] = sum_b part[i][b][c] (c < C[i]), out1[i][c - C[i]] for
+ * C[i] <= c < 2 C[i] when out1[i] != NULL; nb[i] partial rows of stride ld[i].  n <= 4.  Same summation order (same bits)
+ * as the reductions vtx_layernorm_bwd / vtx_wattn_bwd run themselves when given their outputs. */
+int vtx_colreduce_multi(int n, const float* const* part, float* const* out0, float* const* out1, const int* nb,
+                        const int* C, const int* ld, void* stream) {
+  if (!part || !out0 || !nb || !C || !ld) return VTX_ERR_NULL;
+  if (n < 1 || n > 4) return VTX_ERR_SHAPE;
+  ColReduceMulti m;
+  int blk = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int k = i < n ? i : 0;
+    if (!part[k] || !out0[k] || nb[k] <= 0 || C[k] <= 0) return VTX_ERR_NULL;
+    m.part[i] = part[k]; m.out0[i] = out0[k]; m.out1[i] = out1 ? out1[k] : nullptr;
+    m.nb[i] = nb[k]; m.C[i] = C[k]; m.ld[i] = ld[k];
+    m.blk0[i] = blk;
+    if (i < n) blk += ((m.out1[i] ? 2 * C[k] : C[k]) + 31) / 32;
+  }
+  m.blk0[4] = blk;
+  for (int i = n; i < 4; ++i) m.blk0[i] = blk;
+  m.n = n;
+  hipLaunchKernelGGL(colreduce_multi_kernel, dim3(blk), dim3(1024), 0, (hipStream_t)stream, m);
+  return vtx_check_launch();
 }
 
 }  // extern "C"

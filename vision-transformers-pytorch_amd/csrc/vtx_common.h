@@ -159,6 +159,49 @@ static __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __r
 }
 static inline dim3 colreduce_grid(int ncols) { return dim3((ncols + 31) / 32); }
 
+// Up to 4 such reductions in ONE launch (the LayerNorm dgamma / dbeta partials and the rel_pos gradient partials of a
+// transformer layer's backward: three 5-us launches become one): segment s owns blocks [blk0[s], blk0[s + 1]).
+struct ColReduceMulti {
+  const float* part[4]; float* out0[4]; float* out1[4];
+  int nb[4], C[4], ld[4], blk0[5];
+  int n;
+};
+static __global__ __launch_bounds__(1024) void colreduce_multi_kernel(ColReduceMulti m) {
+  __shared__ float red[32][33];
+  int sgm = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < m.n && (int)blockIdx.x >= m.blk0[i]) sgm = i;
+  const float* __restrict__ part = m.part[sgm];
+  float* __restrict__ out0 = m.out0[sgm];
+  float* __restrict__ out1 = m.out1[sgm];
+  const int nb = m.nb[sgm], C = m.C[sgm], ld = m.ld[sgm];
+  const int ncols = out1 ? 2 * C : C;
+  const int nrl = blockDim.x >> 5;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = ((int)blockIdx.x - m.blk0[sgm]) * 32 + cl;
+  float s = 0.f;
+  if (c < ncols) {                                       // the same fixed interleave as colreduce_kernel: identical bits
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = rl;
+    for (; b + 3 * nrl < nb; b += 4 * nrl) {
+      s0 += part[(int64_t)b * ld + c];
+      s1 += part[(int64_t)(b + nrl) * ld + c];
+      s2 += part[(int64_t)(b + 2 * nrl) * ld + c];
+      s3 += part[(int64_t)(b + 3 * nrl) * ld + c];
+    }
+    for (; b < nb; b += nrl) s0 += part[(int64_t)b * ld + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < ncols) {
+    float t = 0.f;
+    for (int r = 0; r < nrl; ++r) t += red[r][cl];
+    if (c < C) out0[c] = t; else out1[c - C] = t;
+  }
+}
+
 // out[i] = sum_z slab[z][i]   (fixed order: deterministic).  n must be a multiple of 4.
 static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int nz) {
   const int64_t n4 = n >> 2;

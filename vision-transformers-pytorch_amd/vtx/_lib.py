@@ -28,6 +28,8 @@ _SIGNATURES = {
     "vtx_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                   c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_layernorm_bwd_workspace": (c_size_t, [c_int64, c_int]),
+    "vtx_layernorm_bwd_blocks": (c_int, [c_int64, c_int]),
+    "vtx_colreduce_multi": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vtx_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p]),
@@ -52,6 +54,8 @@ _SIGNATURES = {
     "vtx_wattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_wattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "vtx_wattn_bwd_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vtx_wattn_bwd_part_ld": (c_int, [c_int]),
     "vtx_wattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_srattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

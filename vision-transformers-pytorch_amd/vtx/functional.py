@@ -154,6 +154,8 @@ def _img(x):
 #     before it reduces a bucket.  Operands are kept alive until the join (the caching allocator would otherwise hand
 #     their memory to the main stream while the side stream still reads it).  Bitwise identical either way.
 _SIDE_ENABLED = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
+# one column-reduce launch per layer (LayerNorm dgamma / dbeta x 2 + rel_pos gradient) instead of three; 0: each kernel reduces its own
+_DEFER_REDUCE = os.environ.get("VTX_DEFER_REDUCE", "1") != "0"
 _deferred = False
 
 
@@ -423,11 +425,13 @@ def _attn_forward(qkv, rel_pos, meta):
     return o, lse, bias
 
 
-def _attn_backward(qkv, o, do, lse, aux, meta, rel_pos=None):
+def _attn_backward(qkv, o, do, lse, aux, meta, rel_pos=None, defer=False):
+    """-> dqkv, drel_pos (an ops.Partials with ``defer`` on the window-attention fast path: reduced later in one launch
+    with the layer's LayerNorm partials)."""
     B = qkv.shape[0]
     if _wattn_ok(rel_pos, meta):
         return ops.wattn_bwd(qkv, o, do, lse, rel_pos.detach(), meta.pos, meta.region, B, meta.L, meta.n_head,
-                             meta.swin, meta.ntab)
+                             meta.swin, meta.ntab, defer=defer)
     return ops.attention_bwd(qkv, o, do, lse, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=aux,
                              mask=meta.mask, csr=meta.csr, ntab=meta.ntab)
 
@@ -488,12 +492,24 @@ class TransformerLayerFn(Function):
         # ---- MLP branch
         dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
         dln2 = dgrad(dz, w1, T)
-        dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
+        if _DEFER_REDUCE:
+            dx1, part2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy, defer=True)
+        else:
+            dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
         do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
-        dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m, rel_pos)
+        dqkv, drel = _attn_backward(qkv, o, do, lse, bias, m, rel_pos, defer=_DEFER_REDUCE)
         dln1 = dgrad(dqkv, wq, T)
-        dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+        if _DEFER_REDUCE:
+            dx, part1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1, defer=True)
+            # ---- the layer's small column reductions (LayerNorm dgamma / dbeta twice, rel_pos gradient): one launch
+            parts = [part2, part1] + ([drel] if isinstance(drel, ops.Partials) else [])
+            red = ops.colreduce_multi(parts)
+            (dg2, dbe2), (dg1, dbe1) = red[0], red[1]
+            if isinstance(drel, ops.Partials):
+                drel = red[2][0].view(m.ntab, m.n_head)
+        else:
+            dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
         # ---- the four weight gradients: one grouped launch (dropped samples' rows are skipped, 1/(1-p) on the accumulators)
         (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, dbq) = layer_wgrads(
             [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c,

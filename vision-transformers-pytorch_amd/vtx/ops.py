@@ -75,8 +75,34 @@ def layernorm_fwd(x, gamma, beta, eps, merge_hw=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, merge_hw=None):
-    """dx (= dres + LN'(dy)), dgamma, dbeta."""
+class Partials:
+    """Per-block partial sums left in a kernel's workspace, to be column-reduced later (colreduce_multi): `ws` keeps
+    the memory alive; outputs = (out0 [C], out1 [C] or None)."""
+    __slots__ = ("ws", "nb", "C", "ld", "two")
+
+    def __init__(self, ws, nb, C, ld, two):
+        self.ws, self.nb, self.C, self.ld, self.two = ws, nb, C, ld, two
+
+
+def colreduce_multi(parts):
+    """One launch for up to 4 deferred reductions (a layer's LayerNorm dgamma / dbeta pairs and its rel_pos gradient):
+    -> [(out0, out1 or None)] in order.  Fixed summation order: the same bits as the kernels' own reductions."""
+    n = len(parts)
+    dev = parts[0].ws.device
+    outs = [(torch.empty(p.C, dtype=torch.float32, device=dev),
+             torch.empty(p.C, dtype=torch.float32, device=dev) if p.two else None) for p in parts]
+    vp = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    ia = lambda xs: (ctypes.c_int * n)(*xs)
+    with _timed("colreduce_multi_kernel", 0.0, sum(4.0 * p.nb * p.ld for p in parts)):
+        check(_lib.load().vtx_colreduce_multi(n, vp([p.ws for p in parts]), vp([o[0] for o in outs]), vp([o[1] for o in outs]),
+                                              ia([p.nb for p in parts]), ia([p.C for p in parts]), ia([p.ld for p in parts]),
+                                              _stream()), "vtx_colreduce_multi")
+    return outs
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, merge_hw=None, defer=False):
+    """dx (= dres + LN'(dy)), dgamma, dbeta -- or with ``defer`` (dx, Partials): the dgamma / dbeta column reduce is left
+    to a later colreduce_multi (one launch per layer instead of one per LayerNorm)."""
     _dev(dy, x, mean, rstd, gamma, dres)
     lib = _lib.load()
     C = dy.shape[-1]
@@ -86,14 +112,17 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, merge_hw=None):
     else:
         merge, (H, W) = 1, merge_hw
     dx = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dgamma = None if defer else torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = None if defer else torch.empty(C, dtype=torch.float32, device=x.device)
     wsb = lib.vtx_layernorm_bwd_workspace(rows, C)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    with _timed("ln_bwd_kernel (+colreduce)", 0.0, (3.0 + (dres is not None)) * rows * C * x.element_size() + 8.0 * rows):
+    with _timed("ln_bwd_kernel" + ("" if defer else " (+colreduce)"), 0.0,
+                (3.0 + (dres is not None)) * rows * C * x.element_size() + 8.0 * rows):
         check(lib.vtx_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dgamma),
                                     _p(dbeta), _p(ws), wsb, rows, C, _dt(x), merge, H, W, _stream()),
               "vtx_layernorm_bwd")
+    if defer:
+        return dx, Partials(ws, lib.vtx_layernorm_bwd_blocks(rows, C), C, 2 * C, True)
     return dx, dgamma, dbeta
 
 
@@ -742,12 +771,13 @@ def wattn_fwd(qkv, rel_pos, pos, region, B, L, n_head, swin):
     return o, lse
 
 
-def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab):
+def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab, defer=False):
+    """-> dqkv, drel_pos [ntab, n_head] -- or with ``defer`` (dqkv, Partials) for a later colreduce_multi."""
     _dev(qkv, o, dout, lse, rel_pos, pos, region)
     lib = _lib.load()
     H, W, win, shift = swin
     dqkv = torch.empty_like(qkv)
-    drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
+    drel = None if defer else torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
     wsb = lib.vtx_wattn_bwd_workspace(B, n_head, H, W, win)
     ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
     nW = (H // win) * (W // win)
@@ -759,4 +789,6 @@ def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab)
           "vtx_wattn_bwd")
     if ev:
         ev[1].record()
+    if defer:
+        return dqkv, Partials(ws, lib.vtx_wattn_bwd_parts(B, n_head, H, W, win), ntab * n_head, lib.vtx_wattn_bwd_part_ld(n_head), False)
     return dqkv, drel
