@@ -30,7 +30,7 @@ def _mm64(a, b_t):
     return a.double() @ b_t.double().t()
 
 
-BIG128 = "gemm_glds_kernel<128, 128, 64, 2, 4>"
+BIG128 = "gemm_glds_pv_kernel<128, 2>"            # 128 x 128 tiles, 4 x 2 waves, wave-private epilogue (the benchmark default)
 
 
 # ------------------------------------------------------------------ the 128-row LDS-DMA GEMM with every fused epilogue
@@ -80,8 +80,8 @@ def test_glds128_droppath_residual_epilogue_vs_oracle(M, N, K, T):
 
 
 def test_glds_tile_and_wave_variants_are_bitwise_identical():
-    """64- vs 128-row tiles and 2 x 2 vs 2 x 4 waves only change which wave owns an output element, not the order its
-    products are summed in: the three epilogues must agree bit for bit."""
+    """64- vs 128-row tiles, 2 x 2 vs 2 x 4 vs 4 x 2 waves and the shared vs wave-private epilogue staging only change which
+    wave / lane owns an output element, not the order its products are summed in: the epilogues must agree bit for bit."""
     from vtx import ops, options
     d = dev()
     M, N, K, T = 25088, 1536, 384, 196
@@ -96,7 +96,9 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
         return h, z, dz, y
 
     base = run()
-    for kw in (dict(GLDS_BM=64), dict(GLDS_BM=128), dict(GLDS_BM=128, GLDS_WAVES=4), dict(GLDS_BM=64, GLDS_WAVES=4)):
+    assert options.get("GLDS_EPI") == 1 and ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    for kw in (dict(GLDS_BM=64), dict(GLDS_BM=128), dict(GLDS_EPI=0), dict(GLDS_EPI=0, GLDS_BM=64), dict(GLDS_EPI=0, GLDS_BM=128),
+               dict(GLDS_EPI=0, GLDS_BM=128, GLDS_WAVES=4), dict(GLDS_EPI=0, GLDS_BM=64, GLDS_WAVES=4)):
         with options.override(**kw):
             assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) != BIG128 or kw == dict(GLDS_BM=128)
             got = run()

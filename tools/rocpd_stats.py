@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="divide totals by this many steps")
     ap.add_argument("--top", type=int, default=45)
     ap.add_argument("--neighbours", default="", help="kernel-name substring: print which kernels run right before / after it")
+    ap.add_argument("--by-grid", default="", help="kernel-name substring: split that kernel's rows by launch grid (one row per shape)")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -45,6 +46,20 @@ def main():
     rows = c.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
                      f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name").fetchall()
     dm = demangle([r[0] for r in rows])
+    if a.by_grid:
+        cols = [r[1] for r in c.execute(f"pragma table_info({kd})")]
+        gx, gy = [x for x in cols if "grid" in x and x.endswith("x")][0], [x for x in cols if "grid" in x and x.endswith("y")][0]
+        wx = [x for x in cols if "workgroup" in x and x.endswith("x")][0]
+        q = c.execute(f"select s.kernel_name, d.{gx}, d.{gy}, d.{wx}, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+                      f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name, d.{gx}, d.{gy}, d.{wx}").fetchall()
+        q = [r for r in q if a.by_grid in short(dm[r[0]])]
+        q.sort(key=lambda r: -r[5])
+        div = a.steps if a.steps else 1
+        print(f"| kernel | grid (workgroups x, y) | calls | total ms{' /step' if a.steps else ''} | avg us | min us | max us |")
+        print("|---|---|---|---|---|---|---|")
+        for name, x, y, w, n, t, mn, mx in q:
+            print(f"| `{short(dm[name])[:60]}` | {x // max(w, 1)} x {y} | {n} | {t / 1e6 / div:.3f} | {t / n / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} |")
+        return
     if a.neighbours:
         seq = c.execute(f"select s.kernel_name, d.start from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
         names = [short(dm[n]) for n, _ in seq]

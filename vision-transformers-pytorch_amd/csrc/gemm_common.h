@@ -3,6 +3,17 @@
 #pragma once
 #include "vtx_common.h"
 
+// phase time stamps for tools/probe/gemm_trace.hip (compiled out of the library)
+#ifndef VTX_TRACE
+#define VTX_TRACE(id)
+#endif
+// phase ablation of the LDS-DMA GEMM for IN-MODEL timing (tools/probe/build_ablate.sh builds separate libraries, selected
+// through VTX_LIBVTX; results are garbage, durations are what is measured): 1 no main loop | 4 no epilogue stores |
+// 8 no epilogue operand loads.  0 in the library.
+#ifndef GLDS_ABLATE
+#define GLDS_ABLATE 0
+#endif
+
 struct GemmArgs {
   const void* A; const void* B; void* C;
   int M, N, K;
@@ -64,7 +75,7 @@ template <typename T, int BM, int BN, int NWN = 2> struct EpiOperands {
       const bool ok = where(p, m0, n0, q / NIT, q % NIT, row, col);
       ein[q] = vec8_zero<T>();
       rsc[q] = 1.f;
-      if (ok) {
+      if (ok && !(GLDS_ABLATE & 8)) {
         if (esrc) ein[q] = load8<T>(esrc + (int64_t)row * p.ldc + col);
         if (p.rowscale) rsc[q] = p.rowscale[row / p.rows_per_scale];
       }
@@ -102,6 +113,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
           cbuf[(wm * (BM / 4) + ii * 16 + g_ * 4 + r) * CSTR + wn * (BN / NWN) + j * 16 + c_] = acc[i][j][r] + eo.bcol[j];
     }
     __syncthreads();
+    VTX_TRACE(3 + 2 * pass);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int q = pass * NIT + it;
@@ -124,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 #pragma unroll
           for (int e = 0; e < 8; ++e) val[e] = gelu_f(z.get(e));
         }
-        if (aux_out) store8<T>(aux_out + off, z);
+        if (aux_out && !(GLDS_ABLATE & 4)) store8<T>(aux_out + off, z);
       } else if (act_bwd) {
         if (p.act == 2) {
 #pragma unroll
@@ -139,8 +151,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
       Vec8<TO> o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.set(e, val[e] * eo.rsc[q] + rv.get(e));
-      store8<TO>(Cout + off, o);
+      if (!(GLDS_ABLATE & 4) || o.get(0) == 12345.678f) store8<TO>(Cout + off, o);
     }
+    VTX_TRACE(4 + 2 * pass);
     if (pass == 0) __syncthreads();
   }
 }

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
+  VTX_TRACE(0);
   EpiOperands<bf16, BM, BN, NWN> eo;               // bias / residual / z / DropPath scale: requested before the first DMA
   eo.load(p, m0, n0, wn, c_);
 
@@ -105,9 +106,10 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
   if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  VTX_TRACE(1);
 
   int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < ((GLDS_ABLATE & 1) ? 0 : nk); ++kt) {
     const bool refill = kt + NS - 1 < nk;
     if (refill) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);   // == (kt + NS - 1) % NS: freed by the last barrier
     const unsigned char* la = glds_smem + buf * STAGE;
@@ -138,7 +140,235 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
+  VTX_TRACE(2);
   gemm_epilogue<bf16, bf16, BM, BN, NWN>(p, acc, glds_smem, m0, n0, 0, wm, wn, c_, g_, eo);
+  VTX_TRACE(7);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Variant with a WAVE-PRIVATE epilogue (option GLDS_EPI = 1, the default): 128-column tiles, 64-deep k-tiles, 2 stages, 8 waves laid out
+// (8 / NWN) x NWN with 32-row wave tiles -- 4 x 2 waves of 32 x 64 for BM = 128 (every wave owns whole 128-byte output
+// lines), 2 x 4 waves of 32 x 32 for BM = 64.  Same main loop.  After the main loop's last barrier each wave transposes
+// ITS OWN accumulators through a private 16-row LDS region (two passes) and stores them: no workgroup barrier in the
+// epilogue -- the phase trace (tools/probe/gemm_trace.hip) shows 1.4 us of a 10.8 us workgroup lifetime spent in the shared
+// staging passes, mostly waiting at their three barriers for the slowest wave.  Element values are those of
+// gemm_epilogue (same expression per element), so the two variants are bitwise interchangeable.
+template <int BM, int NWN> struct PvEpiOperands {
+  static constexpr int WN = 128 / (16 * NWN);          // 16-column tiles per wave: 4 | 2
+  static constexpr int VROW = 2 * WN;                  // 8-element vectors per staged row of the wave tile
+  static constexpr int NIT = 16 * VROW / 64;           // store iterations per 16-row pass: 2 | 1
+  float bcol[WN];
+  float rsc[2 * NIT];
+  Vec8<bf16> ein[2 * NIT];
+  // (row, col) of the 8-vector this lane stores in iteration it of pass i; clamped in range, `ok` says whether it exists
+  static __device__ __forceinline__ bool where(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane, int i, int it,
+                                               int& row, int& col) {
+    const int v = lane + 64 * it, lr = v / VROW, cv = v - lr * VROW;
+    row = m0 + wm * 32 + i * 16 + lr;
+    col = n0 + wn * (16 * WN) + cv * 8;
+    return row < p.M && col < p.N;
+  }
+  __device__ __forceinline__ void load(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+    const int c_ = lane & 15;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn * (16 * WN) + j * 16 + c_;
+      bcol[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+    }
+    const bool act_bwd = p.act == 2 || p.act == 4;
+    const bf16* __restrict__ esrc = act_bwd ? (const bf16*)p.aux_in : (const bf16*)p.resid;
+#pragma unroll
+    for (int q = 0; q < 2 * NIT; ++q) {
+      int row, col;
+      const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col);
+      ein[q] = vec8_zero<bf16>();
+      rsc[q] = 1.f;
+      if (ok) {
+        if (esrc) ein[q] = load8<bf16>(esrc + (int64_t)row * p.ldc + col);
+        if (p.rowscale) rsc[q] = p.rowscale[row / p.rows_per_scale];
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ void glds_wave_sync() {      // orders this wave's own LDS traffic (DS operations issue in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int BM, int NWN>
+__global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
+  constexpr int BN = 128, BK = 64, NS = 2;
+  constexpr int ROWB = BK * 2, CPR = BK / 8, PR = 1024 / ROWB, KS = BK / 32, NWV = 8;
+  constexpr int NWM = NWV / NWN;
+  static_assert(BM == 32 * NWM, "32-row wave tiles");
+  constexpr int WM = 2, WN = BN / (16 * NWN);
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int CSTR = 16 * WN + 4;                      // fp32 row stride of a wave's private staging region
+  constexpr int PVB = 16 * CSTR * 4;                     // bytes per wave: 4 352 | 2 304
+  static_assert(NWV * PVB <= NS * STAGE, "private staging must fit the ring");
+  extern __shared__ __attribute__((aligned(16))) unsigned char glds_smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int c_ = lane & 15, g_ = lane >> 4;
+
+  const int ntn = gridDim.x, ntm = gridDim.y;
+  const int nblk = ntn * ntm;
+  const int did = blockIdx.y * ntn + blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int tn = lid % ntn, tm = lid / ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K / BK;
+
+  const bf16* A = (const bf16*)p.A;
+  const bf16* B = (const bf16*)p.B;
+
+  VTX_TRACE(0);
+  PvEpiOperands<BM, NWN> eo;                             // requested before the first DMA (older on vmcnt than every piece)
+  eo.load(p, m0, n0, wm, wn, lane);
+
+  const int lr = lane / CPR, slot = lane % CPR;
+  constexpr int APW = BM / (NWV * PR), BPW = BN / (NWV * PR);
+  constexpr int LPT = APW + BPW;
+  const bf16* asrc[APW];
+  const bf16* bsrc[BPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int r = wave * (BM / NWV) + j * PR + lr;
+    asrc[j] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int r = wave * (BN / NWV) + j * PR + lr;
+    bsrc[j] = B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + ((slot ^ glds_swz<BK>(r)) << 3);
+  }
+  auto issue = [&](int kt, int buf) {
+    unsigned char* sa = glds_smem + buf * STAGE + wave * (BM / NWV) * ROWB;
+    unsigned char* sb = glds_smem + buf * STAGE + BM * ROWB + wave * (BN / NWV) * ROWB;
+#pragma unroll
+    for (int j = 0; j < APW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + kt * BK), (lds_void_t*)(sa + j * PR * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[j] + kt * BK), (lds_void_t*)(sb + j * PR * ROWB), 16, 0, 0);
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  VTX_TRACE(1);
+
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool refill = kt + 1 < nk;
+    if (refill) issue(kt + 1, buf ^ 1);
+    const unsigned char* la = glds_smem + buf * STAGE;
+    const unsigned char* lb = la + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Vec8<bf16> fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int r = wm * 32 + i * 16 + c_;
+        fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ glds_swz<BK>(r)) << 4)));
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int r = wn * (16 * WN) + j * 16 + c_;
+        fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ glds_swz<BK>(r)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mma16(fa[i], fb[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf ^= 1;
+  }
+  VTX_TRACE(2);
+
+  // ---------------- wave-private epilogue: acc[i][j][r] = C[m0 + 32 wm + 16 i + 4 g + r][n0 + 16 WN wn + 16 j + c]
+  using EO = PvEpiOperands<BM, NWN>;
+  constexpr int VROW = EO::VROW, NIT = EO::NIT;
+  float* cbuf = reinterpret_cast<float*>(glds_smem + wave * PVB);
+  bf16* __restrict__ Cout = (bf16*)p.C;
+  const bf16* __restrict__ resid = (const bf16*)p.resid;
+  bf16* __restrict__ aux_out = (bf16*)p.aux_out;
+  const bool act_fwd = p.act == 1 || p.act == 3, act_bwd = p.act == 2 || p.act == 4;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    if (i) glds_wave_sync();                              // the previous pass's reads are issued before these writes
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cbuf[(g_ * 4 + r) * CSTR + j * 16 + c_] = acc[i][j][r] + eo.bcol[j];
+    glds_wave_sync();
+    VTX_TRACE(3 + 2 * i);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = i * NIT + it;
+      int row, col;
+      if (!EO::where(p, m0, n0, wm, wn, lane, i, it, row, col)) continue;
+      const int64_t off = (int64_t)row * p.ldc + col;
+      const int v = lane + 64 * it, lrow = v / VROW, cv = v - lrow * VROW;
+      const float* cp = cbuf + lrow * CSTR + cv * 8;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
+      float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (act_fwd) {
+        Vec8<bf16> z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z.set(e, val[e]);
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = silu_f(z.get(e));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = gelu_f(z.get(e));
+        }
+        if (aux_out) store8<bf16>(aux_out + off, z);
+      } else if (act_bwd) {
+        if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(eo.ein[q].get(e));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] *= dgelu_f(eo.ein[q].get(e));
+        }
+      }
+      Vec8<bf16> rv = eo.ein[q];
+      if (act_bwd) rv = resid ? load8<bf16>(resid + off) : vec8_zero<bf16>();
+      Vec8<bf16> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, val[e] * eo.rsc[q] + rv.get(e));
+      store8<bf16>(Cout + off, o);
+    }
+    VTX_TRACE(4 + 2 * i);
+  }
+  VTX_TRACE(7);
+}
+
+template <int BM, int NWN> static int glds_launch_pv(const GemmArgs& a, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * (BM + 128) * 128;
+  auto kern = gemm_glds_pv_kernel<BM, NWN>;
+  if (smem > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return VTX_ERR_LAUNCH;
+  dim3 grid((a.N + 127) / 128, (a.M + BM - 1) / BM, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+  return vtx_check_launch();
 }
 
 template <int BM, int BN, int BK, int NS, int NWN = 2> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -167,6 +397,7 @@ template <int BM, int BN> static int glds_launch_t(const GemmArgs& a, hipStream_
   if constexpr (BN == 128) {
     // 2 x 4 waves: fwd 3.95 -> 3.78, dgrad 3.66 -> 3.55 ms per step on the Swin stage-2..4 shapes, ViT-S/16 4.64 -> 4.38 /
     // 4.14 -> 4.07 (the activation epilogues gain most); option GLDS_WAVES = 4 keeps the 2 x 2 variant for comparison
+    if (vtx_opt(VTX_OPT_GLDS_EPI) == 1) return glds_launch_pv<BM, BM == 128 ? 2 : 4>(a, st);
     if (vtx_opt(VTX_OPT_GLDS_WAVES) != 4) return glds_launch_cfg<BM, BN, 64, 2, 4>(a, st);
   }
   return glds_launch_cfg<BM, BN, 64, 2>(a, st);

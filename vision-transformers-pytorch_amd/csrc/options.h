@@ -23,7 +23,8 @@ enum VtxOptionId {
   VTX_OPT_WG_RING = 12,             // weight-gradient LDS ring: 0 / 642 = 64-token k-tiles x 2 stages (default) | 643 | 324 | 323
   VTX_OPT_GEMM_WS = 13,             // 1: persistent wave-specialised GEMM (gemm_ws.hip) for launches with >= 1024 128 x 128 tiles (experimental)
   VTX_OPT_LN_FIT = 14,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
-  VTX_OPT_COUNT = 15
+  VTX_OPT_GLDS_EPI = 15,            // LDS-DMA GEMM epilogue (128-column tiles, 8 waves): 1 = wave-private staging, no workgroup barrier (default) | 0 = shared staging passes
+  VTX_OPT_COUNT = 16
 };
 
 int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip

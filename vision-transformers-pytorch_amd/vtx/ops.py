@@ -231,7 +231,9 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
             bm = 128 if ((N + 127) // 128) * ((M + 127) // 128) >= 800 else 64
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
-        nwn = 4 if (bn == 128 and options.get("GLDS_WAVES") != 4) else 2   # mirrors glds_launch_t
+        if bn == 128 and options.get("GLDS_EPI") == 1:                     # mirrors glds_launch_t: wave-private epilogue
+            return f"gemm_glds_pv_kernel<{bm}, {2 if bm == 128 else 4}>"
+        nwn = 4 if (bn == 128 and options.get("GLDS_WAVES") != 4) else 2
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2, {nwn}>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
     return f"gemm_kernel<{t}, {to}, 128, {bn}, {ta}, {tb}>"
