@@ -100,10 +100,12 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ALL NS stages are free at entry: k-tiles 0 .. NS-1 are requested back to back (their latencies overlap; the loop
+  // itself can only refill a stage after the barrier that frees it, so iteration 0 has nothing to request).
 #pragma unroll
-  for (int s2 = 0; s2 < NS - 1; ++s2)
+  for (int s2 = 0; s2 < NS; ++s2)
     if (s2 < nk) issue(s2, s2);
-  if (nk >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 2) * LPT) : "memory");
+  if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NS - 1) * LPT) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   VTX_TRACE(1);
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
   int buf = 0;
   for (int kt = 0; kt < ((GLDS_ABLATE & 1) ? 0 : nk); ++kt) {
     const bool refill = kt + NS - 1 < nk;
-    if (refill) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);   // == (kt + NS - 1) % NS: freed by the last barrier
+    if (refill && kt >= 1) issue(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);   // == (kt + NS - 1) % NS: freed by the last barrier
     const unsigned char* la = glds_smem + buf * STAGE;
     const unsigned char* lb = la + BM * ROWB;
 #pragma unroll
@@ -169,25 +171,39 @@ template <int BM, int NWN> struct PvEpiOperands {
     col = n0 + wn * (16 * WN) + cv * 8;
     return row < p.M && col < p.N;
   }
-  __device__ __forceinline__ void load(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+  // bias per accumulator column and the DropPath scale per stored row: small, L2-resident; requested before the first DMA
+  __device__ __forceinline__ void load_small(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
     const int c_ = lane & 15;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int col = n0 + wn * (16 * WN) + j * 16 + c_;
       bcol[j] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
     }
-    const bool act_bwd = p.act == 2 || p.act == 4;
-    const bf16* __restrict__ esrc = act_bwd ? (const bf16*)p.aux_in : (const bf16*)p.resid;
 #pragma unroll
     for (int q = 0; q < 2 * NIT; ++q) {
       int row, col;
       const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col);
       ein[q] = vec8_zero<bf16>();
-      rsc[q] = 1.f;
-      if (ok) {
-        if (esrc) ein[q] = load8<bf16>(esrc + (int64_t)row * p.ldc + col);
-        if (p.rowscale) rsc[q] = p.rowscale[row / p.rows_per_scale];
-      }
+      rsc[q] = (ok && p.rowscale) ? p.rowscale[row / p.rows_per_scale] : 1.f;
+    }
+  }
+  // the residual / z vectors: HBM misses.  Loads return in order, so requested before the DMA pieces they hold back the
+  // first k-tile (phase trace: 1.5 -> 2.6 us to the first k-tile) and requested in between they hold back the next one;
+  // the kernel requests them right after its LAST DMA issue, where nothing younger is ever waited for.  EXACTLY NVEC load
+  // instructions per wave when there is a source (no lane predicate: lanes without an element read element 0), so that
+  // the counted vmcnt of the k-loop stays exact.
+  static constexpr int NVEC = 2 * NIT;
+  static __device__ __forceinline__ const bf16* vec_src(const GemmArgs& p) {
+    return (p.act == 2 || p.act == 4) ? (const bf16*)p.aux_in : (const bf16*)p.resid;
+  }
+  __device__ __forceinline__ void load_vec(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+    const bf16* __restrict__ esrc = vec_src(p);
+    if (!esrc || (GLDS_ABLATE & 8)) return;
+#pragma unroll
+    for (int q = 0; q < 2 * NIT; ++q) {
+      int row, col;
+      const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col);
+      ein[q] = load8<bf16>(esrc + (ok ? (int64_t)row * p.ldc + col : (int64_t)0));
     }
   }
 };
@@ -229,8 +245,10 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   const bf16* B = (const bf16*)p.B;
 
   VTX_TRACE(0);
-  PvEpiOperands<BM, NWN> eo;                             // requested before the first DMA (older on vmcnt than every piece)
-  eo.load(p, m0, n0, wm, wn, lane);
+  PvEpiOperands<BM, NWN> eo;
+  eo.load_small(p, m0, n0, wm, wn, lane);
+  const bool has_vec = PvEpiOperands<BM, NWN>::vec_src(p) != nullptr && !(GLDS_ABLATE & 8);
+  constexpr int NVEC = PvEpiOperands<BM, NWN>::NVEC;
 
   const int lr = lane / CPR, slot = lane % CPR;
   constexpr int APW = BM / (NWV * PR), BPW = BN / (NWV * PR);
@@ -264,15 +282,33 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // BOTH stages are free at entry: k-tiles 0 and 1 are requested back to back, so their latencies overlap (the loop
+  // itself can only request k-tile kt + 1 after the barrier that frees its stage).  vmcnt retires in order: waiting for
+  // k-tile 0 leaves exactly the younger requests outstanding (k-tile 1's LPT pieces, the NVEC epilogue vectors when
+  // the last DMA request is already out).
   issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nk >= 2) issue(1, 1);
+  const bool vec_early = nk <= 2;
+  if (vec_early) eo.load_vec(p, m0, n0, wm, wn, lane);
+  if (nk >= 2) {
+    if (vec_early && has_vec) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPT + NVEC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPT) : "memory");
+  } else {
+    if (has_vec) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NVEC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   VTX_TRACE(1);
 
   int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  bool vec_pending = vec_early;                            // the epilogue vectors are the youngest requests
+  for (int kt = 0; kt < ((GLDS_ABLATE & 1) ? 0 : nk); ++kt) {
     const bool refill = kt + 1 < nk;
-    if (refill) issue(kt + 1, buf ^ 1);
+    if (refill && kt >= 1) issue(kt + 1, buf ^ 1);         // (k-tile 1 is already on its way)
+    if (kt >= 1 && kt + 2 == nk) {                        // k-tile nk - 1 was just requested: the vectors go behind it
+      eo.load_vec(p, m0, n0, wm, wn, lane);
+      vec_pending = true;
+    }
     const unsigned char* la = glds_smem + buf * STAGE;
     const unsigned char* lb = la + BM * ROWB;
 #pragma unroll
@@ -293,7 +329,12 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) mma16(fa[i], fb[j], acc[i][j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // k-tile kt + 1 must have landed.  After the last request only the epilogue vectors are younger (left in flight);
+    // in the last iteration no DMA is outstanding any more.
+    if (refill) {
+      if (vec_pending && has_vec) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NVEC) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     buf ^= 1;
