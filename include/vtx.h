@@ -155,9 +155,14 @@ size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win);
  * stay in the workspace (columns (2 win - 1)^2 * nH) for vtx_colreduce_multi. */
 int vtx_wattn_bwd_parts(int B, int nH, int H, int W, int win);
 int vtx_wattn_bwd_part_ld(int nH);
+/* inv_cells [inv_count][(2 win - 1)^2] int32 (device) or NULL: the inverse of pos -- inv_cells[t][b] = the t-th cell
+ * q * 64 + key (row stride 64) with pos[q][key] == b in ascending (q, key) order, padded with the cell L * 64; inv_count = the
+ * largest bin (vtx.tables.pos_inverse).  With it the rel_pos gradient is gathered per bin inside the kernel; NULL: LDS-atomic
+ * scatter (~27 us more per launch, same result up to fp32 summation order). */
 int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
-                  size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream);
+                  size_t ws_bytes, const int* inv_cells, int inv_count, int B, int L, int nH, int H, int W, int win,
+                  int shift, int dtype, void* stream);
 
 /* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66):
  * head dim 64, Lq queries against Lk <= 64 reduced keys per (image, head).

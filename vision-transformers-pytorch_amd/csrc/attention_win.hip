@@ -30,6 +30,11 @@
 #define WA_NBIN 172      // (2*7-1)^2 = 169 padded to a multiple of 4
 #define WA_BSTR 68       // bias table row stride (floats)
 #define WA_WAVES 4       // waves per workgroup
+// phase ablation of the backward for timing (separate builds, tools/probe/build_ablate.sh-style; 0 in the library):
+// 1 no final dS binning | 2 no partial-bin write-out | 4 no phase A (dQ) | 8 no phase B (dK, dV, dS sum)
+#ifndef WA_ABLATE
+#define WA_ABLATE 0
+#endif
 
 struct WinGeom {
   int L, nH, hd, nW, H, W, win, shift, nWx;
@@ -246,7 +251,8 @@ template <typename T, bool MASKED>
 __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
     const T* __restrict__ qkv, const T* __restrict__ oin, const T* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ rel_pos, const int64_t* __restrict__ pos, const uint8_t* __restrict__ region,
-    T* __restrict__ dqkv, float* __restrict__ bins_part, int nbn, int nblk, int xcd_major, WinGeom g) {
+    T* __restrict__ dqkv, float* __restrict__ bins_part, const int* __restrict__ inv_cells, int inv_count, int nbn,
+    int nblk, int xcd_major, WinGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
   float* bias_s = reinterpret_cast<float*>(wa_smem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
     // ---------------- phase A (swapped layout, per query tile): dQ = scale * dS K
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-      if (qt * 16 >= g.L) break;
+      if (qt * 16 >= g.L || (WA_ABLATE & 4)) break;
       const int q = qt * 16 + c_;
       const unsigned rq = MK ? reg_s[q] * 0x01010101u : 0u;
       f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
     // ---------------- phase B (plain layout, per key tile): dV = P^T dO, dK = scale * dS^T Q, dsacc += dS
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      if (kt * 16 >= g.L) break;
+      if (kt * 16 >= g.L || (WA_ABLATE & 8)) break;
       const int key = kt * 16 + c_;
       const unsigned rk = MK ? reg_s[key] * 0x01010101u : 0u;
       f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -398,23 +404,58 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // bin the accumulated dS by relative-position index (ds_add_f32; single wave, program order => deterministic)
+  // Bin the accumulated dS by relative-position index.  With the INVERSE map of pos (inv_cells[t][b], t < inv_count: the
+  // t-th cell q * 64 + key of bin b in ascending (q, key) order, padded with the cell L * 64; built once per module on the
+  // host): the wave spills its dS sum into the LDS region of its operand images (all problems done) and lane b GATHERS
+  // bin b -- inv_count coalesced index loads + plain ds_read_b32 per bin, the same trip count for every lane, fixed order.
+  // The ds_add_f32 scatter it replaces (kept for callers without the map) cost 26-30 us per launch whatever the stage:
+  // 64 LDS atomics per lane with up to 16 lanes on one bin, and all 8 waves of a CU queue on the same LDS atomic unit
+  // (phase ablation, tools/probe/build_ablate_wattn.sh: stage 3 85.8 -> 57.1 us, stage 4 60.9 -> 35.2 us without it).
+  const int ntab = (2 * g.win - 1) * (2 * g.win - 1);
+  if (inv_cells != nullptr && (g.L + 1) * 64 * 4 <= 3 * WaSmem<T>::kImg && !(WA_ABLATE & 1)) {
+    float* ds_s = reinterpret_cast<float*>(wbase);           // [L + 1][64] fp32 over the Kt / Qt / dOt images
+    wa_wave_sync();
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int key = kt * 16 + c_;
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = kt * 16 + c_;
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+      for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = qt * 16 + g_ * 4 + r;
-        if (key < g.L && q < g.L) atomicAdd(&bins[(int)pos[q * g.L + key]], dsacc[kt][qt][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + g_ * 4 + r;
+          if (key < g.L && q < g.L) ds_s[q * 64 + key] = dsacc[kt][qt][r];
+        }
+      }
+    }
+    if (lane == 0) ds_s[g.L * 64] = 0.f;                     // the padding cell
+    wa_wave_sync();
+    for (int b = lane; b < ntab; b += 64) {
+      float sum = 0.f;
+      const int* __restrict__ ic = inv_cells + b;
+#pragma unroll 7
+      for (int t = 0; t < inv_count; ++t) sum += ds_s[ic[t * ntab]];
+      bins[b] = sum;
+    }
+  } else {
+    // ds_add_f32 scatter; single wave, program order => deterministic
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = kt * 16 + c_;
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + g_ * 4 + r;
+          if (key < g.L && q < g.L && !(WA_ABLATE & 1)) atomicAdd(&bins[(int)pos[q * g.L + key]], dsacc[kt][qt][r]);
+        }
       }
     }
   }
   wa_wave_sync();
   // partial layout [wave][bin][head]: the fixed-order column reduce then yields drel_pos[(bin, head)] directly
   float* out = bins_part + ((int64_t)blk * WA_WAVES + wave) * WA_NBIN * g.nH + h;
-  for (int i = lane; i < WA_NBIN; i += 64) out[(int64_t)i * g.nH] = bins[i];
+  if (!(WA_ABLATE & 2))
+    for (int i = lane; i < WA_NBIN; i += 64) out[(int64_t)i * g.nH] = bins[i];
 }
 
 static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift) {
@@ -471,15 +512,15 @@ static int wattn_fwd_launch(const void* qkv, void* o, float* lse, const float* r
 
 template <typename T, bool MASKED>
 static int wattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
-                            const int64_t* pos, const uint8_t* region, void* dqkv, float* part, int nbn,
-                            const WinGeom& g, hipStream_t st) {
+                            const int64_t* pos, const uint8_t* region, void* dqkv, float* part, const int* inv_cells,
+                            int inv_count, int nbn, const WinGeom& g, hipStream_t st) {
   auto kern = wattn_bwd_kernel<T, MASKED>;
   int rc = wa_smem_attr(kern, WaSmem<T>::kBwd);
   if (rc) return rc;
   const int nblk = wattn_bwd_blocks(nbn, g.nH);
   hipLaunchKernelGGL(kern, dim3(nblk * g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kBwd, st,
-                     (const T*)qkv, (const T*)o, (const T*)dout, lse, rel_pos, pos, region, (T*)dqkv, part, nbn, nblk,
-                     wattn_xcd_major(nblk), g);
+                     (const T*)qkv, (const T*)o, (const T*)dout, lse, rel_pos, pos, region, (T*)dqkv, part, inv_cells,
+                     inv_count, nbn, nblk, wattn_xcd_major(nblk), g);
   return vtx_check_launch();
 }
 
@@ -521,9 +562,14 @@ size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win) {
   return (size_t)wattn_bwd_blocks(nbn, nH) * WA_WAVES * nH * WA_NBIN * sizeof(float);
 }
 
+/* inv_cells [inv_count][(2 win - 1)^2] int32 (device) or NULL: the inverse of pos -- inv_cells[t][b] = the t-th cell
+ * q * 64 + key (row stride 64) with pos[q][key] == b in ascending (q, key) order, padded with the cell L * 64;
+ * inv_count = the largest bin.  With it the rel_pos gradient is gathered per bin from LDS; without it is scattered with
+ * LDS atomics (slower, same result up to fp32 summation order). */
 int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
                   const int64_t* pos, const uint8_t* region, void* dqkv, float* drel_pos, void* workspace,
-                  size_t ws_bytes, int B, int L, int nH, int H, int W, int win, int shift, int dtype, void* stream) {
+                  size_t ws_bytes, const int* inv_cells, int inv_count, int B, int L, int nH, int H, int W, int win,
+                  int shift, int dtype, void* stream) {
   if (!qkv || !o || !dout || !lse || !rel_pos || !pos || !dqkv || !workspace) return VTX_ERR_NULL;   // drel_pos NULL: deferred reduce
   WinGeom g;
   int rc = win_geom(g, L, nH, H, W, win, shift);
@@ -531,14 +577,15 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
   const int nbn = B * g.nW;
   if (nbn <= 0) return VTX_OK;
   if (ws_bytes < vtx_wattn_bwd_workspace(B, nH, H, W, win)) return VTX_ERR_WORKSPACE;
+  if (inv_cells != nullptr && (inv_count <= 0 || inv_count > L * L)) return VTX_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   if (dtype == VTX_BF16)
-    rc = region ? wattn_bwd_launch<bf16, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st)
-                : wattn_bwd_launch<bf16, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st);
+    rc = region ? wattn_bwd_launch<bf16, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st)
+                : wattn_bwd_launch<bf16, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st);
   else if (dtype == VTX_F32)
-    rc = region ? wattn_bwd_launch<float, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st)
-                : wattn_bwd_launch<float, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, nbn, g, st);
+    rc = region ? wattn_bwd_launch<float, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st)
+                : wattn_bwd_launch<float, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st);
   else return VTX_ERR_DTYPE;
   if (rc || drel_pos == nullptr) return rc;              // deferred: partials stay in the workspace
   const int ntab = (2 * win - 1) * (2 * win - 1);

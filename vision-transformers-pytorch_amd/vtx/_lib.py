@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class VtxError(RuntimeError):
@@ -57,7 +57,8 @@ _SIGNATURES = {
     "vtx_wattn_bwd_parts": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vtx_wattn_bwd_part_ld": (c_int, [c_int]),
     "vtx_wattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                              c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_void_p]),
     "vtx_srattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_srattn_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_srattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -773,10 +773,28 @@ def wattn_fwd(qkv, rel_pos, pos, region, B, L, n_head, swin):
     return o, lse
 
 
+_POS_INVERSE = {}
+
+
+def _pos_inverse(pos, ntab):
+    """Device copy of tables.pos_inverse(pos), built once per pos buffer (host argsort + one upload, first backward only).
+    Keyed by the buffer's address; valid while the tensor it was built from is alive (a module buffer, never written)."""
+    key = (pos.data_ptr(), pos.device, tuple(pos.shape), ntab)
+    hit = _POS_INVERSE.get(key)
+    if hit is None or hit[0]() is None:
+        import weakref
+        from . import tables
+        cells, count = tables.pos_inverse(pos, ntab)
+        hit = (weakref.ref(pos), cells.to(pos.device), count)
+        _POS_INVERSE[key] = hit
+    return hit[1], hit[2]
+
+
 def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab, defer=False):
     """-> dqkv, drel_pos [ntab, n_head] -- or with ``defer`` (dqkv, Partials) for a later colreduce_multi."""
     _dev(qkv, o, dout, lse, rel_pos, pos, region)
     lib = _lib.load()
+    inv_cells, inv_count = _pos_inverse(pos, ntab)
     H, W, win, shift = swin
     dqkv = torch.empty_like(qkv)
     drel = None if defer else torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
@@ -787,7 +805,8 @@ def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab,
     ev = _attn_bracket(f"wattn_bwd_kernel<{tn}, {'true' if region is not None else 'false'}>", B * nW * n_head, L, 32,
                        B * nW * L, n_head * 32, qkv.element_size(), True)     # (+ the small drel_pos column reduce)
     check(lib.vtx_wattn_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(rel_pos), _p(pos), _p(region), _p(dqkv), _p(drel),
-                            _p(ws), wsb, B, L, n_head, H, W, win, int(bool(shift)), _dt(qkv), _stream()),
+                            _p(ws), wsb, _p(inv_cells), inv_count, B, L, n_head, H, W, win, int(bool(shift)), _dt(qkv),
+                            _stream()),
           "vtx_wattn_bwd")
     if ev:
         ev[1].record()

@@ -50,6 +50,24 @@ def pos_csr(pos, ntab):
     return order, offsets
 
 
+def pos_inverse(pos, ntab):
+    """Inverse of a [L, L] pos table for the window-attention backward (include/vtx.h, vtx_wattn_bwd): int32
+    cells [count, ntab] with cells[t, b] = the t-th entry q * 64 + key (row stride 64) whose pos is b, in ascending
+    (q, key) order, padded with L * 64 (a zero cell); count = the largest bin.  Lane b of the kernel gathers the rel_pos
+    gradient of bin b from its LDS copy of dS in that order."""
+    L = pos.shape[-1]
+    order, offsets = pos_csr(pos, ntab)
+    o = order.to(torch.int64)
+    flat = (o // L) * 64 + (o % L)
+    sizes = (offsets[1:] - offsets[:-1]).to(torch.int64)
+    count = max(int(sizes.max()), 1)
+    cells = torch.full((count, ntab), L * 64, dtype=torch.int32)
+    b = torch.repeat_interleave(torch.arange(ntab), sizes)
+    t = torch.arange(flat.numel()) - offsets[:-1].to(torch.int64)[b]
+    cells[t, b] = flat.to(torch.int32)
+    return cells.contiguous(), count
+
+
 def mask_regions(local_mask):
     """Region ids of a shifted-window mask: -> (region uint8 (nW, 64), ok).
 
