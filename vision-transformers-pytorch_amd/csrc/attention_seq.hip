@@ -33,11 +33,11 @@ __device__ __attribute__((aligned(256))) unsigned int sa_zero_row[64];   // 256 
 struct SeqGeom { int L, nH, hd; float scale; };
 
 // DMA `rows` rows x 64 bf16 of one head (token rows base .. ) into a swizzled row-major LDS image
-template <int LP>
+template <int LP, int NW>
 __device__ __forceinline__ void sa_stage(unsigned char* lds, const bf16* src, int64_t ld, int L, int wave, int lane) {
   const int lr = lane >> 3, slot = lane & 7;
   const bf16* zero = reinterpret_cast<const bf16*>(sa_zero_row);
-  for (int pc = wave; pc < LP / 8; pc += 4) {
+  for (int pc = wave; pc < LP / 8; pc += NW) {
     const int r = pc * 8 + lr;
     const int q = slot ^ (r & 7);
     const bf16* s = r < L ? src + (int64_t)r * ld + (q << 3) : zero + (q << 3);
@@ -103,8 +103,9 @@ __device__ __forceinline__ Vec8<bf16> sa_gload(const bf16* p, bool valid) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+// TP = query tiles a wave works on at a time (2: every K / V fragment read feeds two MFMAs | 1), NW = waves per workgroup
+template <int NKT, int TP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void sattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, SeqGeom g) {
   constexpr int LP = NKT * 16, IMG = LP * SA_ROWB, KSN = NKT / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
@@ -118,38 +119,38 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16* __restric
   const int64_t ld = 3 * (int64_t)g.hd;
   const bf16* base = qkv + (int64_t)b * g.L * ld + h * SA_D;
 
-  sa_stage<LP>(ks, base + g.hd, ld, g.L, wave, lane);
-  sa_stage<LP>(vs, base + 2 * g.hd, ld, g.L, wave, lane);
+  sa_stage<LP, NW>(ks, base + g.hd, ld, g.L, wave, lane);
+  sa_stage<LP, NW>(vs, base + 2 * g.hd, ld, g.L, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int nqt = (g.L + 15) >> 4;
-  for (int qp = wave; qp * 2 < nqt; qp += 4) {
-    Vec8<bf16> qf[2][2];
-    bool qv[2];
+  for (int qp = wave; qp * TP < nqt; qp += NW) {
+    Vec8<bf16> qf[TP][2];
+    bool qv[TP];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int q = (qp * 2 + t) * 16 + c_;
+    for (int t = 0; t < TP; ++t) {
+      const int q = (qp * TP + t) * 16 + c_;
       qv[t] = q < g.L;
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) qf[t][ds] = sa_gload(base + (int64_t)(qv[t] ? q : 0) * ld + ds * 32 + g_ * 8, qv[t]);
     }
-    f32x4 st[2][NKT];
+    f32x4 st[TP][NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      st[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      st[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < TP; ++t) st[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) {
         Vec8<bf16> kf = sa_frag_row(ks, kt * 16 + c_, ds, g_);
-        mma16(kf, qf[0][ds], st[0][kt]);       // st[t][kt][r] = S[q = 16(2qp+t) + c][key = 16 kt + 4g + r]
-        mma16(kf, qf[1][ds], st[1][kt]);
+#pragma unroll
+        for (int t = 0; t < TP; ++t) mma16(kf, qf[t][ds], st[t][kt]);   // st[t][kt][r] = S[q = 16 (TP qp + t) + c][key = 16 kt + 4 g + r]
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    float inv[2];
+    float inv[TP];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TP; ++t) {
       float m = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
@@ -169,29 +170,30 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16* __restric
       l += shfl_xor_f(l, 16);
       l += shfl_xor_f(l, 32);
       inv[t] = 1.f / l;
-      const int q = (qp * 2 + t) * 16 + c_;
+      const int q = (qp * TP + t) * 16 + c_;
       if (qv[t] && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
     }
-    f32x4 oacc[2][4];
+    f32x4 oacc[TP][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TP; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k2 = 0; k2 < KSN; ++k2) {
-      Vec8<bf16> pf0 = sa_frag_acc(st[0][2 * k2] * inv[0], st[0][2 * k2 + 1] * inv[0]);
-      Vec8<bf16> pf1 = sa_frag_acc(st[1][2 * k2] * inv[1], st[1][2 * k2 + 1] * inv[1]);
+      Vec8<bf16> pf[TP];
+#pragma unroll
+      for (int t = 0; t < TP; ++t) pf[t] = sa_frag_acc(st[t][2 * k2] * inv[t], st[t][2 * k2 + 1] * inv[t]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         Vec8<bf16> vf = sa_frag_trp(vs, k2 * 32, dt >> 1, dt & 1, lane);
-        mma16(vf, pf0, oacc[0][dt]);          // oacc[t][2 dp + dtl][r] = O[q = 16 (2 qp + t) + c][32 dp + 8 g + 4 dtl + r]
-        mma16(vf, pf1, oacc[1][dt]);
+#pragma unroll
+        for (int t = 0; t < TP; ++t) mma16(vf, pf[t], oacc[t][dt]);   // oacc[t][2 dp + dtl][r] = O[q = 16 (TP qp + t) + c][32 dp + 8 g + 4 dtl + r]
       }
       __builtin_amdgcn_sched_barrier(0);     // keep the unrolled iterations apart (register pressure)
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int q = (qp * 2 + t) * 16 + c_;
+    for (int t = 0; t < TP; ++t) {
+      const int q = (qp * TP + t) * 16 + c_;
       if (qv[t]) {
         bf16* op = o + ((int64_t)b * g.L + q) * g.hd + h * SA_D + g_ * 8;
         store8<bf16>(op, sa_out8(oacc[t][0], oacc[t][1], 1.f));
@@ -202,8 +204,8 @@ __global__ __launch_bounds__(256, 2) void sattn_fwd_kernel(const bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ oin,
+template <int NKT, int TP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void sattn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ oin,
                                                        const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                        bf16* __restrict__ dqkv, SeqGeom g) {
   constexpr int LP = NKT * 16, IMG = LP * SA_ROWB, KSN = NKT / 2;
@@ -224,22 +226,22 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
   bf16* dqb = dqkv + (int64_t)b * g.L * ld + h * SA_D;
   const int nt = (g.L + 15) >> 4;
 
-  sa_stage<LP>(im0, qb + g.hd, ld, g.L, wave, lane);
-  sa_stage<LP>(im1, qb + 2 * g.hd, ld, g.L, wave, lane);
+  sa_stage<LP, NW>(im0, qb + g.hd, ld, g.L, wave, lane);
+  sa_stage<LP, NW>(im1, qb + 2 * g.hd, ld, g.L, wave, lane);
   // lse * log2 e, +inf for padded query rows: exp2(. - inf) = 0 masks them in both phases without a select
-  for (int i = threadIdx.x; i < LP; i += 256) lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] * 1.4426950408889634f : INFINITY;
+  for (int i = threadIdx.x; i < LP; i += 64 * NW) lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] * 1.4426950408889634f : INFINITY;
   const float sl = g.scale * 1.4426950408889634f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---------------- phase A: wave <-> pairs of query tiles; dQ = scale * dS K
-  for (int qp = wave; qp * 2 < nt; qp += 4) {
-    Vec8<bf16> qf[2][2], dof[2][2];
-    bool qv[2];
-    float dsum[2], lq[2];
+  for (int qp = wave; qp * TP < nt; qp += NW) {
+    Vec8<bf16> qf[TP][2], dof[TP][2];
+    bool qv[TP];
+    float dsum[TP], lq[TP];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int q = (qp * 2 + t) * 16 + c_;
+    for (int t = 0; t < TP; ++t) {
+      const int q = (qp * TP + t) * 16 + c_;
       qv[t] = q < g.L;
       const int qq = qv[t] ? q : 0;
       float s = 0.f;
@@ -257,30 +259,31 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
       lq[t] = lse_s[q];                             // log2 domain; +inf on padded rows (q < LP always)
       if (g_ == 0) dq_s[q] = qv[t] ? s : 0.f;       // q < LP always
     }
-    f32x4 dqacc[2][4];
+    f32x4 dqacc[TP][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TP; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dqacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int k2 = 0; k2 < KSN; ++k2) {
-      f32x4 dsv[2][2];
+      f32x4 dsv[TP][2];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int kt = 2 * k2 + half;
-        f32x4 pt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        f32x4 dpt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 pt[TP], dpt[TP];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) { pt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
           Vec8<bf16> kf = sa_frag_row(im0, kt * 16 + c_, ds, g_);
           Vec8<bf16> vf = sa_frag_row(im1, kt * 16 + c_, ds, g_);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) { mma16(kf, qf[t][ds], pt[t]); mma16(vf, dof[t][ds], dpt[t]); }
+          for (int t = 0; t < TP; ++t) { mma16(kf, qf[t][ds], pt[t]); mma16(vf, dof[t][ds], dpt[t]); }
         }
         // padded keys have zero K / V rows (their dS only has to stay finite): masked in the straddling tile only
         const bool edge = kt * 16 + 16 > g.L;           // uniform
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TP; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float p = __builtin_amdgcn_exp2f(fmaf(pt[t][r], sl, -lq[t]));
@@ -288,18 +291,19 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
             dsv[t][half][r] = p * (dpt[t][r] - dsum[t]);
           }
       }
-      Vec8<bf16> dsf0 = sa_frag_acc(dsv[0][0], dsv[0][1]);
-      Vec8<bf16> dsf1 = sa_frag_acc(dsv[1][0], dsv[1][1]);
+      Vec8<bf16> dsf[TP];
+#pragma unroll
+      for (int t = 0; t < TP; ++t) dsf[t] = sa_frag_acc(dsv[t][0], dsv[t][1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         Vec8<bf16> kf = sa_frag_trp(im0, k2 * 32, dt >> 1, dt & 1, lane);
-        mma16(kf, dsf0, dqacc[0][dt]);        // dqacc[t][2 dp + dtl][r] = dQ[q = .. + c][32 dp + 8 g + 4 dtl + r] / scale
-        mma16(kf, dsf1, dqacc[1][dt]);
+#pragma unroll
+        for (int t = 0; t < TP; ++t) mma16(kf, dsf[t], dqacc[t][dt]);   // dqacc[t][2 dp + dtl][r] = dQ[q = .. + c][32 dp + 8 g + 4 dtl + r] / scale
       }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int q = (qp * 2 + t) * 16 + c_;
+    for (int t = 0; t < TP; ++t) {
+      const int q = (qp * TP + t) * 16 + c_;
       if (qv[t]) {
         bf16* p = dqb + (int64_t)q * ld + g_ * 8;
         store8<bf16>(p, sa_out8(dqacc[t][0], dqacc[t][1], g.scale));
@@ -308,18 +312,18 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
     }
   }
   __syncthreads();                                   // K / V images are dead; dq_s complete
-  sa_stage<LP>(im0, qb, ld, g.L, wave, lane);                       // Q
-  sa_stage<LP>(im1, dob, (int64_t)g.hd, g.L, wave, lane);           // dO
+  sa_stage<LP, NW>(im0, qb, ld, g.L, wave, lane);                       // Q
+  sa_stage<LP, NW>(im1, dob, (int64_t)g.hd, g.L, wave, lane);           // dO
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---------------- phase B: wave <-> pairs of key tiles; dV = P^T dO, dK = scale * dS^T Q
-  for (int kp = wave; kp * 2 < nt; kp += 4) {
-    Vec8<bf16> kf[2][2], vf[2][2];
-    bool kv[2];
+  for (int kp = wave; kp * TP < nt; kp += NW) {
+    Vec8<bf16> kf[TP][2], vf[TP][2];
+    bool kv[TP];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int key = (kp * 2 + t) * 16 + c_;
+    for (int t = 0; t < TP; ++t) {
+      const int key = (kp * TP + t) * 16 + c_;
       kv[t] = key < g.L;
       const int kk = kv[t] ? key : 0;
 #pragma unroll
@@ -328,31 +332,32 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
         vf[t][ds] = sa_gload(qb + 2 * g.hd + (int64_t)kk * ld + ds * 32 + g_ * 8, kv[t]);
       }
     }
-    f32x4 dkacc[2][4], dvacc[2][4];
+    f32x4 dkacc[TP][4], dvacc[TP][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TP; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { dkacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int q2 = 0; q2 < KSN; ++q2) {
-      f32x4 pp[2][2], dss[2][2];
+      f32x4 pp[TP][2], dss[TP][2];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qt = 2 * q2 + half;
-        f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 s[TP], dp[TP];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) { s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
           Vec8<bf16> qf = sa_frag_row(im0, qt * 16 + c_, ds, g_);
           Vec8<bf16> dof = sa_frag_row(im1, qt * 16 + c_, ds, g_);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) { mma16(qf, kf[t][ds], s[t]); mma16(dof, vf[t][ds], dp[t]); }
+          for (int t = 0; t < TP; ++t) { mma16(qf, kf[t][ds], s[t]); mma16(dof, vf[t][ds], dp[t]); }
         }
         const int q0 = qt * 16 + g_ * 4;                     // rows of these accumulators: q0 + r
         const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + q0);
         const f32x4 dd = *reinterpret_cast<const f32x4*>(dq_s + q0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TP; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             // padded query rows: ls = +inf -> p = 0; padded key columns (zero K / V fragments) only feed their own,
@@ -362,21 +367,23 @@ __global__ __launch_bounds__(256, 2) void sattn_bwd_kernel(const bf16* __restric
             dss[t][half][r] = p * (dp[t][r] - dd[r]);
           }
       }
-      Vec8<bf16> pf0 = sa_frag_acc(pp[0][0], pp[0][1]), pf1 = sa_frag_acc(pp[1][0], pp[1][1]);
-      Vec8<bf16> sf0 = sa_frag_acc(dss[0][0], dss[0][1]), sf1 = sa_frag_acc(dss[1][0], dss[1][1]);
+      Vec8<bf16> pf[TP], sf[TP];
+#pragma unroll
+      for (int t = 0; t < TP; ++t) { pf[t] = sa_frag_acc(pp[t][0], pp[t][1]); sf[t] = sa_frag_acc(dss[t][0], dss[t][1]); }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         Vec8<bf16> dotf = sa_frag_trp(im1, q2 * 32, dt >> 1, dt & 1, lane);
         Vec8<bf16> qtf = sa_frag_trp(im0, q2 * 32, dt >> 1, dt & 1, lane);
-        mma16(dotf, pf0, dvacc[0][dt]);       // d{k,v}acc[t][2 dp + dtl][r] = d{K,V}[key = .. + c][32 dp + 8 g + 4 dtl + r]
-        mma16(dotf, pf1, dvacc[1][dt]);
-        mma16(qtf, sf0, dkacc[0][dt]);
-        mma16(qtf, sf1, dkacc[1][dt]);
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {         // d{k,v}acc[t][2 dp + dtl][r] = d{K,V}[key = .. + c][32 dp + 8 g + 4 dtl + r]
+          mma16(dotf, pf[t], dvacc[t][dt]);
+          mma16(qtf, sf[t], dkacc[t][dt]);
+        }
       }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int key = (kp * 2 + t) * 16 + c_;
+    for (int t = 0; t < TP; ++t) {
+      const int key = (kp * TP + t) * 16 + c_;
       if (kv[t]) {
         bf16* p = dqb + (int64_t)key * ld + g_ * 8;
         store8<bf16>(p + g.hd, sa_out8(dkacc[t][0], dkacc[t][1], g.scale));
@@ -392,16 +399,25 @@ bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
   return vtx_opt(VTX_OPT_SATTN) && dtype == VTX_BF16 && D == 64 && !swin && bias == nullptr && L >= 1 && L <= 224;
 }
 
+// option SATTN_WAVES: 4 = four waves on PAIRS of 16-token tiles (round 1) | 8 = eight waves on single tiles: half the tiles per
+// wave (13 tiles at L = 197: 2 + 2 + ... vs 4 + 4 + 4 + 2) and twice the waves per SIMD to hide the LDS / exp latencies
 template <int NKT> static int sattn_fwd_t(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB;
-  hipLaunchKernelGGL((sattn_fwd_kernel<NKT>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
+  if (vtx_opt(VTX_OPT_SATTN_WAVES) == 8)
+    hipLaunchKernelGGL((sattn_fwd_kernel<NKT, 1, 8>), dim3(B * g.nH), dim3(512), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
+  else
+    hipLaunchKernelGGL((sattn_fwd_kernel<NKT, 2, 4>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
   return vtx_check_launch();
 }
 template <int NKT> static int sattn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
                                           int B, const SeqGeom& g, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB + 2 * NKT * 16 * sizeof(float);
-  hipLaunchKernelGGL((sattn_bwd_kernel<NKT>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (const bf16*)o,
-                     (const bf16*)dout, lse, (bf16*)dqkv, g);
+  if (vtx_opt(VTX_OPT_SATTN_WAVES) == 8)
+    hipLaunchKernelGGL((sattn_bwd_kernel<NKT, 1, 8>), dim3(B * g.nH), dim3(512), smem, st, (const bf16*)qkv, (const bf16*)o,
+                       (const bf16*)dout, lse, (bf16*)dqkv, g);
+  else
+    hipLaunchKernelGGL((sattn_bwd_kernel<NKT, 2, 4>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (const bf16*)o,
+                       (const bf16*)dout, lse, (bf16*)dqkv, g);
   return vtx_check_launch();
 }
 

@@ -24,7 +24,8 @@ enum VtxOptionId {
   VTX_OPT_GEMM_WS = 13,             // 1: persistent wave-specialised GEMM (gemm_ws.hip) for launches with >= 1024 128 x 128 tiles (experimental)
   VTX_OPT_LN_FIT = 14,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
   VTX_OPT_GLDS_EPI = 15,            // LDS-DMA GEMM epilogue (128-column tiles, 8 waves): 1 = wave-private staging, no workgroup barrier (default) | 0 = shared staging passes
-  VTX_OPT_COUNT = 16
+  VTX_OPT_SATTN_WAVES = 16,         // ViT attention fast path: 4 waves on pairs of 16-token tiles | 8 waves on single tiles
+  VTX_OPT_COUNT = 17
 };
 
 int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip

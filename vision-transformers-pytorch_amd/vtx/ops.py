@@ -697,6 +697,11 @@ def pos_csr(pos, ntab):
     return order, offsets
 
 
+def _sattn_cfg():
+    """(tiles per wave step, waves) template arguments of the ViT attention kernels (mirrors attention_seq.hip)."""
+    return "1, 8" if options.get("SATTN_WAVES") == 8 else "2, 4"
+
+
 def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
     """o [rows, h*D], lse.  swin = (H, W, win, shift) for window attention, None for global."""
     _dev(qkv, bias, mask)
@@ -710,7 +715,7 @@ def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
     fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224      # mirrors sattn_ok
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
     long_ = swin is None and bias is None and mask is None and L > 224
-    ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
+    ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
                        B * nW * n_head, L, D, rows, n_head * D, qkv.element_size(), False)
     check(_lib.load().vtx_attention_fwd(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
                                         int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), _stream()),
@@ -738,7 +743,7 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
     fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
     long_ = swin is None and bias is None and mask is None and L > 224
-    ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
+    ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
                        rows // L * n_head, L, D, rows, n_head * D, qkv.element_size(), True)
     check(lib.vtx_attention_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
                                 _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
