@@ -7,7 +7,7 @@ import bench
 from vtx.optim import FusedAdamW
 from vtx.train_step import MixLoss, make_param_groups, train_step
 dev = torch.device("cuda")
-for name, B, dp in (("swin_s", 128, 0.3), ("vit_s16", 256, 0.1)):
+for name, B, dp in (("swin_s", 128, 0.3), ("vit_s16", 256, 0.1), ("pvt_small", 128, 0.1)):
     model = bench.build_model(name, dp).to(dev).train()
     opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3)
     x = torch.randn(B, 3, 224, 224, device=dev); l1 = torch.randint(0, 1000, (B,), device=dev)

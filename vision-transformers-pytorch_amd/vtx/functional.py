@@ -92,10 +92,17 @@ def weight_scope(module, x):
         return
     plan = module.__dict__.get("_vtx_weight_plan")
     # keyed by the module objects AND their current weight Parameters (load_state_dict(assign=True) / a later
-    # weight_norm replace Parameters without touching the module tree)
-    ids = [(id(m), id(m._parameters.get("weight"))) for m in module.modules()]
+    # weight_norm replace Parameters without touching the module tree).  The Parameters are compared on every forward
+    # over the cached module list (60 us); the recursive walk of the tree (0.7 ms for Swin-S) is repeated on every
+    # 32nd forward only -- a submodule added after the first forward is picked up within 32 steps.
+    if plan is not None:
+        plan[3][0] += 1
+        mods = plan[2] if plan[3][0] % 32 else list(module.modules())
+    else:
+        mods = list(module.modules())
+    ids = [(id(m), id(m._parameters.get("weight"))) for m in mods]
     if plan is None or plan[0] != ids:
-        plan = (ids, WeightPlan(module))
+        plan = (ids, WeightPlan(module), mods, [0])
         module.__dict__["_vtx_weight_plan"] = plan
     _tls.scope = plan[1].cast_all()
     try:

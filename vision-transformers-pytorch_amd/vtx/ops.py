@@ -38,7 +38,16 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  Called once per kernel launch (~500 times per Swin-S
+    step): the two raw C accessors cost ~0.3 us; torch.cuda.current_stream().cuda_stream builds a Stream object through
+    four Python frames (~9 us, 1.7 ms of host time per step -- tools/probe/host_profile.py)."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -281,7 +290,7 @@ _tickets = {}
 def _ticket_buffer(device):
     """Per (device, stream) int32 ticket counters of the fused split-K reduction (vtx.h: zero on entry, re-armed to zero
     by the kernel): launches of ONE stream run in order, so they can share a buffer; two streams must not."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _stream())
     t = _tickets.get(key)
     if t is None:
         t = _tickets[key] = torch.zeros(_lib.load().vtx_wgrad_tickets(), dtype=torch.int32, device=device)

@@ -9,9 +9,16 @@ import contextlib
 from . import _lib
 
 
+_IDS = None
+
+
 def _ids():
-    lib = _lib.load()
-    return {lib.vtx_option_name(i).decode()[4:]: i for i in range(lib.vtx_option_count())}
+    """name -> id of the loaded library's switches (one library per process: built once; get() sits on per-launch paths)."""
+    global _IDS
+    if _IDS is None:
+        lib = _lib.load()
+        _IDS = {lib.vtx_option_name(i).decode()[4:]: i for i in range(lib.vtx_option_count())}
+    return _IDS
 
 
 def names():
