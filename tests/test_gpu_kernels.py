@@ -242,6 +242,41 @@ def test_window_attention_fast_path(dtype, B, H, W, nH, shift):
     check(f"wattn fwd {tag}", o, orf, t["out"] * 1.5)
     check(f"wattn dqkv {tag}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"wattn drel_pos {tag}", drel, drr, 2e-5 if dtype == torch.float32 else 1e-2)
+    # the LDS-atomic scatter (callers of the C ABI without the inverse pos map) sums the same dS in another order
+    dqkv3, drel3 = ops.wattn_bwd(qkv.to(d), o, do.to(d), lse, reld, pos, region, B, L, nH, swin, ntab, use_inverse=False)
+    assert torch.equal(dqkv3, dqkv)
+    check(f"wattn drel_pos, scatter vs gather {tag}", drel3, drel.double(), 2e-5)
+
+
+def test_wattn_rel_pos_gradient_with_an_arbitrary_pos_table():
+    """The gather over tables.pos_inverse makes no assumption about pos (any [L, L] table into the (2 win - 1)^2 bins, one
+    bin crowded beyond L entries): against the generic relative-position-bias gradient path of the same cores."""
+    from vtx import ops
+    d = dev()
+    B, H, W, nH, D, win = 3, 14, 14, 4, 32, 7
+    L, ntab = win * win, (2 * win - 1) ** 2
+    g = torch.Generator().manual_seed(91)
+    pos = torch.randint(0, ntab, (L, L), generator=g)
+    pos[0, :] = 7
+    pos[1, :10] = 7
+    pos = pos.to(d)
+    qkv = _mk((B, H, W, 3 * nH * D), 92, torch.float32).to(d)
+    do = _mk((B, H, W, nH * D), 93, torch.float32).to(d)
+    rel = _mk((ntab, nH), 94, torch.float32, 0.5).to(d)
+    swin = (H, W, win, False)
+    o, lse = ops.wattn_fwd(qkv, rel, pos, None, B, L, nH, swin)
+    dqkv, drel = ops.wattn_bwd(qkv, o, do, lse, rel, pos, None, B, L, nH, swin, ntab)
+    dqkv2, drel2 = ops.wattn_bwd(qkv, o, do, lse, rel, pos, None, B, L, nH, swin, ntab, use_inverse=False)
+    assert torch.equal(dqkv, dqkv2)
+    check("wattn drel_pos, arbitrary pos: gather vs scatter", drel, drel2.double(), 2e-5)
+    # fp64 reference through autograd on the window partition
+    q = qkv.double().cpu().view(B, H // win, win, W // win, win, 3, nH, D).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, -1, nH, L, D)
+    rr = rel.double().cpu().requires_grad_(True)
+    bias = rr[pos.cpu().reshape(-1)].view(L, L, nH).permute(2, 0, 1)
+    att = torch.softmax(q[0] @ q[1].transpose(-1, -2) / D ** 0.5 + bias, -1) @ q[2]          # [B nW, nH, L, D]
+    dor = do.double().cpu().view(B, H // win, win, W // win, win, nH, D).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, nH, L, D)
+    (drr,) = torch.autograd.grad(att, [rr], dor)
+    check("wattn drel_pos, arbitrary pos vs fp64 autograd", drel, drr, 2e-5)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

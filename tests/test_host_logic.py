@@ -150,6 +150,31 @@ def test_mask_regions_structure():
     assert mask_regions(bad)[1] is False
 
 
+@pytest.mark.parametrize("win", [7, 4])
+def test_pos_inverse_lists_every_cell_of_every_bin_once(win):
+    """tables.pos_inverse (the map the window-attention backward gathers the rel_pos gradient over, include/vtx.h
+    vtx_wattn_bwd): column b holds exactly the cells q * 64 + key with pos[q][key] == b, in ascending (q, key) order, then
+    the padding cell L * 64; together the columns cover every cell once.  Also for an arbitrary (non-Swin) table."""
+    from vtx import tables
+    L, ntab = win * win, (2 * win - 1) ** 2
+    pos, _ = tables.make_pos_mask((2 * win, 2 * win), win, True)
+    rnd = torch.randint(0, ntab, (L, L), generator=torch.Generator().manual_seed(5))
+    rnd[0, :] = 3                                          # one crowded bin: count > L
+    for tab in (pos, rnd):
+        cells, count = tables.pos_inverse(tab, ntab)
+        assert cells.shape == (count, ntab) and cells.dtype == torch.int32
+        assert count == int(torch.bincount(tab.reshape(-1), minlength=ntab).max())
+        seen = []
+        for b in range(ntab):
+            col = cells[:, b].tolist()
+            real = [c for c in col if c != L * 64]
+            assert col == real + [L * 64] * (count - len(real)), "padding only at the end"
+            assert real == sorted(real)
+            assert all(int(tab[c // 64, c % 64]) == b for c in real)
+            seen += real
+        assert sorted(seen) == sorted(q * 64 + k for q in range(L) for k in range(L))
+
+
 def test_swin_region_cache_follows_buffer():
     from models.swin_transformer import MultiHeadedLocalAttention
     m = MultiHeadedLocalAttention(96, 3, 32, (14, 14), 7, True)

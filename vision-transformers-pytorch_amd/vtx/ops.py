@@ -804,11 +804,13 @@ def _pos_inverse(pos, ntab):
     return hit[1], hit[2]
 
 
-def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab, defer=False):
-    """-> dqkv, drel_pos [ntab, n_head] -- or with ``defer`` (dqkv, Partials) for a later colreduce_multi."""
+def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab, defer=False, use_inverse=True):
+    """-> dqkv, drel_pos [ntab, n_head] -- or with ``defer`` (dqkv, Partials) for a later colreduce_multi.
+    ``use_inverse=False`` (tests) takes the kernel's LDS-atomic scatter of the rel_pos gradient instead of the gather over
+    the inverse pos map."""
     _dev(qkv, o, dout, lse, rel_pos, pos, region)
     lib = _lib.load()
-    inv_cells, inv_count = _pos_inverse(pos, ntab)
+    inv_cells, inv_count = _pos_inverse(pos, ntab) if use_inverse else (None, 0)
     H, W, win, shift = swin
     dqkv = torch.empty_like(qkv)
     drel = None if defer else torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
