@@ -308,13 +308,30 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
 
 int vtx_wgrad_tickets(void) { return 4096; }
 
+// weight (+ bias) slabs of one weight gradient -> dW (+ dbias), one launch
 static int reduce_slabs(const float* slabs, const float* bias_part, float* dW, float* dbias, int N, int Kin, int nz,
                         hipStream_t st) {
-  const int64_t n = (int64_t)N * Kin;
-  hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(n), dim3(256), 0, st, slabs, dW, n, nz);
-  int rc = vtx_check_launch();
-  if (rc || !dbias) return rc;
-  hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(N), dim3(256), 0, st, bias_part, dbias, (int64_t)N, nz);
+  const long long nw = (long long)N * Kin;
+  if ((nw & 3) || (dbias && (N & 3))) {                       // (float4 path needs multiples of 4: odd shapes keep the scalar-tail kernel)
+    hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(nw), dim3(256), 0, st, slabs, dW, (int64_t)nw, nz);
+    int rc = vtx_check_launch();
+    if (rc || !dbias) return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, slab_reduce_grid(N), dim3(256), 0, st, bias_part, dbias, (int64_t)N, nz);
+    return vtx_check_launch();
+  }
+  SlabReduceMulti m;
+  for (int i = 0; i < 16; ++i) { m.slabs[i] = nullptr; m.out[i] = nullptr; m.n[i] = 0; }
+  m.nz = nz; m.blk0[0] = 0;
+  m.slabs[0] = slabs; m.out[0] = dW; m.n[0] = nw;
+  m.blk0[1] = (int)(((nw >> 2) + 255) / 256);
+  m.nseg = 1;
+  if (dbias) {
+    m.slabs[1] = bias_part; m.out[1] = dbias; m.n[1] = N;
+    m.blk0[2] = m.blk0[1] + (int)((((long long)N >> 2) + 255) / 256);
+    m.nseg = 2;
+  }
+  for (int i = m.nseg; i < 16; ++i) m.blk0[i + 1] = m.blk0[m.nseg];
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)m.blk0[m.nseg]), dim3(256), 0, st, m);
   return vtx_check_launch();
 }
 
@@ -415,9 +432,24 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
   const bool fused = tickets != nullptr && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE);
   int rc = wgrad_glds_group_launch(nprob, hp, mtok, rows_per_scale, scale_const, nz, kchunk, fused ? tickets : nullptr, st);
   if (rc || nz == 1 || fused) return rc;
-  for (int i = 0; i < nprob && !rc; ++i)
-    rc = reduce_slabs(hp[i].slab, hp[i].ksum_part, hp[i].out, hp[i].ksum_out, N[i], Kin[i], nz, st);
-  return rc;
+  // one reduction launch for all weight and bias slabs of the group (kernel boundary = visibility: the slabs were
+  // written with plain stores)
+  SlabReduceMulti m;
+  m.nseg = 0; m.nz = nz; m.blk0[0] = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const long long nw = (long long)N[i] * Kin[i];
+    m.slabs[m.nseg] = hp[i].slab; m.out[m.nseg] = hp[i].out; m.n[m.nseg] = nw;
+    m.blk0[m.nseg + 1] = m.blk0[m.nseg] + (int)(((nw >> 2) + 255) / 256);
+    ++m.nseg;
+    if (hp[i].ksum_out) {
+      m.slabs[m.nseg] = hp[i].ksum_part; m.out[m.nseg] = hp[i].ksum_out; m.n[m.nseg] = N[i];
+      m.blk0[m.nseg + 1] = m.blk0[m.nseg] + (int)((((long long)N[i] >> 2) + 255) / 256);
+      ++m.nseg;
+    }
+  }
+  for (int i = m.nseg; i < 16; ++i) { m.slabs[i] = nullptr; m.out[i] = nullptr; m.n[i] = 0; m.blk0[i + 1] = m.blk0[m.nseg]; }
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)m.blk0[m.nseg]), dim3(256), 0, st, m);
+  return vtx_check_launch();
 }
 
 }  // extern "C"

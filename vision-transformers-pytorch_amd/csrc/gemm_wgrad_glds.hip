@@ -17,6 +17,12 @@
 #include "gemm_common.h"
 #include "options.h"
 
+// phase ablation for IN-MODEL timing (tools/probe/build_ablate.sh wgrad N): 1 no DMA requests | 2 no fragment reads + MFMA |
+// 4 no epilogue (slab / output stores, ticket, in-launch reduction) | 8 no bias-gradient column sums.  0 in the library.
+#ifndef WG_ABLATE
+#define WG_ABLATE 0
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   auto issue = [&](int kt, int buf) __attribute__((always_inline)) {          // called with kt = 0, 1, 2, ... in order
     unsigned char* sa = wg_smem + buf * STAGE + wave * RPW * ROWB;
     unsigned char* sb = sa + OPB;
+    if (WG_ABLATE & 1) return;
     if (kt < nfull) {
 #pragma unroll
       for (int j = 0; j < IPW; ++j) {
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // bias gradient partials: thread (chunk = tid & 15, row group = tid >> 4) sums 8 columns over rows rg, rg+16, ...
-  const bool have_ksum = q.ksum_out != nullptr && tk == 0;
+  const bool have_ksum = q.ksum_out != nullptr && tk == 0 && !(WG_ABLATE & 8);
   float ks8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
@@ -321,7 +328,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
         for (int e = 0; e < 8; ++e) ks8[e] += t.get(e);
       }
     }
-    if constexpr (NW == 8) {
+    if constexpr ((WG_ABLATE & 2) != 0) {
+    } else if constexpr (NW == 8) {
       // fragment reads issued up front (asm, see wg_tr2); the MFMAs of k-step 0 start once its 12 reads have returned
       // (LDS returns in order: the 12 younger ones of k-step 1 may still be outstanding)
       const unsigned tb = (unsigned)(buf * STAGE);
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     buf = buf + 1 == NS ? 0 : buf + 1;
   }
 
+  if (WG_ABLATE & 4) { if (acc[0][0][0] == 12345.678f) q.out[threadIdx.x] = acc[1][3][2]; return; }
   const float sc = rowscale != nullptr ? p.scale_const : 1.f;
   const bool split = p.nz > 1;                                // wave-uniform (kernel argument)
   if (have_ksum) {
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
         const float* cp = cbuf + lr * CSTR + cv * 8;
         float* dst = Cout + (int64_t)row * Kin + col;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
-        if (split) { store16_sc1(dst, lo); store16_sc1(dst + 4, hi); }
+        if (split && p.tickets != nullptr) { store16_sc1(dst, lo); store16_sc1(dst + 4, hi); }   // read back inside THIS launch
         else { *reinterpret_cast<f32x4*>(dst) = lo; *reinterpret_cast<f32x4*>(dst + 4) = hi; }
       }
     }
@@ -436,28 +445,58 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   }
   __syncthreads();
   if (*last_flag == 0u) return;
+  // The last arriver is by construction the LATEST workgroup of its tile: everything it still does extends the launch
+  // (in-model ablation, tools/probe/build_ablate.sh wgrad 4: the epilogue is 0.96 of the kernel's 3.90 ms per Swin-S
+  // step).  So all loads of the reduction are in flight at once -- 128 rows x 16 eight-float pieces = ITER pieces per
+  // thread, two pieces x four slices at a time = 16 16-byte loads per thread in flight (the accumulators are dead)
+  // -- and summed in slice order (bitwise = slab_reduce_kernel).
   const int64_t nk = (int64_t)N * Kin;
-  for (int v = threadIdx.x; v < 128 * 16; v += NT) {          // 128 rows x 16 eight-float pieces
-    const int lr = v >> 4, cv = v & 15;
-    const int row = n0 + lr, col = k0 + cv * 8;
-    if (row >= N || col >= Kin) continue;
-    const float* src = q.slab + (int64_t)row * Kin + col;
-    f32x4 s_lo = {0.f, 0.f, 0.f, 0.f}, s_hi = {0.f, 0.f, 0.f, 0.f};
+  constexpr int ITER = 128 * 16 / NT;                          // 4 (8 waves) | 8 (4 waves)
+  constexpr int IB = 2;                                        // pieces per batch: 2 x 4 slices x 2 x 16 B = 64 VGPRs (the kernel stays at 4 waves per SIMD)
+#pragma unroll 1
+  for (int i0 = 0; i0 < ITER; i0 += IB) {
+    f32x4 s_lo[IB], s_hi[IB];
+    const float* src[IB];
+    bool ok[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int v = threadIdx.x + (i0 + i) * NT;
+      const int lr = v >> 4, cv = v & 15;
+      const int row = n0 + lr, col = k0 + cv * 8;
+      ok[i] = row < N && col < Kin;
+      src[i] = q.slab + (ok[i] ? (int64_t)row * Kin + col : (int64_t)0);
+      s_lo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s_hi[i] = s_lo[i];
+    }
     int z = 0;
-    for (; z + 4 <= p.nz; z += 4) {                           // 8 loads in flight, summed in slice order
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk), a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk + 4);
-      f32x4 b0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 1) * nk), b1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 1) * nk + 4);
-      f32x4 c0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2) * nk), c1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2) * nk + 4);
-      f32x4 d0 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3) * nk), d1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3) * nk + 4);
-      s_lo += a0; s_hi += a1; s_lo += b0; s_hi += b1; s_lo += c0; s_hi += c1; s_lo += d0; s_hi += d1;
+    for (; z + 4 <= p.nz; z += 4) {
+      f32x4 a[IB][4][2];
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) {
+          a[i][zz][0] = *reinterpret_cast<const f32x4*>(src[i] + (int64_t)(z + zz) * nk);
+          a[i][zz][1] = *reinterpret_cast<const f32x4*>(src[i] + (int64_t)(z + zz) * nk + 4);
+        }
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) { s_lo[i] += a[i][zz][0]; s_hi[i] += a[i][zz][1]; }
     }
     for (; z < p.nz; ++z) {
-      s_lo += *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk);
-      s_hi += *reinterpret_cast<const f32x4*>(src + (int64_t)z * nk + 4);
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        s_lo[i] += *reinterpret_cast<const f32x4*>(src[i] + (int64_t)z * nk);
+        s_hi[i] += *reinterpret_cast<const f32x4*>(src[i] + (int64_t)z * nk + 4);
+      }
     }
-    float* dst = q.out + (int64_t)row * Kin + col;
-    *reinterpret_cast<f32x4*>(dst) = s_lo;
-    *reinterpret_cast<f32x4*>(dst + 4) = s_hi;
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      if (!ok[i]) continue;
+      float* dst = q.out + (src[i] - q.slab);
+      *reinterpret_cast<f32x4*>(dst) = s_lo[i];
+      *reinterpret_cast<f32x4*>(dst + 4) = s_hi[i];
+    }
   }
   if (have_ksum && threadIdx.x < 128 && n0 + (int)threadIdx.x < N) {
     float s = 0.f;

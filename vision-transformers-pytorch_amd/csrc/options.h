@@ -16,8 +16,9 @@ enum VtxOptionId {
   VTX_OPT_WATTN_FWD_WAVES = 7,  // persistent window-attention forward: resident waves (4096)
   VTX_OPT_WATTN_BWD_WAVES = 8,  // ... backward (2048)
   VTX_OPT_SRATTN_WGS = 9,       // PVT spatial-reduction attention: target workgroups (2048)
-  VTX_OPT_WGRAD_FUSED_REDUCE = 10,  // 1: the split-K slabs are summed inside the weight-gradient launch by each tile's
-                                    //    last-arriving workgroup (ticket counter); 0: separate slab_reduce launches
+  VTX_OPT_WGRAD_FUSED_REDUCE = 10,  // 0 (default): the split-K slabs of a (grouped) weight gradient are summed by ONE following
+                                    //    slab_reduce_multi launch; 1: inside the weight-gradient launch by each tile's
+                                    //    last-arriving workgroup (ticket counter) -- measured 27-76 us slower per launch
   VTX_OPT_WATTN_XCD_MAJOR = 11,     // 1: window-attention workgroups ordered head-fastest per XCD (the heads sharing a
                                     //    128-byte line run back to back on one L2); 0: all blocks of head 0, then head 1, ...
   VTX_OPT_WG_RING = 12,             // weight-gradient LDS ring: 0 / 642 = 64-token k-tiles x 2 stages (default) | 643 | 324 | 323

@@ -217,6 +217,46 @@ static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float
     reinterpret_cast<f32x4*>(out)[i] = s;
   }
 }
+// The same for up to 16 (slab set, output) pairs in ONE launch -- the weight and bias gradients of a grouped weight-gradient
+// launch: seg[s] covers blocks blk0[s] .. blk0[s + 1] - 1, each block 256 threads x one float4.
+struct SlabReduceMulti {
+  const float* slabs[16];
+  float* out[16];
+  long long n[16];          // elements per slab (multiples of 4)
+  int blk0[17];
+  int nseg, nz;
+};
+static __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabReduceMulti a) {
+  // (static indices only: a dynamically indexed by-value kernel argument is copied to scratch)
+  const float* slabs = a.slabs[0];
+  float* out = a.out[0];
+  long long n = a.n[0];
+  int b0 = 0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i)
+    if (i < a.nseg && (int)blockIdx.x >= a.blk0[i]) { slabs = a.slabs[i]; out = a.out[i]; n = a.n[i]; b0 = a.blk0[i]; }
+  const int64_t n4 = n >> 2;
+  const int64_t i = (int64_t)((int)blockIdx.x - b0) * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + i;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const int nz = a.nz;
+  int z = 0;
+  for (; z + 8 <= nz; z += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(z + j) * n4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; z + 4 <= nz; z += 4) {
+    f32x4 b0 = p[(int64_t)z * n4], b1 = p[(int64_t)(z + 1) * n4], b2 = p[(int64_t)(z + 2) * n4], b3 = p[(int64_t)(z + 3) * n4];
+    s += b0; s += b1; s += b2; s += b3;
+  }
+  for (; z < nz; ++z) s += p[(int64_t)z * n4];
+  reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
 static inline dim3 slab_reduce_grid(int64_t n) {
   int64_t nb = ((n >> 2) + 255) / 256;
   return dim3((unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)));
