@@ -25,6 +25,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// phase ablation of the backward for timing (separate builds; 0 in the library): 1 no phase A (dQ) | 2 no phase B (dK, dV)
+#ifndef SA_ABLATE
+#define SA_ABLATE 0
+#endif
 #define SA_D 64
 #define SA_ROWB 128
 
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_bwd_kernel(const bf16* __res
   __syncthreads();
 
   // ---------------- phase A: wave <-> pairs of query tiles; dQ = scale * dS K
-  for (int qp = wave; qp * TP < nt; qp += NW) {
+  for (int qp = wave; qp * TP < nt && !(SA_ABLATE & 1); qp += NW) {
     Vec8<bf16> qf[TP][2], dof[TP][2];
     bool qv[TP];
     float dsum[TP], lq[TP];
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_bwd_kernel(const bf16* __res
   __syncthreads();
 
   // ---------------- phase B: wave <-> pairs of key tiles; dV = P^T dO, dK = scale * dS^T Q
-  for (int kp = wave; kp * TP < nt; kp += NW) {
+  for (int kp = wave; kp * TP < nt && !(SA_ABLATE & 2); kp += NW) {
     Vec8<bf16> kf[TP][2], vf[TP][2];
     bool kv[TP];
 #pragma unroll
@@ -400,7 +404,9 @@ bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
 }
 
 // option SATTN_WAVES: 4 = four waves on PAIRS of 16-token tiles (round 1) | 8 = eight waves on single tiles: half the tiles per
-// wave (13 tiles at L = 197: 2 + 2 + ... vs 4 + 4 + 4 + 2) and twice the waves per SIMD to hide the LDS / exp latencies
+// wave (13 tiles at L = 197: 2 + 2 + ... vs 4 + 4 + 4 + 2) and twice the waves per SIMD to hide the LDS / exp latencies.
+// (Eight waves on pairs -- half the LDS fragment traffic per MFMA, but 170 registers = one workgroup per CU: backward
+//  112 -> 132 us.  Phase ablation, SA_ABLATE: staging + loads 23 us, phase A 44-54, phase B 36-46 of the 113-us backward.)
 template <int NKT> static int sattn_fwd_t(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB;
   if (vtx_opt(VTX_OPT_SATTN_WAVES) == 8)

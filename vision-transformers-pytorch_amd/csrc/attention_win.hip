@@ -31,7 +31,8 @@
 #define WA_BSTR 68       // bias table row stride (floats)
 #define WA_WAVES 4       // waves per workgroup
 // phase ablation of the backward for timing (separate builds, tools/probe/build_ablate.sh-style; 0 in the library):
-// 1 no final dS binning | 2 no partial-bin write-out | 4 no phase A (dQ) | 8 no phase B (dK, dV, dS sum)
+// 1 no final dS binning | 2 no partial-bin write-out | 4 no phase A (dQ) | 8 no phase B (dK, dV, dS sum) |
+// 16 no bias-table build (forward and backward) | 32 forward: no score / softmax / PV compute (loads + stores only)
 #ifndef WA_ABLATE
 #define WA_ABLATE 0
 #endif
@@ -107,6 +108,7 @@ __device__ __forceinline__ void wa_wave_sync() {
 __device__ __forceinline__ void wa_build_bias(float* bias_s, float* relh, const float* __restrict__ rel_pos,
                                               const int64_t* __restrict__ pos, int L, int nH, int h, int ntab) {
   constexpr int PER = 64 * 64 / (64 * WA_WAVES);
+  if (WA_ABLATE & 16) return;
   int pidx[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -199,6 +201,12 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
     wa_wave_sync();
 
     constexpr bool MK = MASKED;
+    if (WA_ABLATE & 32) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+        if (val[qt]) store8<T>(o + row[qt] * (int64_t)g.hd + h * WA_D + g_ * 8, qf[qt]);
+      continue;
+    }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       if (qt * 16 >= g.L) break;
