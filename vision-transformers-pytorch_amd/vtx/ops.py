@@ -798,6 +798,8 @@ def _pos_inverse(pos, ntab):
     if hit is None or hit[0]() is None:
         import weakref
         from . import tables
+        for k in [k for k, v in _POS_INVERSE.items() if v[0]() is None]:      # maps of buffers that no longer exist
+            del _POS_INVERSE[k]
         cells, count = tables.pos_inverse(pos, ntab)
         hit = (weakref.ref(pos), cells.to(pos.device), count)
         _POS_INVERSE[key] = hit
