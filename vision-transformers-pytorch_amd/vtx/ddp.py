@@ -15,6 +15,7 @@ is left exposed after backward ends), one flat fp32 buffer
 per bucket filled by a single multi-tensor copy, averaged by the collective itself (ncclAvg).
 World size 1 bypasses all of it.  Works on CPU tensors with the gloo backend (used by the tests).
 """
+import contextlib
 from typing import List
 
 import torch
@@ -136,21 +137,26 @@ class GradAllReduce:
         return hook
 
     def _launch(self, b):
+        side = None
         if b.params[0].is_cuda:
             from . import functional as VF
-            VF.side_join()              # weight gradients computed on the side stream (functional.deferred_wgrad)
-        dst, src = [], []
-        for p, v in zip(b.params, b.views):           # gradients that already live in the bucket need no packing
-            g = p.grad
-            if g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
-                dst.append(v)
-                src.append(g)
-        if dst:
-            torch._foreach_copy_(dst, src)            # one multi-tensor copy of the rest into the flat bucket
-        if self._avg is not None:
-            b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
-        else:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # weight gradients computed on the side stream (functional.deferred_wgrad): the bucket is packed and reduced
+            # BEHIND them on that stream; the main stream only joins at the end of backward / in finish()
+            side = VF.side_stream_after_current(b.params[0].device)
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            dst, src = [], []
+            for p, v in zip(b.params, b.views):           # gradients that already live in the bucket need no packing
+                g = p.grad
+                if g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                    dst.append(v)
+                    src.append(g)
+            if dst:
+                torch._foreach_copy_(dst, src)            # one multi-tensor copy of the rest into the flat bucket
+            if self._avg is not None:
+                b.work = dist.all_reduce(b.flat, op=self._avg, group=self.group, async_op=True)
+            else:
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Wait (stream-wise) for every bucket, install the averaged gradients, re-arm for the next backward."""

@@ -190,6 +190,18 @@ def deferred_wgrad(enabled=True):
         side_join()
 
 
+def side_stream_after_current(dev):
+    """The side stream of ``dev`` if weight gradients are pending on it, after making it wait for everything enqueued on
+    the current stream so far -- else None.  vtx.ddp launches a bucket's packing copy and all-reduce under it: the
+    COLLECTIVE then waits for the side-stream weight gradients (and, through this wait, for the main-stream ones), while the
+    main stream -- the dgrad chain, the critical path of backward -- never stalls on a bucket boundary."""
+    st = _side_states.get(dev)
+    if st is None or not st.pending:
+        return None
+    st.stream.wait_stream(torch.cuda.current_stream(dev))
+    return st.stream
+
+
 def side_join():
     """The current stream of every device with outstanding side-stream weight gradients waits for them."""
     for dev, st in _side_states.items():
