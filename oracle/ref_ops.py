@@ -184,8 +184,9 @@ def vit_patch_embedding(x_nchw, w, b, patch):
 
 
 # --------------------------------------------------------------------------- A13
-def mix_loss(logits, t1, t2, ratio, eps):
-    """MixLoss (loss.py:53-86): KL(sum)/B between log_softmax and the mixed smoothed one-hots."""
+def mix_loss(logits, t1, t2, ratio, eps, reduction="mean"):
+    """MixLoss (loss.py:53-86): KL between log_softmax and the mixed smoothed one-hots; 'mean' = sum / B (train.py's),
+    'none' = per-sample sums, anything else = the plain sum (loss.py:73-84)."""
     B, K = logits.shape
     logp = torch.log_softmax(logits, -1)
     on, off = 1 - eps + eps / K, eps / K
@@ -196,7 +197,9 @@ def mix_loss(logits, t1, t2, ratio, eps):
     r = ratio.reshape(B, 1).to(logp.dtype)
     td = r * d1 + (1 - r) * d2
     kl = torch.where(td > 0, td * (td.log() - logp), torch.zeros_like(td))
-    return kl.sum() / B
+    if reduction == "none":
+        return kl.sum(1)
+    return kl.sum() / B if reduction == "mean" else kl.sum()
 
 
 def clip_grad_norm(grads, max_norm):

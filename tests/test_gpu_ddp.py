@@ -32,16 +32,23 @@ def _data(n):
     return x, l1, l1.roll(1), torch.rand(n, generator=g)
 
 
-def _train(model, data, steps, ddp=None):
+def _train(model, data, steps, ddp=None, grad_accum=1, ddp_sync="boundary"):
+    """``grad_accum`` > 1: every optimizer step consumes grad_accum micro-batches = equal slices of ``data``."""
     from vtx.optim import FusedAdamW
     from vtx.train_step import MixLoss, make_param_groups, train_step
     opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3)
+    n = data[0].shape[0] // grad_accum
+    i = 0
     for _ in range(steps):
-        train_step(model, MixLoss(0.1), opt, data, clip_grad_norm=5.0, autocast_dtype=None, ddp=ddp)
+        for a in range(grad_accum):
+            micro = tuple(t[a * n:(a + 1) * n] for t in data)
+            train_step(model, MixLoss(0.1), opt, micro, clip_grad_norm=5.0, autocast_dtype=None, ddp=ddp,
+                       grad_accum=grad_accum, micro_step=i, ddp_sync=ddp_sync)
+            i += 1
     return [p.detach().cpu() for p in model.parameters()]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, grad_accum=1, ddp_sync="boundary"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "vision-transformers-pytorch_amd")):
@@ -57,21 +64,26 @@ def _worker(rank, world, port, q):
         torch.manual_seed(10 + rank)                       # different init per rank: the broadcast must fix it
         model = SwinTransformer(**CFG, drop_path=0.0).to(dev).train()
         ddp = GradAllReduce(model, bucket_bytes=1 << 20, first_bucket_bytes=1 << 18)
-        x, l1, l2, r = _data(4)
-        sl = slice(2 * rank, 2 * rank + 2)
-        params = _train(model, (x[sl].to(dev), l1[sl].to(dev), l2[sl].to(dev), r[sl].to(dev)), 2, ddp)
+        per = 2 * grad_accum
+        x, l1, l2, r = _data(world * per)
+        sl = slice(per * rank, per * rank + per)
+        params = _train(model, (x[sl].to(dev), l1[sl].to(dev), l2[sl].to(dev), r[sl].to(dev)), 2, ddp, grad_accum, ddp_sync)
         q.put((rank, [t.numpy() for t in params]))       # by value (tensor handles die with the worker)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_full_batch():
+@pytest.mark.parametrize("grad_accum,ddp_sync", [(1, "boundary"), (2, "boundary"), (2, "every")])
+def test_two_ranks_match_single_process_full_batch(grad_accum, ddp_sync):
+    """grad_accum 2 = the headline model's own configuration (config/swin-transformer-s.conf:33): 2 ranks x 2 micro-batches
+    of 2 images per optimizer step == 1 process x one batch of 8, for the all-reduce on the boundary only and for the
+    reference's all-reduce on every micro-batch (VERDICT r2 #1c)."""
     from gpu_util import dev, report
     from models import SwinTransformer
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, grad_accum, ddp_sync)) for r in range(world)]
     for p in procs:
         p.start()
     got = {r: [torch.from_numpy(a) for a in ps] for r, ps in (q.get(timeout=600) for _ in range(world))}
@@ -82,8 +94,9 @@ def test_two_ranks_match_single_process_full_batch():
         assert torch.equal(a, b), "ranks diverged"
     torch.manual_seed(10)                                  # rank 0's init = what the broadcast installs everywhere
     model = SwinTransformer(**CFG, drop_path=0.0).to(dev()).train()
-    x, l1, l2, r = _data(4)
+    x, l1, l2, r = _data(world * 2 * grad_accum)
     ref = _train(model, (x.to(dev()), l1.to(dev()), l2.to(dev()), r.to(dev())), 2)
     num = sum(((a.double() - b.double()).norm() ** 2).item() for a, b in zip(got[0], ref))
     den = sum((b.double().norm() ** 2).item() for b in ref)
-    assert report("2 ranks x half batch vs 1 process x full batch: parameters after 2 steps (rel-L2)", (num / den) ** 0.5, 2e-5)
+    assert report(f"2 ranks x {grad_accum} micro-batches ({ddp_sync}) vs 1 process x full batch: parameters after 2 steps "
+                  "(rel-L2)", (num / den) ** 0.5, 2e-5)

@@ -454,6 +454,31 @@ def test_mix_loss_kernel(dtype, B, K, eps):
     check(f"mix loss d logits {dtype} B{B} K{K}", x.grad, gr, 2e-5 if dtype == torch.float32 else 6e-3)
 
 
+@pytest.mark.parametrize("reduction", ["none", "sum", "batchmean"])
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float16])
+def test_mix_loss_reductions(dtype, reduction):
+    """the reference's MixLoss takes every reduction (loss.py:73-84: 'none' -> per-sample sums, 'mean' -> sum / B,
+    any other string -> the plain sum) and any floating dtype; all of them run on the fused kernel."""
+    from vtx.train_step import MixLoss
+    d = dev()
+    B, K, eps = 9, 40, 0.1
+    gen = torch.Generator().manual_seed(23)
+    logits = (torch.randn(B, K, generator=gen) * 2).to(dtype)
+    l1, l2 = torch.randint(0, K, (B,), generator=gen), torch.randint(0, K, (B,), generator=gen)
+    r = torch.rand(B, generator=gen)
+    cot = torch.randn(B, generator=gen).double() if reduction == "none" else torch.tensor(0.7).double()
+    x = logits.to(d).requires_grad_(True)
+    loss = MixLoss(eps, reduction)(x, l1.to(d), l2.to(d), r.to(d))
+    (loss.double() * cot.to(d)).sum().backward()
+    xr = logits.double().requires_grad_(True)
+    lr = R.mix_loss(xr, l1, l2, r.double(), eps, reduction)
+    (gr,) = torch.autograd.grad((lr * cot).sum(), [xr])
+    assert loss.shape == lr.shape and x.grad.dtype == dtype
+    lo = dtype != torch.float32
+    check(f"mix loss reduction={reduction} {dtype}", loss, lr, 2e-6)
+    check(f"mix loss reduction={reduction} d logits {dtype}", x.grad, gr, 6e-3 if lo else 2e-5)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_deferred_column_reductions_match_the_kernels_own_bit_for_bit(dtype):
     """LayerNorm dgamma / dbeta and the window-attention rel_pos gradient, reduced later by ONE colreduce_multi launch

@@ -231,6 +231,57 @@ def test_one_train_step_fp32_vs_reference():
         report(f"train step: param {k} after step", e, 2e-2)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_train_step_grad_accum_2_equals_one_double_batch_and_the_oracle(bf16):
+    """VERDICT r2 #1b: `train_step(grad_accum=2)` on one GPU.  Two micro-batches of 2 images with loss / 2 each accumulate
+    the gradient of the 4-image mean loss: compared with ONE 4-image step (SGD lr 1, no clip: parameter delta = -gradient)
+    and, in fp32, with the CPU oracle's gradient of the concatenated batch."""
+    from vtx.train_step import MixLoss, train_step
+    dt = torch.bfloat16 if bf16 else None
+    cfg = dict(image_size=(224, 224), n_class=16, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32,
+               n_heads=(1, 2, 4, 8), dim_ffs=(128, 256, 512, 1024), window_size=7)
+    from models import SwinTransformer
+    torch.manual_seed(11)
+    base = SwinTransformer(**cfg, drop_path=0.0)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 3, 224, 224, generator=gen)
+    l1 = torch.randint(0, 16, (4,), generator=gen)
+    l2, ratio = l1.roll(1), torch.rand(4, generator=gen)
+    data = tuple(t.to(dev()) for t in (x, l1, l2, ratio))
+
+    def run(accum):
+        m = SwinTransformer(**cfg, drop_path=0.0)
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        opt = torch.optim.SGD(m.parameters(), lr=1.0)
+        n = 4 // accum
+        for i in range(accum):
+            if accum > 1 and i == 0:
+                with pytest.raises(ValueError, match="micro_step"):     # ADVICE r2: a defaulted index never stepped
+                    train_step(m, MixLoss(0.1), opt, tuple(t[:n] for t in data), 0.0, dt, grad_accum=accum)
+            train_step(m, MixLoss(0.1), opt, tuple(t[i * n:(i + 1) * n] for t in data), clip_grad_norm=0.0,
+                       autocast_dtype=dt, grad_accum=accum, micro_step=i)
+            if i + 1 < accum:
+                assert all(p.grad is not None for p in m.parameters()), "non-boundary micro-batch must keep its gradients"
+        assert all(p.grad is None for p in m.parameters())
+        return {k: (sd[k].to(dev()) - p.detach()) for k, p in m.named_parameters()}
+
+    g2, g1 = run(2), run(1)
+    num = sum(((g2[k].double() - g1[k].double()).norm() ** 2).item() for k in g1)
+    den = sum((g1[k].double().norm() ** 2).item() for k in g1)
+    assert report(f"grad_accum 2 vs one double batch ({'bf16' if bf16 else 'fp32'}): all-parameter gradient",
+                  (num / den) ** 0.5, 8e-3 if bf16 else 2e-5)
+    if not bf16:
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+        keys = [k for k, _ in base.named_parameters()]
+        loss = R.mix_loss(M.swin_forward(P, x, cfg), l1, l2, ratio, 0.1)
+        gr = dict(zip(keys, torch.autograd.grad(loss, [P[k] for k in keys])))
+        num = sum(((g2[k].double().cpu() - gr[k].double()).norm() ** 2).item() for k in keys)
+        den = sum((gr[k].double().norm() ** 2).item() for k in keys)
+        assert report("grad_accum 2 vs CPU oracle on the concatenated batch: all-parameter gradient", (num / den) ** 0.5, 1e-4)
+
+
 def test_state_dict_round_trip_and_cpu_refusal():
     from models import SwinTransformer
     from vtx._lib import VtxError

@@ -22,6 +22,9 @@ import torch
 import torch.distributed as dist
 
 MIB = 1 << 20
+SLOT_ALIGN = 32      # floats: every parameter's slot in a flat bucket starts on a 128-byte boundary (the weight-gradient
+                     # kernels store 16-byte vectors straight into the slots; Swin's 507-float rel_pos tables would
+                     # otherwise leave every following slot on an odd 4-byte offset)
 
 
 class _Bucket:
@@ -34,6 +37,8 @@ class _Bucket:
         self.views = []
         self.pending = 0
         self.work = None
+        self.offsets = []          # start of every parameter's slot in `flat` (floats, SLOT_ALIGN-aligned)
+        self.flat_numel = 0
 
 
 def assign_buckets(named_params, bucket_bytes, first_bucket_bytes, last_bucket_bytes=0):
@@ -94,14 +99,19 @@ class GradAllReduce:
         self.buckets = assign_buckets(named, bucket_bytes, first_bucket_bytes, last_bucket_bytes)
         self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else None
         self._slot = {}
+        self._sunk = set()         # ids of the parameters whose bucket slot was handed out as a gradient sink since finish()
+        self._sync = True          # False inside no_sync(): hooks do not count, nothing is reduced
         for b in self.buckets:
             dev = b.params[0].device
-            b.flat = torch.zeros(b.numel, dtype=torch.float32, device=dev)
             off = 0
             for p in b.params:
-                b.views.append(b.flat[off:off + p.numel()].view_as(p))
-                self._slot[id(p)] = (b, off)
-                off += p.numel()
+                b.offsets.append(off)
+                off += (p.numel() + SLOT_ALIGN - 1) // SLOT_ALIGN * SLOT_ALIGN
+            b.flat_numel = off
+            b.flat = torch.zeros(off, dtype=torch.float32, device=dev)     # (the pad floats stay zero: harmless in the sum)
+            for p, o in zip(b.params, b.offsets):
+                b.views.append(b.flat[o:o + p.numel()].view_as(p))
+                self._slot[id(p)] = (b, o)
             b.pending = len(b.params)
             for p in b.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
@@ -124,16 +134,41 @@ class GradAllReduce:
         """A FRESH view of ``p``'s slot in its bucket (functional.grad_sink): a kernel that writes the gradient there and
         returns this tensor from backward makes autograd adopt it as ``p.grad`` -- no packing copy before the all-reduce."""
         ent = self._slot.get(id(p)) if self.active else None
-        if ent is None:
+        if ent is None or id(p) in self._sunk:
+            # At most ONE sink per parameter between two finish() calls: a weight shared by two graph nodes of one
+            # backward (DINO's backbone runs once per crop resolution, train_dino.py:229-236) gets two gradients BEFORE
+            # autograd's AccumulateGrad sets .grad -- handing both nodes the same slot would make the second kernel
+            # overwrite the first node's gradient while it waits in the engine's input buffer.  The second node gets None:
+            # a fresh tensor, summed by the engine as usual.
             return None
+        self._sunk.add(id(p))
         b, off = ent
         return b.flat[off:off + p.numel()].view_as(p)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside this context only ACCUMULATE local gradients (torch DDP's ``no_sync``): the bucket hooks do
+        not count and nothing is reduced.  The next backward outside the context reduces the accumulated sum -- by linearity
+        the mean over ranks of the summed micro-batch gradients, i.e. what the reference's all-reduce-per-micro-batch
+        (train.py:283-299 under DDP, no no_sync) arrives at, with 1 / grad_accum of its xGMI traffic."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
+
     def _make_hook(self, bucket):
         def hook(param):
+            if not self._sync:
+                return
             bucket.pending -= 1
             if bucket.pending == 0:
                 self._launch(bucket)
+            elif bucket.pending < 0:
+                raise RuntimeError(
+                    "GradAllReduce: a second backward() reached an already-reduced bucket before finish() -- with gradient "
+                    "accumulation either call finish() after EVERY backward (the reference's all-reduce per micro-batch) "
+                    "or wrap the non-boundary backwards in no_sync()")
         return hook
 
     def _launch(self, b):
@@ -162,10 +197,18 @@ class GradAllReduce:
         """Wait (stream-wise) for every bucket, install the averaged gradients, re-arm for the next backward."""
         if not self.active:
             return
-        missing = [n for b in self.buckets if b.pending != 0 for n, p in zip(b.names, b.params) if p.grad is None]
         if any(b.pending != 0 for b in self.buckets):
-            raise RuntimeError("GradAllReduce.finish(): parameters received no gradient in this backward "
-                               f"(unused parameters are not supported): {missing[:8]}")
+            for b in self.buckets:                      # leave the object usable for the caller's next attempt
+                if b.work is not None:
+                    b.work.wait()
+                b.work, b.pending = None, len(b.params)
+            self._sunk.clear()
+            missing = [n for b in self.buckets for n, p in zip(b.names, b.params) if p.grad is None]
+            if missing:
+                raise RuntimeError("GradAllReduce.finish(): parameters received no gradient in this backward "
+                                   f"(unused parameters are not supported): {missing[:8]}")
+            raise RuntimeError("GradAllReduce.finish(): not every bucket was reduced -- no backward() ran outside no_sync() "
+                               "since the last finish()")
         for b in self.buckets:
             b.work.wait()
             if self._avg is None:
@@ -174,6 +217,7 @@ class GradAllReduce:
                 p.grad = v
             b.work = None
             b.pending = len(b.params)
+        self._sunk.clear()
 
     def remove(self):
         for h in self._handles:

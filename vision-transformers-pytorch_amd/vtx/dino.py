@@ -85,18 +85,22 @@ def cancel_last_layer_grad(epoch, model, freeze):
 
 
 def dino_train_step(student, teacher, criterion, optimizer, crops, epoch, momentum, clip_grad_norm=3.0,
-                    freeze_last_layer=1, autocast_dtype=torch.bfloat16, grad_accum=1, ddp=None, micro_step=0):
+                    freeze_last_layer=1, autocast_dtype=torch.bfloat16, grad_accum=1, ddp=None, micro_step=None,
+                    ddp_sync="boundary"):
     """One DINO micro-batch on a list of crops (2 global first, then the local ones) resident on the device.  Like the
     reference (train_dino.py:239-263) clip, cancel_last_layer_grad, the optimizer step, zero_grad and the momentum
     update run only when ``(micro_step + 1) % grad_accum == 0``."""
     from .optim import FusedAdamW
+    from .train_step import accumulation_boundary, backward_ddp
+    boundary = accumulation_boundary(grad_accum, micro_step)
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
         with torch.no_grad():
             teacher_out = teacher(crops[:2])
         student_out = student(crops)
         loss = criterion(student_out, teacher_out, epoch) / grad_accum
-    loss.backward()          # (multi-crop: the backbone's parameters get one gradient per resolution -- no side stream)
-    if (micro_step + 1) % grad_accum != 0:
+    # (multi-crop: the backbone's parameters get one gradient per resolution -- no side stream)
+    backward_ddp(loss, ddp, boundary, ddp_sync, fresh=False)
+    if not boundary:
         return loss
     if ddp is not None:
         ddp.finish()

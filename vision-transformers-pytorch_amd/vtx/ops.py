@@ -569,8 +569,10 @@ def mix_normalize_erase(images, plan, mean, std, fills=None, nhwc_bf16=False):
     return out
 
 
-def mix_loss(logits, label1, label2, ratio, eps):
-    """MixLoss value (scalar tensor, reduction 'mean') and d loss / d logits, one kernel."""
+def mix_loss(logits, label1, label2, ratio, eps, reduction="mean"):
+    """MixLoss value and its gradient w.r.t. the logits, one kernel.  reduction 'mean': (scalar, d mean / d logits);
+    'sum' (the reference treats every other string as sum, loss.py:77-84): (scalar, d sum / d logits); 'none':
+    (per-sample losses [B], the per-row Jacobian softmax - target -- the caller scales row b by the incoming gradient)."""
     _dev(logits, label1, label2, ratio)
     x = logits if logits.is_contiguous() else logits.contiguous()
     B, K = x.shape
@@ -579,9 +581,12 @@ def mix_loss(logits, label1, label2, ratio, eps):
     r = torch.as_tensor(ratio, device=x.device).to(torch.float32).expand(B).contiguous()
     dl = torch.empty_like(x)
     rows = torch.empty(B, dtype=torch.float32, device=x.device)
-    check(_lib.load().vtx_mix_loss(_p(x), _p(l1), _p(l2), _p(r), _p(dl), _p(rows), B, K, float(eps), 1.0, _dt(x), _stream()),
+    gscale = 1.0 if reduction == "mean" else float(B)          # the kernel writes gscale / B * (softmax - target)
+    check(_lib.load().vtx_mix_loss(_p(x), _p(l1), _p(l2), _p(r), _p(dl), _p(rows), B, K, float(eps), gscale, _dt(x), _stream()),
           "vtx_mix_loss")
-    return rows.sum() / B, dl
+    if reduction == "none":
+        return rows, dl
+    return (rows.sum() / B if reduction == "mean" else rows.sum()), dl
 
 
 def l2norm_fwd(x, eps=1e-12):

@@ -4,7 +4,7 @@ The reference's train.py never ships; this is the harness the benchmark and the 
 Same op order: autocast forward -> MixLoss / grad_accum -> backward (DDP all-reduce overlapped) ->
 clip_grad_norm_ -> optimizer step -> zero_grad(set_to_none).  With ``vtx.optim.FusedAdamW`` clipping + AdamW run as
 two multi-tensor HIP kernels; any torch optimizer works too (clip_grad_norm_ + step()).
-MixLoss is one fused HIP kernel (value + gradient); there is no torch-composed fallback.
+MixLoss is one fused HIP kernel (value + gradient) for every reduction the reference has; no CPU fallback.
 """
 import torch
 from torch import nn
@@ -18,20 +18,26 @@ class _MixLossFn(torch.autograd.Function):
     """Value + gradient of MixLoss in one sweep (csrc/dino.hip mix_loss_kernel)."""
 
     @staticmethod
-    def forward(ctx, output, target1, target2, interpolation, eps):
+    def forward(ctx, output, target1, target2, interpolation, eps, reduction):
         from . import ops
-        loss, dl = ops.mix_loss(output.detach(), target1, target2, interpolation, eps)
+        loss, dl = ops.mix_loss(output.detach(), target1, target2, interpolation, eps, reduction)
         ctx.save_for_backward(dl)
+        ctx.per_row = reduction == "none"
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g.to(dl.dtype), None, None, None, None      # (not in place: a second backward must see dl unscaled)
+        g = g.to(dl.dtype)
+        # (not in place: a second backward must see dl unscaled)
+        return dl * (g.unsqueeze(1) if ctx.per_row else g), None, None, None, None, None
 
 
 class MixLoss(nn.Module):
-    """Label-smoothed KL between log-softmax and a mix of two one-hot targets (reference loss.py:53-86)."""
+    """Label-smoothed KL between log-softmax and a mix of two one-hot targets (reference loss.py:53-86): reductions
+    'mean' (train.py's), 'none' (per-sample) and 'sum' (what the reference does for any other string) -- one HIP kernel
+    for value and gradient.  Logits of other floating dtypes are computed in fp32 and the gradient cast back.  CPU logits
+    are refused: this package has no CPU path by design (the CPU restatement lives in oracle/, outside the product)."""
 
     def __init__(self, eps=0, reduction="mean"):
         super().__init__()
@@ -39,11 +45,12 @@ class MixLoss(nn.Module):
         self.reduction = reduction
 
     def forward(self, output, target1, target2, interpolation):
-        if self.reduction != "mean":
-            raise NotImplementedError("vtx: MixLoss supports reduction='mean' (the reference's train.py setting)")
-        if not output.is_cuda or output.dim() != 2 or output.dtype not in (torch.float32, torch.bfloat16):
-            raise VtxError("vtx: MixLoss needs (B, classes) fp32 / bf16 logits on the GPU (no CPU fallback)")
-        return _MixLossFn.apply(output, target1, target2, interpolation, float(self.eps))   # one HIP kernel
+        if not output.is_cuda or output.dim() != 2 or not output.is_floating_point():
+            raise VtxError("vtx: MixLoss needs (B, classes) floating-point logits on the GPU (no CPU fallback)")
+        if output.dtype not in (torch.float32, torch.bfloat16):
+            output = output.float()             # (autograd casts the gradient back to the caller's dtype)
+        red = self.reduction if self.reduction in ("mean", "none") else "sum"
+        return _MixLossFn.apply(output, target1, target2, interpolation, float(self.eps), red)
 
 
 def wd_skip(skip_type):
@@ -72,25 +79,60 @@ def make_param_groups(named_parameters, weight_decay, skip_type="vit"):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
+def accumulation_boundary(grad_accum, micro_step):
+    """True when this micro-batch closes an accumulation window: ``(i + 1) % grad_accum == 0`` with the loader index
+    ``i`` (train.py:285).  With grad_accum > 1 the caller MUST pass the index -- a defaulted 0 would never step."""
+    if grad_accum <= 1:
+        return True
+    if micro_step is None:
+        raise ValueError("vtx: grad_accum > 1 needs micro_step (the loader index i of train.py:285)")
+    return (micro_step + 1) % grad_accum == 0
+
+
+def backward_ddp(loss, ddp, boundary, ddp_sync, fresh):
+    """``loss.backward()`` with the data-parallel exchange of this micro-batch.
+
+    ``ddp_sync="boundary"`` (default): non-boundary micro-batches accumulate locally (``GradAllReduce.no_sync``), the
+    boundary backward all-reduces the accumulated sum, overlapped with itself.  ``"every"``: the reference's pattern --
+    DDP without no_sync (train.py:102-107, 283-299) all-reduces on EVERY micro-batch: finish() after each backward, so the
+    next micro-batch accumulates onto averaged gradients.  Both give mean_ranks(sum_micro g) (linearity of the mean);
+    "boundary" moves 1 / grad_accum of the bytes over xGMI."""
+    if ddp_sync not in ("boundary", "every"):
+        raise ValueError("vtx: ddp_sync must be 'boundary' or 'every'")
+    if ddp is None or not ddp.active:
+        with VF.deferred_wgrad(fresh):
+            loss.backward()
+        return
+    if boundary or ddp_sync == "every":
+        with VF.deferred_wgrad(fresh):
+            loss.backward()
+        if not boundary:
+            ddp.finish()        # "every": averaged gradients installed before the next micro-batch accumulates onto them
+    else:
+        with ddp.no_sync(), VF.deferred_wgrad(fresh):
+            loss.backward()
+
+
 def train_step(model, criterion, optimizer, batch, clip_grad_norm=5.0, autocast_dtype=torch.bfloat16,
-               grad_accum=1, ddp=None, micro_step=0):
+               grad_accum=1, ddp=None, micro_step=None, ddp_sync="boundary"):
     """One micro-batch of the reference's loop body (train.py:273-299).  ``batch`` = (input NCHW fp32, label1, label2,
     ratio) on the device.  Like the reference, clip + optimizer step + zero_grad run only on accumulation boundaries:
-    ``(micro_step + 1) % grad_accum == 0`` (``micro_step`` = the loader index ``i``); in between, gradients accumulate.
+    ``(micro_step + 1) % grad_accum == 0`` (``micro_step`` = the loader index ``i``, required when grad_accum > 1); in
+    between, gradients accumulate.
 
     ``ddp`` (vtx.ddp.GradAllReduce) overlaps the gradient all-reduce with backward; its ``finish()`` is the
-    only synchronisation point before clipping.  Returns the (unsynchronised) loss tensor.
+    only synchronisation point before clipping (``ddp_sync``: see backward_ddp).  Returns the (unsynchronised) loss tensor.
     """
     x, l1, l2, ratio = batch
+    boundary = accumulation_boundary(grad_accum, micro_step)
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
         out = model(x)
         loss = criterion(out, l1, l2, ratio) / grad_accum
     # Side-stream weight gradients (functional.deferred_wgrad) need "one gradient per parameter, .grad None on entry":
     # true for the first micro-batch after zero_grad(set_to_none) of these single-pass models, not while accumulating.
     fresh = grad_accum == 1 or micro_step % grad_accum == 0
-    with VF.deferred_wgrad(fresh):
-        loss.backward()
-    if (micro_step + 1) % grad_accum != 0:
+    backward_ddp(loss, ddp, boundary, ddp_sync, fresh)
+    if not boundary:
         return loss
     if ddp is not None:
         ddp.finish()
