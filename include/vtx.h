@@ -90,14 +90,11 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
  * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that
  * every rowscale value is either 0 or scale_const (DropPath: mask / (1 - p)), which lets the LDS-DMA kernel
  * skip dropped samples' rows instead of scaling; pass 0 for arbitrary scales.
- * Deterministic: split-K over tokens into fp32 slabs, summed in slice order -- inside the launch by each output tile's
- * last-arriving workgroup when `tickets` is given (int32 [vtx_wgrad_tickets()], ZERO on entry, re-armed to zero by the
- * kernel; launches sharing a ticket buffer must be ordered, i.e. one buffer per stream), else (tickets NULL, option
- * WGRAD_FUSED_REDUCE 0, or the register-staged kernels) by separate reduce launches: bitwise the same result. */
-int vtx_wgrad_tickets(void);
+ * Deterministic: split-K over tokens into fp32 slabs in `workspace`, summed in slice order by ONE following reduce launch.
+ * dW needs 16-byte alignment (the kernels store 16-byte vectors): VTX_ERR_ALIGN otherwise. */
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
               int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
-              void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream);
+              void* workspace, size_t ws_bytes, void* stream);
 /* Grouped form: the weight gradients of nprob <= vtx_wgrad_group_max() linears over the SAME mtok tokens in ONE launch
  * -- the four of a transformer layer's backward (fc2, fc1, proj, qkv: models/vit.py:59-63, swin_transformer.py:193-197,
  * layer.py:191-196).  Split-K only exists to fill the chip, so four problems together need a quarter of the slices (and
@@ -111,7 +108,7 @@ size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_
 int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
-                    void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream);
+                    void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order
  * [q|k|v][head][d] (models/vit.py:30-34, models/swin_transformer.py:128); o is [rows, nH*D].

@@ -106,29 +106,6 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
             assert torch.equal(a, g), f"{name} differs under {kw}"
 
 
-def test_wave_specialised_persistent_gemm_is_bitwise_the_shipped_kernel():
-    """csrc/gemm_ws.hip (option GEMM_WS, off by default: measured slower): producer / consumer waves, persistent tiles --
-    the same summation order per output element, so every fused epilogue must give the shipped kernel's bits."""
-    from vtx import ops, options
-    d = dev()
-    for M, N, K, T in ((25088, 1536, 384, 196), (50432, 384, 1536, 197), (16500, 1280, 64, 100)):
-        x, w = _mk((M, K), 171, BF, device=d), _mk((N, K), 172, BF, 0.05, device=d)
-        b, res = _mk((N,), 173, torch.float32, 0.1, device=d), _mk((M, N), 174, BF, device=d)
-        keep = (torch.rand(M // T, device=d) < 0.8).float() / 0.8
-
-        def run():
-            h, z = ops.gemm(x, w, 0, bias=b, act=ops.ACT_SILU, want_aux=True)
-            dz = ops.gemm(x, w, 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep, rows_per_scale=T)
-            y = ops.gemm(x, w, 0, bias=b, resid=res, rowscale=keep, rows_per_scale=T)
-            return h, z, dz, y
-
-        base = run()
-        with options.override(GEMM_WS=1):
-            got = run()
-        for a, g, name in zip(base, got, ("h", "z", "dz", "y")):
-            assert torch.equal(a, g), f"{name} differs ({M}x{N}x{K})"
-
-
 # ------------------------------------------------------------------ weight gradients at the real token counts
 def _wgrad_ref(dy, x, keep, T, c):
     m = None if keep is None else (keep > 0).double().repeat_interleave(T)[:, None]
@@ -173,9 +150,8 @@ def _layer_jobs(B, T, C, ff, d, seed=140):
                                       (128, 3136, 96, 384),        # stage 1: ragged 96-wide tiles, 51 slices
                                       (256, 197, 384, 1536)])      # ViT-S/16 B = 256
 def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
-    """The grouped launch of a layer's four weight gradients (fc2 and proj through DropPath) vs fp64; fused in-launch
-    split-K reduction vs separate reduce launches: bit-identical; 8 vs 4 waves: dW bit-identical; rerun: bit-identical
-    (deterministic), including the re-armed ticket counters."""
+    """The grouped launch of a layer's four weight gradients (fc2 and proj through DropPath) vs fp64; the grouped launch vs
+    one launch per problem; 8 vs 4 waves: dW bit-identical; rerun: bit-identical (deterministic)."""
     from vtx import ops, options
     d = dev()
     cpu, gpu, c = _layer_jobs(B, T, C, ff, d)
@@ -186,29 +162,15 @@ def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
         check(f"grouped wgrad dW {name} B{B} T{T} C{C}", dW, rW, 2e-5)
         check(f"grouped wgrad db {name} B{B} T{T} C{C}", db, rb, 2e-5)
     again = ops.wgrad_group(gpu, T, c)
-    with options.override(WGRAD_FUSED_REDUCE=0):
-        sep = ops.wgrad_group(gpu, T, c)
     with options.override(WG_WAVES=4):
         w4 = ops.wgrad_group(gpu, T, c)
-    for other, what in ((again, "rerun"), (sep, "separate reduce launches")):
-        for (a, ab), (g, gb) in zip(res, other):
-            assert torch.equal(a, g) and torch.equal(ab, gb), f"grouped wgrad differs: {what}"
+    for (a, ab), (g, gb) in zip(res, again):
+        assert torch.equal(a, g) and torch.equal(ab, gb), "grouped wgrad differs on a rerun"
     # 4 waves: every dW element is summed in the same order (bit-identical); the bias gradient's row groups are
     # 16 instead of 32 per workgroup, i.e. a different (still fixed) summation order
     for (a, ab), (g, gb) in zip(res, w4):
         assert torch.equal(a, g), "grouped wgrad dW differs with 4 waves"
         check("grouped wgrad db, 4 vs 8 waves", gb, ab, 2e-6)
-    assert int(ops._ticket_buffer(d).abs().sum().item()) == 0, "ticket counters must be re-armed to zero"
-
-
-def test_single_wgrad_fused_reduce_is_bitwise_the_separate_reduce():
-    from vtx import ops, options
-    d = dev()
-    dy, x = _mk((25088, 1152), 151, BF, device=d), _mk((25088, 384), 152, BF, device=d)
-    a = ops.wgrad(dy, x)
-    with options.override(WGRAD_FUSED_REDUCE=0):
-        b = ops.wgrad(dy, x)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 # ------------------------------------------------------------------ persistent window attention at B = 128

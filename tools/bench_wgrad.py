@@ -2,7 +2,7 @@
 """Micro-benchmark of the grouped weight-gradient launch on the per-layer shapes of Swin-S (B = 128) and ViT-S/16
 (B = 256), through DropPath, for the dispatch switches given on the command line:
 
-    python tools/bench_wgrad.py [WG_RING=643 ...]     (each "NAME=VALUE" set is timed against the default)
+    python tools/bench_wgrad.py [WG_WAVES=4 ...]     (each "NAME=VALUE" set is timed against the default)
 """
 import os
 import sys

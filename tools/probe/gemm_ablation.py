@@ -19,7 +19,7 @@ for name, M, N, K, kind in [("s3 fc1 fwd", 25088, 1536, 384, "silu"), ("s3 qkv f
               dsilu=dict(act=ops.ACT_DSILU, aux_in=z))[kind]
     line = f"{name:13s} {ops.gemm_kernel_name(torch.bfloat16, N, 0, K=K, M=M)[16:34]:18s}"
     for bits in (0, 1, 2, 4, 8, 3, 7, 15, 12):
-        with options.override(WG_RING=1000 + bits):
+        with options.override(GLDS_ABLATE_BITS=bits):   # needs a library built with the ablation switch (tools/probe/build_ablate.sh)
             line += f" {bits:2d}:{timeit(lambda: ops.gemm(x, w, 0, **kw)):6.1f}"
     print(line)
 print("bits: 1 no main-loop DMA | 2 no frag reads + MFMA | 4 no stores | 8 no epilogue operand loads")

@@ -16,9 +16,11 @@
 //   * the shifted-window -inf mask is carried as one REGION id per token (local_mask[n][a][b] == region[n][a] !=
 //     region[n][b]; the host verifies that the module's local_mask buffer has this structure, else the generic
 //     kernels of attention.hip run): 64 bytes per problem in LDS instead of a 16 KB mask table per window;
-//   * the rel_pos gradient: dS is summed over all problems of the persistent wave in registers and binned ONCE
-//     per wave into 172 wave-private LDS bins (ds_add_f32 costs ~100 LDS cycles per instruction; single wave,
-//     program order => deterministic), then reduced over waves in fixed order.
+//   * the rel_pos gradient: dS is summed over all problems of the persistent wave in registers, spilled ONCE per wave into
+//     the LDS region of its operand images and GATHERED per table bin over a host-built inverse map of `pos`
+//     (tables.pos_inverse: lane b adds up bin b in a fixed order => deterministic), then reduced over waves in fixed order.
+//     (Round 1 binned with ds_add_f32 -- ~100 LDS cycles per instruction, 26-30 us of every backward launch: replaced in
+//     round 2; the scatter survives only behind inv_cells == NULL for the tests.)
 #include <stdlib.h>
 
 #include "options.h"

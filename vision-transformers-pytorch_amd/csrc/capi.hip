@@ -10,8 +10,7 @@ struct OptDef { const char* env; int dflt; };
 const OptDef kOptDefs[VTX_OPT_COUNT] = {
     {"VTX_GEMM_GLDS", 1},   {"VTX_GLDS_BM", 0},          {"VTX_GLDS_WAVES", 8},   {"VTX_WGRAD_GLDS", 1},
     {"VTX_WG_WAVES", 8},    {"VTX_WGRAD_BLOCKS", 512},   {"VTX_SATTN", 1},        {"VTX_WATTN_FWD_WAVES", 4096},
-    {"VTX_WATTN_WAVES", 2048}, {"VTX_SRATTN_WGS", 2048}, {"VTX_WGRAD_FUSED_REDUCE", 0},
-    {"VTX_WATTN_XCD_MAJOR", 1},   {"VTX_WG_RING", 0},   {"VTX_GEMM_WS", 0},
+    {"VTX_WATTN_WAVES", 2048}, {"VTX_SRATTN_WGS", 2048}, {"VTX_WATTN_XCD_MAJOR", 1},
     {"VTX_LN_FIT", 1},      {"VTX_GLDS_EPI", 1},    {"VTX_SATTN_WAVES", 8},
 };
 struct OptTable {
@@ -52,6 +51,6 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 7; }
+int vtx_abi_version(void) { return 8; }
 
 }  // extern "C"

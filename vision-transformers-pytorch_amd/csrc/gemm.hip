@@ -281,7 +281,6 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VTX_BF16 && mode == 0 && gemm_glds_ok(N, K) && gemm_glds_enabled()) {
-    if (gemm_ws_ok(a)) return gemm_ws_launch(a, st);
     return gemm_glds_launch(a, st);
   }
   if (dtype == VTX_BF16)
@@ -305,8 +304,6 @@ size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin) {
   const int nz = wgrad_slices(mtok, N, Kin);
   return ((size_t)nz * (size_t)N * (size_t)Kin + (size_t)nz * (size_t)N) * sizeof(float);
 }
-
-int vtx_wgrad_tickets(void) { return 4096; }
 
 // weight (+ bias) slabs of one weight gradient -> dW (+ dbias), one launch
 static int reduce_slabs(const float* slabs, const float* bias_part, float* dW, float* dbias, int N, int Kin, int nz,
@@ -338,8 +335,9 @@ static int reduce_slabs(const float* slabs, const float* bias_part, float* dW, f
 // dW[N,Kin] = sum_m s[m] * dy[m,N]^T x[m,Kin]  (fp32 out);  dbias[N] = sum_m s[m] * dy[m,:] (same kernel)
 int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias, int64_t mtok, int N, int Kin,
               int64_t ld_dy, int64_t ld_x, const float* rowscale, int rows_per_scale, float scale_const,
-              void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream) {
+              void* workspace, size_t ws_bytes, void* stream) {
   if (!dy || !x || !dW || !workspace) return VTX_ERR_NULL;
+  if (((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return VTX_ERR_ALIGN;   // 16-byte vector stores into dW / the slabs
   if (mtok <= 0 || mtok > 0x7fffffff) return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_wgrad_workspace(mtok, N, Kin)) return VTX_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -361,9 +359,8 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
     WgradProbHost hp;
     hp.dy = dy; hp.x = x; hp.slab = (float*)workspace; hp.out = dW; hp.ksum_part = bias_part; hp.ksum_out = dbias;
     hp.rowscale = rowscale; hp.ld_dy = ld_dy; hp.ld_x = ld_x; hp.N = N; hp.Kin = Kin;
-    const bool fused = tickets != nullptr && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE) && wgrad_glds_tiles(N, Kin) <= vtx_wgrad_tickets();
-    rc = wgrad_glds_group_launch(1, &hp, mtok, a.k_per_scale, scale_const, nz, a.kchunk, fused ? tickets : nullptr, st);
-    if (rc || nz == 1 || fused) return rc;
+    rc = wgrad_glds_group_launch(1, &hp, mtok, a.k_per_scale, scale_const, nz, a.kchunk, st);
+    if (rc || nz == 1) return rc;
     return reduce_slabs((const float*)workspace, bias_part, dW, dbias, N, Kin, nz, st);
   }
   if (dtype == VTX_BF16) rc = gemm_pick_bn<bf16, float, true, true>(a, nz, st);
@@ -386,7 +383,6 @@ int vtx_wgrad_group_ok(int dtype, int nprob, const int* N, const int* Kin, int64
     if (!wgrad_glds_ok(dtype, N[i], Kin[i], rs, scale_const)) return 0;
     tiles += wgrad_glds_tiles(N[i], Kin[i]);
   }
-  if (tiles > vtx_wgrad_tickets()) return 0;
   const int nz = wgrad_glds_slices(mtok, tiles);
   if (has_rowscale && chunk_of(mtok, nz) / (rows_per_scale > 0 ? rows_per_scale : 1) + 2 > 512) return 0;
   return 1;
@@ -408,7 +404,7 @@ size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_
 int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
-                    void* workspace, size_t ws_bytes, unsigned int* tickets, void* stream) {
+                    void* workspace, size_t ws_bytes, void* stream) {
   if (!dy || !x || !dW || !N || !Kin || !ld_dy || !ld_x || !workspace) return VTX_ERR_NULL;
   bool any_scale = false;
   if (nprob >= 1 && nprob <= wgrad_glds_max_problems())
@@ -422,6 +418,7 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
   float* w = (float*)workspace;
   for (int i = 0; i < nprob; ++i) {
     if (!dy[i] || !x[i] || !dW[i]) return VTX_ERR_NULL;
+    if ((uintptr_t)dW[i] & 15) return VTX_ERR_ALIGN;                                 // 16-byte vector stores into dW
     if ((N[i] & 7) || (Kin[i] & 7) || (ld_dy[i] & 7) || (ld_x[i] & 7)) return VTX_ERR_ALIGN;
     hp[i].dy = dy[i]; hp[i].x = x[i]; hp[i].out = dW[i]; hp[i].ksum_out = dbias ? dbias[i] : nullptr;
     hp[i].rowscale = rowscale ? rowscale[i] : nullptr; hp[i].ld_dy = ld_dy[i]; hp[i].ld_x = ld_x[i];
@@ -429,9 +426,8 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
     hp[i].slab = w; w += (size_t)nz * N[i] * Kin[i];
     hp[i].ksum_part = w; w += (size_t)nz * N[i];
   }
-  const bool fused = tickets != nullptr && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE);
-  int rc = wgrad_glds_group_launch(nprob, hp, mtok, rows_per_scale, scale_const, nz, kchunk, fused ? tickets : nullptr, st);
-  if (rc || nz == 1 || fused) return rc;
+  int rc = wgrad_glds_group_launch(nprob, hp, mtok, rows_per_scale, scale_const, nz, kchunk, st);
+  if (rc || nz == 1) return rc;
   // one reduction launch for all weight and bias slabs of the group (kernel boundary = visibility: the slabs were
   // written with plain stores)
   SlabReduceMulti m;

@@ -162,13 +162,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st);
 bool gemm_glds_enabled();
 bool gemm_glds_ok(int N, int K);
-// persistent wave-specialised variant (gemm_ws.hip; option GEMM_WS)
-bool gemm_ws_ok(const GemmArgs& a);
-int gemm_ws_launch(const GemmArgs& a, hipStream_t st);
 
 // LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N and Kin multiples of 8 and >= 64,
 // rowscale values restricted to {0, scale_const}.  Grouped: up to wgrad_glds_max_problems() weight gradients over the
-// same tokens in one launch, split-K partials summed in-launch by each tile's last arriver (tickets) or left as slabs.
+// same tokens in one launch, split-K partials left as fp32 slabs (the caller reduces them in one launch).
 struct WgradProbHost {
   const void* dy; const void* x;
   float* slab; float* out; float* ksum_part; float* ksum_out;
@@ -182,4 +179,4 @@ int wgrad_glds_max_problems();
 int wgrad_glds_tiles(int N, int Kin);
 int wgrad_glds_slices(int64_t mtok, int ntiles);
 int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
-                            int nz, int kchunk, unsigned int* tickets, hipStream_t st);
+                            int nz, int kchunk, hipStream_t st);

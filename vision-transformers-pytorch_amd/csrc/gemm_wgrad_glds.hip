@@ -18,7 +18,7 @@
 #include "options.h"
 
 // phase ablation for IN-MODEL timing (tools/probe/build_ablate.sh wgrad N): 1 no DMA requests | 2 no fragment reads + MFMA |
-// 4 no epilogue (slab / output stores, ticket, in-launch reduction) | 8 no bias-gradient column sums.  0 in the library.
+// 4 no epilogue (slab / output stores) | 8 no bias-gradient column sums.  0 in the library.
 #ifndef WG_ABLATE
 #define WG_ABLATE 0
 #endif
@@ -55,7 +55,6 @@ struct WgradArgs {
   int kchunk;         // tokens per split-K slice (multiple of 64)
   int nz;             // slices
   int ntiles;         // tiles per slice over all problems; grid = ntiles * nz workgroups
-  unsigned int* tickets;   // [ntiles] zero on entry, zero again on exit: fused in-launch reduction; null: slabs only
 };
 
 __device__ __forceinline__ int wg_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
@@ -127,14 +126,6 @@ __device__ __forceinline__ void wg_mma12(const s16x4 (&r)[12], f32x4 (&acc)[2][4
     for (int j = 0; j < 4; ++j) mma16(wg_join(r[2 * i], r[2 * i + 1]), wg_join(r[4 + 2 * j], r[5 + 2 * j]), acc[i][j]);
 }
 
-// 16-byte write-through (sc1) store: a split-K slab is read by another workgroup of the SAME launch (the tile's last
-// arriver), possibly on another XCD whose L2 is not coherent with ours -- write-through + vmcnt(0) + ticket publishes
-// it without a release fence (cdna guide, Guideline 16 R1; 64 KB per workgroup: 3.0 vs 8.2 us for fence-published
-// plain stores).  hipcc does not count an asm store: the caller drains with its own s_waitcnt vmcnt(0).
-__device__ __forceinline__ void store16_sc1(float* dst, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-}
-
 // BKT tokens per k-tile, NS-stage LDS ring.  The operands are streamed from HBM (activations, read once per XCD
 // through its L2), so a k-tile costs an HBM-miss latency: what matters is how many bytes each CU keeps in flight.
 // NS-1 tiles are always requested ahead (counted s_waitcnt vmcnt + raw s_barrier, never a draining __syncthreads);
@@ -146,9 +137,10 @@ __device__ __forceinline__ void store16_sc1(float* dst, f32x4 v) {
 // re-read per launch -- while the layer's four together have 108 tiles and need 4: a quarter of the slab traffic and
 // of the launches, and a 4x longer k-loop per workgroup to amortise its prologue / epilogue.
 //
-// FUSED REDUCTION (tickets != null, nz > 1): every workgroup writes its slab tile write-through, takes a ticket of its
-// tile; the workgroup that draws nz - 1 acquires and sums the tile's nz slabs in slice order (the same fixed order as
-// slab_reduce_kernel: bitwise identical, deterministic) into dW, the bias partials likewise, and re-arms the ticket.
+// SPLIT-K SUM: plain fp32 slab stores; the host follows with ONE slab_reduce_multi launch for all weight and bias slabs
+// of the group (slice order, deterministic).  An in-launch sum by each tile's last-arriving workgroup (write-through
+// stores, ticket counters) was built in round 2, measured 27-76 us SLOWER per launch (a synchronised store-drain / ticket /
+// read-back burst at the end of every launch: profiles/round2_wgrad_phase_ablation.txt) and removed in round 3.
 // NW waves per workgroup: 4 (2 x 2 waves of 64 x 64) or 8 (4 x 2 waves of 32 x 64 -- half the DMA requests and MFMAs per
 // wave and k-tile, twice the waves per SIMD to interleave them).
 template <int BKT, int NS, int NW>
@@ -163,10 +155,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   constexpr int RING = NS * STAGE;
   static_assert(RING >= 64 * (BT + 4) * 4, "C staging must fit");
   // ONE shared array (a second __shared__ object makes hipcc drain vmcnt before the first ds_read of every k-step):
-  // [NS][A | B] ring, then the DropPath liveness table, then the "I am the last arriver" word
+  // [NS][A | B] ring, then the DropPath liveness table
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
   unsigned char* live_tab = wg_smem + RING;
-  unsigned int* last_flag = reinterpret_cast<unsigned int*>(wg_smem + RING + WG_MAXSAMPLES);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -382,8 +373,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
 #pragma unroll
       for (int qd = 0; qd < NT / 16; ++qd) s += red[qd * 128 + threadIdx.x];
       if (n0 + (int)threadIdx.x < N) {
-        if (split) __hip_atomic_store(q.ksum_part + (int64_t)tz * N + n0 + threadIdx.x, s * sc, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);                       // 4-byte sc1 store
+        if (split) q.ksum_part[(int64_t)tz * N + n0 + threadIdx.x] = s * sc;
         else q.ksum_out[n0 + threadIdx.x] = s * sc;
       }
     }
@@ -423,85 +413,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
         const float* cp = cbuf + lr * CSTR + cv * 8;
         float* dst = Cout + (int64_t)row * Kin + col;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(cp), hi = *reinterpret_cast<const f32x4*>(cp + 4);
-        if (split && p.tickets != nullptr) { store16_sc1(dst, lo); store16_sc1(dst + 4, hi); }   // read back inside THIS launch
-        else { *reinterpret_cast<f32x4*>(dst) = lo; *reinterpret_cast<f32x4*>(dst + 4) = hi; }
+        *reinterpret_cast<f32x4*>(dst) = lo;
+        *reinterpret_cast<f32x4*>(dst + 4) = hi;
       }
     }
     if (pass == 0) __syncthreads();
-  }
-  if (!split || p.tickets == nullptr) return;
-
-  // ---- fused split-K reduction: publish (every storing wave drains, then ONE ticket), last arriver sums
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int old = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int last = old == (unsigned int)(p.nz - 1);
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale L1 lines of the slabs
-      __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-    }
-    *last_flag = last;
-  }
-  __syncthreads();
-  if (*last_flag == 0u) return;
-  // The last arriver is by construction the LATEST workgroup of its tile: everything it still does extends the launch
-  // (in-model ablation, tools/probe/build_ablate.sh wgrad 4: the epilogue is 0.96 of the kernel's 3.90 ms per Swin-S
-  // step).  So all loads of the reduction are in flight at once -- 128 rows x 16 eight-float pieces = ITER pieces per
-  // thread, two pieces x four slices at a time = 16 16-byte loads per thread in flight (the accumulators are dead)
-  // -- and summed in slice order (bitwise = slab_reduce_kernel).
-  const int64_t nk = (int64_t)N * Kin;
-  constexpr int ITER = 128 * 16 / NT;                          // 4 (8 waves) | 8 (4 waves)
-  constexpr int IB = 2;                                        // pieces per batch: 2 x 4 slices x 2 x 16 B = 64 VGPRs (the kernel stays at 4 waves per SIMD)
-#pragma unroll 1
-  for (int i0 = 0; i0 < ITER; i0 += IB) {
-    f32x4 s_lo[IB], s_hi[IB];
-    const float* src[IB];
-    bool ok[IB];
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      const int v = threadIdx.x + (i0 + i) * NT;
-      const int lr = v >> 4, cv = v & 15;
-      const int row = n0 + lr, col = k0 + cv * 8;
-      ok[i] = row < N && col < Kin;
-      src[i] = q.slab + (ok[i] ? (int64_t)row * Kin + col : (int64_t)0);
-      s_lo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s_hi[i] = s_lo[i];
-    }
-    int z = 0;
-    for (; z + 4 <= p.nz; z += 4) {
-      f32x4 a[IB][4][2];
-#pragma unroll
-      for (int i = 0; i < IB; ++i)
-#pragma unroll
-        for (int zz = 0; zz < 4; ++zz) {
-          a[i][zz][0] = *reinterpret_cast<const f32x4*>(src[i] + (int64_t)(z + zz) * nk);
-          a[i][zz][1] = *reinterpret_cast<const f32x4*>(src[i] + (int64_t)(z + zz) * nk + 4);
-        }
-#pragma unroll
-      for (int i = 0; i < IB; ++i)
-#pragma unroll
-        for (int zz = 0; zz < 4; ++zz) { s_lo[i] += a[i][zz][0]; s_hi[i] += a[i][zz][1]; }
-    }
-    for (; z < p.nz; ++z) {
-#pragma unroll
-      for (int i = 0; i < IB; ++i) {
-        s_lo[i] += *reinterpret_cast<const f32x4*>(src[i] + (int64_t)z * nk);
-        s_hi[i] += *reinterpret_cast<const f32x4*>(src[i] + (int64_t)z * nk + 4);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      if (!ok[i]) continue;
-      float* dst = q.out + (src[i] - q.slab);
-      *reinterpret_cast<f32x4*>(dst) = s_lo[i];
-      *reinterpret_cast<f32x4*>(dst + 4) = s_hi[i];
-    }
-  }
-  if (have_ksum && threadIdx.x < 128 && n0 + (int)threadIdx.x < N) {
-    float s = 0.f;
-    for (int z = 0; z < p.nz; ++z) s += q.ksum_part[(int64_t)z * N + n0 + threadIdx.x];
-    q.ksum_out[n0 + threadIdx.x] = s;
   }
 }
 
@@ -523,7 +439,7 @@ bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale
 }
 
 template <int BKT, int NS, int NW> static int wgrad_glds_launch_cfg(const WgradArgs& a, hipStream_t st) {
-  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES + 16;
+  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES;
   auto kern = wgrad_glds_kernel<BKT, NS, NW>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -549,7 +465,7 @@ int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) /
 
 // slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)
 int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
-                            int nz, int kchunk, unsigned int* tickets, hipStream_t st) {
+                            int nz, int kchunk, hipStream_t st) {
   if (nprob < 1 || nprob > WG_MAXPROB) return VTX_ERR_SHAPE;
   WgradArgs a;
   int t0 = 0;
@@ -566,18 +482,12 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
   for (int i = nprob; i < WG_MAXPROB; ++i) a.pr[i] = a.pr[0];
   a.nprob = nprob; a.M = (int)mtok; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   a.scale_const = scale_const; a.kchunk = kchunk; a.nz = nz; a.ntiles = t0;
-  a.tickets = (nz > 1 && vtx_opt(VTX_OPT_WGRAD_FUSED_REDUCE)) ? tickets : nullptr;
   if (any_scale && kchunk / a.rows_per_scale + 2 > WG_MAXSAMPLES) return VTX_ERR_SHAPE;
   // 8 waves per workgroup: every shape of Swin-S / ViT-S 9-11 % faster than with 4 (stage-2..4 weight gradients 5.20 ->
   // 4.72 ms, ViT-S/16 4.66 -> 4.16 ms per step); 16 waves (one workgroup per CU: 73 registers) 5.6 vs 4.25 ms.
   // option WG_WAVES = 4 keeps the 2 x 2 variant for comparison
   if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
-  switch (vtx_opt(VTX_OPT_WG_RING)) {            // experimental ring geometries: 10 * tokens per k-tile + stages
-    case 643: return wgrad_glds_launch_cfg<64, 3, 8>(a, st);      // 96 KB: one workgroup per CU, two tiles ahead
-    case 324: return wgrad_glds_launch_cfg<32, 4, 8>(a, st);      // 64 KB: three half-tiles ahead
-    case 323: return wgrad_glds_launch_cfg<32, 3, 8>(a, st);      // 48 KB: three workgroups per CU
-    case 325: return wgrad_glds_launch_cfg<32, 5, 8>(a, st);      // 80 KB: two workgroups per CU, four half-tiles ahead
-    default: break;
-  }
+  // (ring geometries measured in round 2 and removed: 64 tokens x 3 stages, 32 x 3 / 4 / 5 -- all slower than 64 x 2,
+  //  profiles/round2_wgrad_ring_variants.txt)
   return wgrad_glds_launch_cfg<64, 2, 8>(a, st);
 }

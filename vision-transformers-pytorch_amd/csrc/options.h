@@ -16,17 +16,12 @@ enum VtxOptionId {
   VTX_OPT_WATTN_FWD_WAVES = 7,  // persistent window-attention forward: resident waves (4096)
   VTX_OPT_WATTN_BWD_WAVES = 8,  // ... backward (2048)
   VTX_OPT_SRATTN_WGS = 9,       // PVT spatial-reduction attention: target workgroups (2048)
-  VTX_OPT_WGRAD_FUSED_REDUCE = 10,  // 0 (default): the split-K slabs of a (grouped) weight gradient are summed by ONE following
-                                    //    slab_reduce_multi launch; 1: inside the weight-gradient launch by each tile's
-                                    //    last-arriving workgroup (ticket counter) -- measured 27-76 us slower per launch
-  VTX_OPT_WATTN_XCD_MAJOR = 11,     // 1: window-attention workgroups ordered head-fastest per XCD (the heads sharing a
+  VTX_OPT_WATTN_XCD_MAJOR = 10,     // 1: window-attention workgroups ordered head-fastest per XCD (the heads sharing a
                                     //    128-byte line run back to back on one L2); 0: all blocks of head 0, then head 1, ...
-  VTX_OPT_WG_RING = 12,             // weight-gradient LDS ring: 0 / 642 = 64-token k-tiles x 2 stages (default) | 643 | 324 | 323
-  VTX_OPT_GEMM_WS = 13,             // 1: persistent wave-specialised GEMM (gemm_ws.hip) for launches with >= 1024 128 x 128 tiles (experimental)
-  VTX_OPT_LN_FIT = 14,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
-  VTX_OPT_GLDS_EPI = 15,            // LDS-DMA GEMM epilogue (128-column tiles, 8 waves): 1 = wave-private staging, no workgroup barrier (default) | 0 = shared staging passes
-  VTX_OPT_SATTN_WAVES = 16,         // ViT attention fast path: 4 waves on pairs of 16-token tiles | 8 waves on single tiles
-  VTX_OPT_COUNT = 17
+  VTX_OPT_LN_FIT = 11,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
+  VTX_OPT_GLDS_EPI = 12,            // LDS-DMA GEMM epilogue (128-column tiles, 8 waves): 1 = wave-private staging, no workgroup barrier (default) | 0 = shared staging passes
+  VTX_OPT_SATTN_WAVES = 13,         // ViT attention fast path: 4 waves on pairs of 16-token tiles | 8 waves on single tiles
+  VTX_OPT_COUNT = 14
 };
 
 int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip

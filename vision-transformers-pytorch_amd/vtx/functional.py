@@ -150,7 +150,7 @@ def _img(x):
 # The weight-gradient GEMMs of a layer's backward feed nothing downstream in that backward.  Two things follow:
 #   * GROUPING: the four of a transformer layer (fc2, fc1, proj, qkv) run as ONE launch (ops.wgrad_group): split-K is
 #     only there to fill the chip, and four problems together need a quarter of the slices of one -- a quarter of the
-#     fp32 slab traffic, and the slab sum happens inside the launch (ticket counters) instead of in 8 more launches;
+#     fp32 slab traffic, and ONE reduce launch sums all slabs of the group instead of 8;
 #   * SIDE STREAM (opt-in per backward pass: ``deferred_wgrad()``): the grouped launch goes to a second HIP stream and
 #     fills the CUs the activation-gradient chain of the NEXT layers leaves idle (consecutive kernels of one stream run
 #     strictly one after the other: every launch pays its ramp-up and its partly filled last round).  fork = the side

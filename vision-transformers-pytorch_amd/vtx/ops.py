@@ -284,19 +284,6 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     return (c, aux) if want_aux else c
 
 
-_tickets = {}
-
-
-def _ticket_buffer(device):
-    """Per (device, stream) int32 ticket counters of the fused split-K reduction (vtx.h: zero on entry, re-armed to zero
-    by the kernel): launches of ONE stream run in order, so they can share a buffer; two streams must not."""
-    key = (device, _stream())
-    t = _tickets.get(key)
-    if t is None:
-        t = _tickets[key] = torch.zeros(_lib.load().vtx_wgrad_tickets(), dtype=torch.int32, device=device)
-    return t
-
-
 def wgrad_kernel_name(dtype, N, Kin, glds):
     if glds:
         return f"wgrad_glds_kernel<64, 2, {4 if options.get('WG_WAVES') == 4 else 8}>"
@@ -327,7 +314,7 @@ def wgrad(dy, x, want_bias=True, rowscale=None, rows_per_scale=1, scale_const=0.
     with _timed(wgrad_kernel_name(x.dtype, N, Kin, glds) + " (+split-K reduce)", 2.0 * M * N * Kin,
                 x.element_size() * M * (N + Kin) + 4.0 * N * Kin):
         check(lib.vtx_wgrad(_dt(x), _p(dy), _p(x), _p(dW), _p(db), M, N, Kin, N, Kin, _p(rowscale),
-                            int(rows_per_scale), float(scale_const), _p(ws), wsb, _p(_ticket_buffer(x.device)), _stream()),
+                            int(rows_per_scale), float(scale_const), _p(ws), wsb, _stream()),
               "vtx_wgrad")
     return dW, db
 
@@ -354,7 +341,7 @@ def wgrad_group_ok(jobs, rows_per_scale=1, scale_const=0.0):
 def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None):
     """The weight gradients of several linears over the SAME tokens in one launch (csrc/gemm_wgrad_glds.hip):
     jobs = [(dy [M, N_i], x [M, Kin_i], want_bias, rowscale or None), ...] -> [(dW_i fp32 [N_i, Kin_i], db_i or None)].
-    Split-K partials are summed inside the launch (ticket counters) -- deterministic, fixed slice order."""
+    Split-K partials are summed by one following reduce launch -- deterministic, fixed slice order."""
     lib = _lib.load()
     n = len(jobs)
     for dy, x, _, rs in jobs:
@@ -377,7 +364,7 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None):
     with _timed(wgrad_kernel_name(torch.bfloat16, 0, 0, True) + " (+split-K reduce)", flops, nbytes):
         check(lib.vtx_wgrad_group(BF16, n, vp([j[0] for j in jobs]), vp([j[1] for j in jobs]), vp(dWs), vp(dbs), Ns, Ks,
                                   lds, ldx, vp([j[3] for j in jobs]), int(rows_per_scale), float(scale_const), M, _p(ws),
-                                  wsb, _p(_ticket_buffer(dev)), _stream()), "vtx_wgrad_group")
+                                  wsb, _stream()), "vtx_wgrad_group")
     return list(zip(dWs, dbs))
 
 
