@@ -53,7 +53,7 @@ def pmc_traffic(model, kernel):
     run inside the timed process, so the figure comes from profiles/ (newest round first) together with the commit
     the profile was taken at (`_meta.commit` in the file; the kernels may have changed since: compare with HEAD);
     None when no summary is committed or the kernel is not in it."""
-    for rnd in (2, 1):
+    for rnd in (3, 2, 1):
         path = os.path.join(REPO, "profiles", f"round{rnd}_pmc_traffic_{model}.json")
         try:
             tab = json.load(open(path))
@@ -214,55 +214,21 @@ def selftest_launch(rank, world):
         print(json.dumps({"selftest_launch": True, "world_size_observed": seen, "sum": t.item()}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small", "dino"])
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / pvt_small, 256 vit_s16, 64 dino)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--event-every", type=int, default=0,
-                    help="HIP-event brackets around every kernel launch in every N-th timed step; 0 (default): only in the "
-                         "first timed step.  A sampled step runs single-stream and each bracket costs ~2 us of stream "
-                         "time (~600 launches: the sampled step is ~15 %% slower than the others; it is inside the timed "
-                         "region and counted in `value`)")
-    ap.add_argument("--cpu-batch", type=int, default=32)      # BASELINE.md section 3
-    ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--selftest-launch", action="store_true", help="launcher plumbing only (gloo on CPU, no model)")
-    args = ap.parse_args()
+def default_batch(name):
+    """Per-GPU batch of BASELINE.json's configurations: 256 ViT-S/16 (cfg-2), 128 Swin-S / PVT-Small (cfg-3 / 4), 64 DINO (cfg-5)."""
+    return 256 if name == "vit_s16" else (64 if name == "dino" else 128)
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)                                     # never returns
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
-    if args.selftest_launch:
-        return selftest_launch(rank, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from vtx import functional as VF
+def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
+    """`warmup` untimed + `steps` timed train steps of one workload (barrier + synchronize on both sides, max over ranks);
+    -> dict(value, ms_per_step, workload, roofline)."""
     from vtx import ops
     from vtx.ddp import GradAllReduce
     from vtx.train_step import MixLoss, make_param_groups, train_step
 
-    batch = args.batch or (256 if args.model == "vit_s16" else (64 if args.model == "dino" else 128))
-    drop_path = 0.3 if args.model == "swin_s" else 0.1
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps)
-
+    drop_path = 0.3 if model_name == "swin_s" else 0.1
     torch.manual_seed(0)                       # identical init on every rank (+ rank-0 broadcast in GradAllReduce)
-    model = build_model(args.model, drop_path).to(dev).train()
+    model = build_model(model_name, drop_path).to(dev).train()
     ddp = GradAllReduce(model)
     ac = torch.bfloat16 if args.dtype == "bf16" else None
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -274,7 +240,7 @@ def main():
             return FusedAdamW(groups, lr=lr)                      # clip + AdamW: two multi-tensor HIP kernels
         return torch.optim.AdamW(groups, lr=lr, fused=True)       # torch's fused AdamW + foreach clip_grad_norm_
 
-    if args.model == "dino":
+    if model_name == "dino":
         # train_dino.py:188-288 with config/dino_deit-s-16.conf: 2 global 224^2 + 8 local 96^2 crops per image, momentum
         # teacher (no grad), DINOLoss over 65536 outputs, AdamW (wd_skip dino), clip 3.0; epoch >= freeze_last_layer
         from vtx.dino import DINOLoss, dino_train_step
@@ -300,13 +266,13 @@ def main():
         l2 = l1.roll(1)
         ratio = torch.rand(batch, device=dev, generator=g)
         data = (x, l1, l2, ratio)
-        workload = (f"{args.model} 224x224 train step, batch {batch}/GPU, drop_path {drop_path}, "
+        workload = (f"{model_name} 224x224 train step, batch {batch}/GPU, drop_path {drop_path}, "
                     "MixLoss(eps 0.1), clip 5.0, AdamW(lr 1e-3, wd 0.05), grad_accum 1")
 
         def step():
             return train_step(model, criterion, opt, data, clip_grad_norm=5.0, autocast_dtype=ac, ddp=ddp)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     timer = None if args.no_kernel_events else ops.KernelTimer()
     nsampled = 0
@@ -316,7 +282,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_events = []
-    for i in range(args.steps):
+    for i in range(steps):
         sampled = timer is not None and (i % args.event_every == 0 if args.event_every > 0 else i == 0)
         if sampled:                                   # inside the timed region, on the launch stream
             ops.set_kernel_timer(timer)
@@ -339,9 +305,9 @@ def main():
         dt = t.item()
     assert torch.isfinite(loss).item(), "non-finite loss"
 
+    value = batch * world * steps / dt
+    roof = None
     if rank == 0:
-        value = batch * world * args.steps / dt
-        roof = None
         if timer is not None:
             allk = timer.summary()
             peak = PEAK_BF16_TFLOPS if ac else PEAK_F32_TFLOPS
@@ -361,7 +327,7 @@ def main():
 
             table = {k: row(k, v) for k, v in sorted(allk.items(), key=lambda kv: -kv[1]["ms"])}
             name, d = max(allk.items(), key=lambda kv: kv[1]["ms"])
-            traffic, tsrc, tcommit = pmc_traffic(args.model, name)
+            traffic, tsrc, tcommit = pmc_traffic(model_name, name)
             # the roofline that bounds the kernel: MFMA when its algorithmic intensity (FLOP per algorithmic HBM byte)
             # exceeds the machine balance 2.5 PFLOP/s / 8 TB/s = 312 FLOP/B, else HBM.  With K = C <= 768 and fused
             # epilogue streams every GEMM-class kernel of these models sits BELOW the balance point (forward / dgrad
@@ -380,23 +346,88 @@ def main():
                         algorithmic_flops_per_launch=round(d["flops"] / d["launches"]),
                         launches_per_step=round(d["launches"] / nsampled, 1), event_sampled_steps=nsampled,
                         avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
-                        end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[args.model] / 1e3 / peak, 4),
+                        end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[model_name] / 1e3 / peak, 4),
                         # every launch class of the step (HIP events on the launch stream, sampled steps are
                         # single-stream): coverage = sum of the table / GPU time of the sampled steps
                         sampled_step_ms=round(sampled_ms, 3),
                         kernels_coverage=round(sum(v["ms"] for v in allk.values()) / nsampled / sampled_ms, 4),
                         kernels=table)
+    return dict(value=value, ms_per_step=1e3 * dt / steps, workload=workload, roofline=roof)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small", "dino"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / pvt_small, 256 vit_s16, 64 dino)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="HIP-event brackets around every kernel launch in every N-th timed step; 0 (default): only in the "
+                         "first timed step.  A sampled step runs single-stream and each bracket costs ~2 us of stream "
+                         "time (~600 launches: the sampled step is ~15 %% slower than the others; it is inside the timed "
+                         "region and counted in `value`)")
+    ap.add_argument("--cpu-batch", type=int, default=32)      # BASELINE.md section 3
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--selftest-launch", action="store_true", help="launcher plumbing only (gloo on CPU, no model)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short ViT-S/16 / PVT-Small / DINO runs that follow the headline at --gpus 1 (`secondary`)")
+    ap.add_argument("--secondary-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                     # never returns
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if args.selftest_launch:
+        return selftest_launch(rank, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    batch = args.batch or default_batch(args.model)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps)
+
+    from vtx import functional as VF
+    res = run_workload(args.model, batch, args.steps, args.warmup, args, dev, rank, world)
+    secondary = None
+    if world == 1 and not args.no_secondary and args.model == "swin_s" and args.dtype == "bf16":
+        # the other BASELINE.json configurations (cfg-2 / 4 / 5) in the same process, after the headline's timed region:
+        # ~10 steps each, one event-sampled step; headline keys and timing untouched
+        secondary = []
+        for name in ("vit_s16", "pvt_small", "dino"):
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()               # the previous workload's model / activations: start from an empty allocator
+            r = run_workload(name, default_batch(name), args.secondary_steps, 3, args, dev, rank, world)
+            rf = r["roofline"] or {}
+            secondary.append({"workload": r["workload"], "model": name, "value": round(r["value"], 2), "unit": "images/sec",
+                              "ms_per_step": round(r["ms_per_step"], 3), "steps": args.secondary_steps, "warmup": 3,
+                              "roofline": {k: rf.get(k) for k in ("kernel", "bound", "frac", "frac_hbm", "frac_mfma",
+                                                                  "avg_launch_us", "launches_per_step", "end_to_end_frac")}})
+    if rank == 0:
         line = {
-            "metric": "images/sec training (fwd+bwd+step)", "value": round(value, 2), "unit": "images/sec",
+            "metric": "images/sec training (fwd+bwd+step)", "value": round(res["value"], 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if ac else "f32", "data": "synthetic",
-            "config": {"workload": workload,
+            "ms_per_step": round(res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": res["workload"],
                        "global_batch": batch * world, "parallelism": f"dp{world}"},
             "world_size_observed": dist.get_world_size() if world > 1 else 1,
             "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 else None,
             "side_stream_wgrad": bool(VF._SIDE_ENABLED),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": res["roofline"], "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line))
     if world > 1:
