@@ -156,11 +156,10 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
 // epilogue -- the phase trace (tools/probe/gemm_trace.hip) shows 1.4 us of a 10.8 us workgroup lifetime spent in the shared
 // staging passes, mostly waiting at their three barriers for the slowest wave.  Element values are those of
 // gemm_epilogue (same expression per element), so the two variants are bitwise interchangeable.
-template <int BM, int NWN, int BN = 128> struct PvEpiOperands {
-  static constexpr int WN = BN / (16 * NWN);           // 16-column tiles per wave: 4 | 2 (BN 128), 6 (BN 192 on 4 x 2 waves)
+template <int BM, int NWN> struct PvEpiOperands {
+  static constexpr int WN = 128 / (16 * NWN);          // 16-column tiles per wave: 4 | 2
   static constexpr int VROW = 2 * WN;                  // 8-element vectors per staged row of the wave tile
-  static constexpr int NIT = 16 * VROW / 64;           // store iterations per 16-row pass: 2 | 1 | 3
-  static_assert(NIT * 64 == 16 * VROW, "a 16-row pass is a whole number of 64-lane store iterations");
+  static constexpr int NIT = 16 * VROW / 64;           // store iterations per 16-row pass: 2 | 1
   float bcol[WN];
   float rsc[2 * NIT];
   Vec8<bf16> ein[2 * NIT];
@@ -215,9 +214,9 @@ __device__ __forceinline__ void glds_wave_sync() {      // orders this wave's ow
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int BM, int NWN, int BN = 128>
-__global__ __launch_bounds__(512, BN == 192 ? 4 : 2) void gemm_glds_pv_kernel(GemmArgs p) {
-  constexpr int BK = 64, NS = 2;
+template <int BM, int NWN>
+__global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
+  constexpr int BN = 128, BK = 64, NS = 2;
   constexpr int ROWB = BK * 2, CPR = BK / 8, PR = 1024 / ROWB, KS = BK / 32, NWV = 8;
   constexpr int NWM = NWV / NWN;
   static_assert(BM == 32 * NWM, "32-row wave tiles");
@@ -246,10 +245,10 @@ __global__ __launch_bounds__(512, BN == 192 ? 4 : 2) void gemm_glds_pv_kernel(Ge
   const bf16* B = (const bf16*)p.B;
 
   VTX_TRACE(0);
-  PvEpiOperands<BM, NWN, BN> eo;
+  PvEpiOperands<BM, NWN> eo;
   eo.load_small(p, m0, n0, wm, wn, lane);
-  const bool has_vec = PvEpiOperands<BM, NWN, BN>::vec_src(p) != nullptr && !(GLDS_ABLATE & 8);
-  constexpr int NVEC = PvEpiOperands<BM, NWN, BN>::NVEC;
+  const bool has_vec = PvEpiOperands<BM, NWN>::vec_src(p) != nullptr && !(GLDS_ABLATE & 8);
+  constexpr int NVEC = PvEpiOperands<BM, NWN>::NVEC;
 
   const int lr = lane / CPR, slot = lane % CPR;
   constexpr int APW = BM / (NWV * PR), BPW = BN / (NWV * PR);
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(512, BN == 192 ? 4 : 2) void gemm_glds_pv_kernel(Ge
   VTX_TRACE(2);
 
   // ---------------- wave-private epilogue: acc[i][j][r] = C[m0 + 32 wm + 16 i + 4 g + r][n0 + 16 WN wn + 16 j + c]
-  using EO = PvEpiOperands<BM, NWN, BN>;
+  using EO = PvEpiOperands<BM, NWN>;
   constexpr int VROW = EO::VROW, NIT = EO::NIT;
   float* cbuf = reinterpret_cast<float*>(glds_smem + wave * PVB);
   bf16* __restrict__ Cout = (bf16*)p.C;
@@ -402,13 +401,13 @@ __global__ __launch_bounds__(512, BN == 192 ? 4 : 2) void gemm_glds_pv_kernel(Ge
   VTX_TRACE(7);
 }
 
-template <int BM, int NWN, int BN = 128> static int glds_launch_pv(const GemmArgs& a, hipStream_t st) {
-  constexpr size_t smem = (size_t)2 * (BM + BN) * 128;
-  auto kern = gemm_glds_pv_kernel<BM, NWN, BN>;
+template <int BM, int NWN> static int glds_launch_pv(const GemmArgs& a, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * (BM + 128) * 128;
+  auto kern = gemm_glds_pv_kernel<BM, NWN>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
+  dim3 grid((a.N + 127) / 128, (a.M + BM - 1) / BM, 1);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
   return vtx_check_launch();
 }
