@@ -100,7 +100,10 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
  * layer.py:191-196).  Split-K only exists to fill the chip, so four problems together need a quarter of the slices (and
  * of the fp32 slab traffic) of one.  bf16, every (N[i], Kin[i]) a multiple of 8 and >= 64 (vtx_wgrad_group_ok tells;
  * otherwise call vtx_wgrad per problem).  Arrays are HOST arrays of nprob entries; dbias / rowscale may be NULL or hold
- * NULL entries; rowscale values in {0, scale_const} (scale_const > 0) as for vtx_wgrad; same determinism contract. */
+ * NULL entries; rowscale values in {0, scale_const} (scale_const > 0) as for vtx_wgrad; same determinism contract.
+ * ncol (0..4) deferred column reductions (the arguments of vtx_colreduce_multi: a layer's LayerNorm dgamma / dbeta partials,
+ * its rel_pos gradient partials) ride in the group's ONE reduce launch -- same bits as vtx_colreduce_multi, one launch less
+ * per layer.  They must have been enqueued on `stream` (or be ordered before it) like the operands. */
 int vtx_wgrad_group_max(void);
 int vtx_wgrad_group_ok(int dtype, int nprob, const int* N, const int* Kin, int64_t mtok, int has_rowscale,
                        int rows_per_scale, float scale_const);
@@ -108,7 +111,8 @@ size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_
 int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
-                    void* workspace, size_t ws_bytes, void* stream);
+                    void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
+                    float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, void* stream);
 
 /* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order
  * [q|k|v][head][d] (models/vit.py:30-34, models/swin_transformer.py:128); o is [rows, nH*D].

@@ -510,3 +510,17 @@ def test_deferred_column_reductions_match_the_kernels_own_bit_for_bit(dtype):
     assert torch.equal(dx_a, dx_b) and torch.equal(dq_a, dq_b)
     assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b) and torch.equal(dg_a, dg_c) and torch.equal(db_a, db_c)
     assert torch.equal(drel_a, drel_b.view(ntab, nH))
+    if dtype == torch.bfloat16:
+        # round 3: the same reductions riding in the reduce launch of a grouped weight gradient (one launch less per layer)
+        M = 25088                                        # 108 tiles -> 4 split-K slices (slab segments + column segments) ...
+        jobs = [(_mk((M, 384), 511, dtype).to(d), _mk((M, 1536), 512, dtype).to(d), True, None),
+                (_mk((M, 1536), 513, dtype).to(d), _mk((M, 384), 514, dtype).to(d), True, None)]
+        small = [(j[0][:256].contiguous(), j[1][:256].contiguous(), True, None) for j in jobs]   # ... and nz = 1 (columns only)
+        for jj in (jobs, small):
+            assert ops.wgrad_group_ok(jj)
+            plain = ops.wgrad_group(jj)
+            got, red = ops.wgrad_group(jj, colparts=[part_ln, part_ln, part_rel])
+            for (a, ab), (g2, gb) in zip(plain, got):
+                assert torch.equal(a, g2) and torch.equal(ab, gb)
+            assert torch.equal(red[0][0], dg_a) and torch.equal(red[0][1], db_a) and torch.equal(red[1][0], dg_a)
+            assert torch.equal(red[2][0].view(ntab, nH), drel_a) and red[2][1] is None

@@ -404,7 +404,8 @@ size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_
 int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
-                    void* workspace, size_t ws_bytes, void* stream) {
+                    void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
+                    float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, void* stream) {
   if (!dy || !x || !dW || !N || !Kin || !ld_dy || !ld_x || !workspace) return VTX_ERR_NULL;
   bool any_scale = false;
   if (nprob >= 1 && nprob <= wgrad_glds_max_problems())
@@ -426,25 +427,38 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
     hp[i].slab = w; w += (size_t)nz * N[i] * Kin[i];
     hp[i].ksum_part = w; w += (size_t)nz * N[i];
   }
+  if (ncol < 0 || ncol > 4 || (ncol > 0 && (!col_part || !col_out0 || !col_nb || !col_C || !col_ld))) return VTX_ERR_SHAPE;
   int rc = wgrad_glds_group_launch(nprob, hp, mtok, rows_per_scale, scale_const, nz, kchunk, st);
-  if (rc || nz == 1) return rc;
-  // one reduction launch for all weight and bias slabs of the group (kernel boundary = visibility: the slabs were
-  // written with plain stores)
-  SlabReduceMulti m;
-  m.nseg = 0; m.nz = nz; m.blk0[0] = 0;
-  for (int i = 0; i < nprob; ++i) {
-    const long long nw = (long long)N[i] * Kin[i];
-    m.slabs[m.nseg] = hp[i].slab; m.out[m.nseg] = hp[i].out; m.n[m.nseg] = nw;
-    m.blk0[m.nseg + 1] = m.blk0[m.nseg] + (int)(((nw >> 2) + 255) / 256);
-    ++m.nseg;
-    if (hp[i].ksum_out) {
-      m.slabs[m.nseg] = hp[i].ksum_part; m.out[m.nseg] = hp[i].ksum_out; m.n[m.nseg] = N[i];
-      m.blk0[m.nseg + 1] = m.blk0[m.nseg] + (int)((((long long)N[i] >> 2) + 255) / 256);
+  if (rc || (nz == 1 && ncol == 0)) return rc;
+  // ONE reduction launch behind the group: all weight and bias slabs (kernel boundary = visibility: the slabs were written
+  // with plain stores) and the layer's deferred column reductions (LayerNorm dgamma / dbeta, rel_pos gradient)
+  LayerReduce m;
+  m.nseg = 0; m.nz = nz; m.ncol = ncol; m.blk0[0] = 0;
+  if (nz > 1) {
+    for (int i = 0; i < nprob; ++i) {
+      const long long nw = (long long)N[i] * Kin[i];
+      m.slabs[m.nseg] = hp[i].slab; m.out[m.nseg] = hp[i].out; m.n[m.nseg] = nw;
+      m.blk0[m.nseg + 1] = m.blk0[m.nseg] + (int)(((nw >> 2) + 1023) / 1024);
       ++m.nseg;
+      if (hp[i].ksum_out) {
+        m.slabs[m.nseg] = hp[i].ksum_part; m.out[m.nseg] = hp[i].ksum_out; m.n[m.nseg] = N[i];
+        m.blk0[m.nseg + 1] = m.blk0[m.nseg] + (int)((((long long)N[i] >> 2) + 1023) / 1024);
+        ++m.nseg;
+      }
     }
   }
   for (int i = m.nseg; i < 16; ++i) { m.slabs[i] = nullptr; m.out[i] = nullptr; m.n[i] = 0; m.blk0[i + 1] = m.blk0[m.nseg]; }
-  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)m.blk0[m.nseg]), dim3(256), 0, st, m);
+  m.cblk0[0] = m.blk0[m.nseg];
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < ncol;
+    if (on && (!col_part[i] || !col_out0[i] || col_nb[i] <= 0 || col_C[i] <= 0)) return VTX_ERR_NULL;
+    m.part[i] = on ? col_part[i] : nullptr; m.out0[i] = on ? col_out0[i] : nullptr;
+    m.out1[i] = (on && col_out1) ? col_out1[i] : nullptr;
+    m.nb[i] = on ? col_nb[i] : 0; m.C[i] = on ? col_C[i] : 0; m.ld[i] = on ? col_ld[i] : 0;
+    const int cols = on ? (m.out1[i] ? 2 * m.C[i] : m.C[i]) : 0;
+    m.cblk0[i + 1] = m.cblk0[i] + (cols + 31) / 32;
+  }
+  hipLaunchKernelGGL(layer_reduce_kernel, dim3((unsigned)m.cblk0[4]), dim3(1024), 0, st, m);
   return vtx_check_launch();
 }
 

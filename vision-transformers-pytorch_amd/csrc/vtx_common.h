@@ -257,6 +257,91 @@ static __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabReduc
   reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
+// ONE launch for every small reduction a transformer layer's backward leaves behind (round 3): the split-K slabs of the
+// grouped weight gradient (up to 16 (slab set, output) pairs, as slab_reduce_multi_kernel) AND up to 4 column reductions
+// (LayerNorm dgamma / dbeta partials x 2, rel_pos gradient partials, as colreduce_multi_kernel).  1024-thread blocks;
+// segment s owns blocks [blk0[s], blk0[s + 1]): slab segments first (1024 float4 per block), then the column segments
+// (32 columns x 32 row lanes per block).  Per output element the summation orders are those of the two kernels it
+// replaces: identical bits.
+struct LayerReduce {
+  const float* slabs[16]; float* out[16]; long long n[16];
+  const float* part[4]; float* out0[4]; float* out1[4];
+  int nb[4], C[4], ld[4];
+  int blk0[17];             // slab segments: blocks [blk0[s], blk0[s + 1])
+  int cblk0[5];             // column segments, behind all slab blocks (cblk0[0] = number of slab blocks)
+  int nseg, nz, ncol;
+};
+static __global__ __launch_bounds__(1024) void layer_reduce_kernel(LayerReduce a) {
+  __shared__ float red[32][33];
+  const int bid = (int)blockIdx.x;
+  if (bid < a.cblk0[0]) {                                  // ---- a split-K slab segment (block-uniform branch; static indices only)
+    const float* slabs = a.slabs[0];
+    float* out = a.out[0];
+    long long n = a.n[0];
+    int b0 = 0;
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+      if (i < a.nseg && bid >= a.blk0[i]) { slabs = a.slabs[i]; out = a.out[i]; n = a.n[i]; b0 = a.blk0[i]; }
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)(bid - b0) * 1024 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + i;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int nz = a.nz;
+    int z = 0;
+    for (; z + 8 <= nz; z += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(z + j) * n4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; z + 4 <= nz; z += 4) {
+      f32x4 c0 = p[(int64_t)z * n4], c1 = p[(int64_t)(z + 1) * n4], c2 = p[(int64_t)(z + 2) * n4], c3 = p[(int64_t)(z + 3) * n4];
+      s += c0; s += c1; s += c2; s += c3;
+    }
+    for (; z < nz; ++z) s += p[(int64_t)z * n4];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+    return;
+  }
+  // ---- a column-reduce segment (the code of colreduce_multi_kernel)
+  int sgm = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < a.ncol && bid >= a.cblk0[i]) sgm = i;
+  const float* __restrict__ part = a.part[0];
+  float* __restrict__ out0 = a.out0[0];
+  float* __restrict__ out1 = a.out1[0];
+  int nb = a.nb[0], C = a.C[0], ld = a.ld[0], cb0 = a.cblk0[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i == sgm) { part = a.part[i]; out0 = a.out0[i]; out1 = a.out1[i]; nb = a.nb[i]; C = a.C[i]; ld = a.ld[i]; cb0 = a.cblk0[i]; }
+  const int ncols = out1 ? 2 * C : C;
+  const int nrl = 32;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (bid - cb0) * 32 + cl;
+  float s = 0.f;
+  if (c < ncols) {                                       // the same fixed interleave as colreduce_kernel: identical bits
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = rl;
+    for (; b + 3 * nrl < nb; b += 4 * nrl) {
+      s0 += part[(int64_t)b * ld + c];
+      s1 += part[(int64_t)(b + nrl) * ld + c];
+      s2 += part[(int64_t)(b + 2 * nrl) * ld + c];
+      s3 += part[(int64_t)(b + 3 * nrl) * ld + c];
+    }
+    for (; b < nb; b += nrl) s0 += part[(int64_t)b * ld + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < ncols) {
+    float t = 0.f;
+    for (int r = 0; r < nrl; ++r) t += red[r][cl];
+    if (c < C) out0[c] = t; else out1[c - C] = t;
+  }
+}
+
 static inline dim3 slab_reduce_grid(int64_t n) {
   int64_t nb = ((n >> 2) + 255) / 256;
   return dim3((unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)));

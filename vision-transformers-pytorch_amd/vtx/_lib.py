@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class VtxError(RuntimeError):
@@ -42,7 +42,8 @@ _SIGNATURES = {
     "vtx_wgrad_group_ok": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_float]),
     "vtx_wgrad_group_workspace": (c_size_t, [c_int, c_void_p, c_void_p, c_int64]),
     "vtx_wgrad_group": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_void_p, c_void_p, c_int, c_float, c_int64, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_void_p, c_int, c_float, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vtx_relpos_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vtx_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -237,11 +237,13 @@ def grad_sink(param):
     return None
 
 
-def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None):
+def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None, colparts=None):
     """Weight (and bias) gradients of several linears over the same tokens: jobs = [(dy, x, want_bias, rowscale)].
     -> [(dW, db)] (+ ``post(result)`` evaluated on the same stream).  One grouped launch when every problem is eligible
     (bf16, LDS-DMA shapes), else one launch each.  ``params``: the weight Parameters, so that gradients can be written
-    straight into a gradient bucket (grad_sink)."""
+    straight into a gradient bucket (grad_sink).  ``colparts``: the layer's deferred column reductions (ops.Partials:
+    LayerNorm dgamma / dbeta, rel_pos gradient) -- they ride in the grouped launch's ONE reduce launch (else in one
+    colreduce_multi launch); the result is then (gradients, [(out0, out1)])."""
     outs = None
     if params is not None and _grad_sink_providers:
         outs = [grad_sink(p) for p in params]
@@ -249,13 +251,19 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
             outs = None
 
     def run():
+        red = None
         if len(jobs) > 1 and ops.wgrad_group_ok(jobs, rows_per_scale, scale_const):
-            res = ops.wgrad_group(jobs, rows_per_scale, scale_const, outs=outs)
+            res = ops.wgrad_group(jobs, rows_per_scale, scale_const, outs=outs, colparts=colparts)
+            if colparts is not None:
+                res, red = res
         else:
             res = [ops.wgrad(dy, x, want_bias=wb, rowscale=rs, rows_per_scale=rows_per_scale,
                              scale_const=scale_const if rs is not None else 0.0,
                              out=None if outs is None else outs[i]) for i, (dy, x, wb, rs) in enumerate(jobs)]
-        return post(res) if post is not None else res
+            if colparts is not None:
+                red = ops.colreduce_multi(colparts)
+        res = post(res) if post is not None else res
+        return (res, red) if colparts is not None else res
 
     dev = jobs[0][0].device
     # (bench.py's event-sampled steps stay single-stream: with two kernels sharing the chip per-kernel durations are
@@ -268,7 +276,7 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
     st.stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(st.stream):
         res = run()
-    st.keep.append(jobs)
+    st.keep.append((jobs, colparts))              # (the partials' workspaces were allocated on the main stream too)
     st.pending = True
     return res
 
@@ -521,18 +529,22 @@ class TransformerLayerFn(Function):
         dln1 = dgrad(dqkv, wq, T)
         if _DEFER_REDUCE:
             dx, part1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1, defer=True)
-            # ---- the layer's small column reductions (LayerNorm dgamma / dbeta twice, rel_pos gradient): one launch
+            # ---- the layer's small column reductions (LayerNorm dgamma / dbeta twice, rel_pos gradient) ride in the
+            #      reduce launch of the grouped weight gradients below: no launch of their own
             parts = [part2, part1] + ([drel] if isinstance(drel, ops.Partials) else [])
-            red = ops.colreduce_multi(parts)
+        else:
+            dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+            parts = None
+        # ---- the four weight gradients: one grouped launch (dropped samples' rows are skipped, 1/(1-p) on the accumulators)
+        res = layer_wgrads(
+            [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c,
+            params=(fc2_w, fc1_w, proj_w, qkv_w), colparts=parts)
+        if parts is not None:
+            res, red = res
             (dg2, dbe2), (dg1, dbe1) = red[0], red[1]
             if isinstance(drel, ops.Partials):
                 drel = red[2][0].view(m.ntab, m.n_head)
-        else:
-            dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
-        # ---- the four weight gradients: one grouped launch (dropped samples' rows are skipped, 1/(1-p) on the accumulators)
-        (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, dbq) = layer_wgrads(
-            [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c,
-            params=(fc2_w, fc1_w, proj_w, qkv_w))
+        (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, dbq) = res
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
 

@@ -338,10 +338,12 @@ def wgrad_group_ok(jobs, rows_per_scale=1, scale_const=0.0):
     return bool(lib.vtx_wgrad_group_ok(BF16, n, Ns, Ks, M, has_rs, int(rows_per_scale), float(scale_const)))
 
 
-def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None):
+def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=None):
     """The weight gradients of several linears over the SAME tokens in one launch (csrc/gemm_wgrad_glds.hip):
     jobs = [(dy [M, N_i], x [M, Kin_i], want_bias, rowscale or None), ...] -> [(dW_i fp32 [N_i, Kin_i], db_i or None)].
-    Split-K partials are summed by one following reduce launch -- deterministic, fixed slice order."""
+    Split-K partials are summed by one following reduce launch -- deterministic, fixed slice order.
+    ``colparts``: up to 4 deferred column reductions (Partials) that ride in that reduce launch; the result is then
+    (gradients, [(out0, out1 or None)]) with the bits of colreduce_multi."""
     lib = _lib.load()
     n = len(jobs)
     for dy, x, _, rs in jobs:
@@ -361,11 +363,21 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     flops = sum(2.0 * M * a * b for a, b in zip(Nl, Kl))
     nbytes = sum(2.0 * M * (a + b) + 4.0 * a * b for a, b in zip(Nl, Kl))
-    with _timed(wgrad_kernel_name(torch.bfloat16, 0, 0, True) + " (+split-K reduce)", flops, nbytes):
+    nc = len(colparts) if colparts else 0
+    couts = [(torch.empty(p.C, dtype=torch.float32, device=dev),
+              torch.empty(p.C, dtype=torch.float32, device=dev) if p.two else None) for p in (colparts or [])]
+    cvp = lambda ts: (ctypes.c_void_p * max(nc, 1))(*[None if t is None else t.data_ptr() for t in ts]) if nc else None
+    cia = lambda xs: (ctypes.c_int * max(nc, 1))(*xs) if nc else None
+    cp = colparts or []
+    with _timed(wgrad_kernel_name(torch.bfloat16, 0, 0, True) + (" (+split-K and column reduce)" if nc else " (+split-K reduce)"),
+                flops, nbytes + sum(4.0 * p.nb * p.ld for p in cp)):
         check(lib.vtx_wgrad_group(BF16, n, vp([j[0] for j in jobs]), vp([j[1] for j in jobs]), vp(dWs), vp(dbs), Ns, Ks,
                                   lds, ldx, vp([j[3] for j in jobs]), int(rows_per_scale), float(scale_const), M, _p(ws),
-                                  wsb, _stream()), "vtx_wgrad_group")
-    return list(zip(dWs, dbs))
+                                  wsb, nc, cvp([p.ws for p in cp]), cvp([o[0] for o in couts]), cvp([o[1] for o in couts]),
+                                  cia([p.nb for p in cp]), cia([p.C for p in cp]), cia([p.ld for p in cp]), _stream()),
+              "vtx_wgrad_group")
+    res = list(zip(dWs, dbs))
+    return (res, couts) if colparts is not None else res
 
 
 # ------------------------------------------------------------------------------- PVT: spatial-reduction attention
