@@ -103,7 +103,10 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
  * NULL entries; rowscale values in {0, scale_const} (scale_const > 0) as for vtx_wgrad; same determinism contract.
  * ncol (0..4) deferred column reductions (the arguments of vtx_colreduce_multi: a layer's LayerNorm dgamma / dbeta partials,
  * its rel_pos gradient partials) ride in the group's ONE reduce launch -- same bits as vtx_colreduce_multi, one launch less
- * per layer.  They must have been enqueued on `stream` (or be ordered before it) like the operands. */
+ * per layer.  They must have been enqueued on `stream` (or be ordered before it) like the operands.
+ * accumulate != 0 (needs vtx_wgrad_group_slices() >= 2): every output (dW, dbias, col_out0 / 1) becomes out + result -- a
+ * parameter's second gradient inside one backward (DINO's multi-crop backbone, train_dino.py:229-236) lands on the first
+ * instead of in a tensor of its own that autograd then has to add (one `add` launch per parameter). */
 int vtx_wgrad_group_max(void);
 int vtx_wgrad_group_ok(int dtype, int nprob, const int* N, const int* Kin, int64_t mtok, int has_rowscale,
                        int rows_per_scale, float scale_const);
@@ -112,7 +115,10 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
                     void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
-                    float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, void* stream);
+                    float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, int accumulate,
+                    void* stream);
+/* split-K slices such a group runs with (>= 2: its outputs come from the reduce launch, so `accumulate` is available) */
+int vtx_wgrad_group_slices(int nprob, const int* N, const int* Kin, int64_t mtok);
 
 /* ---- Attention cores.  qkv is the QKV-projection output [rows, 3*nH*D] with channel order
  * [q|k|v][head][d] (models/vit.py:30-34, models/swin_transformer.py:128); o is [rows, nH*D].

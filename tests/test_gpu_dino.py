@@ -278,3 +278,41 @@ def test_dino_multicrop_under_grad_allreduce_matches_the_plain_step(grad_accum):
     den = sum((plain[n].double().norm() ** 2).item() for n in plain)
     assert report(f"dino multi-crop, GradAllReduce forced on (grad_accum {grad_accum}) vs plain: parameters after 2 steps",
                   (num / den) ** 0.5, 1e-6)
+
+
+def test_second_gradient_added_inside_the_reduce_launch_is_bitwise_autograds_sum():
+    """Round 3: inside functional.shared_param_backward() a layer's second gradient of one backward (the other crop
+    resolution's pass) is ADDED onto the first by the reduce launch (out + sum) instead of reaching autograd as a second tensor.
+    One addition of the same two finished sums either way: every parameter gradient must be bit-identical, and the
+    `add` launches must be gone (no gradient tensor of a transformer layer is produced twice)."""
+    from models.vit import dino
+    from vtx import functional as VF
+    from vtx.dino import DINOLoss
+    d = dev()
+    torch.manual_seed(21)
+    student = dino(image_size=224, window_size=16, depth=2, dim=384, n_head=6, dim_ff=1536, dropout=0.0, drop_attn=0.0,
+                   drop_ff=0.0, drop_path=0.1, dim_head_out=1024, use_bn=False, norm_last_layer=True, depth_head=3,
+                   dim_head_ff=256, dim_head_bottleneck=64).to(d).train()
+    gen = torch.Generator().manual_seed(22)
+    crops = [torch.randn(16, 3, 224, 224, generator=gen).to(d) for _ in range(2)] + \
+            [torch.randn(16, 3, 96, 96, generator=gen).to(d) for _ in range(4)]
+    crit = DINOLoss(1024, 6, 0.04, 0.07, 30, 100).to(d)
+
+    def grads(shared):
+        student.zero_grad(set_to_none=True)
+        torch.manual_seed(23)                                   # the same DropPath draws
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad():
+                t = student(crops[:2])
+            loss = crit(student(crops), t, 1)
+        with VF.shared_param_backward(shared):
+            if shared:
+                loss.backward()
+                assert len(VF._shared_grads) == 2 * 12, "both layers must have registered their 12 parameter gradients"
+            else:
+                loss.backward()
+        return {n: p.grad.clone() for n, p in student.named_parameters()}
+
+    a, b = grads(False), grads(True)
+    for n in a:
+        assert torch.equal(a[n], b[n]), f"{n}: accumulated-in-launch gradient differs from autograd's sum"

@@ -394,6 +394,11 @@ static int group_tiles(int nprob, const int* N, const int* Kin) {
   return tiles;
 }
 
+int vtx_wgrad_group_slices(int nprob, const int* N, const int* Kin, int64_t mtok) {
+  if (nprob < 1 || nprob > wgrad_glds_max_problems() || !N || !Kin || mtok <= 0) return 0;
+  return wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+}
+
 size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_t mtok) {
   const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
   size_t fl = 0;
@@ -405,7 +410,8 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
                     void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
-                    float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, void* stream) {
+                    float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, int accumulate,
+                    void* stream) {
   if (!dy || !x || !dW || !N || !Kin || !ld_dy || !ld_x || !workspace) return VTX_ERR_NULL;
   bool any_scale = false;
   if (nprob >= 1 && nprob <= wgrad_glds_max_problems())
@@ -414,6 +420,7 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
   if (ws_bytes < vtx_wgrad_group_workspace(nprob, N, Kin, mtok)) return VTX_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  if (accumulate && nz < 2) return VTX_ERR_SHAPE;          // accumulation lives in the slab reduce (vtx_wgrad_group_slices tells)
   const int kchunk = (int)chunk_of(mtok, nz);
   WgradProbHost hp[8];
   float* w = (float*)workspace;
@@ -433,7 +440,7 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
   // ONE reduction launch behind the group: all weight and bias slabs (kernel boundary = visibility: the slabs were written
   // with plain stores) and the layer's deferred column reductions (LayerNorm dgamma / dbeta, rel_pos gradient)
   LayerReduce m;
-  m.nseg = 0; m.nz = nz; m.ncol = ncol; m.blk0[0] = 0;
+  m.nseg = 0; m.nz = nz; m.ncol = ncol; m.blk0[0] = 0; m.accumulate = accumulate ? 1 : 0;
   if (nz > 1) {
     for (int i = 0; i < nprob; ++i) {
       const long long nw = (long long)N[i] * Kin[i];

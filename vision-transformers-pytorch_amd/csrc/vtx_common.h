@@ -270,6 +270,7 @@ struct LayerReduce {
   int blk0[17];             // slab segments: blocks [blk0[s], blk0[s + 1])
   int cblk0[5];             // column segments, behind all slab blocks (cblk0[0] = number of slab blocks)
   int nseg, nz, ncol;
+  int accumulate;           // 1: every output is out + sum (a parameter's SECOND gradient of one backward lands on the first)
 };
 static __global__ __launch_bounds__(1024) void layer_reduce_kernel(LayerReduce a) {
   __shared__ float red[32][33];
@@ -301,6 +302,7 @@ static __global__ __launch_bounds__(1024) void layer_reduce_kernel(LayerReduce a
       s += c0; s += c1; s += c2; s += c3;
     }
     for (; z < nz; ++z) s += p[(int64_t)z * n4];
+    if (a.accumulate) s = reinterpret_cast<const f32x4*>(out)[i] + s;      // one add of two finished sums = autograd's a + b
     reinterpret_cast<f32x4*>(out)[i] = s;
     return;
   }
@@ -338,7 +340,8 @@ static __global__ __launch_bounds__(1024) void layer_reduce_kernel(LayerReduce a
   if (rl == 0 && c < ncols) {
     float t = 0.f;
     for (int r = 0; r < nrl; ++r) t += red[r][cl];
-    if (c < C) out0[c] = t; else out1[c - C] = t;
+    float* dst = c < C ? out0 + c : out1 + (c - C);
+    *dst = a.accumulate ? *dst + t : t;
   }
 }
 

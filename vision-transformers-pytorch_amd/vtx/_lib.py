@@ -43,7 +43,8 @@ _SIGNATURES = {
     "vtx_wgrad_group_workspace": (c_size_t, [c_int, c_void_p, c_void_p, c_int64]),
     "vtx_wgrad_group": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int, c_float, c_int64, c_void_p, c_size_t, c_int, c_void_p, c_void_p,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vtx_wgrad_group_slices": (c_int, [c_int, c_void_p, c_void_p, c_int64]),
     "vtx_relpos_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vtx_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -99,7 +99,9 @@ def dino_train_step(student, teacher, criterion, optimizer, crops, epoch, moment
         student_out = student(crops)
         loss = criterion(student_out, teacher_out, epoch) / grad_accum
     # (multi-crop: the backbone's parameters get one gradient per resolution -- no side stream)
-    backward_ddp(loss, ddp, boundary, ddp_sync, fresh=False)
+    from . import functional as VF
+    with VF.shared_param_backward():      # a layer's second gradient (other crop resolution) is added inside its reduce launch
+        backward_ddp(loss, ddp, boundary, ddp_sync, fresh=False)
     if not boundary:
         return loss
     if ddp is not None:

@@ -211,6 +211,26 @@ def side_join():
             st.keep.clear()
 
 
+# A parameter used by TWO graph nodes of one backward (DINO's multi-crop backbone: one pass per crop resolution,
+# train_dino.py:229-236) gets two gradients that autograd then adds -- one `add` launch per parameter, 152 per DINO step.
+# Inside ``shared_param_backward()`` (vtx.dino wraps loss.backward() in it) the first TransformerLayerFn node of a layer
+# registers where its parameter gradients live; the second node's reduce launch ADDS its results there (ops.wgrad_group
+# accumulate: out + sum, the very addition autograd would make -- same bits) and returns None for them.  Addresses only: the
+# engine's input buffer keeps the first node's tensors alive until AccumulateGrad runs (after both nodes), and a reference
+# held here would make AccumulateGrad clone them instead of adopting them.
+_shared_grads = None
+
+
+@contextlib.contextmanager
+def shared_param_backward(enabled=True):
+    global _shared_grads
+    prev, _shared_grads = _shared_grads, ({} if enabled else None)
+    try:
+        yield
+    finally:
+        _shared_grads = prev
+
+
 _grad_sink_providers = []      # weak references to objects with .grad_sink(param) (vtx.ddp.GradAllReduce)
 
 
@@ -237,21 +257,24 @@ def grad_sink(param):
     return None
 
 
-def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None, colparts=None):
+def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None, colparts=None, accumulate=None):
     """Weight (and bias) gradients of several linears over the same tokens: jobs = [(dy, x, want_bias, rowscale)].
     -> [(dW, db)] (+ ``post(result)`` evaluated on the same stream).  One grouped launch when every problem is eligible
     (bf16, LDS-DMA shapes), else one launch each.  ``params``: the weight Parameters, so that gradients can be written
     straight into a gradient bucket (grad_sink).  ``colparts``: the layer's deferred column reductions (ops.Partials:
     LayerNorm dgamma / dbeta, rel_pos gradient) -- they ride in the grouped launch's ONE reduce launch (else in one
-    colreduce_multi launch); the result is then (gradients, [(out0, out1)])."""
+    colreduce_multi launch); the result is then (gradients, [(out0, out1)]).  ``accumulate``: ops.wgrad_group's (the
+    caller checked that the grouped launch applies); returns None."""
     outs = None
-    if params is not None and _grad_sink_providers:
+    if accumulate is None and params is not None and _grad_sink_providers:
         outs = [grad_sink(p) for p in params]
         if not any(o is not None for o in outs):
             outs = None
 
     def run():
         red = None
+        if accumulate is not None:
+            return ops.wgrad_group(jobs, rows_per_scale, scale_const, colparts=colparts, accumulate=accumulate)
         if len(jobs) > 1 and ops.wgrad_group_ok(jobs, rows_per_scale, scale_const):
             res = ops.wgrad_group(jobs, rows_per_scale, scale_const, outs=outs, colparts=colparts)
             if colparts is not None:
@@ -505,6 +528,8 @@ class TransformerLayerFn(Function):
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
                               mean2, rstd2, ln2, z, h, bias, s1, s2, rel_pos)
         ctx.meta, ctx.rps, ctx.dp_c = meta, rps, float(dp_c)
+        # identities of the 12 parameters in the order backward returns their gradients (shared_param_backward)
+        ctx.pids = tuple(map(id, (ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b)))
         return y
 
     @staticmethod
@@ -536,15 +561,26 @@ class TransformerLayerFn(Function):
             dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
             parts = None
         # ---- the four weight gradients: one grouped launch (dropped samples' rows are skipped, 1/(1-p) on the accumulators)
-        res = layer_wgrads(
-            [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)], rps, dp_c,
-            params=(fc2_w, fc1_w, proj_w, qkv_w), colparts=parts)
+        jobs = [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dqkv, ln1, True, None)]
+        shared = _shared_grads if (parts is not None and len(parts) == 2 and rel_pos is None) else None
+        if shared is not None:
+            first = [shared.get(pid) for pid in ctx.pids]
+            if all(a is not None for a in first) and ops.wgrad_group_ok(jobs, rps, dp_c) and ops.wgrad_group_slices(jobs) >= 2:
+                # this layer's parameters already have a gradient in this backward (the other crop resolution's pass): add
+                # onto it inside the reduce launch instead of handing autograd a second tensor per parameter to add
+                g1, b1, wq, bq, wo, bo, g2, b2, w1, bb1, w2, bb2 = first
+                layer_wgrads(jobs, rps, dp_c, colparts=parts, accumulate=((w2, w1, wo, wq), (bb2, bb1, bo, bq), [(g2, b2), (g1, b1)]))
+                return (dx,) + (None,) * 17
+        res = layer_wgrads(jobs, rps, dp_c, params=(fc2_w, fc1_w, proj_w, qkv_w), colparts=parts)
         if parts is not None:
             res, red = res
             (dg2, dbe2), (dg1, dbe1) = red[0], red[1]
             if isinstance(drel, ops.Partials):
                 drel = red[2][0].view(m.ntab, m.n_head)
         (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, dbq) = res
+        if shared is not None and not any(pid in shared for pid in ctx.pids):
+            for pid, t in zip(ctx.pids, (dg1, dbe1, dWq, dbq, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2)):
+                shared[pid] = t.data_ptr()
         return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
 
 

@@ -338,12 +338,35 @@ def wgrad_group_ok(jobs, rows_per_scale=1, scale_const=0.0):
     return bool(lib.vtx_wgrad_group_ok(BF16, n, Ns, Ks, M, has_rs, int(rows_per_scale), float(scale_const)))
 
 
-def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=None):
+def wgrad_group_slices(jobs):
+    """Split-K slices the grouped launch of ``jobs`` runs with (>= 2: its outputs come from the reduce launch, which can
+    then accumulate onto existing gradients -- ``wgrad_group(accumulate=...)``)."""
+    n = len(jobs)
+    M = jobs[0][0].numel() // jobs[0][0].shape[-1]
+    Ns = (ctypes.c_int * n)(*[j[0].shape[-1] for j in jobs])
+    Ks = (ctypes.c_int * n)(*[j[1].shape[-1] for j in jobs])
+    return int(_lib.load().vtx_wgrad_group_slices(n, Ns, Ks, M))
+
+
+class RawPtr:
+    """A device address standing in for a tensor somebody else keeps alive (wgrad_group(accumulate=...))."""
+    __slots__ = ("ptr",)
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
+
+    def data_ptr(self):
+        return self.ptr
+
+
+def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=None, accumulate=None):
     """The weight gradients of several linears over the SAME tokens in one launch (csrc/gemm_wgrad_glds.hip):
     jobs = [(dy [M, N_i], x [M, Kin_i], want_bias, rowscale or None), ...] -> [(dW_i fp32 [N_i, Kin_i], db_i or None)].
     Split-K partials are summed by one following reduce launch -- deterministic, fixed slice order.
     ``colparts``: up to 4 deferred column reductions (Partials) that ride in that reduce launch; the result is then
-    (gradients, [(out0, out1 or None)]) with the bits of colreduce_multi."""
+    (gradients, [(out0, out1 or None)]) with the bits of colreduce_multi.
+    ``accumulate`` = (dW addresses [n], dbias addresses [n], [(out0, out1) addresses per colpart]): nothing is allocated,
+    every result is ADDED onto the fp32 gradient at that address (needs wgrad_group_slices(jobs) >= 2); returns None."""
     lib = _lib.load()
     n = len(jobs)
     for dy, x, _, rs in jobs:
@@ -352,9 +375,13 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=Non
     M = jobs[0][0].numel() // jobs[0][0].shape[-1]
     Nl = [j[0].shape[-1] for j in jobs]
     Kl = [j[1].shape[-1] for j in jobs]
-    dWs = [outs[i] if outs is not None and outs[i] is not None else
-           torch.empty((Nl[i], Kl[i]), dtype=torch.float32, device=dev) for i in range(n)]
-    dbs = [torch.empty(Nl[i], dtype=torch.float32, device=dev) if jobs[i][2] else None for i in range(n)]
+    if accumulate is not None:
+        dWs = [RawPtr(a) for a in accumulate[0]]
+        dbs = [RawPtr(a) if jobs[i][2] else None for i, a in enumerate(accumulate[1])]
+    else:
+        dWs = [outs[i] if outs is not None and outs[i] is not None else
+               torch.empty((Nl[i], Kl[i]), dtype=torch.float32, device=dev) for i in range(n)]
+        dbs = [torch.empty(Nl[i], dtype=torch.float32, device=dev) if jobs[i][2] else None for i in range(n)]
     Ns, Ks = (ctypes.c_int * n)(*Nl), (ctypes.c_int * n)(*Kl)
     lds = (ctypes.c_int64 * n)(*Nl)
     ldx = (ctypes.c_int64 * n)(*Kl)
@@ -364,8 +391,11 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=Non
     flops = sum(2.0 * M * a * b for a, b in zip(Nl, Kl))
     nbytes = sum(2.0 * M * (a + b) + 4.0 * a * b for a, b in zip(Nl, Kl))
     nc = len(colparts) if colparts else 0
-    couts = [(torch.empty(p.C, dtype=torch.float32, device=dev),
-              torch.empty(p.C, dtype=torch.float32, device=dev) if p.two else None) for p in (colparts or [])]
+    if accumulate is not None:
+        couts = [(RawPtr(a), RawPtr(b) if p.two else None) for p, (a, b) in zip(colparts or [], accumulate[2])]
+    else:
+        couts = [(torch.empty(p.C, dtype=torch.float32, device=dev),
+                  torch.empty(p.C, dtype=torch.float32, device=dev) if p.two else None) for p in (colparts or [])]
     cvp = lambda ts: (ctypes.c_void_p * max(nc, 1))(*[None if t is None else t.data_ptr() for t in ts]) if nc else None
     cia = lambda xs: (ctypes.c_int * max(nc, 1))(*xs) if nc else None
     cp = colparts or []
@@ -374,8 +404,11 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=Non
         check(lib.vtx_wgrad_group(BF16, n, vp([j[0] for j in jobs]), vp([j[1] for j in jobs]), vp(dWs), vp(dbs), Ns, Ks,
                                   lds, ldx, vp([j[3] for j in jobs]), int(rows_per_scale), float(scale_const), M, _p(ws),
                                   wsb, nc, cvp([p.ws for p in cp]), cvp([o[0] for o in couts]), cvp([o[1] for o in couts]),
-                                  cia([p.nb for p in cp]), cia([p.C for p in cp]), cia([p.ld for p in cp]), _stream()),
+                                  cia([p.nb for p in cp]), cia([p.C for p in cp]), cia([p.ld for p in cp]),
+                                  int(accumulate is not None), _stream()),
               "vtx_wgrad_group")
+    if accumulate is not None:
+        return None
     res = list(zip(dWs, dbs))
     return (res, couts) if colparts is not None else res
 
