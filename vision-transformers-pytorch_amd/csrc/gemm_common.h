@@ -9,7 +9,7 @@
 #endif
 // phase ablation of the LDS-DMA GEMM for IN-MODEL timing (tools/probe/build_ablate.sh builds separate libraries, selected
 // through VTX_LIBVTX; results are garbage, durations are what is measured): 1 no main loop | 4 no epilogue stores |
-// 8 no epilogue operand loads.  0 in the library.
+// 8 no epilogue operand loads | 16 SiLU applied to the A fragments after the LDS read (cost probe of "fc2 reads z").  0 in the library.
 #ifndef GLDS_ABLATE
 #define GLDS_ABLATE 0
 #endif

@@ -318,6 +318,10 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
       for (int i = 0; i < WM; ++i) {
         const int r = wm * 32 + i * 16 + c_;
         fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ glds_swz<BK>(r)) << 4)));
+        if constexpr ((GLDS_ABLATE & 16) != 0) {          // timing probe (round 3): SiLU on the A fragments after the LDS read
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fa[i].set(e, silu_f(fa[i].get(e)));
+        }
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
