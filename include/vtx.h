@@ -171,6 +171,59 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
                   size_t ws_bytes, const int* inv_cells, int inv_count, int B, int L, int nH, int H, int W, int win,
                   int shift, int dtype, void* stream);
 
+/* ---- One call per transformer layer (csrc/layer.hip): the pre-LN block of models/vit.py:59-63 and
+ * models/swin_transformer.py:193-197 --  x1 = x + s1 * proj(attn(qkv(LN1 x)));  y = x1 + s2 * fc2(silu(fc1(LN2 x1)))  -- as
+ * ONE descriptor: vtx_layer_fwd enqueues the 7 launches, vtx_layer_bwd the 8 + 2 of the backward (the entry points above, in
+ * the order vtx.functional.TransformerLayerFn issues them: bit-identical results), so that the host pays one call and one
+ * activation buffer per layer instead of ~19 calls and ~28 allocations (host time per Swin-S step 13.9 -> see DESIGN).
+ * All pointers are device addresses the caller keeps alive; weights (wq, wo, w1, w2: [out][in]) are in the compute dtype,
+ * the transposed copies (w?t: [in][out]) may be NULL (then every dgrad takes the register-staged kernel); s1 / s2 are the
+ * per-sample DropPath scales (NULL: none) with values in {0, scale_const}.
+ *   attn_kind VTX_ATTN_WINDOW: vtx_wattn_fwd / _bwd (rel_pos, pos, region, H, W, win, shift; B images, L = win^2);
+ *             VTX_ATTN_GLOBAL: vtx_attention_fwd / _bwd without bias / mask (B images of L tokens, head dim C / nH).
+ * Backward: dz / dln2 / dx1 / dout / dqkv / dln1 are scratch; ln?_ws (vtx_layernorm_bwd_workspace), attn_ws
+ * (vtx_wattn_bwd_workspace / vtx_attention_bwd_workspace) and wgrad_ws (vtx_wgrad_group_workspace for the problems
+ * (C, ff), (ff, C), (C, C), (3C, C)) are workspaces; dW? / db? / dg? / dbe? (/ drel) receive the parameter gradients (fp32).
+ * `side_stream` != NULL sends the grouped weight gradient + its reduce there behind an event fork; the caller joins.
+ * accumulate: as for vtx_wgrad_group. */
+enum { VTX_ATTN_WINDOW = 1, VTX_ATTN_GLOBAL = 2 };
+typedef struct VtxLayerFwd {
+  int dtype, attn_kind;
+  int64_t M;                                   /* tokens */
+  int C, ff, nH, L, B, rows_per_scale;
+  int H, W, win, shift;
+  float eps;
+  const void* x;
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  const void *wq, *wo, *w1, *w2;
+  const float *bq, *bo, *b1, *b2;
+  const float* rel_pos; const int64_t* pos; const uint8_t* region;
+  const float *s1, *s2;
+  void *ln1, *qkv, *o, *x1, *ln2, *z, *h, *y;  /* z may be NULL (no backward will run) */
+  float *mean1, *rstd1, *mean2, *rstd2, *lse;
+} VtxLayerFwd;
+int vtx_layer_fwd(const VtxLayerFwd* a, void* stream);
+typedef struct VtxLayerBwd {
+  int dtype, attn_kind;
+  int64_t M;
+  int C, ff, nH, L, B, rows_per_scale;
+  int H, W, win, shift;
+  float scale_const;
+  int accumulate, inv_count;
+  const void *dy, *x, *ln1, *qkv, *o, *x1, *ln2, *z, *h;
+  const float *mean1, *rstd1, *mean2, *rstd2, *lse;
+  const float *ln1_w, *ln2_w;
+  const void *wq, *wo, *w1, *w2, *wqt, *wot, *w1t, *w2t;
+  const float* rel_pos; const int64_t* pos; const uint8_t* region; const int* inv_cells;
+  const float *s1, *s2;
+  void *dz, *dln2, *dx1, *dout, *dqkv, *dln1, *dx;
+  void *ln1_ws, *ln2_ws, *attn_ws, *wgrad_ws;
+  size_t ln_ws_bytes, attn_ws_bytes, wgrad_ws_bytes;
+  float *dWq, *dbq, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2, *drel;
+} VtxLayerBwd;
+int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream);
+int vtx_layer_desc_bytes(int which);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */
+
 /* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66):
  * head dim 64, Lq queries against Lk <= 64 reduced keys per (image, head).
  *   q [B*Lq, nH*64] (= linear_q output), kv [B*Lk, 2*nH*64] (= linear_kv output: k | v halves, pvt.py:51),

@@ -251,3 +251,88 @@ def test_train_step_side_stream_wgrads_are_bitwise_the_single_stream_step():
     assert torch.equal(la, lb)
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert torch.equal(a, b), f"parameter {i} differs between the side-stream and the single-stream step"
+
+
+# ------------------------------------------------------------------ one C call per layer (csrc/layer.hip)
+def _layer_io(model, x, bf16, seed):
+    """logits-free probe of a whole model: output + every parameter gradient of one forward / backward."""
+    from vtx import functional as VF
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(seed)                                  # the DropPath draws
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        out = model(x)
+    with VF.deferred_wgrad(True):
+        out.float().square().mean().backward()
+    return out.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+@pytest.mark.parametrize("family", ["swin", "vit", "vit_multicrop"])
+def test_one_call_per_layer_is_bitwise_the_call_by_call_path(family, bf16, monkeypatch):
+    """vtx_layer_fwd / vtx_layer_bwd enqueue the launches of functional.TransformerLayerFn from one descriptor (window
+    attention with / without shift and DropPath, global attention; weight gradients on the side stream): outputs and all
+    parameter gradients must equal the call-by-call path bit for bit, in bf16 and in the fp32 parity mode."""
+    from vtx import functional as VF
+    d = dev()
+    torch.manual_seed(31)
+    if family == "swin":
+        from models import SwinTransformer
+        model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(2, 2, 2, 2), dims=(32, 64, 128, 256), dim_head=32,
+                                n_heads=(1, 2, 4, 8), dim_ffs=(128, 256, 512, 1024), window_size=7, drop_path=0.2)
+        for m in model.modules():
+            if hasattr(m, "rel_pos"):
+                torch.nn.init.normal_(m.rel_pos.weight, std=0.3)
+        x = torch.randn(6, 3, 224, 224, device=d)
+    else:
+        from models import VisionTransformer
+        from vtx.nn import Linear
+        model = VisionTransformer(Linear(128, 16), 224, 16, 3, 128, 2, 512, 0.0, 0.0, 0.0, 0.1)
+        x = torch.randn(5, 3, 224, 224, device=d)
+        if family == "vit_multicrop":
+            x = [x, torch.randn(5, 3, 96, 96, device=d), torch.randn(5, 3, 96, 96, device=d)]
+    model.to(d).train()
+    calls = []
+    real = VF.TransformerLayerFn._forward_one_call
+    monkeypatch.setattr(VF.TransformerLayerFn, "_forward_one_call", staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1]))
+    monkeypatch.setattr(VF, "_LAYER_CALL", True)
+    out_a, g_a = _layer_io(model, x, bf16, 77)
+    assert len(calls) >= 3, "the one-call path did not run"
+    n = len(calls)
+    monkeypatch.setattr(VF, "_LAYER_CALL", False)
+    out_b, g_b = _layer_io(model, x, bf16, 77)
+    assert len(calls) == n, "VTX_LAYER_CALL = 0 must take the call-by-call path"
+    assert torch.equal(out_a, out_b)
+    assert g_a.keys() == g_b.keys() and len(g_a) > 20
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), f"{family}: gradient of {k} differs between the one-call and the call-by-call layer"
+
+
+def test_one_call_layer_under_no_grad_and_shared_param_backward():
+    """The one-call layer without a graph (teacher / evaluation: no pre-activation kept) gives the training forward's bits,
+    and inside shared_param_backward() (DINO) its second gradient is accumulated in the reduce launch -- bitwise autograd's sum."""
+    from models import VisionTransformer
+    from vtx import functional as VF
+    from vtx.nn import Linear
+    d = dev()
+    torch.manual_seed(33)
+    model = VisionTransformer(Linear(384, 16), 224, 16, 2, 384, 6, 1536, 0.0, 0.0, 0.0, 0.0).to(d).train()
+    crops = [torch.randn(16, 3, 224, 224, device=d), torch.randn(32, 3, 96, 96, device=d)]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ref = model(crops)
+        with torch.no_grad():
+            ng = model(crops)
+    assert torch.equal(ref, ng)
+
+    def grads(shared):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(crops).float().square().mean()
+        with VF.shared_param_backward(shared):
+            loss.backward()
+            if shared:
+                assert len(VF._shared_grads) == 2 * 12
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    a, b = grads(False), grads(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

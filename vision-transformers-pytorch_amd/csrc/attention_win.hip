@@ -44,16 +44,33 @@ struct WinGeom {
   float scale;
 };
 
-__device__ __forceinline__ int64_t win_token_row(const WinGeom& g, int b, int n, int i) {
-  const int wi = n / g.nWx, wj = n - wi * g.nWx;
-  const int ay = i / g.win, ax = i - ay * g.win;
-  int y = wi * g.win + ay + g.shift; if (y >= g.H) y -= g.H;
-  int x = wj * g.win + ax + g.shift; if (x >= g.W) x -= g.W;
-  return ((int64_t)b * g.H + y) * g.W + x;
+// Round 3: the per-problem address arithmetic was 550 of the backward's ~2 650 instructions per problem (a runtime division
+// by the window size per token, 64-bit products and an exec-masked branch around each of the 20 loads -- the kernel is
+// instruction-issue bound at 2 waves per SIMD).  A lane's token (16 t4 + c) always sits at the same (ay, ax) of its window:
+// computed ONCE per kernel; per problem only the window origin changes.  Tokens past L (the padding of the last 16-token
+// tile) read the window's token 0 instead of being predicated off: their keys carry a -inf bias and their queries a +inf
+// lse, so every product they enter is multiplied by an exact 0 -- same bits as the zero fill it replaces, no branches.
+struct WaTok {
+  int ay[4], ax[4];
+  bool val[4];
+};
+__device__ __forceinline__ void wa_tok_init(WaTok& k, const WinGeom& g, int c) {
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    const int tok = 16 * t4 + c;
+    k.val[t4] = tok < g.L;
+    const int t = k.val[t4] ? tok : 0;
+    k.ay[t4] = t / g.win;
+    k.ax[t4] = t - k.ay[t4] * g.win;
+  }
 }
-
-template <typename T> __device__ __forceinline__ Vec8<T> wa_load(const T* p, bool valid) {
-  return valid ? load8<T>(p) : vec8_zero<T>();
+// token row of window (wi, wj) of image b (rows < 2^31: checked by the entry points)
+__device__ __forceinline__ int wa_row(const WinGeom& g, const WaTok& k, int t4, int b, int wi, int wj) {
+  int y = wi * g.win + k.ay[t4] + g.shift;
+  y -= y >= g.H ? g.H : 0;
+  int x = wj * g.win + k.ax[t4] + g.shift;
+  x -= x >= g.W ? g.W : 0;
+  return (b * g.H + y) * g.W + x;
 }
 template <typename T> __device__ __forceinline__ Vec8<T> wa_frag_acc(const f32x4& lo, const f32x4& hi) {
   Vec8<T> f;
@@ -178,22 +195,23 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
   wa_build_bias(bias_s, reinterpret_cast<float*>(wa_smem + WaSmem<T>::kBias), rel_pos, pos, g.L, g.nH, h,
                 (2 * g.win - 1) * (2 * g.win - 1));
   __syncthreads();                                    // table complete; the relh scratch (wave 0's region) is free again
+  WaTok tk;
+  wa_tok_init(tk, g, c_);
 
   for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
     const int n = bn % g.nW, b = bn / g.nW;
+    const int wi = n / g.nWx, wj = n - wi * g.nWx;      // (wave-uniform: scalar arithmetic)
     const int prob = bn * g.nH + h;
-    int64_t row[4];
-    bool val[4];
+    int row[4];
+    const bool (&val)[4] = tk.val;
     Vec8<T> qf[4], kf[4], vf[4];
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      const int tok = 16 * t4 + c_;
-      val[t4] = tok < g.L;
-      row[t4] = val[t4] ? win_token_row(g, b, n, tok) : 0;
-      const T* p = qkv + row[t4] * ld + h * WA_D + g_ * 8;
-      qf[t4] = wa_load<T>(p, val[t4]);
-      kf[t4] = wa_load<T>(p + g.hd, val[t4]);
-      vf[t4] = wa_load<T>(p + 2 * g.hd, val[t4]);
+      row[t4] = wa_row(g, tk, t4, b, wi, wj);
+      const T* p = qkv + (int64_t)row[t4] * ld + h * WA_D + g_ * 8;
+      qf[t4] = load8<T>(p);
+      kf[t4] = load8<T>(p + g.hd);
+      vf[t4] = load8<T>(p + 2 * g.hd);
     }
     uint8_t myreg = 0;
     if (MASKED) myreg = region[(int64_t)n * 64 + lane];
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
     if (WA_ABLATE & 32) {
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
-        if (val[qt]) store8<T>(o + row[qt] * (int64_t)g.hd + h * WA_D + g_ * 8, qf[qt]);
+        if (val[qt]) store8<T>(o + (int64_t)row[qt] * g.hd + h * WA_D + g_ * 8, qf[qt]);
       continue;
     }
 #pragma unroll
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
         for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), pf, oacc[dt]);
       }
       // oacc[dt][r] = O[q = 16 qt + c][d = 8 g + 4 dt + r]
-      if (val[qt]) store8<T>(o + row[qt] * (int64_t)g.hd + h * WA_D + g_ * 8, wa_out8<T>(oacc[0], oacc[1], 1.f));
+      if (val[qt]) store8<T>(o + (int64_t)row[qt] * g.hd + h * WA_D + g_ * 8, wa_out8<T>(oacc[0], oacc[1], 1.f));
     }
   }
 }
@@ -288,27 +306,30 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dsacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  WaTok tk;
+  wa_tok_init(tk, g, c_);
 
   for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
     const int n = bn % g.nW, b = bn / g.nW;
+    const int wi = n / g.nWx, wj = n - wi * g.nWx;      // (wave-uniform: scalar arithmetic)
     const int prob = bn * g.nH + h;
 
-    int64_t row[4];
-    bool val[4];
+    int row[4];
+    const bool (&val)[4] = tk.val;
     Vec8<T> qf[4], kf[4], vf[4], dof[4];
     float dsum[4], lq[4];
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      const int tok = 16 * t4 + c_;
-      val[t4] = tok < g.L;
-      row[t4] = val[t4] ? win_token_row(g, b, n, tok) : 0;
-      const T* p = qkv + row[t4] * ld + h * WA_D + g_ * 8;
-      qf[t4] = wa_load<T>(p, val[t4]);
-      kf[t4] = wa_load<T>(p + g.hd, val[t4]);
-      vf[t4] = wa_load<T>(p + 2 * g.hd, val[t4]);
-      dof[t4] = wa_load<T>(dout + row[t4] * g.hd + h * WA_D + g_ * 8, val[t4]);
-      Vec8<T> of = wa_load<T>(oin + row[t4] * g.hd + h * WA_D + g_ * 8, val[t4]);
-      lq[t4] = val[t4] ? lse[(int64_t)prob * g.L + tok] : INFINITY;   // padded query rows: exp(. - inf) = 0
+      row[t4] = wa_row(g, tk, t4, b, wi, wj);
+      const T* p = qkv + (int64_t)row[t4] * ld + h * WA_D + g_ * 8;
+      const int64_t ro = (int64_t)row[t4] * g.hd + h * WA_D + g_ * 8;
+      qf[t4] = load8<T>(p);
+      kf[t4] = load8<T>(p + g.hd);
+      vf[t4] = load8<T>(p + 2 * g.hd);
+      dof[t4] = load8<T>(dout + ro);
+      Vec8<T> of = load8<T>(oin + ro);
+      const float lv = lse[(int64_t)prob * g.L + (val[t4] ? 16 * t4 + c_ : 0)];
+      lq[t4] = val[t4] ? lv : INFINITY;               // padded query rows: exp(. - inf) = 0
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += of.get(e) * dof[t4].get(e);
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
         for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(kt_s + (dt * 16 + c_) * WA_STR + ks * 32, g_), dsf, dqacc[dt]);
       }
       // dqacc[dt][r] = dQ[q = 16 qt + c][d = 8 g + 4 dt + r] / scale
-      if (val[qt]) store8<T>(dqkv + row[qt] * ld + h * WA_D + g_ * 8, wa_out8<T>(dqacc[0], dqacc[1], g.scale));
+      if (val[qt]) store8<T>(dqkv + (int64_t)row[qt] * ld + h * WA_D + g_ * 8, wa_out8<T>(dqacc[0], dqacc[1], g.scale));
       __builtin_amdgcn_sched_barrier(0);   // keep iterations apart: no cross-iteration hoisting (register pressure)
     }
 
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
       }
       // d{k,v}acc[dt][r] = d{K,V}[key = 16 kt + c][d = 8 g + 4 dt + r]
       if (val[kt]) {
-        T* p = dqkv + row[kt] * ld + h * WA_D + g_ * 8;
+        T* p = dqkv + (int64_t)row[kt] * ld + h * WA_D + g_ * 8;
         store8<T>(p + g.hd, wa_out8<T>(dkacc[0], dkacc[1], g.scale));
         store8<T>(p + 2 * g.hd, wa_out8<T>(dvacc[0], dvacc[1], 1.f));
       }

@@ -1,0 +1,138 @@
+// One C-ABI call per transformer layer (round 3).
+//
+// A Swin-S train step is ~500 kernel launches; enqueueing them one vtx_* call at a time costs the Python host 13.9 ms
+// per step against 17.9 ms of GPU time (tools/probe/host_time.py) -- ~19 ctypes calls and ~28 tensor allocations per layer.
+// vtx_layer_fwd / vtx_layer_bwd enqueue the SAME launches in the SAME order (they call the entry points of this
+// library), from one descriptor: the host allocates one activation buffer per layer and passes addresses.  Results are
+// bit-identical to the call-by-call path (tests/test_gpu_dispatch.py).
+//
+// Reference: the block  x1 = x + s1 * proj(attn(qkv(LN1 x)));  y = x1 + s2 * fc2(silu(fc1(LN2 x1)))  of
+// models/vit.py:59-63 and models/swin_transformer.py:193-197 (window attention: :103-160), DropPath models/layer.py:172-180.
+#include <hip/hip_runtime.h>
+
+#include "gemm_common.h"
+#include "../../include/vtx.h"    // (after the internal header: its VTX_* macros shadow the internal enum of the same values)
+
+namespace {
+
+struct EventRing {                       // fork events for the side stream (never synchronised on the host)
+  hipEvent_t ev[64];
+  int n = 0, next = 0;
+  hipEvent_t get() {
+    if (n < 64) {
+      if (hipEventCreateWithFlags(&ev[n], hipEventDisableTiming) != hipSuccess) return nullptr;
+      return ev[n++];
+    }
+    hipEvent_t e = ev[next];
+    next = (next + 1) & 63;
+    return e;
+  }
+};
+thread_local EventRing g_events;
+
+// dx = epi(dy @ W): the LDS-DMA kernel on the transposed weight copy where it applies (K = out-features, N =
+// in-features), else the register-staged NN kernel on W itself -- the rule of vtx.functional.dgrad
+int layer_dgrad(int dtype, const void* dy, const void* w, const void* wt, void* dx, int64_t M, int n_in, int k_out,
+                const void* resid, const float* rowscale, int rps, const void* aux_in, int act, void* st) {
+  if (dtype == VTX_BF16 && wt != nullptr && gemm_glds_ok(n_in, k_out))
+    return vtx_gemm(0, dtype, dy, wt, dx, (int)M, n_in, k_out, k_out, k_out, n_in, nullptr, resid, rowscale, rps, nullptr,
+                    aux_in, act, st);
+  return vtx_gemm(1, dtype, dy, w, dx, (int)M, n_in, k_out, k_out, n_in, n_in, nullptr, resid, rowscale, rps, nullptr,
+                  aux_in, act, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* sizeof the descriptors (0: VtxLayerFwd, 1: VtxLayerBwd): the bindings check their mirror structures against it */
+int vtx_layer_desc_bytes(int which) { return which == 0 ? (int)sizeof(VtxLayerFwd) : (which == 1 ? (int)sizeof(VtxLayerBwd) : 0); }
+
+int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
+  if (!a || !a->x || !a->y || !a->ln1 || !a->qkv || !a->o || !a->x1 || !a->ln2 || !a->h) return VTX_ERR_NULL;
+  if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0) return VTX_ERR_SHAPE;
+  const int dt = a->dtype, M = (int)a->M, C = a->C, ff = a->ff;
+  int rc = vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream);
+  if (rc) return rc;
+  rc = vtx_gemm(0, dt, a->ln1, a->wq, a->qkv, M, 3 * C, C, C, C, 3 * C, a->bq, nullptr, nullptr, 1, nullptr, nullptr, 0, stream);
+  if (rc) return rc;
+  if (a->attn_kind == VTX_ATTN_WINDOW)
+    rc = vtx_wattn_fwd(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift,
+                       dt, stream);
+  else if (a->attn_kind == VTX_ATTN_GLOBAL)
+    rc = vtx_attention_fwd(a->qkv, a->o, a->lse, nullptr, nullptr, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream);
+  else
+    return VTX_ERR_SHAPE;
+  if (rc) return rc;
+  rc = vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream);
+  if (rc) return rc;
+  rc = vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream);
+  if (rc) return rc;
+  rc = vtx_gemm(0, dt, a->ln2, a->w1, a->h, M, ff, C, C, C, ff, a->b1, nullptr, nullptr, 1, a->z, nullptr, 1, stream);
+  if (rc) return rc;
+  return vtx_gemm(0, dt, a->h, a->w2, a->y, M, C, ff, ff, ff, C, a->b2, a->x1, a->s2, a->rows_per_scale, nullptr, nullptr, 0,
+                  stream);
+}
+
+int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
+  if (!a || !a->dy || !a->dx || !a->x || !a->z || !a->dz || !a->dln2 || !a->dx1 || !a->dout || !a->dqkv || !a->dln1)
+    return VTX_ERR_NULL;
+  if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0) return VTX_ERR_SHAPE;
+  const int dt = a->dtype, C = a->C, ff = a->ff, rps = a->rows_per_scale;
+  const int64_t M = a->M;
+  // ---- MLP branch
+  int rc = layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream);
+  if (rc) return rc;
+  rc = layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream);
+  if (rc) return rc;
+  rc = vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
+                         M, C, dt, 0, 0, 0, stream);
+  if (rc) return rc;
+  // ---- attention branch
+  rc = layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream);
+  if (rc) return rc;
+  if (a->attn_kind == VTX_ATTN_WINDOW)
+    rc = vtx_wattn_bwd(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, nullptr, a->attn_ws, a->attn_ws_bytes,
+                       a->inv_cells, a->inv_count, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+  else if (a->attn_kind == VTX_ATTN_GLOBAL)
+    rc = vtx_attention_bwd(a->qkv, a->o, a->dout, a->lse, nullptr, nullptr, nullptr, nullptr, a->dqkv, nullptr, 0, a->attn_ws,
+                           a->attn_ws_bytes, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream);
+  else
+    return VTX_ERR_SHAPE;
+  if (rc) return rc;
+  rc = layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream);
+  if (rc) return rc;
+  rc = vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
+                         M, C, dt, 0, 0, 0, stream);
+  if (rc) return rc;
+  // ---- the four weight gradients + the layer's column reductions: one grouped launch + one reduce launch, on the side
+  //      stream when given (fork: it waits for everything enqueued on `stream` so far; the caller joins once per backward)
+  void* ws = stream;
+  if (side_stream != nullptr && side_stream != stream) {
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, (hipStream_t)stream) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)side_stream, e, 0) != hipSuccess)
+      return VTX_ERR_LAUNCH;
+    ws = side_stream;
+  }
+  const void* dys[4] = {a->dy, a->dz, a->dx1, a->dqkv};
+  const void* xs[4] = {a->h, a->ln2, a->o, a->ln1};
+  float* dWs[4] = {a->dW2, a->dW1, a->dWo, a->dWq};
+  float* dbs[4] = {a->db2, a->db1, a->dbo, a->dbq};
+  const int Ns[4] = {C, ff, C, 3 * C}, Ks[4] = {ff, C, C, C};
+  const int64_t ldy[4] = {C, ff, C, 3 * C}, ldx[4] = {ff, C, C, C};
+  const float* rs[4] = {a->s2, nullptr, a->s1, nullptr};
+  const int ncol = a->attn_kind == VTX_ATTN_WINDOW ? 3 : 2;
+  const float* cpart[4] = {(const float*)a->ln2_ws, (const float*)a->ln1_ws, (const float*)a->attn_ws, nullptr};
+  float* cout0[4] = {a->dg2, a->dg1, a->drel, nullptr};
+  float* cout1[4] = {a->dbe2, a->dbe1, nullptr, nullptr};
+  const int ntab = (2 * a->win - 1) * (2 * a->win - 1);
+  const int cnb[4] = {vtx_layernorm_bwd_blocks(M, C), vtx_layernorm_bwd_blocks(M, C),
+                      ncol == 3 ? vtx_wattn_bwd_parts(a->B, a->nH, a->H, a->W, a->win) : 0, 0};
+  const int cC[4] = {C, C, ncol == 3 ? ntab * a->nH : 0, 0};
+  const int cld[4] = {2 * C, 2 * C, ncol == 3 ? vtx_wattn_bwd_part_ld(a->nH) : 0, 0};
+  return vtx_wgrad_group(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, rps, a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes,
+                         ncol, cpart, cout0, cout1, cnb, cC, cld, a->accumulate, ws);
+}
+
+}  // extern "C"

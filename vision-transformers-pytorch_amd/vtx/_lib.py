@@ -11,14 +11,45 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class VtxError(RuntimeError):
     pass
 
 
+_I, _L, _F, _P, _Z = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class LayerFwd(ctypes.Structure):
+    """include/vtx.h VtxLayerFwd (field order = the header's; load() checks sizeof against the library)."""
+    _fields_ = ([("dtype", _I), ("attn_kind", _I), ("M", _L)] +
+                [(n, _I) for n in ("C", "ff", "nH", "L", "B", "rows_per_scale", "H", "W", "win", "shift")] + [("eps", _F)] +
+                [(n, _P) for n in ("x", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wo", "w1", "w2", "bq", "bo", "b1", "b2",
+                                   "rel_pos", "pos", "region", "s1", "s2", "ln1", "qkv", "o", "x1", "ln2", "z", "h", "y",
+                                   "mean1", "rstd1", "mean2", "rstd2", "lse")])
+
+
+class LayerBwd(ctypes.Structure):
+    """include/vtx.h VtxLayerBwd."""
+    _fields_ = ([("dtype", _I), ("attn_kind", _I), ("M", _L)] +
+                [(n, _I) for n in ("C", "ff", "nH", "L", "B", "rows_per_scale", "H", "W", "win", "shift")] +
+                [("scale_const", _F), ("accumulate", _I), ("inv_count", _I)] +
+                [(n, _P) for n in ("dy", "x", "ln1", "qkv", "o", "x1", "ln2", "z", "h", "mean1", "rstd1", "mean2", "rstd2", "lse",
+                                   "ln1_w", "ln2_w", "wq", "wo", "w1", "w2", "wqt", "wot", "w1t", "w2t", "rel_pos", "pos",
+                                   "region", "inv_cells", "s1", "s2", "dz", "dln2", "dx1", "dout", "dqkv", "dln1", "dx",
+                                   "ln1_ws", "ln2_ws", "attn_ws", "wgrad_ws")] +
+                [(n, _Z) for n in ("ln_ws_bytes", "attn_ws_bytes", "wgrad_ws_bytes")] +
+                [(n, _P) for n in ("dWq", "dbq", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "drel")])
+
+
+ATTN_WINDOW, ATTN_GLOBAL = 1, 2
+
+
 _SIGNATURES = {
+    "vtx_layer_fwd": (c_int, [c_void_p, c_void_p]),
+    "vtx_layer_bwd": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vtx_layer_desc_bytes": (c_int, [c_int]),
     "vtx_strerror": (c_char_p, [c_int]),
     "vtx_abi_version": (c_int, []),
     "vtx_option_count": (c_int, []),
@@ -119,6 +150,8 @@ def load():
         fn.argtypes = args
     if lib.vtx_abi_version() != ABI_VERSION:
         raise VtxError(f"libvtx.so ABI {lib.vtx_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    if lib.vtx_layer_desc_bytes(0) != ctypes.sizeof(LayerFwd) or lib.vtx_layer_desc_bytes(1) != ctypes.sizeof(LayerBwd):
+        raise VtxError("libvtx.so layer descriptors do not match the bindings (VtxLayerFwd / VtxLayerBwd): rebuild")
     _lib = lib
     return lib
 

@@ -7,6 +7,7 @@ optimizer keep working).  Activations are stored in the compute dtype T (fp32, o
 ``torch.autocast(dtype=torch.bfloat16)``); statistics / parameter gradients are fp32.
 """
 import contextlib
+import ctypes
 import os
 import struct
 import threading
@@ -14,7 +15,7 @@ import threading
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import _lib, ops
 from .ops import ACT_DGELU, ACT_DSILU, ACT_GELU, ACT_SILU, VtxError
 
 
@@ -304,6 +305,96 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
     return res
 
 
+
+# ------------------------------------------------------------------------------------------- one C call per layer
+# vtx_layer_fwd / vtx_layer_bwd (csrc/layer.hip) enqueue a transformer layer's launches from ONE descriptor: the same
+# entry points in the same order as the call-by-call code below (bit-identical), but one ctypes call and one activation
+# buffer per layer instead of ~19 calls and ~28 tensor allocations -- the Python host path was 13.9 ms per Swin-S step
+# against 17.9 ms of GPU time (tools/probe/host_time.py).  Taken for the two layer kinds the benchmarks run (window
+# attention fast path; global attention without bias / mask); everything else, and bench.py's event-sampled steps (which
+# bracket each launch), take the call-by-call path.  VTX_LAYER_CALL=0 disables.
+_LAYER_CALL = os.environ.get("VTX_LAYER_CALL", "1") != "0"
+_ALIGN = 256
+
+
+def _layer_kind(x, rel_pos, meta):
+    if not (_LAYER_CALL and _DEFER_REDUCE and x.is_cuda and not ops.timing()):
+        return 0
+    if _wattn_ok(rel_pos, meta):
+        return _lib.ATTN_WINDOW
+    if rel_pos is None and meta.swin is None and meta.mask is None and meta.csr is None:
+        return _lib.ATTN_GLOBAL
+    return 0
+
+
+class _LayerPlan:
+    """Shape-dependent part of the two descriptors of one layer: buffer layouts, workspace sizes, prefilled structures."""
+
+    def __init__(self, kind, meta, B, M, C, ff, T, want_z):
+        lib = _lib.load()
+        es = 2 if T == torch.bfloat16 else 4
+        nH, L = meta.n_head, meta.L
+        H, W, win, shift = meta.swin if kind == _lib.ATTN_WINDOW else (0, 0, 0, 0)
+        n_lse = (M // L) * nH * L
+        off = [0]
+
+        def carve(nbytes):
+            o = off[0]
+            off[0] = (o + nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+            return o
+        self.f_off = {k: carve(n * es) for k, n in (("ln1", M * C), ("qkv", 3 * M * C), ("o", M * C), ("x1", M * C),
+                                                     ("ln2", M * C), ("h", M * ff))}
+        self.f_off["z"] = carve(M * ff * es) if want_z else None
+        for k, n in (("mean1", M), ("rstd1", M), ("mean2", M), ("rstd2", M), ("lse", n_lse)):
+            self.f_off[k] = carve(4 * n)
+        self.f_bytes = off[0]
+        off[0] = 0
+        self.ln_wsb = lib.vtx_layernorm_bwd_workspace(M, C)
+        if kind == _lib.ATTN_WINDOW:
+            self.attn_wsb = lib.vtx_wattn_bwd_workspace(B, nH, H, W, win)
+        else:
+            self.attn_wsb = lib.vtx_attention_bwd_workspace(B, L, nH, 0, 0, 0, 1) if L > 224 else 0
+        n4 = ctypes.c_int * 4
+        Ns, Ks = n4(C, ff, C, 3 * C), n4(ff, C, C, C)
+        self.wgrad_wsb = lib.vtx_wgrad_group_workspace(4, Ns, Ks, M)
+        self.slices = lib.vtx_wgrad_group_slices(4, Ns, Ks, M)
+        self.b_off = {k: carve(n * es) for k, n in (("dz", M * ff), ("dln2", M * C), ("dx1", M * C), ("dout", M * C),
+                                                     ("dqkv", 3 * M * C), ("dln1", M * C))}
+        for k, n in (("ln1_ws", self.ln_wsb), ("ln2_ws", self.ln_wsb), ("attn_ws", self.attn_wsb), ("wgrad_ws", self.wgrad_wsb)):
+            self.b_off[k] = carve(n) if n else None
+        self.b_bytes = off[0]
+        common = dict(dtype=ops.BF16 if T == torch.bfloat16 else ops.F32, attn_kind=kind, M=M, C=C, ff=ff, nH=nH, L=L, B=B,
+                      H=H, W=W, win=win, shift=int(bool(shift)))
+        self.fwd = _lib.LayerFwd(eps=float(meta.eps), **common)
+        self.bwd = _lib.LayerBwd(ln_ws_bytes=self.ln_wsb, attn_ws_bytes=self.attn_wsb, wgrad_ws_bytes=self.wgrad_wsb, **common)
+        self.ntab = (2 * win - 1) ** 2 if kind == _lib.ATTN_WINDOW else 0
+
+
+def _layer_plan(kind, meta, B, M, C, ff, T, want_z):
+    plans = meta.__dict__.setdefault("_layer_plans", {})
+    key = (kind, B, M, C, ff, T, want_z)
+    pl = plans.get(key)
+    if pl is None:
+        pl = plans[key] = _LayerPlan(kind, meta, B, M, C, ff, T, want_z)
+    return pl
+
+
+def _copy_desc(d):
+    return type(d).from_buffer_copy(d)
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_layer_inputs(x, T, *f32s):
+    if not x.is_contiguous() or x.numel() == 0:
+        raise VtxError("vtx: layer input must be a non-empty contiguous device tensor")
+    for t in f32s:
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous()):
+            raise VtxError("vtx: layer parameters must be contiguous float32 device tensors")
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
@@ -517,6 +608,17 @@ class TransformerLayerFn(Function):
         T = x.dtype
         B, C = x.shape[0], x.shape[-1]
         rps = (x.numel() // C) // B
+        # identities of the 12 parameters in the order backward returns their gradients (shared_param_backward)
+        ctx.pids = tuple(map(id, (ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b)))
+        ctx.meta, ctx.rps, ctx.dp_c = meta, rps, float(dp_c)
+        kind = _layer_kind(x, rel_pos, meta)
+        if kind and (qkv_w.shape[0] != 3 * C or proj_w.shape[1] != C or meta.n_head * meta.dim_head != C or qkv_b is None or
+                     proj_b is None or fc1_b is None or fc2_b is None):
+            kind = 0                         # (the one-call path assumes heads x head dim == dim and biased linears)
+        ctx.kind = kind
+        if kind:
+            return TransformerLayerFn._forward_one_call(ctx, kind, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b,
+                                                        ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b, s1, s2, meta)
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), meta.eps)
         wq, wo, w1, w2 = ctx.wp = (wcast(qkv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T))
         qkv = ops.gemm(ln1, wq[0], 0, bias=qkv_b.detach())
@@ -527,13 +629,115 @@ class TransformerLayerFn(Function):
         y = ops.gemm(h, w2[0], 0, bias=fc2_b.detach(), resid=x1, rowscale=s2, rows_per_scale=rps)
         ctx.save_for_backward(x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1,
                               mean2, rstd2, ln2, z, h, bias, s1, s2, rel_pos)
-        ctx.meta, ctx.rps, ctx.dp_c = meta, rps, float(dp_c)
-        # identities of the 12 parameters in the order backward returns their gradients (shared_param_backward)
-        ctx.pids = tuple(map(id, (ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b)))
+        return y
+
+    # ---- the same layer through ONE C call (csrc/layer.hip)
+    @staticmethod
+    def _forward_one_call(ctx, kind, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b,
+                          fc2_w, fc2_b, s1, s2, meta):
+        T = x.dtype
+        B, C = x.shape[0], x.shape[-1]
+        M, ff = x.numel() // C, fc1_w.shape[0]
+        _check_layer_inputs(x, T, ln1_w, ln1_b, qkv_b, proj_b, ln2_w, ln2_b, fc1_b, fc2_b, s1, s2)
+        want_z = any(ctx.needs_input_grad)
+        pl = _layer_plan(kind, meta, B, M, C, ff, T, want_z)
+        wq, wo, w1, w2 = ctx.wp = (wcast(qkv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T))
+        buf = torch.empty(pl.f_bytes, dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        base, fo = buf.data_ptr(), pl.f_off
+        d = _copy_desc(pl.fwd)
+        d.rows_per_scale = ctx.rps
+        d.x, d.y = x.data_ptr(), y.data_ptr()
+        d.ln1_w, d.ln1_b, d.ln2_w, d.ln2_b = ln1_w.data_ptr(), ln1_b.data_ptr(), ln2_w.data_ptr(), ln2_b.data_ptr()
+        d.wq, d.wo, d.w1, d.w2 = wq[0].data_ptr(), wo[0].data_ptr(), w1[0].data_ptr(), w2[0].data_ptr()
+        d.bq, d.bo, d.b1, d.b2 = qkv_b.data_ptr(), proj_b.data_ptr(), fc1_b.data_ptr(), fc2_b.data_ptr()
+        if kind == _lib.ATTN_WINDOW:
+            d.rel_pos, d.pos, d.region = rel_pos.data_ptr(), meta.pos.data_ptr(), _dp(meta.region)
+        d.s1, d.s2 = _dp(s1), _dp(s2)
+        d.ln1, d.qkv, d.o, d.x1, d.ln2, d.h = (base + fo["ln1"], base + fo["qkv"], base + fo["o"], base + fo["x1"],
+                                               base + fo["ln2"], base + fo["h"])
+        d.z = base + fo["z"] if want_z else None
+        d.mean1, d.rstd1, d.mean2, d.rstd2, d.lse = (base + fo["mean1"], base + fo["rstd1"], base + fo["mean2"],
+                                                     base + fo["rstd2"], base + fo["lse"])
+        _lib.check(_lib.load().vtx_layer_fwd(ctypes.byref(d), ops._stream()), "vtx_layer_fwd")
+        ctx.save_for_backward(x, buf, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, s1, s2, rel_pos)
+        ctx.plan = pl
         return y
 
     @staticmethod
+    def _backward_one_call(ctx, dy):
+        x, buf, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, s1, s2, rel_pos = ctx.saved_tensors
+        pl, m, kind = ctx.plan, ctx.meta, ctx.kind
+        if pl.f_off["z"] is None:
+            raise VtxError("vtx: this layer's forward ran without a graph (no pre-activation was kept)")
+        dy = _c(dy)
+        dev = x.device
+        C = x.shape[-1]
+        ff = fc1_w.shape[0]
+        wq, wo, w1, w2 = ctx.wp
+        scratch = torch.empty(pl.b_bytes, dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(x)
+        f32 = dict(dtype=torch.float32, device=dev)
+        shared = _shared_grads if rel_pos is None else None
+        acc = None
+        if shared is not None:
+            first = [shared.get(pid) for pid in ctx.pids]
+            if all(a is not None for a in first) and pl.slices >= 2:
+                acc = first
+        outs = None
+        if acc is None:
+            sinks = [grad_sink(p) for p in (qkv_w, proj_w, fc1_w, fc2_w)] if _grad_sink_providers else (None,) * 4
+            dWq, dWo, dW1, dW2 = [sk if sk is not None else torch.empty(p.shape, **f32)
+                                  for sk, p in zip(sinks, (qkv_w, proj_w, fc1_w, fc2_w))]
+            dbq, dbo, db1, db2 = (torch.empty(3 * C, **f32), torch.empty(C, **f32), torch.empty(ff, **f32), torch.empty(C, **f32))
+            dg1, dbe1, dg2, dbe2 = (torch.empty(C, **f32) for _ in range(4))
+            drel = torch.empty((pl.ntab, m.n_head), **f32) if kind == _lib.ATTN_WINDOW else None
+            outs = (dg1, dbe1, dWq, dbq, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2)
+            gp = [t.data_ptr() for t in outs]
+        else:
+            gp, drel = acc, None
+        base, fo, sb, bo = buf.data_ptr(), pl.f_off, scratch.data_ptr(), pl.b_off
+        d = _copy_desc(pl.bwd)
+        d.rows_per_scale, d.scale_const, d.accumulate = ctx.rps, ctx.dp_c, int(acc is not None)
+        d.dy, d.x, d.dx = dy.data_ptr(), x.data_ptr(), dx.data_ptr()
+        (d.ln1, d.qkv, d.o, d.x1, d.ln2, d.z, d.h) = (base + fo["ln1"], base + fo["qkv"], base + fo["o"], base + fo["x1"],
+                                                      base + fo["ln2"], base + fo["z"], base + fo["h"])
+        d.mean1, d.rstd1, d.mean2, d.rstd2, d.lse = (base + fo["mean1"], base + fo["rstd1"], base + fo["mean2"],
+                                                     base + fo["rstd2"], base + fo["lse"])
+        d.ln1_w, d.ln2_w = ln1_w.data_ptr(), ln2_w.data_ptr()
+        d.wq, d.wo, d.w1, d.w2 = (wq[0].data_ptr(), wo[0].data_ptr(), w1[0].data_ptr(), w2[0].data_ptr())
+        d.wqt, d.wot, d.w1t, d.w2t = _dp(wq[1]), _dp(wo[1]), _dp(w1[1]), _dp(w2[1])
+        if kind == _lib.ATTN_WINDOW:
+            inv_cells, inv_count = ops._pos_inverse(m.pos, m.ntab)
+            d.rel_pos, d.pos, d.region = rel_pos.data_ptr(), m.pos.data_ptr(), _dp(m.region)
+            d.inv_cells, d.inv_count = inv_cells.data_ptr(), inv_count
+            d.drel = drel.data_ptr()
+        d.s1, d.s2 = _dp(s1), _dp(s2)
+        d.dz, d.dln2, d.dx1, d.dout, d.dqkv, d.dln1 = (sb + bo["dz"], sb + bo["dln2"], sb + bo["dx1"], sb + bo["dout"],
+                                                       sb + bo["dqkv"], sb + bo["dln1"])
+        d.ln1_ws, d.ln2_ws, d.wgrad_ws = sb + bo["ln1_ws"], sb + bo["ln2_ws"], sb + bo["wgrad_ws"]
+        d.attn_ws = sb + bo["attn_ws"] if bo["attn_ws"] is not None else None
+        (d.dg1, d.dbe1, d.dWq, d.dbq, d.dWo, d.dbo, d.dg2, d.dbe2, d.dW1, d.db1, d.dW2, d.db2) = gp
+        side = None
+        if _deferred:
+            st = _side_states.get(dev)
+            if st is None:
+                st = _side_states[dev] = _SideState(dev)
+            side = st.stream.cuda_stream
+            st.keep.append((scratch, buf, dy, x, s1, s2, ctx.wp))     # what the side stream still reads after this returns
+            st.pending = True
+        _lib.check(_lib.load().vtx_layer_bwd(ctypes.byref(d), ops._stream(), side), "vtx_layer_bwd")
+        if acc is not None:
+            return (dx,) + (None,) * 17
+        if shared is not None and not any(pid in shared for pid in ctx.pids):
+            for pid, a in zip(ctx.pids, gp):
+                shared[pid] = a
+        return (dx, dg1, dbe1, dWq, dbq, drel, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.kind:
+            return TransformerLayerFn._backward_one_call(ctx, dy)
         (x, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, mean1, rstd1, ln1, qkv, o, lse, x1, mean2, rstd2, ln2, z, h,
          bias, s1, s2, rel_pos) = ctx.saved_tensors
         m, rps, dp_c = ctx.meta, ctx.rps, ctx.dp_c
