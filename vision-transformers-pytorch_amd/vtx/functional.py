@@ -330,7 +330,7 @@ def _layer_kind(x, rel_pos, meta):
 class _LayerPlan:
     """Shape-dependent part of the two descriptors of one layer: buffer layouts, workspace sizes, prefilled structures."""
 
-    def __init__(self, kind, meta, B, M, C, ff, T, want_z):
+    def __init__(self, kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c):
         lib = _lib.load()
         es = 2 if T == torch.bfloat16 else 4
         nH, L = meta.n_head, meta.L
@@ -358,6 +358,9 @@ class _LayerPlan:
         Ns, Ks = n4(C, ff, C, 3 * C), n4(ff, C, C, C)
         self.wgrad_wsb = lib.vtx_wgrad_group_workspace(4, Ns, Ks, M)
         self.slices = lib.vtx_wgrad_group_slices(4, Ns, Ks, M)
+        # the backward's ONE grouped weight-gradient launch must apply (bf16, LDS-DMA shapes); else: call-by-call path
+        self.ok = bool(lib.vtx_wgrad_group_ok(ops.BF16 if T == torch.bfloat16 else ops.F32, 4, Ns, Ks, M, int(has_rs), int(rps),
+                                              float(dp_c)))
         self.b_off = {k: carve(n * es) for k, n in (("dz", M * ff), ("dln2", M * C), ("dx1", M * C), ("dout", M * C),
                                                      ("dqkv", 3 * M * C), ("dln1", M * C))}
         for k, n in (("ln1_ws", self.ln_wsb), ("ln2_ws", self.ln_wsb), ("attn_ws", self.attn_wsb), ("wgrad_ws", self.wgrad_wsb)):
@@ -370,12 +373,12 @@ class _LayerPlan:
         self.ntab = (2 * win - 1) ** 2 if kind == _lib.ATTN_WINDOW else 0
 
 
-def _layer_plan(kind, meta, B, M, C, ff, T, want_z):
+def _layer_plan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c):
     plans = meta.__dict__.setdefault("_layer_plans", {})
-    key = (kind, B, M, C, ff, T, want_z)
+    key = (kind, B, M, C, ff, T, want_z, has_rs, rps, dp_c)
     pl = plans.get(key)
     if pl is None:
-        pl = plans[key] = _LayerPlan(kind, meta, B, M, C, ff, T, want_z)
+        pl = plans[key] = _LayerPlan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c)
     return pl
 
 
@@ -615,9 +618,15 @@ class TransformerLayerFn(Function):
         if kind and (qkv_w.shape[0] != 3 * C or proj_w.shape[1] != C or meta.n_head * meta.dim_head != C or qkv_b is None or
                      proj_b is None or fc1_b is None or fc2_b is None):
             kind = 0                         # (the one-call path assumes heads x head dim == dim and biased linears)
+        pl = None
+        if kind:
+            pl = _layer_plan(kind, meta, B, x.numel() // C, C, fc1_w.shape[0], T, any(ctx.needs_input_grad),
+                             s1 is not None or s2 is not None, rps, float(dp_c))
+            if not pl.ok:
+                kind = 0
         ctx.kind = kind
         if kind:
-            return TransformerLayerFn._forward_one_call(ctx, kind, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b,
+            return TransformerLayerFn._forward_one_call(ctx, kind, pl, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b,
                                                         ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b, s1, s2, meta)
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), meta.eps)
         wq, wo, w1, w2 = ctx.wp = (wcast(qkv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T))
@@ -633,14 +642,13 @@ class TransformerLayerFn(Function):
 
     # ---- the same layer through ONE C call (csrc/layer.hip)
     @staticmethod
-    def _forward_one_call(ctx, kind, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b,
+    def _forward_one_call(ctx, kind, pl, x, ln1_w, ln1_b, qkv_w, qkv_b, rel_pos, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b,
                           fc2_w, fc2_b, s1, s2, meta):
         T = x.dtype
         B, C = x.shape[0], x.shape[-1]
         M, ff = x.numel() // C, fc1_w.shape[0]
         _check_layer_inputs(x, T, ln1_w, ln1_b, qkv_b, proj_b, ln2_w, ln2_b, fc1_b, fc2_b, s1, s2)
         want_z = any(ctx.needs_input_grad)
-        pl = _layer_plan(kind, meta, B, M, C, ff, T, want_z)
         wq, wo, w1, w2 = ctx.wp = (wcast(qkv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T))
         buf = torch.empty(pl.f_bytes, dtype=torch.uint8, device=x.device)
         y = torch.empty_like(x)
