@@ -373,12 +373,15 @@ class _LayerPlan:
         self.ntab = (2 * win - 1) ** 2 if kind == _lib.ATTN_WINDOW else 0
 
 
+_layer_plans = {}      # by geometry only (a plan holds sizes, offsets and the geometry fields of the descriptors, no addresses)
+
+
 def _layer_plan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c):
-    plans = meta.__dict__.setdefault("_layer_plans", {})
-    key = (kind, B, M, C, ff, T, want_z, has_rs, rps, dp_c)
-    pl = plans.get(key)
+    key = (kind, meta.n_head, meta.L, meta.swin if kind == _lib.ATTN_WINDOW else None, meta.eps, B, M, C, ff, T, want_z,
+           has_rs, rps, dp_c)
+    pl = _layer_plans.get(key)
     if pl is None:
-        pl = plans[key] = _LayerPlan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c)
+        pl = _layer_plans[key] = _LayerPlan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c)
     return pl
 
 
@@ -697,9 +700,11 @@ class TransformerLayerFn(Function):
             sinks = [grad_sink(p) for p in (qkv_w, proj_w, fc1_w, fc2_w)] if _grad_sink_providers else (None,) * 4
             dWq, dWo, dW1, dW2 = [sk if sk is not None else torch.empty(p.shape, **f32)
                                   for sk, p in zip(sinks, (qkv_w, proj_w, fc1_w, fc2_w))]
-            dbq, dbo, db1, db2 = (torch.empty(3 * C, **f32), torch.empty(C, **f32), torch.empty(ff, **f32), torch.empty(C, **f32))
-            dg1, dbe1, dg2, dbe2 = (torch.empty(C, **f32) for _ in range(4))
-            drel = torch.empty((pl.ntab, m.n_head), **f32) if kind == _lib.ATTN_WINDOW else None
+            # the nine small gradients: one allocation, one split (views of it go back to autograd)
+            nrel = pl.ntab * m.n_head
+            small = torch.empty(8 * C + ff + nrel, **f32).split((C, C, 3 * C, C, C, C, ff, C) + ((nrel,) if nrel else ()))
+            dg1, dbe1, dbq, dbo, dg2, dbe2, db1, db2 = small[:8]
+            drel = small[8].view(pl.ntab, m.n_head) if nrel else None
             outs = (dg1, dbe1, dWq, dbq, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2)
             gp = [t.data_ptr() for t in outs]
         else:

@@ -46,7 +46,11 @@ def drop_path_scope(model, batch, device):
     if not model.training or getattr(_dp, "rows", None) is not None:
         yield
         return
-    ps = [m.p for m in model.modules() if isinstance(m, _DropPathBase) and m.p > 0 for _ in range(2)]
+    # (the module walk is cached: 0.3 ms of host time per Swin-S forward; p itself is read every time -- set_drop_path)
+    dps = model.__dict__.get("_vtx_dp_modules")
+    if dps is None or dps[0] != len(model._modules):
+        dps = model.__dict__["_vtx_dp_modules"] = (len(model._modules), [m for m in model.modules() if isinstance(m, _DropPathBase)])
+    ps = [m.p for m in dps[1] if m.p > 0 for _ in range(2)]
     if not ps:
         yield
         return

@@ -509,13 +509,17 @@ def _ptr_array(ts):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
-def grad_sqnorm(grads):
-    """[sum g^2, sqrt(sum g^2)] over a list of fp32 gradient tensors (deterministic two-level reduction)."""
-    _dev(*grads)
+def grad_sqnorm(grads, static=None):
+    """[sum g^2, sqrt(sum g^2)] over a list of fp32 gradient tensors (deterministic two-level reduction).
+    ``static`` = (numel array, chunk count) of a caller that runs the same tensor list every step (FusedAdamW)."""
     lib = _lib.load()
-    chunk = lib.vtx_opt_chunk()
-    numel = (ctypes.c_int64 * len(grads))(*[g.numel() for g in grads])
-    nchunks = sum((g.numel() + chunk - 1) // chunk for g in grads)
+    if static is None:
+        _dev(*grads)
+        chunk = lib.vtx_opt_chunk()
+        numel = (ctypes.c_int64 * len(grads))(*[g.numel() for g in grads])
+        nchunks = sum((g.numel() + chunk - 1) // chunk for g in grads)
+    else:
+        numel, nchunks = static
     dev = grads[0].device
     partial = torch.empty(max(nchunks, 1), dtype=torch.float32, device=dev)
     out = torch.empty(2, dtype=torch.float32, device=dev)
@@ -524,14 +528,21 @@ def grad_sqnorm(grads):
     return out
 
 
-def adamw_step(params, grads, exp_avg, exp_avg_sq, lrs, wds, norm, max_norm, beta1, beta2, eps, t):
-    """torch.optim.AdamW step t of the listed tensors in one multi-tensor pass (csrc/optim.hip)."""
-    _dev(*params, *grads, *exp_avg, *exp_avg_sq, norm)
-    n = len(params)
-    numel = (ctypes.c_int64 * n)(*[p.numel() for p in params])
-    with _timed("adamw_step_kernel", 0.0, 28.0 * sum(p.numel() for p in params)):     # p, g, m, v read; p, m, v written
-        check(_lib.load().vtx_adamw_step(n, _ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg),
-                                         _ptr_array(exp_avg_sq), numel, (ctypes.c_float * n)(*lrs),
+def adamw_step(params, grads, exp_avg, exp_avg_sq, lrs, wds, norm, max_norm, beta1, beta2, eps, t, static=None):
+    """torch.optim.AdamW step t of the listed tensors in one multi-tensor pass (csrc/optim.hip).
+    ``static`` = (param / exp_avg / exp_avg_sq address arrays, numel array, total elements) of a caller that steps the same,
+    already validated, tensors every time (FusedAdamW): only the gradients are looked at per step."""
+    n = len(grads)
+    if static is None:
+        _dev(*params, *grads, *exp_avg, *exp_avg_sq, norm)
+        pa, ma, va = _ptr_array(params), _ptr_array(exp_avg), _ptr_array(exp_avg_sq)
+        numel = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+        total = sum(p.numel() for p in params)
+    else:
+        pa, ma, va, numel, total = static
+    with _timed("adamw_step_kernel", 0.0, 28.0 * total):     # p, g, m, v read; p, m, v written
+        check(_lib.load().vtx_adamw_step(n, pa, _ptr_array(grads), ma,
+                                         va, numel, (ctypes.c_float * n)(*lrs),
                                          (ctypes.c_float * n)(*wds), _p(norm), float(max_norm), float(beta1), float(beta2),
                                          float(eps), int(t), _stream()), "vtx_adamw_step")
 

@@ -19,35 +19,65 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._steps = {}
+        self._recs = None           # static per-parameter records (see _records)
+        self._plans = {}
 
-    def _tensors(self):
-        out = []
+    # ---- host-side bookkeeping.  A step touches ~330 parameters; looking at each one's state dict, validating four
+    # tensors per parameter, building four address arrays and bumping 330 CPU step tensors cost ~2.4 ms of host time per
+    # step (tools/probe/host_profile.py).  Everything that does not change from step to step is recorded once:
+    # (parameter, state, group) triples in group order, the address arrays of params / exp_avg / exp_avg_sq per launch,
+    # and ALL ``state["step"]`` tensors as 0-dim views of ONE CPU tensor, so that a step is one ``add_`` (the state
+    # layout stays torch.optim.AdamW's: ``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, checkpoints interchangeable).
+    def _records(self):
+        key = tuple(id(p) for g in self.param_groups for p in g["params"])
+        if self._recs is not None and self._recs[0] == key and all(st["step"] is v for (_, st, _), v in zip(self._recs[1], self._recs[3])):
+            return self._recs
+        recs = []
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if p.grad.is_sparse or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
-                    raise ops.VtxError("FusedAdamW: dense fp32 parameters / gradients on the GPU only")
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise ops.VtxError("FusedAdamW: dense contiguous fp32 parameters on the GPU only")
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                out.append((p, g, st, group))
-        return out
+                recs.append((p, st, group))
+        flat = torch.tensor([float(st["step"]) for _, st, _ in recs], dtype=torch.float32)
+        views = []
+        for i, (_, st, _) in enumerate(recs):
+            st["step"] = flat[i]                       # 0-dim view: float(st["step"]) / state_dict() see the live count
+            views.append(st["step"])
+        self._recs = (key, recs, flat, views, [int(v) for v in flat.tolist()])
+        self._plans = {}
+        return self._recs
 
-    def _step_of(self, st):
-        """Step count of one parameter as a Python int.  state["step"] stays a tensor (torch.optim.AdamW's format, so
-        optimizer checkpoints are interchangeable); reading ~330 of them with .item() and bumping each with a tensor add
-        costs ~2 ms of host time per step, so the ints are mirrored here and re-read only when the tensor object changes
-        (load_state_dict)."""
-        t = st["step"]
-        ent = self._steps.get(id(st))
-        if ent is None or ent[0] is not t:
-            ent = self._steps[id(st)] = [t, int(t)]
-        return ent[1]
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._recs = None
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._recs = None
+
+    def _launch_plan(self, idx, recs):
+        """Address arrays of one multi-tensor launch over the parameters ``idx`` (a tuple), built once."""
+        pl = self._plans.get(idx)
+        if pl is None:
+            import ctypes
+            ps = [recs[i][0] for i in idx]
+            ms = [recs[i][1]["exp_avg"] for i in idx]
+            vs = [recs[i][1]["exp_avg_sq"] for i in idx]
+            ops._dev(*ps, *ms, *vs)
+            chunk = ops._lib.load().vtx_opt_chunk()
+            numel = (ctypes.c_int64 * len(idx))(*[p.numel() for p in ps])
+            pl = self._plans[idx] = (ops._ptr_array(ps), ops._ptr_array(ms), ops._ptr_array(vs), numel,
+                                     sum(p.numel() for p in ps), sum((p.numel() + chunk - 1) // chunk for p in ps),
+                                     tuple(id(m) for m in ms))
+        elif pl[6] != tuple(id(recs[i][1]["exp_avg"]) for i in idx):      # state tensors were replaced: rebuild
+            del self._plans[idx]
+            return self._launch_plan(idx, recs)
+        return pl
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=0.0):
@@ -58,27 +88,40 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        tensors = self._tensors()
-        if not tensors:
+        _, recs, flat, _, counts = self._records()
+        live, gs = [], []
+        for i, (p, _, _) in enumerate(recs):
+            g = p.grad
+            if g is None:
+                continue
+            if g.dtype != torch.float32 or g.is_sparse or not g.is_cuda:
+                raise ops.VtxError("FusedAdamW: dense fp32 gradients on the GPU only")
+            live.append(i)
+            gs.append(g if g.is_contiguous() else g.contiguous())
+        if not live:
             return loss
-        ps = [p for p, _, _, _ in tensors]
-        gs = [g for _, g, _, _ in tensors]
+        live = tuple(live)
         norm = None
-        if max_grad_norm and max_grad_norm > 0:
-            norm = ops.grad_sqnorm(gs)                       # over ALL gradients, whatever their step counts
+        if max_grad_norm and max_grad_norm > 0:              # over ALL gradients, whatever their step counts
+            pl = self._launch_plan(live, recs)
+            norm = ops.grad_sqnorm(gs, static=(pl[3], pl[5]))
         # torch.optim.AdamW keeps a step count PER PARAMETER (a parameter that gets its first gradient late -- DINO's
         # last layer is frozen during epoch 0, train_dino.py:250 -- starts at step 1 then): one multi-tensor launch per
         # distinct (betas, eps, step) -- a single one in the steady state
         by_key = {}
-        for i, (_, _, st, g) in enumerate(tensors):
-            by_key.setdefault((g["betas"], g["eps"], self._step_of(st)), []).append(i)
-        for (betas, eps, t0), idx in by_key.items():
-            sel = [tensors[i] for i in idx]
-            ops.adamw_step([ps[i] for i in idx], [gs[i] for i in idx], [st["exp_avg"] for _, _, st, _ in sel],
-                           [st["exp_avg_sq"] for _, _, st, _ in sel], [float(g["lr"]) for _, _, _, g in sel],
-                           [float(g["weight_decay"]) for _, _, _, g in sel], norm, float(max_grad_norm or 0.0),
-                           betas[0], betas[1], eps, t0 + 1)
-        torch._foreach_add_([st["step"] for _, _, st, _ in tensors], 1)        # one call for all step tensors
-        for _, _, st, _ in tensors:
-            self._steps[id(st)][1] += 1
+        for j, i in enumerate(live):
+            g = recs[i][2]
+            by_key.setdefault((g["betas"], g["eps"], counts[i]), []).append(j)
+        for (betas, eps, t0), js in by_key.items():
+            idx = live if len(js) == len(live) else tuple(live[j] for j in js)
+            pl = self._launch_plan(idx, recs)
+            ops.adamw_step(None, gs if len(js) == len(live) else [gs[j] for j in js], None, None,
+                           [float(recs[i][2]["lr"]) for i in idx], [float(recs[i][2]["weight_decay"]) for i in idx], norm,
+                           float(max_grad_norm or 0.0), betas[0], betas[1], eps, t0 + 1, static=pl[:5])
+        if len(live) == len(recs):
+            flat.add_(1.0)                                   # every state["step"] is a view of this one tensor
+        else:
+            flat[list(live)] += 1.0
+        for i in live:
+            counts[i] += 1
         return norm[1] if norm is not None else loss
