@@ -702,7 +702,7 @@ class TransformerLayerFn(Function):
                                   for sk, p in zip(sinks, (qkv_w, proj_w, fc1_w, fc2_w))]
             # the nine small gradients: one allocation, one split (views of it go back to autograd)
             nrel = pl.ntab * m.n_head
-            small = torch.empty(10 * C + ff + nrel, **f32).split((C, C, 3 * C, C, C, C, ff, C) + ((nrel,) if nrel else ()))
+            small = torch.empty(9 * C + ff + nrel, **f32).split((C, C, 3 * C, C, C, C, ff, C) + ((nrel,) if nrel else ()))
             dg1, dbe1, dbq, dbo, dg2, dbe2, db1, db2 = small[:8]
             drel = small[8].view(pl.ntab, m.n_head) if nrel else None
             outs = (dg1, dbe1, dWq, dbq, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2)
