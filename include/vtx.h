@@ -60,6 +60,13 @@ int vtx_set_option(int id, int value);   /* VTX_ERR_SHAPE for an unknown id */
  * Saves mean / rstd [rows] for the backward. */
 int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int64_t rows, int C, float eps, int dtype, int merge, int H, int W, void* stream);
+/* Over the kept samples of a stochastic-depth branch only (csrc/layer.hip drives these): logical row r is row
+ * perm[r / T] * T + r % T of every row-indexed tensor, perm [samples] int32 on the device with the kept samples first. */
+int vtx_layernorm_fwd_mapped(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                             int64_t rows, int C, float eps, int dtype, const int* perm, int T, void* stream);
+int vtx_layernorm_bwd_mapped(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                             const void* dres, void* dx, void* workspace, size_t ws_bytes, int64_t rows, int64_t live, int C,
+                             int dtype, const int* perm, int T, void* stream);
 size_t vtx_layernorm_bwd_workspace(int64_t rows, int C);
 /* dx = dres + LN'(dy)  (dres optional, plain layout only), dgamma / dbeta fp32 [C] (overwritten).
  * dgamma == dbeta == NULL defers the final column reduce: the per-block partials stay in the workspace as
@@ -117,6 +124,14 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
                     void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
                     float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, int accumulate,
                     void* stream);
+/* ... with a per-problem live_only flag (host array or NULL): rowscale[i] then only marks the samples whose rows exist (the
+ * others are skipped, they may be unwritten memory) and the constant is not applied to that problem. */
+int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                         float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                         const float* const* rowscale, const int* live_only, int rows_per_scale, float scale_const,
+                         int64_t mtok, void* workspace, size_t ws_bytes, int ncol, const float* const* col_part,
+                         float* const* col_out0, float* const* col_out1, const int* col_nb, const int* col_C,
+                         const int* col_ld, int accumulate, void* stream);
 /* split-K slices such a group runs with (>= 2: its outputs come from the reduce launch, so `accumulate` is available) */
 int vtx_wgrad_group_slices(int nprob, const int* N, const int* Kin, int64_t mtok);
 
@@ -157,6 +172,13 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
 int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
                   const uint8_t* region, int B, int L, int nH, int H, int W, int win, int shift, int dtype,
                   void* stream);
+int vtx_wattn_fwd_mapped(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
+                         const uint8_t* region, const int* perm, int Bk, int L, int nH, int H, int W, int win, int shift,
+                         int dtype, void* stream);     /* the b-th image worked on is image perm[b], b < Bk */
+int vtx_wattn_bwd_mapped(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
+                         const int64_t* pos, const uint8_t* region, void* dqkv, void* workspace, size_t ws_bytes,
+                         const int* inv_cells, int inv_count, const int* perm, int Bk, int L, int nH, int H, int W, int win,
+                         int shift, int dtype, void* stream);
 size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win);
 /* drel_pos == NULL defers the rel_pos-gradient reduce: vtx_wattn_bwd_parts() partial rows of stride vtx_wattn_bwd_part_ld(nH)
  * stay in the workspace (columns (2 win - 1)^2 * nH) for vtx_colreduce_multi. */
@@ -201,6 +223,11 @@ typedef struct VtxLayerFwd {
   const float *s1, *s2;
   void *ln1, *qkv, *o, *x1, *ln2, *z, *h, *y;  /* z may be NULL (no backward will run) */
   float *mean1, *rstd1, *mean2, *rstd2, *lse;
+  /* stochastic-depth compaction (both NULL: off): perm1 / perm2 [B] int32 on the device list the samples of the attention /
+   * MLP branch, kept ones (s? != 0) first, Bk1 / Bk2 >= 1 of them -- each branch is computed for its kept samples only, the
+   * others pass through (bf16, VTX_ATTN_WINDOW, C and ff multiples of 128, rows_per_scale = tokens per sample) */
+  const int *perm1, *perm2;
+  int Bk1, Bk2;
 } VtxLayerFwd;
 int vtx_layer_fwd(const VtxLayerFwd* a, void* stream);
 typedef struct VtxLayerBwd {
@@ -220,6 +247,8 @@ typedef struct VtxLayerBwd {
   void *ln1_ws, *ln2_ws, *attn_ws, *wgrad_ws;
   size_t ln_ws_bytes, attn_ws_bytes, wgrad_ws_bytes;
   float *dWq, *dbq, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2, *drel;
+  const int *perm1, *perm2;                    /* the forward's (see VtxLayerFwd) */
+  int Bk1, Bk2;
 } VtxLayerBwd;
 int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream);
 int vtx_layer_desc_bytes(int which);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */

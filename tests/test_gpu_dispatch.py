@@ -337,3 +337,43 @@ def test_one_call_layer_under_no_grad_and_shared_param_backward():
     a, b = grads(False), grads(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("p", [0.45, 0.1])
+def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(p, monkeypatch):
+    """Round 3: with host-drawn DropPath masks every branch of a Swin layer runs over its KEPT samples only (row-mapped
+    LayerNorm / LDS-DMA GEMMs / window attention, copy-only tiles for the dropped samples, weight gradients skipping their
+    rows: csrc/layer.hip) instead of being computed for all samples and multiplied by 0.  Same masks, same per-row math:
+    the output and every gradient that is a per-row quantity or a weight-gradient sum must be BIT-identical to the
+    compute-and-scale path; LayerNorm gamma / beta and rel_pos gradients are summed over a different partition of the rows
+    (1e-5).  Also: some branch must actually have been compacted, and nothing may be NaN although the dropped samples'
+    activations are never written."""
+    from models import SwinTransformer
+    from vtx import functional as VF
+    d = dev()
+    torch.manual_seed(41)
+    model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=(64, 128, 384, 768), dim_head=32,
+                            n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=p).to(d).train()
+    for m in model.modules():
+        if hasattr(m, "rel_pos"):
+            torch.nn.init.normal_(m.rel_pos.weight, std=0.3)
+    x = torch.randn(10, 3, 224, 224, device=d)
+    used = []
+    real = VF._layer_perms
+    monkeypatch.setattr(VF, "_layer_perms", lambda *a: (used.append(real(*a)), used[-1])[1])
+    monkeypatch.setattr(VF, "_LAYER_CALL", True)
+    # poison the allocator's free memory: what compaction leaves unwritten must never be read
+    junk = torch.full((1 << 28,), float("nan"), device=d, dtype=torch.bfloat16)
+    del junk
+    out_a, g_a = _layer_io(model, x, True, 91)
+    assert sum(u is not None and (u[0][1] < 10 or u[1][1] < 10) for u in used) >= 2, "no branch was compacted"
+    monkeypatch.setattr(VF, "_LAYER_CALL", False)                      # call-by-call: every sample computed, then scaled
+    out_b, g_b = _layer_io(model, x, True, 91)
+    assert torch.isfinite(out_a).all() and all(torch.isfinite(v).all() for v in g_a.values())
+    assert torch.equal(out_a, out_b)
+    loose = ("norm", "rel_pos")
+    for k in g_a:
+        if any(t in k for t in loose):
+            check(f"compaction: d {k}", g_a[k], g_b[k], 1e-5)
+        else:
+            assert torch.equal(g_a[k], g_b[k]), f"gradient of {k} differs under stochastic-depth compaction"

@@ -23,6 +23,16 @@ for name, B, dp in (("swin_s", 128, 0.3), ("vit_s16", 256, 0.1), ("pvt_small", 1
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"{name}: host enqueue {1e3 * (t1 - t0) / 20:.2f} ms/step, wall {1e3 * (t2 - t0) / 20:.2f} ms/step")
+    # pure host cost: the first steps after a synchronise run ahead of the GPU (nothing to wait for yet)
+    ahead = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        train_step(model, crit, opt, data)
+        train_step(model, crit, opt, data)
+        ahead.append((time.perf_counter() - t0) / 2)
+    torch.cuda.synchronize()
+    print(f"{name}: run-ahead enqueue (2 steps after a synchronise, GPU not yet the limiter) {1e3 * min(ahead):.2f} ms/step")
     # host-only cost: how long does the python side take when the GPU is not the limiter?  (tiny batch)
     xs = torch.randn(2, 3, 224, 224, device=dev); ls = torch.randint(0, 1000, (2,), device=dev)
     ds = (xs, ls, ls.roll(1), torch.rand(2, device=dev))

@@ -42,6 +42,7 @@
 struct WinGeom {
   int L, nH, hd, nW, H, W, win, shift, nWx;
   float scale;
+  const int* perm;     // stochastic-depth compaction: the b-th image a kernel works on is image perm[b] (null: identity)
 };
 
 // Round 3: the per-problem address arithmetic was 550 of the backward's ~2 650 instructions per problem (a runtime division
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
   wa_tok_init(tk, g, c_);
 
   for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
-    const int n = bn % g.nW, b = bn / g.nW;
+    const int n = bn % g.nW, b = g.perm ? g.perm[bn / g.nW] : bn / g.nW;
     const int wi = n / g.nWx, wj = n - wi * g.nWx;      // (wave-uniform: scalar arithmetic)
     const int prob = bn * g.nH + h;
     int row[4];
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
   wa_tok_init(tk, g, c_);
 
   for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
-    const int n = bn % g.nW, b = bn / g.nW;
+    const int n = bn % g.nW, b = g.perm ? g.perm[bn / g.nW] : bn / g.nW;
     const int wi = n / g.nWx, wj = n - wi * g.nWx;      // (wave-uniform: scalar arithmetic)
     const int prob = bn * g.nH + h;
 
@@ -495,6 +496,7 @@ static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift)
   g.L = L; g.nH = nH; g.hd = nH * WA_D; g.H = H; g.W = W; g.win = win;
   g.nWx = W / win; g.nW = (H / win) * (W / win); g.shift = shift ? win / 2 : 0;
   g.scale = 1.0f / sqrtf((float)WA_D);
+  g.perm = nullptr;
   return VTX_OK;
 }
 
@@ -580,6 +582,28 @@ int vtx_wattn_fwd(const void* qkv, void* o, float* lse, const float* rel_pos, co
   return VTX_ERR_DTYPE;
 }
 
+/* The same over Bk <= B images only: the b-th one is image perm[b] (perm [B] int32 on the device: the kept samples of a
+ * stochastic-depth branch first); lse is indexed by b, i.e. private to the (forward, backward) pair that shares perm. */
+int vtx_wattn_fwd_mapped(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
+                         const uint8_t* region, const int* perm, int Bk, int L, int nH, int H, int W, int win, int shift,
+                         int dtype, void* stream) {
+  if (!qkv || !o || !lse || !rel_pos || !pos || !perm) return VTX_ERR_NULL;
+  WinGeom g;
+  int rc = win_geom(g, L, nH, H, W, win, shift);
+  if (rc) return rc;
+  g.perm = perm;
+  const int nbn = Bk * g.nW;
+  if (nbn <= 0) return VTX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16)
+    return region ? wattn_fwd_launch<bf16, true>(qkv, o, lse, rel_pos, pos, region, nbn, g, st)
+                  : wattn_fwd_launch<bf16, false>(qkv, o, lse, rel_pos, pos, region, nbn, g, st);
+  if (dtype == VTX_F32)
+    return region ? wattn_fwd_launch<float, true>(qkv, o, lse, rel_pos, pos, region, nbn, g, st)
+                  : wattn_fwd_launch<float, false>(qkv, o, lse, rel_pos, pos, region, nbn, g, st);
+  return VTX_ERR_DTYPE;
+}
+
 /* partial rows ([rows][172 * nH] fp32, the first (2 win - 1)^2 * nH columns used) vtx_wattn_bwd leaves in its workspace when
  * drel_pos == NULL (the caller reduces them with vtx_colreduce_multi: C = (2 win - 1)^2 * nH, ld = 172 * nH) */
 int vtx_wattn_bwd_parts(int B, int nH, int H, int W, int win) {
@@ -624,6 +648,32 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(ntab * nH), dim3(1024), 0, st, (const float*)part, drel_pos,
                      (float*)nullptr, nwaves, ntab * nH, WA_NBIN * nH);
   return vtx_check_launch();
+}
+
+/* Backward over Bk <= B images (see vtx_wattn_fwd_mapped); the rel_pos-gradient partials stay in the workspace
+ * (vtx_wattn_bwd_parts(Bk, ...) rows: deferred reduce).  dqkv rows of the other images are not written. */
+int vtx_wattn_bwd_mapped(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
+                         const int64_t* pos, const uint8_t* region, void* dqkv, void* workspace, size_t ws_bytes,
+                         const int* inv_cells, int inv_count, const int* perm, int Bk, int L, int nH, int H, int W, int win,
+                         int shift, int dtype, void* stream) {
+  if (!qkv || !o || !dout || !lse || !rel_pos || !pos || !dqkv || !workspace || !perm) return VTX_ERR_NULL;
+  WinGeom g;
+  int rc = win_geom(g, L, nH, H, W, win, shift);
+  if (rc) return rc;
+  g.perm = perm;
+  const int nbn = Bk * g.nW;
+  if (nbn <= 0) return VTX_ERR_SHAPE;
+  if (ws_bytes < vtx_wattn_bwd_workspace(Bk, nH, H, W, win)) return VTX_ERR_WORKSPACE;
+  if (inv_cells != nullptr && (inv_count <= 0 || inv_count > L * L)) return VTX_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == VTX_BF16)
+    return region ? wattn_bwd_launch<bf16, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st)
+                  : wattn_bwd_launch<bf16, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st);
+  if (dtype == VTX_F32)
+    return region ? wattn_bwd_launch<float, true>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st)
+                  : wattn_bwd_launch<float, false>(qkv, o, dout, lse, rel_pos, pos, region, dqkv, part, inv_cells, inv_count, nbn, g, st);
+  return VTX_ERR_DTYPE;
 }
 
 }  // extern "C"

@@ -51,6 +51,6 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 10; }
+int vtx_abi_version(void) { return 11; }
 
 }  // extern "C"

@@ -275,6 +275,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   a.aux_out = aux_out; a.aux_in = aux_in; a.act = act; a.kscale = nullptr; a.k_per_scale = 1; a.kscale_const = 0.f;
   a.ksum_out = nullptr;
   a.kchunk = ((K + 127) / 128) * 128;
+  gemm_args_nomap(a);
   if (mode != 0 && mode != 1) return VTX_ERR_SHAPE;
   if (act < 0 || act > 4) return VTX_ERR_SHAPE;
   int rc = gemm_validate(a, mode);
@@ -349,6 +350,7 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   a.aux_out = nullptr; a.aux_in = nullptr; a.act = 0;
   a.kscale = rowscale; a.k_per_scale = rows_per_scale > 0 ? rows_per_scale : 1; a.kscale_const = scale_const;
   a.kchunk = (int)chunk_of(mtok, nz);
+  gemm_args_nomap(a);
   float* bias_part = (float*)workspace + (size_t)nz * N * Kin;
   a.ksum_out = dbias ? (nz == 1 ? dbias : bias_part) : nullptr;
   int rc = gemm_validate(a, 2);
@@ -358,7 +360,7 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const) && (rowscale == nullptr || a.kchunk / a.k_per_scale + 2 <= 512)) {
     WgradProbHost hp;
     hp.dy = dy; hp.x = x; hp.slab = (float*)workspace; hp.out = dW; hp.ksum_part = bias_part; hp.ksum_out = dbias;
-    hp.rowscale = rowscale; hp.ld_dy = ld_dy; hp.ld_x = ld_x; hp.N = N; hp.Kin = Kin;
+    hp.rowscale = rowscale; hp.ld_dy = ld_dy; hp.ld_x = ld_x; hp.N = N; hp.Kin = Kin; hp.live_only = 0;
     rc = wgrad_glds_group_launch(1, &hp, mtok, a.k_per_scale, scale_const, nz, a.kchunk, st);
     if (rc || nz == 1) return rc;
     return reduce_slabs((const float*)workspace, bias_part, dW, dbias, N, Kin, nz, st);
@@ -406,12 +408,33 @@ size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_
   return (fl + 4) * sizeof(float);
 }
 
+int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                         float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                         const float* const* rowscale, const int* live_only, int rows_per_scale, float scale_const,
+                         int64_t mtok, void* workspace, size_t ws_bytes, int ncol, const float* const* col_part,
+                         float* const* col_out0, float* const* col_out1, const int* col_nb, const int* col_C,
+                         const int* col_ld, int accumulate, void* stream);
+
 int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
                     const float* const* rowscale, int rows_per_scale, float scale_const, int64_t mtok,
                     void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
                     float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, int accumulate,
                     void* stream) {
+  return vtx_wgrad_group_live(dtype, nprob, dy, x, dW, dbias, N, Kin, ld_dy, ld_x, rowscale, nullptr, rows_per_scale, scale_const,
+                              mtok, workspace, ws_bytes, ncol, col_part, col_out0, col_out1, col_nb, col_C, col_ld, accumulate,
+                              stream);
+}
+
+/* vtx_wgrad_group with a per-problem `live_only` flag (host array or NULL): rowscale[i] then only marks which samples' rows
+ * exist -- dropped samples' rows are skipped (they may hold garbage: stochastic-depth compaction never writes them) while the
+ * constant is NOT applied to that problem's result (its dy already carries the DropPath scale). */
+int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                         float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                         const float* const* rowscale, const int* live_only, int rows_per_scale, float scale_const,
+                         int64_t mtok, void* workspace, size_t ws_bytes, int ncol, const float* const* col_part,
+                         float* const* col_out0, float* const* col_out1, const int* col_nb, const int* col_C,
+                         const int* col_ld, int accumulate, void* stream) {
   if (!dy || !x || !dW || !N || !Kin || !ld_dy || !ld_x || !workspace) return VTX_ERR_NULL;
   bool any_scale = false;
   if (nprob >= 1 && nprob <= wgrad_glds_max_problems())
@@ -431,6 +454,7 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
     hp[i].dy = dy[i]; hp[i].x = x[i]; hp[i].out = dW[i]; hp[i].ksum_out = dbias ? dbias[i] : nullptr;
     hp[i].rowscale = rowscale ? rowscale[i] : nullptr; hp[i].ld_dy = ld_dy[i]; hp[i].ld_x = ld_x[i];
     hp[i].N = N[i]; hp[i].Kin = Kin[i];
+    hp[i].live_only = (live_only && hp[i].rowscale) ? live_only[i] : 0;
     hp[i].slab = w; w += (size_t)nz * N[i] * Kin[i];
     hp[i].ksum_part = w; w += (size_t)nz * N[i];
   }

@@ -30,7 +30,15 @@ struct GemmArgs {
   float kscale_const;       // > 0: every kscale value is 0 or this constant (rows are masked, the constant scales the accumulators)
   int kchunk;               // contraction length per grid.z slice (multiple of the LDS k-tile)
   float* ksum_out;          // TA only: [grid.z][M] fp32 = sum over the contraction of opA (bias gradient), or null
+  // Stochastic-depth compaction (round 3; LDS-DMA kernels with the wave-private epilogue only): the M logical rows are the
+  // samples of `perm` in order -- logical row r is row perm[r / map_T] * map_T + r % map_T of EVERY row-indexed operand
+  // (A, C, resid, aux_in, aux_out; rowscale is indexed by perm[r / map_T]).  The kept samples come first: rows [0, Mk) are
+  // computed, rows [Mk, M) belong to dropped samples and are copy-only (C = resid; only launched when there is a resid).
+  const int* perm;          // [samples] int32 or null (no map: logical row == row, Mk == M)
+  int map_T;                // rows per sample
+  int Mk;
 };
+__host__ __device__ inline void gemm_args_nomap(GemmArgs& a) { a.perm = nullptr; a.map_T = 1; a.Mk = a.M; }
 
 
 // Global operands of the epilogue, requested ahead of it (EpiOperands::load) -- by the LDS-DMA kernel before its main
@@ -162,6 +170,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st);
 bool gemm_glds_enabled();
 bool gemm_glds_ok(int N, int K);
+// mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE
+int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st);
 
 // LDS-DMA + transpose-read weight-gradient kernel (gemm_wgrad_glds.hip): bf16, N and Kin multiples of 8 and >= 64,
 // rowscale values restricted to {0, scale_const}.  Grouped: up to wgrad_glds_max_problems() weight gradients over the
@@ -172,6 +182,7 @@ struct WgradProbHost {
   const float* rowscale;
   int64_t ld_dy, ld_x;
   int N, Kin;
+  int live_only;      // 1: rowscale only says which samples' rows exist (dropped ones are skipped); dy already carries the scale
 };
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const);
 int wgrad_glds_resident();

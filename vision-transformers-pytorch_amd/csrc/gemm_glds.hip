@@ -156,6 +156,13 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
 // epilogue -- the phase trace (tools/probe/gemm_trace.hip) shows 1.4 us of a 10.8 us workgroup lifetime spent in the shared
 // staging passes, mostly waiting at their three barriers for the slowest wave.  Element values are those of
 // gemm_epilogue (same expression per element), so the two variants are bitwise interchangeable.
+// logical row -> row of the operands (GemmArgs::perm: stochastic-depth compaction; identity without a map)
+__device__ __forceinline__ int glds_orow(const GemmArgs& p, int row) {
+  if (p.perm == nullptr) return row;
+  const int s = row / p.map_T;
+  return p.perm[s] * p.map_T + (row - s * p.map_T);
+}
+
 template <int BM, int NWN> struct PvEpiOperands {
   static constexpr int WN = 128 / (16 * NWN);          // 16-column tiles per wave: 4 | 2
   static constexpr int VROW = 2 * WN;                  // 8-element vectors per staged row of the wave tile
@@ -164,12 +171,23 @@ template <int BM, int NWN> struct PvEpiOperands {
   float rsc[2 * NIT];
   Vec8<bf16> ein[2 * NIT];
   // (row, col) of the 8-vector this lane stores in iteration it of pass i; clamped in range, `ok` says whether it exists
+  // `row` is the row of the operands (mapped: GemmArgs::perm); `srow` the sample whose DropPath scale applies
   static __device__ __forceinline__ bool where(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane, int i, int it,
-                                               int& row, int& col) {
+                                               int& row, int& col, int* srow = nullptr) {
     const int v = lane + 64 * it, lr = v / VROW, cv = v - lr * VROW;
-    row = m0 + wm * 32 + i * 16 + lr;
+    const int lrow = m0 + wm * 32 + i * 16 + lr;
     col = n0 + wn * (16 * WN) + cv * 8;
-    return row < p.M && col < p.N;
+    const bool ok = lrow < p.M && col < p.N;
+    if (p.perm == nullptr) {
+      row = lrow;
+      if (srow) *srow = lrow / p.rows_per_scale;
+    } else {
+      const int lc = ok ? lrow : 0;
+      const int s = lc / p.map_T, smp = p.perm[s];
+      row = smp * p.map_T + (lc - s * p.map_T);
+      if (srow) *srow = smp;
+    }
+    return ok;
   }
   // bias per accumulator column and the DropPath scale per stored row: small, L2-resident; requested before the first DMA
   __device__ __forceinline__ void load_small(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
@@ -181,10 +199,10 @@ template <int BM, int NWN> struct PvEpiOperands {
     }
 #pragma unroll
     for (int q = 0; q < 2 * NIT; ++q) {
-      int row, col;
-      const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col);
+      int row, col, srow;
+      const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col, &srow);
       ein[q] = vec8_zero<bf16>();
-      rsc[q] = (ok && p.rowscale) ? p.rowscale[row / p.rows_per_scale] : 1.f;
+      rsc[q] = (ok && p.rowscale) ? p.rowscale[srow] : 1.f;
     }
   }
   // the residual / z vectors: HBM misses.  Loads return in order, so requested before the DMA pieces they hold back the
@@ -244,6 +262,22 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
+  const int live_rows = p.perm != nullptr ? p.Mk : p.M;
+  if (m0 >= live_rows) {
+    // copy-only tile of a mapped launch: the rows of DROPPED samples (DropPath scale 0): C = resid, no operands touched
+    const bf16* __restrict__ rs = (const bf16*)p.resid;
+    bf16* __restrict__ cd = (bf16*)p.C;
+    if (rs != nullptr)
+      for (int v = threadIdx.x; v < BM * 16; v += 512) {
+        const int lrow = m0 + (v >> 4), col = n0 + (v & 15) * 8;
+        if (lrow < p.M && col < p.N) {
+          const int64_t off = (int64_t)glds_orow(p, lrow) * p.ldc + col;
+          store8<bf16>(cd + off, load8<bf16>(rs + off));
+        }
+      }
+    return;
+  }
+
   VTX_TRACE(0);
   PvEpiOperands<BM, NWN> eo;
   eo.load_small(p, m0, n0, wm, wn, lane);
@@ -258,7 +292,9 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int r = wave * (BM / NWV) + j * PR + lr;
-    asrc[j] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
+    // rows past the computed ones (past M; past Mk in a tile that straddles the kept / dropped boundary of a mapped
+    // launch) are never stored or are scaled by an exact 0: any valid, FINITE row will do -- the last computed one
+    asrc[j] = A + (int64_t)glds_orow(p, min(m0 + r, live_rows - 1)) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
@@ -471,6 +507,14 @@ template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {
 
 bool gemm_glds_enabled() {
   return vtx_opt(VTX_OPT_GEMM_GLDS) != 0;
+}
+
+int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st) {
+  if (a.perm == nullptr || a.map_T <= 0 || a.Mk <= 0 || a.Mk > a.M) return VTX_ERR_SHAPE;
+  if (a.N % 128 != 0 || a.K % 64 != 0 || vtx_opt(VTX_OPT_GLDS_EPI) != 1) return VTX_ERR_SHAPE;   // wave-private epilogue kernels only
+  if (a.rowscale != nullptr && a.rows_per_scale != a.map_T) return VTX_ERR_SHAPE;
+  if (a.Mk < a.M && a.resid == nullptr) return VTX_ERR_SHAPE;       // copy-only rows need something to copy
+  return glds_launch_bn<128>(a, st);
 }
 
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st) {

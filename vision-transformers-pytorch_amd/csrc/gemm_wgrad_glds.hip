@@ -45,6 +45,7 @@ struct WgradProb {
   int N, Kin;
   int ntk;            // Kin tiles (128 wide); N tiles = ceil(N / 128)
   int tile0;          // first tile id of this problem inside a slice
+  int live_only;      // rowscale marks live samples only; the constant is NOT applied (dy already carries it)
 };
 
 struct WgradArgs {
@@ -242,9 +243,12 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     if (kt < nfull) {
 #pragma unroll
       for (int j = 0; j < IPW; ++j) {
+        // BOTH operands of a dropped sample's rows come from the zero row: with stochastic-depth compaction the rows of
+        // dropped samples are never written (0 x garbage could be 0 x NaN)
         const bf16* srca = nlive[j] ? pa[j] : pz[j];
+        const bf16* srcb = nlive[j] ? pb[j] : pz[j];
         __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)pb[j], (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
         pa[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pa[j]) + inca[j]);
         pb[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pb[j]) + incb[j]);
       }
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
         const int tok = mbeg + kt * BKT + r;
         const int qq = pslot ^ wg_swz(r);
         bool live = tok < mend;
-        const bf16* srcb = (live && k0 + (qq << 3) < Kin) ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
         if (live && has_rs) live = live_tab[tok / rps - s0] != 0;
+        const bf16* srcb = (live && k0 + (qq << 3) < Kin) ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
         const bf16* srca = (live && n0 + (qq << 3) < N) ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : pz[j];
         __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   }
 
   if (WG_ABLATE & 4) { if (acc[0][0][0] == 12345.678f) q.out[threadIdx.x] = acc[1][3][2]; return; }
-  const float sc = rowscale != nullptr ? p.scale_const : 1.f;
+  const float sc = (rowscale != nullptr && !q.live_only) ? p.scale_const : 1.f;
   const bool split = p.nz > 1;                                // wave-uniform (kernel argument)
   if (have_ksum) {
     float* red = reinterpret_cast<float*>(wg_smem);         // [NT / 16 row groups][128 cols]
@@ -475,7 +479,7 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
     q.dy = (const bf16*)hp[i].dy; q.x = (const bf16*)hp[i].x; q.slab = hp[i].slab; q.out = hp[i].out;
     q.ksum_part = hp[i].ksum_part; q.ksum_out = hp[i].ksum_out; q.rowscale = hp[i].rowscale;
     q.ld_dy = hp[i].ld_dy; q.ld_x = hp[i].ld_x; q.N = hp[i].N; q.Kin = hp[i].Kin;
-    q.ntk = (hp[i].Kin + 127) / 128; q.tile0 = t0;
+    q.ntk = (hp[i].Kin + 127) / 128; q.tile0 = t0; q.live_only = hp[i].live_only;
     t0 += wgrad_glds_tiles(hp[i].N, hp[i].Kin);
     any_scale = any_scale || hp[i].rowscale != nullptr;
   }

@@ -41,6 +41,19 @@ int layer_dgrad(int dtype, const void* dy, const void* w, const void* wt, void* 
                   aux_in, act, st);
 }
 
+// One GEMM of a compacted branch (GemmArgs::perm): C[rows of perm order] = epi(A W^T) on the wave-private LDS-DMA kernel
+int layer_gemm_mapped(const void* A, const void* W, void* Cc, int M, int Mk, int N, int K, const float* bias, const void* resid,
+                      const float* rowscale, int T, void* aux_out, const void* aux_in, int act, const int* perm, void* st) {
+  GemmArgs a;
+  a.A = A; a.B = W; a.C = Cc; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
+  a.bias = bias; a.resid = resid; a.rowscale = rowscale; a.rows_per_scale = T; a.aux_out = aux_out; a.aux_in = aux_in;
+  a.act = act; a.kscale = nullptr; a.k_per_scale = 1; a.kscale_const = 0.f; a.kchunk = ((K + 127) / 128) * 128;
+  a.ksum_out = nullptr; a.perm = perm; a.map_T = T; a.Mk = Mk;
+  if (!A || !W || !Cc || !perm) return VTX_ERR_NULL;
+  if ((act == 2 || act == 4) && !aux_in) return VTX_ERR_NULL;
+  return gemm_glds_launch_mapped(a, (hipStream_t)st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -52,6 +65,30 @@ int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
   if (!a || !a->x || !a->y || !a->ln1 || !a->qkv || !a->o || !a->x1 || !a->ln2 || !a->h) return VTX_ERR_NULL;
   if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0) return VTX_ERR_SHAPE;
   const int dt = a->dtype, M = (int)a->M, C = a->C, ff = a->ff;
+  if (a->perm1 != nullptr || a->perm2 != nullptr) {
+    // ---- stochastic-depth compaction: each branch runs over ITS kept samples only (perm?: kept first, Bk? of them); the
+    //      rows of dropped samples pass through (x1 = x, y = x1: copy-only tiles of the residual GEMMs), their saved
+    //      activations are never written and never read.  bf16, window attention, N % 128 == 0, K % 64 == 0.
+    const int T = a->rows_per_scale;
+    if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || a->attn_kind != VTX_ATTN_WINDOW || T <= 0 || M != a->B * T ||
+        a->Bk1 <= 0 || a->Bk1 > a->B || a->Bk2 <= 0 || a->Bk2 > a->B)
+      return VTX_ERR_SHAPE;
+    const int M1 = a->Bk1 * T, M2 = a->Bk2 * T;
+    int rc = vtx_layernorm_fwd_mapped(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, M1, C, a->eps, dt, a->perm1, T, stream);
+    if (rc) return rc;
+    rc = layer_gemm_mapped(a->ln1, a->wq, a->qkv, M1, M1, 3 * C, C, a->bq, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream);
+    if (rc) return rc;
+    rc = vtx_wattn_fwd_mapped(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W,
+                              a->win, a->shift, dt, stream);
+    if (rc) return rc;
+    rc = layer_gemm_mapped(a->o, a->wo, a->x1, M, M1, C, C, a->bo, a->x, a->s1, T, nullptr, nullptr, 0, a->perm1, stream);
+    if (rc) return rc;
+    rc = vtx_layernorm_fwd_mapped(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, M2, C, a->eps, dt, a->perm2, T, stream);
+    if (rc) return rc;
+    rc = layer_gemm_mapped(a->ln2, a->w1, a->h, M2, M2, ff, C, a->b1, nullptr, nullptr, T, a->z, nullptr, 1, a->perm2, stream);
+    if (rc) return rc;
+    return layer_gemm_mapped(a->h, a->w2, a->y, M, M2, C, ff, a->b2, a->x1, a->s2, T, nullptr, nullptr, 0, a->perm2, stream);
+  }
   int rc = vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream);
   if (rc) return rc;
   rc = vtx_gemm(0, dt, a->ln1, a->wq, a->qkv, M, 3 * C, C, C, C, 3 * C, a->bq, nullptr, nullptr, 1, nullptr, nullptr, 0, stream);
@@ -80,31 +117,59 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
   if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0) return VTX_ERR_SHAPE;
   const int dt = a->dtype, C = a->C, ff = a->ff, rps = a->rows_per_scale;
   const int64_t M = a->M;
-  // ---- MLP branch
-  int rc = layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream);
-  if (rc) return rc;
-  rc = layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream);
-  if (rc) return rc;
-  rc = vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
-                         M, C, dt, 0, 0, 0, stream);
-  if (rc) return rc;
-  // ---- attention branch
-  rc = layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream);
-  if (rc) return rc;
-  if (a->attn_kind == VTX_ATTN_WINDOW)
-    rc = vtx_wattn_bwd(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, nullptr, a->attn_ws, a->attn_ws_bytes,
-                       a->inv_cells, a->inv_count, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
-  else if (a->attn_kind == VTX_ATTN_GLOBAL)
-    rc = vtx_attention_bwd(a->qkv, a->o, a->dout, a->lse, nullptr, nullptr, nullptr, nullptr, a->dqkv, nullptr, 0, a->attn_ws,
-                           a->attn_ws_bytes, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream);
-  else
-    return VTX_ERR_SHAPE;
-  if (rc) return rc;
-  rc = layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream);
-  if (rc) return rc;
-  rc = vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
-                         M, C, dt, 0, 0, 0, stream);
-  if (rc) return rc;
+  const bool mapped = a->perm1 != nullptr || a->perm2 != nullptr;
+  if (mapped) {
+    const int T = rps;
+    if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || a->attn_kind != VTX_ATTN_WINDOW || T <= 0 || M != (int64_t)a->B * T ||
+        a->Bk1 <= 0 || a->Bk1 > a->B || a->Bk2 <= 0 || a->Bk2 > a->B || !a->w2t || !a->w1t || !a->wot || !a->wqt ||
+        !a->s1 || !a->s2)
+      return VTX_ERR_SHAPE;
+    const int M1 = a->Bk1 * T, M2 = a->Bk2 * T;
+    int rc = layer_gemm_mapped(a->dy, a->w2t, a->dz, M2, M2, ff, C, nullptr, nullptr, a->s2, T, nullptr, a->z, 2, a->perm2, stream);
+    if (rc) return rc;
+    rc = layer_gemm_mapped(a->dz, a->w1t, a->dln2, M2, M2, C, ff, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm2, stream);
+    if (rc) return rc;
+    rc = vtx_layernorm_bwd_mapped(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, a->ln2_ws, a->ln_ws_bytes, M, M2, C, dt,
+                                  a->perm2, T, stream);
+    if (rc) return rc;
+    rc = layer_gemm_mapped(a->dx1, a->wot, a->dout, M1, M1, C, C, nullptr, nullptr, a->s1, T, nullptr, nullptr, 0, a->perm1, stream);
+    if (rc) return rc;
+    rc = vtx_wattn_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, a->attn_ws, a->attn_ws_bytes,
+                              a->inv_cells, a->inv_count, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+    if (rc) return rc;
+    rc = layer_gemm_mapped(a->dqkv, a->wqt, a->dln1, M1, M1, C, 3 * C, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream);
+    if (rc) return rc;
+    rc = vtx_layernorm_bwd_mapped(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, a->ln1_ws, a->ln_ws_bytes, M, M1, C, dt,
+                                  a->perm1, T, stream);
+    if (rc) return rc;
+  }
+  if (!mapped) {
+    // ---- MLP branch
+    int rc = layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream);
+    if (rc) return rc;
+    rc = layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream);
+    if (rc) return rc;
+    rc = vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
+                           M, C, dt, 0, 0, 0, stream);
+    if (rc) return rc;
+    // ---- attention branch
+    rc = layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream);
+    if (rc) return rc;
+    if (a->attn_kind == VTX_ATTN_WINDOW)
+      rc = vtx_wattn_bwd(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, nullptr, a->attn_ws, a->attn_ws_bytes,
+                         a->inv_cells, a->inv_count, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+    else if (a->attn_kind == VTX_ATTN_GLOBAL)
+      rc = vtx_attention_bwd(a->qkv, a->o, a->dout, a->lse, nullptr, nullptr, nullptr, nullptr, a->dqkv, nullptr, 0, a->attn_ws,
+                             a->attn_ws_bytes, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream);
+    else
+      return VTX_ERR_SHAPE;
+    if (rc) return rc;
+    rc = layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream);
+    if (rc) return rc;
+    rc = vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
+                           M, C, dt, 0, 0, 0, stream);
+    if (rc) return rc;
+  }
   // ---- the four weight gradients + the layer's column reductions: one grouped launch + one reduce launch, on the side
   //      stream when given (fork: it waits for everything enqueued on `stream` so far; the caller joins once per backward)
   void* ws = stream;
@@ -121,18 +186,21 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
   float* dbs[4] = {a->db2, a->db1, a->dbo, a->dbq};
   const int Ns[4] = {C, ff, C, 3 * C}, Ks[4] = {ff, C, C, C};
   const int64_t ldy[4] = {C, ff, C, 3 * C}, ldx[4] = {ff, C, C, C};
-  const float* rs[4] = {a->s2, nullptr, a->s1, nullptr};
+  // compacted: dz / dqkv rows of dropped samples were never written -- every problem skips them (rowscale as liveness); the
+  // DropPath constant is applied where dy does not carry it yet (fc2: dy, proj: dx1), not on dz / dqkv (live_only)
+  const float* rs[4] = {a->s2, mapped ? a->s2 : nullptr, a->s1, mapped ? a->s1 : nullptr};
+  const int live_only[4] = {0, 1, 0, 1};
   const int ncol = a->attn_kind == VTX_ATTN_WINDOW ? 3 : 2;
   const float* cpart[4] = {(const float*)a->ln2_ws, (const float*)a->ln1_ws, (const float*)a->attn_ws, nullptr};
   float* cout0[4] = {a->dg2, a->dg1, a->drel, nullptr};
   float* cout1[4] = {a->dbe2, a->dbe1, nullptr, nullptr};
   const int ntab = (2 * a->win - 1) * (2 * a->win - 1);
   const int cnb[4] = {vtx_layernorm_bwd_blocks(M, C), vtx_layernorm_bwd_blocks(M, C),
-                      ncol == 3 ? vtx_wattn_bwd_parts(a->B, a->nH, a->H, a->W, a->win) : 0, 0};
+                      ncol == 3 ? vtx_wattn_bwd_parts(mapped ? a->Bk1 : a->B, a->nH, a->H, a->W, a->win) : 0, 0};
   const int cC[4] = {C, C, ncol == 3 ? ntab * a->nH : 0, 0};
   const int cld[4] = {2 * C, 2 * C, ncol == 3 ? vtx_wattn_bwd_part_ld(a->nH) : 0, 0};
-  return vtx_wgrad_group(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, rps, a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes,
-                         ncol, cpart, cout0, cout1, cnb, cC, cld, a->accumulate, ws);
+  return vtx_wgrad_group_live(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, mapped ? live_only : nullptr, rps, a->scale_const, M,
+                              a->wgrad_ws, a->wgrad_ws_bytes, ncol, cpart, cout0, cout1, cnb, cC, cld, a->accumulate, ws);
 }
 
 }  // extern "C"

@@ -13,7 +13,18 @@
 struct LnAddr {
   int merge;   // 0: x is [rows, C];  1: x is (B, H, W, Cs) with C = 4*Cs and row = (b, i, j) of the H/2 x W/2 grid
   int H, W, Cs;
+  // stochastic-depth compaction (round 3, plain layout only): logical row r is row perm[r / T] * T + r % T of EVERY
+  // row-indexed tensor; the forward runs over the kept samples' rows only; the backward runs over all rows, [live, rows)
+  // being the rows of dropped samples whose gradient is the residual stream's alone (dx = dres)
+  const int* perm;
+  int T;
+  int64_t live;
 };
+__device__ __forceinline__ int64_t ln_orow(const LnAddr& a, int64_t row) {
+  if (a.perm == nullptr) return row;
+  const int64_t s = row / a.T;
+  return (int64_t)a.perm[s] * a.T + (row - s * a.T);
+}
 
 __device__ __forceinline__ int64_t ln_src_offset(const LnAddr& a, int64_t row, int col, int C) {
   if (!a.merge) return row * (int64_t)C + col;
@@ -55,14 +66,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int64_t stride = (int64_t)gridDim.x * GPB;
   for (int64_t row0 = (int64_t)blockIdx.x * GPB + grp; row0 < rows; row0 += stride * ROWS) {
     float xv[ROWS][NV][8];
+    int64_t orow[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const int64_t row = row0 + rr * stride;
+      orow[rr] = row < rows ? ln_orow(addr, row) : 0;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int v = lig + k * G;
         if (v < nvec && row < rows) {
-          Vec8<T> t = load8<T>(x + ln_src_offset(addr, row, v * 8, C));
+          Vec8<T> t = load8<T>(x + ln_src_offset(addr, orow[rr], v * 8, C));
 #pragma unroll
           for (int e = 0; e < 8; ++e) xv[rr][k][e] = t.get(e);
         } else {
@@ -98,10 +111,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
           Vec8<T> o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o.set(e, (xv[rr][k][e] - mu) * rs * gm[k][e] + bt[k][e]);
-          store8<T>(y + row * (int64_t)C + v * 8, o);
+          store8<T>(y + orow[rr] * (int64_t)C + v * 8, o);
         }
       }
-      if (lig == 0) { mean[row] = mu; rstd[row] = rs; }
+      if (lig == 0) { mean[orow[rr]] = mu; rstd[orow[rr]] = rs; }
     }
   }
 }
@@ -132,7 +145,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int e = 0; e < 8; ++e) { dg[k][e] = 0.f; db[k][e] = 0.f; }
   }
   const float invC = 1.f / (float)C;
-  for (int64_t row = (int64_t)blockIdx.x * GPB + grp; row < rows; row += (int64_t)gridDim.x * GPB) {
+  for (int64_t lrow = (int64_t)blockIdx.x * GPB + grp; lrow < rows; lrow += (int64_t)gridDim.x * GPB) {
+    const int64_t row = ln_orow(addr, lrow);
+    if (addr.perm != nullptr && lrow >= addr.live) {           // a dropped sample's row: dx = dres (uniform within the group)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = lig + k * G;
+        if (v < nvec) {
+          const int64_t off = row * (int64_t)C + v * 8;
+          store8<T>(dx + off, dres != nullptr ? load8<T>(dres + off) : vec8_zero<T>());
+        }
+      }
+      continue;
+    }
     const float mu = mean[row], rs = rstd[row];
     float xh[NV][8], gv[NV][8];
     float s1 = 0.f, s2 = 0.f;
@@ -249,6 +274,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
 
 static int ln_make_addr(LnAddr& a, int64_t rows, int C, int merge, int H, int W) {
   a.merge = merge; a.H = H; a.W = W; a.Cs = C / 4;
+  a.perm = nullptr; a.T = 1; a.live = rows;
   if (C <= 0 || (C & 7)) return VTX_ERR_SHAPE;
   if (merge) {
     if ((C & 31) || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return VTX_ERR_SHAPE;
@@ -266,6 +292,23 @@ int vtx_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
   LnAddr a;
   int rc = ln_make_addr(a, rows, C, merge, H, W);
   if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16) LN_DISPATCH(ln_fwd_launch, bf16, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
+  if (dtype == VTX_F32) LN_DISPATCH(ln_fwd_launch, float, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
+  return VTX_ERR_DTYPE;
+}
+
+/* The same over the KEPT samples of a stochastic-depth branch only: logical row r (r < rows = kept samples x T) is row
+ * perm[r / T] * T + r % T of x, y, mean and rstd (perm [samples] int32 on the device, kept samples first). */
+int vtx_layernorm_fwd_mapped(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                             int64_t rows, int C, float eps, int dtype, const int* perm, int T, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || !perm) return VTX_ERR_NULL;
+  if (rows <= 0) return VTX_OK;
+  if (T <= 0 || rows % T) return VTX_ERR_SHAPE;
+  LnAddr a;
+  int rc = ln_make_addr(a, rows, C, 0, 0, 0);
+  if (rc) return rc;
+  a.perm = perm; a.T = T;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VTX_BF16) LN_DISPATCH(ln_fwd_launch, bf16, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
   if (dtype == VTX_F32) LN_DISPATCH(ln_fwd_launch, float, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
@@ -304,6 +347,29 @@ int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
     LN_DISPATCH(ln_bwd_launch, bf16, 2, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
   if (dtype == VTX_F32)
     LN_DISPATCH(ln_bwd_launch, float, 2, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, ws, rows, C, a, st);
+  return VTX_ERR_DTYPE;
+}
+
+/* Backward over a stochastic-depth branch: all `rows` logical rows are visited in perm order (see _fwd_mapped); rows
+ * [0, live) are the kept samples' (dx = dres + LN'(dy)), rows [live, rows) the dropped samples' (dx = dres: dy, mean, rstd are
+ * never read there).  Partials stay in the workspace (deferred reduce, vtx_layernorm_bwd_blocks(rows, C) rows). */
+int vtx_layernorm_bwd_mapped(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                             const void* dres, void* dx, void* workspace, size_t ws_bytes, int64_t rows, int64_t live, int C,
+                             int dtype, const int* perm, int T, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || !workspace || !perm || !dres) return VTX_ERR_NULL;
+  if (ws_bytes < vtx_layernorm_bwd_workspace(rows, C)) return VTX_ERR_WORKSPACE;
+  if (T <= 0 || rows <= 0 || rows % T || live < 0 || live > rows || live % T) return VTX_ERR_SHAPE;
+  LnAddr a;
+  int rc = ln_make_addr(a, rows, C, 0, 0, 0);
+  if (rc) return rc;
+  a.perm = perm; a.T = T; a.live = live;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  float* nul = nullptr;
+  if (dtype == VTX_BF16)
+    LN_DISPATCH(ln_bwd_launch, bf16, 2, dy, x, mean, rstd, gamma, dres, dx, nul, nul, ws, rows, C, a, st);
+  if (dtype == VTX_F32)
+    LN_DISPATCH(ln_bwd_launch, float, 2, dy, x, mean, rstd, gamma, dres, dx, nul, nul, ws, rows, C, a, st);
   return VTX_ERR_DTYPE;
 }
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class VtxError(RuntimeError):
@@ -27,7 +27,7 @@ class LayerFwd(ctypes.Structure):
                 [(n, _I) for n in ("C", "ff", "nH", "L", "B", "rows_per_scale", "H", "W", "win", "shift")] + [("eps", _F)] +
                 [(n, _P) for n in ("x", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "wq", "wo", "w1", "w2", "bq", "bo", "b1", "b2",
                                    "rel_pos", "pos", "region", "s1", "s2", "ln1", "qkv", "o", "x1", "ln2", "z", "h", "y",
-                                   "mean1", "rstd1", "mean2", "rstd2", "lse")])
+                                   "mean1", "rstd1", "mean2", "rstd2", "lse", "perm1", "perm2")] + [("Bk1", _I), ("Bk2", _I)])
 
 
 class LayerBwd(ctypes.Structure):
@@ -40,7 +40,8 @@ class LayerBwd(ctypes.Structure):
                                    "region", "inv_cells", "s1", "s2", "dz", "dln2", "dx1", "dout", "dqkv", "dln1", "dx",
                                    "ln1_ws", "ln2_ws", "attn_ws", "wgrad_ws")] +
                 [(n, _Z) for n in ("ln_ws_bytes", "attn_ws_bytes", "wgrad_ws_bytes")] +
-                [(n, _P) for n in ("dWq", "dbq", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "drel")])
+                [(n, _P) for n in ("dWq", "dbq", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "drel",
+                                   "perm1", "perm2")] + [("Bk1", _I), ("Bk2", _I)])
 
 
 ATTN_WINDOW, ATTN_GLOBAL = 1, 2
@@ -50,6 +51,12 @@ _SIGNATURES = {
     "vtx_layer_fwd": (c_int, [c_void_p, c_void_p]),
     "vtx_layer_bwd": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vtx_layer_desc_bytes": (c_int, [c_int]),
+    "vtx_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
+    "vtx_layernorm_bwd_mapped": (c_int, [c_void_p] * 8 + [c_size_t, c_int64, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "vtx_wattn_fwd_mapped": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
+    "vtx_wattn_bwd_mapped": (c_int, [c_void_p] * 9 + [c_size_t, c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "vtx_wgrad_group_live": (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_int, c_float, c_int64, c_void_p, c_size_t, c_int] +
+                             [c_void_p] * 6 + [c_int, c_void_p]),
     "vtx_strerror": (c_char_p, [c_int]),
     "vtx_abi_version": (c_int, []),
     "vtx_option_count": (c_int, []),

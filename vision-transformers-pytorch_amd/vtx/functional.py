@@ -15,7 +15,7 @@ import threading
 import torch
 from torch.autograd import Function
 
-from . import _lib, ops
+from . import _lib, ops, options
 from .ops import ACT_DGELU, ACT_DSILU, ACT_GELU, ACT_SILU, VtxError
 
 
@@ -385,6 +385,19 @@ def _layer_plan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c):
     return pl
 
 
+def _layer_perms(kind, T, C, ff, s1, s2):
+    """((perm1, Bk1), (perm2, Bk2)) when this layer can run its two branches over their kept samples only (stochastic-depth
+    compaction, csrc/layer.hip): the DropPath scales carry the host-drawn sample orders (vtx.nn.drop_path_scope), bf16,
+    window attention, and every GEMM of the layer on the wave-private LDS-DMA kernel (N % 128 == 0, K % 64 == 0)."""
+    p1 = getattr(s1, "_vtx_perm", None) if s1 is not None else None
+    p2 = getattr(s2, "_vtx_perm", None) if s2 is not None else None
+    if p1 is None or p2 is None or kind != _lib.ATTN_WINDOW or T != torch.bfloat16 or C % 128 or ff % 128:
+        return None
+    if options.get("GLDS_EPI") != 1 or not options.get("GEMM_GLDS"):
+        return None
+    return p1, p2
+
+
 def _copy_desc(d):
     return type(d).from_buffer_copy(d)
 
@@ -665,6 +678,10 @@ class TransformerLayerFn(Function):
         if kind == _lib.ATTN_WINDOW:
             d.rel_pos, d.pos, d.region = rel_pos.data_ptr(), meta.pos.data_ptr(), _dp(meta.region)
         d.s1, d.s2 = _dp(s1), _dp(s2)
+        ctx.perms = _layer_perms(kind, T, C, ff, s1, s2)
+        if ctx.perms is not None:
+            (p1, d.Bk1), (p2, d.Bk2) = ctx.perms
+            d.perm1, d.perm2 = p1.data_ptr(), p2.data_ptr()
         d.ln1, d.qkv, d.o, d.x1, d.ln2, d.h = (base + fo["ln1"], base + fo["qkv"], base + fo["o"], base + fo["x1"],
                                                base + fo["ln2"], base + fo["h"])
         d.z = base + fo["z"] if want_z else None
@@ -726,6 +743,9 @@ class TransformerLayerFn(Function):
             d.inv_cells, d.inv_count = inv_cells.data_ptr(), inv_count
             d.drel = drel.data_ptr()
         d.s1, d.s2 = _dp(s1), _dp(s2)
+        if ctx.perms is not None:
+            (p1, d.Bk1), (p2, d.Bk2) = ctx.perms
+            d.perm1, d.perm2 = p1.data_ptr(), p2.data_ptr()
         d.dz, d.dln2, d.dx1, d.dout, d.dqkv, d.dln1 = (sb + bo["dz"], sb + bo["dln2"], sb + bo["dx1"], sb + bo["dout"],
                                                        sb + bo["dqkv"], sb + bo["dln1"])
         d.ln1_ws, d.ln2_ws, d.wgrad_ws = sb + bo["ln1_ws"], sb + bo["ln2_ws"], sb + bo["wgrad_ws"]
@@ -737,7 +757,7 @@ class TransformerLayerFn(Function):
             if st is None:
                 st = _side_states[dev] = _SideState(dev)
             side = st.stream.cuda_stream
-            st.keep.append((scratch, buf, dy, x, s1, s2, ctx.wp))     # what the side stream still reads after this returns
+            st.keep.append((scratch, buf, dy, x, s1, s2, ctx.wp, ctx.perms))     # what the side stream still reads after this returns
             st.pending = True
         _lib.check(_lib.load().vtx_layer_bwd(ctypes.byref(d), ops._stream(), side), "vtx_layer_bwd")
         if acc is not None:

@@ -5,6 +5,7 @@
 dtypes are exactly the reference's; only ``forward`` differs.
 """
 import contextlib
+import os
 import threading
 
 import torch
@@ -30,6 +31,9 @@ class LayerNorm(nn.LayerNorm):
 
 
 _dp = threading.local()
+# 1 (default): on a GPU the DropPath masks of a forward are drawn on the host so that the layers can skip dropped branches
+# (VTX_DP_COMPACT=0: drawn on the device as in rounds 1-2, every branch computed and scaled)
+_DP_HOST_DRAW = os.environ.get("VTX_DP_COMPACT", "1") != "0"
 
 
 @contextlib.contextmanager
@@ -42,7 +46,8 @@ def drop_path_scope(model, batch, device):
     draw over (2 x layers, batch), compared against each layer's keep probability and scaled by 1 / keep (3 launches);
     ``drop_path_scale`` then hands out rows in call order.  Same distribution, independent masks; the stream of torch's
     global generator is consumed differently from the reference's per-layer ``bernoulli_`` calls (outside a scope --
-    a layer used on its own -- the per-call draw below is used)."""
+    a layer used on its own -- the per-call draw below is used).  On a GPU the draw comes from torch's CPU generator
+    (``torch.manual_seed`` seeds both): see the comment at the draw."""
     if not model.training or getattr(_dp, "rows", None) is not None:
         yield
         return
@@ -54,13 +59,33 @@ def drop_path_scope(model, batch, device):
     if not ps:
         yield
         return
-    cache = model.__dict__.setdefault("_vtx_dp_keep", {})
-    key = (tuple(ps), str(device))
-    keep = cache.get(key)
-    if keep is None:
-        cache.clear()
-        keep = cache[key] = (1.0 - torch.tensor(ps, dtype=torch.float32)).view(-1, 1).to(device)
-    scale = (torch.rand(len(ps), batch, device=device) < keep).to(torch.float32) / keep
+    if device.type == "cuda" and _DP_HOST_DRAW:
+        # Drawn on the HOST (torch's CPU generator): the host then knows which samples every branch keeps, and the layer
+        # runs each branch over its kept samples only (stochastic-depth compaction, csrc/layer.hip) -- a dropped branch costs
+        # nothing instead of being computed and multiplied by 0.  One (2 x layers, batch) uniform draw; the scales and the
+        # per-branch sample orders (kept first) go up through pinned memory, asynchronously.
+        keep = 1.0 - torch.tensor(ps, dtype=torch.float32).view(-1, 1)
+        mask = torch.rand(len(ps), batch) < keep
+        host = (mask.to(torch.float32) / keep).pin_memory()
+        order = torch.argsort(~mask, dim=1, stable=True).to(torch.int32).pin_memory()     # kept samples first, ascending
+        nkeep = mask.sum(1).tolist()
+        scale = host.to(device, non_blocking=True)
+        perm = order.to(device, non_blocking=True)
+        rows = []
+        for k in range(len(ps)):
+            r = scale[k]
+            if 0 < nkeep[k]:
+                r._vtx_perm = (perm[k], int(nkeep[k]))
+            rows.append(r)
+        scale = rows
+    else:
+        cache = model.__dict__.setdefault("_vtx_dp_keep", {})
+        key = (tuple(ps), str(device))
+        keep = cache.get(key)
+        if keep is None:
+            cache.clear()
+            keep = cache[key] = (1.0 - torch.tensor(ps, dtype=torch.float32)).view(-1, 1).to(device)
+        scale = (torch.rand(len(ps), batch, device=device) < keep).to(torch.float32) / keep
     _dp.rows, _dp.ps, _dp.next, _dp.batch = scale, ps, 0, batch
     try:
         yield
