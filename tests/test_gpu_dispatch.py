@@ -295,6 +295,7 @@ def test_one_call_per_layer_is_bitwise_the_call_by_call_path(family, bf16, monke
     real = VF.TransformerLayerFn._forward_one_call
     monkeypatch.setattr(VF.TransformerLayerFn, "_forward_one_call", staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1]))
     monkeypatch.setattr(VF, "_LAYER_CALL", True)
+    monkeypatch.setattr(VF, "_layer_perms", lambda *a: None)     # (stochastic-depth compaction has its own test below)
     side = family != "vit_multicrop"
     out_a, g_a = _layer_io(model, x, bf16, 77, side)
     assert len(calls) >= (3 if bf16 else 0), "the one-call path did not run"     # (fp32: grouped weight gradients are bf16-only)
