@@ -205,6 +205,9 @@ class SwinTransformer(nn.Module):
         self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(1), Linear(dims[-1], n_class))
         self.apply(self.init_weights)
         self.set_dropout(None, drop_path)
+        # vtx.nn.drop_path_scope draws this model's DropPath masks on the host, so that the layers whose GEMMs allow it
+        # (dim and dim_ff multiples of 128: stages 3-4 of Swin-S) compute each branch for its kept samples only
+        self._vtx_dp_compaction = any(d % 128 == 0 and f % 128 == 0 for d, f in zip(dims, dim_ffs))
 
     init_weights = staticmethod(reset_transformer_parameters)
 

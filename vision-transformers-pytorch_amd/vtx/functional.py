@@ -351,7 +351,9 @@ class _LayerPlan:
         off[0] = 0
         self.ln_wsb = lib.vtx_layernorm_bwd_workspace(M, C)
         if kind == _lib.ATTN_WINDOW:
-            self.attn_wsb = lib.vtx_wattn_bwd_workspace(B, nH, H, W, win)
+            # (compaction runs the kernel over Bk <= B images; its persistent grid -- and with it the partial rows -- is
+            #  not monotonic in the image count)
+            self.attn_wsb = max(lib.vtx_wattn_bwd_workspace(b, nH, H, W, win) for b in range(1, B + 1))
         else:
             self.attn_wsb = lib.vtx_attention_bwd_workspace(B, L, nH, 0, 0, 0, 1) if L > 224 else 0
         n4 = ctypes.c_int * 4

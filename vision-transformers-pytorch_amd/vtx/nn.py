@@ -59,7 +59,7 @@ def drop_path_scope(model, batch, device):
     if not ps:
         yield
         return
-    if device.type == "cuda" and _DP_HOST_DRAW:
+    if device.type == "cuda" and _DP_HOST_DRAW and getattr(model, "_vtx_dp_compaction", False):
         # Drawn on the HOST (torch's CPU generator): the host then knows which samples every branch keeps, and the layer
         # runs each branch over its kept samples only (stochastic-depth compaction, csrc/layer.hip) -- a dropped branch costs
         # nothing instead of being computed and multiplied by 0.  One (2 x layers, batch) uniform draw; the scales and the
