@@ -124,14 +124,16 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
                     void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
                     float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, int accumulate,
                     void* stream);
-/* ... with a per-problem live_only flag (host array or NULL): rowscale[i] then only marks the samples whose rows exist (the
- * others are skipped, they may be unwritten memory) and the constant is not applied to that problem. */
-int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
-                         float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
-                         const float* const* rowscale, const int* live_only, int rows_per_scale, float scale_const,
-                         int64_t mtok, void* workspace, size_t ws_bytes, int ncol, const float* const* col_part,
-                         float* const* col_out0, float* const* col_out1, const int* col_nb, const int* col_C,
-                         const int* col_ld, int accumulate, void* stream);
+/* ... over the KEPT samples of stochastic-depth branches (csrc/layer.hip drives it): problem i with perm[i] != NULL
+ * contracts over the mtok_kept[i] tokens of its kept samples only, in perm[i] order (logical token t = row
+ * perm[i][t / rows_per_scale] * rows_per_scale + t % rows_per_scale of dy[i] and x[i]; dropped samples' rows are never read)
+ * and multiplies its result by scale[i]; rowscale[i] must be NULL for it.  perm == NULL: exactly vtx_wgrad_group. */
+int vtx_wgrad_group_mapped(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                           float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                           const float* const* rowscale, const int* const* perm, const int* mtok_kept, const float* scale,
+                           int rows_per_scale, float scale_const, int64_t mtok, void* workspace, size_t ws_bytes, int ncol,
+                           const float* const* col_part, float* const* col_out0, float* const* col_out1, const int* col_nb,
+                           const int* col_C, const int* col_ld, int accumulate, void* stream);
 /* split-K slices such a group runs with (>= 2: its outputs come from the reduce launch, so `accumulate` is available) */
 int vtx_wgrad_group_slices(int nprob, const int* N, const int* Kin, int64_t mtok);
 

@@ -360,7 +360,7 @@ int vtx_wgrad(int dtype, const void* dy, const void* x, float* dW, float* dbias,
   if (wgrad_glds_ok(dtype, N, Kin, rowscale, scale_const) && (rowscale == nullptr || a.kchunk / a.k_per_scale + 2 <= 512)) {
     WgradProbHost hp;
     hp.dy = dy; hp.x = x; hp.slab = (float*)workspace; hp.out = dW; hp.ksum_part = bias_part; hp.ksum_out = dbias;
-    hp.rowscale = rowscale; hp.ld_dy = ld_dy; hp.ld_x = ld_x; hp.N = N; hp.Kin = Kin; hp.live_only = 0;
+    hp.rowscale = rowscale; hp.ld_dy = ld_dy; hp.ld_x = ld_x; hp.N = N; hp.Kin = Kin; hp.live_only = 0; hp.perm = nullptr; hp.Mtok = (int)mtok; hp.scale = 1.f;
     rc = wgrad_glds_group_launch(1, &hp, mtok, a.k_per_scale, scale_const, nz, a.kchunk, st);
     if (rc || nz == 1) return rc;
     return reduce_slabs((const float*)workspace, bias_part, dW, dbias, N, Kin, nz, st);
@@ -408,12 +408,12 @@ size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_
   return (fl + 4) * sizeof(float);
 }
 
-int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
-                         float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
-                         const float* const* rowscale, const int* live_only, int rows_per_scale, float scale_const,
-                         int64_t mtok, void* workspace, size_t ws_bytes, int ncol, const float* const* col_part,
-                         float* const* col_out0, float* const* col_out1, const int* col_nb, const int* col_C,
-                         const int* col_ld, int accumulate, void* stream);
+int vtx_wgrad_group_mapped(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                           float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                           const float* const* rowscale, const int* const* perm, const int* mtok_kept, const float* scale,
+                           int rows_per_scale, float scale_const, int64_t mtok, void* workspace, size_t ws_bytes, int ncol,
+                           const float* const* col_part, float* const* col_out0, float* const* col_out1, const int* col_nb,
+                           const int* col_C, const int* col_ld, int accumulate, void* stream);
 
 int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
                     float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
@@ -421,20 +421,21 @@ int vtx_wgrad_group(int dtype, int nprob, const void* const* dy, const void* con
                     void* workspace, size_t ws_bytes, int ncol, const float* const* col_part, float* const* col_out0,
                     float* const* col_out1, const int* col_nb, const int* col_C, const int* col_ld, int accumulate,
                     void* stream) {
-  return vtx_wgrad_group_live(dtype, nprob, dy, x, dW, dbias, N, Kin, ld_dy, ld_x, rowscale, nullptr, rows_per_scale, scale_const,
-                              mtok, workspace, ws_bytes, ncol, col_part, col_out0, col_out1, col_nb, col_C, col_ld, accumulate,
-                              stream);
+  return vtx_wgrad_group_mapped(dtype, nprob, dy, x, dW, dbias, N, Kin, ld_dy, ld_x, rowscale, nullptr, nullptr, nullptr,
+                                rows_per_scale, scale_const, mtok, workspace, ws_bytes, ncol, col_part, col_out0, col_out1, col_nb,
+                                col_C, col_ld, accumulate, stream);
 }
 
-/* vtx_wgrad_group with a per-problem `live_only` flag (host array or NULL): rowscale[i] then only marks which samples' rows
- * exist -- dropped samples' rows are skipped (they may hold garbage: stochastic-depth compaction never writes them) while the
- * constant is NOT applied to that problem's result (its dy already carries the DropPath scale). */
-int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
-                         float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
-                         const float* const* rowscale, const int* live_only, int rows_per_scale, float scale_const,
-                         int64_t mtok, void* workspace, size_t ws_bytes, int ncol, const float* const* col_part,
-                         float* const* col_out0, float* const* col_out1, const int* col_nb, const int* col_C,
-                         const int* col_ld, int accumulate, void* stream) {
+/* vtx_wgrad_group over the KEPT samples of stochastic-depth branches: problem i with perm[i] != NULL contracts over the
+ * mtok_kept[i] tokens of its kept samples only, in perm[i] order (logical token t = row perm[i][t / rows_per_scale] *
+ * rows_per_scale + t % rows_per_scale of dy[i] and x[i]; dropped samples' rows are never read) and multiplies its result by
+ * scale[i]; rowscale[i] must be NULL for it.  perm == NULL: exactly vtx_wgrad_group.  Slices / workspace as for mtok tokens. */
+int vtx_wgrad_group_mapped(int dtype, int nprob, const void* const* dy, const void* const* x, float* const* dW,
+                           float* const* dbias, const int* N, const int* Kin, const int64_t* ld_dy, const int64_t* ld_x,
+                           const float* const* rowscale, const int* const* perm, const int* mtok_kept, const float* scale,
+                           int rows_per_scale, float scale_const, int64_t mtok, void* workspace, size_t ws_bytes, int ncol,
+                           const float* const* col_part, float* const* col_out0, float* const* col_out1, const int* col_nb,
+                           const int* col_C, const int* col_ld, int accumulate, void* stream) {
   if (!dy || !x || !dW || !N || !Kin || !ld_dy || !ld_x || !workspace) return VTX_ERR_NULL;
   bool any_scale = false;
   if (nprob >= 1 && nprob <= wgrad_glds_max_problems())
@@ -444,7 +445,6 @@ int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void
   hipStream_t st = (hipStream_t)stream;
   const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
   if (accumulate && nz < 2) return VTX_ERR_SHAPE;          // accumulation lives in the slab reduce (vtx_wgrad_group_slices tells)
-  const int kchunk = (int)chunk_of(mtok, nz);
   WgradProbHost hp[8];
   float* w = (float*)workspace;
   for (int i = 0; i < nprob; ++i) {
@@ -454,12 +454,22 @@ int vtx_wgrad_group_live(int dtype, int nprob, const void* const* dy, const void
     hp[i].dy = dy[i]; hp[i].x = x[i]; hp[i].out = dW[i]; hp[i].ksum_out = dbias ? dbias[i] : nullptr;
     hp[i].rowscale = rowscale ? rowscale[i] : nullptr; hp[i].ld_dy = ld_dy[i]; hp[i].ld_x = ld_x[i];
     hp[i].N = N[i]; hp[i].Kin = Kin[i];
-    hp[i].live_only = (live_only && hp[i].rowscale) ? live_only[i] : 0;
+    hp[i].live_only = 0;
+    hp[i].perm = perm ? perm[i] : nullptr; hp[i].Mtok = (int)mtok; hp[i].scale = 1.f;
+    if (hp[i].perm) {
+      if (hp[i].rowscale || !mtok_kept || !scale || mtok_kept[i] <= 0 || mtok_kept[i] > mtok || rows_per_scale <= 0 ||
+          mtok_kept[i] % rows_per_scale)
+        return VTX_ERR_SHAPE;
+      hp[i].Mtok = mtok_kept[i]; hp[i].scale = scale[i];
+    }
     hp[i].slab = w; w += (size_t)nz * N[i] * Kin[i];
     hp[i].ksum_part = w; w += (size_t)nz * N[i];
   }
   if (ncol < 0 || ncol > 4 || (ncol > 0 && (!col_part || !col_out0 || !col_nb || !col_C || !col_ld))) return VTX_ERR_SHAPE;
-  int rc = wgrad_glds_group_launch(nprob, hp, mtok, rows_per_scale, scale_const, nz, kchunk, st);
+  int64_t mmax = 0;                                         // (mapped problems contract over their kept tokens only)
+  for (int i = 0; i < nprob; ++i) mmax = hp[i].Mtok > mmax ? hp[i].Mtok : mmax;
+  const int kchunk = (int)chunk_of(mmax, nz);
+  int rc = wgrad_glds_group_launch(nprob, hp, mmax, rows_per_scale, scale_const, nz, kchunk, st);
   if (rc || (nz == 1 && ncol == 0)) return rc;
   // ONE reduction launch behind the group: all weight and bias slabs (kernel boundary = visibility: the slabs were written
   // with plain stores) and the layer's deferred column reductions (LayerNorm dgamma / dbeta, rel_pos gradient)

@@ -183,6 +183,9 @@ struct WgradProbHost {
   int64_t ld_dy, ld_x;
   int N, Kin;
   int live_only;      // 1: rowscale only says which samples' rows exist (dropped ones are skipped); dy already carries the scale
+  const int* perm;    // stochastic-depth compaction: contract over the Mtok tokens of the kept samples only, in perm order
+  int Mtok;
+  float scale;        // accumulator scale of a mapped problem
 };
 bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale_const);
 int wgrad_glds_resident();

@@ -46,6 +46,11 @@ struct WgradProb {
   int ntk;            // Kin tiles (128 wide); N tiles = ceil(N / 128)
   int tile0;          // first tile id of this problem inside a slice
   int live_only;      // rowscale marks live samples only; the constant is NOT applied (dy already carries it)
+  // stochastic-depth compaction: the contraction runs over the Mtok tokens of the KEPT samples only, in the order of `perm`
+  // (logical token t is row perm[t / rps] * rps + t % rps of dy and x); no liveness then: every token of the loop is live
+  const int* perm;    // [samples] int32 or null
+  int Mtok;           // tokens of this problem (== WgradArgs::M without a map)
+  float scale;        // applied to the accumulators of a mapped problem (the DropPath constant, or 1)
 };
 
 struct WgradArgs {
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   // [NS][A | B] ring, then the DropPath liveness table
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
   unsigned char* live_tab = wg_smem + RING;
+  int* perm_tab = reinterpret_cast<int*>(wg_smem + RING + WG_MAXSAMPLES);   // [WG_MAXSAMPLES] rows-of-sample bases (mapped)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -187,11 +193,19 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   const int64_t ld_dy = q.ld_dy, ld_x = q.ld_x;
   const float* rowscale = q.rowscale;
   const int mbeg = tz * p.kchunk;
-  const int mend = min(p.M, mbeg + p.kchunk);
+  const int mend = min(q.Mtok, mbeg + p.kchunk);
   const int nkt = mend > mbeg ? (mend - mbeg + BKT - 1) / BKT : 0;
 
   // DropPath liveness of the samples this slice touches (host guarantees they fit the table)
   const int s0 = mbeg / p.rows_per_scale;
+  const int* __restrict__ gperm = q.perm;
+  const bool mapped = gperm != nullptr;                     // wave-uniform
+  if (mapped && nkt > 0) {
+    const int ns = (mend - 1) / p.rows_per_scale - s0 + 1;
+    for (int i = threadIdx.x; i < ns; i += NT) perm_tab[i] = gperm[s0 + i] * p.rows_per_scale;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if (rowscale != nullptr && nkt > 0) {
     const int ns = (mend - 1) / p.rows_per_scale - s0 + 1;
     for (int i = threadIdx.x; i < ns; i += NT) live_tab[i] = rowscale[s0 + i] != 0.f;
@@ -227,20 +241,52 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
     const int tok = mbeg + r;
     const bool ca = n0 + (qq << 3) < N, cb = k0 + (qq << 3) < Kin;
     pz[j] = zero + (qq << 3);
-    pa[j] = ca ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : pz[j];
-    pb[j] = cb ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
-    inca[j] = ca ? (unsigned)(BKT * ld_dy * 2) : 0u;
-    incb[j] = cb ? (unsigned)(BKT * ld_x * 2) : 0u;
     smp[j] = tok / rps - s0;
     rem[j] = tok % rps;
-    nlive[j] = has_rs ? live_tab[smp[j]] : 1;
+    if (mapped) {
+      // compacted contraction: pa / pb = the lane's COLUMN base, inca / incb = bytes per row (0: parked on the zero row),
+      // nlive = the operands' row of this lane's logical token in the NEXT tile (sample base from the LDS table + offset)
+      pa[j] = ca ? gdy + n0 + (qq << 3) : pz[j];
+      pb[j] = cb ? gx + k0 + (qq << 3) : pz[j];
+      inca[j] = ca ? (unsigned)(ld_dy * 2) : 0u;
+      incb[j] = cb ? (unsigned)(ld_x * 2) : 0u;
+      nlive[j] = nkt > 0 ? perm_tab[smp[j]] + rem[j] : 0;
+    } else {
+      pa[j] = ca ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : pz[j];
+      pb[j] = cb ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
+      inca[j] = ca ? (unsigned)(BKT * ld_dy * 2) : 0u;
+      incb[j] = cb ? (unsigned)(BKT * ld_x * 2) : 0u;
+      nlive[j] = has_rs ? live_tab[smp[j]] : 1;
+    }
   }
 
   auto issue = [&](int kt, int buf) __attribute__((always_inline)) {          // called with kt = 0, 1, 2, ... in order
     unsigned char* sa = wg_smem + buf * STAGE + wave * RPW * ROWB;
     unsigned char* sb = sa + OPB;
     if (WG_ABLATE & 1) return;
-    if (kt < nfull) {
+    if (mapped && kt < nfull) {
+      // every token of a compacted contraction is live: row addresses from the sample table, no zero-row redirection
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) {
+        const uint64_t ro = (uint64_t)(unsigned)nlive[j];
+        const char* srca = reinterpret_cast<const char*>(pa[j]) + ro * inca[j];
+        const char* srcb = reinterpret_cast<const char*>(pb[j]) + ro * incb[j];
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) {
+        rem[j] += BKT;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bool w = rem[j] >= rps;
+          rem[j] -= w ? rps : 0;
+          smp[j] += w ? 1 : 0;
+        }
+        if (rps * 2 < BKT) { while (rem[j] >= rps) { rem[j] -= rps; ++smp[j]; } }
+        nlive[j] = perm_tab[min(smp[j], WG_MAXSAMPLES - 1)] + rem[j];   // consumed by the NEXT call (a tile past the slice reads a stale entry: never issued)
+      }
+    } else if (kt < nfull) {
 #pragma unroll
       for (int j = 0; j < IPW; ++j) {
         // BOTH operands of a dropped sample's rows come from the zero row: with stochastic-depth compaction the rows of
@@ -274,8 +320,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
         const int qq = pslot ^ wg_swz(r);
         bool live = tok < mend;
         if (live && has_rs) live = live_tab[tok / rps - s0] != 0;
-        const bf16* srcb = (live && k0 + (qq << 3) < Kin) ? gx + (int64_t)tok * ld_x + k0 + (qq << 3) : pz[j];
-        const bf16* srca = (live && n0 + (qq << 3) < N) ? gdy + (int64_t)tok * ld_dy + n0 + (qq << 3) : pz[j];
+        int64_t ro = tok;
+        if (mapped && live) { const int sq = tok / rps; ro = (int64_t)perm_tab[sq - s0] + (tok - sq * rps); }
+        const bf16* srcb = (live && k0 + (qq << 3) < Kin) ? gx + ro * ld_x + k0 + (qq << 3) : pz[j];
+        const bf16* srca = (live && n0 + (qq << 3) < N) ? gdy + ro * ld_dy + n0 + (qq << 3) : pz[j];
         __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
       }
@@ -364,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
   }
 
   if (WG_ABLATE & 4) { if (acc[0][0][0] == 12345.678f) q.out[threadIdx.x] = acc[1][3][2]; return; }
-  const float sc = (rowscale != nullptr && !q.live_only) ? p.scale_const : 1.f;
+  const float sc = mapped ? q.scale : ((rowscale != nullptr && !q.live_only) ? p.scale_const : 1.f);
   const bool split = p.nz > 1;                                // wave-uniform (kernel argument)
   if (have_ksum) {
     float* red = reinterpret_cast<float*>(wg_smem);         // [NT / 16 row groups][128 cols]
@@ -443,7 +491,7 @@ bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale
 }
 
 template <int BKT, int NS, int NW> static int wgrad_glds_launch_cfg(const WgradArgs& a, hipStream_t st) {
-  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES;
+  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES + WG_MAXSAMPLES * 4;
   auto kern = wgrad_glds_kernel<BKT, NS, NW>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -480,6 +528,8 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
     q.ksum_part = hp[i].ksum_part; q.ksum_out = hp[i].ksum_out; q.rowscale = hp[i].rowscale;
     q.ld_dy = hp[i].ld_dy; q.ld_x = hp[i].ld_x; q.N = hp[i].N; q.Kin = hp[i].Kin;
     q.ntk = (hp[i].Kin + 127) / 128; q.tile0 = t0; q.live_only = hp[i].live_only;
+    q.perm = hp[i].perm; q.Mtok = hp[i].perm ? hp[i].Mtok : (int)mtok; q.scale = hp[i].scale;
+    any_scale = any_scale || hp[i].perm != nullptr;          // (the sample table of a mapped problem has the same bound)
     t0 += wgrad_glds_tiles(hp[i].N, hp[i].Kin);
     any_scale = any_scale || hp[i].rowscale != nullptr;
   }

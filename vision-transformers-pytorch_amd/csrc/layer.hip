@@ -186,10 +186,12 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
   float* dbs[4] = {a->db2, a->db1, a->dbo, a->dbq};
   const int Ns[4] = {C, ff, C, 3 * C}, Ks[4] = {ff, C, C, C};
   const int64_t ldy[4] = {C, ff, C, 3 * C}, ldx[4] = {ff, C, C, C};
-  // compacted: dz / dqkv rows of dropped samples were never written -- every problem skips them (rowscale as liveness); the
-  // DropPath constant is applied where dy does not carry it yet (fc2: dy, proj: dx1), not on dz / dqkv (live_only)
-  const float* rs[4] = {a->s2, mapped ? a->s2 : nullptr, a->s1, mapped ? a->s1 : nullptr};
-  const int live_only[4] = {0, 1, 0, 1};
+  // compacted: every problem contracts over the kept samples' tokens only (the rows of dropped samples were never written);
+  // the DropPath constant goes onto the problems whose dy does not carry it yet (fc2: dy, proj: dx1), not onto dz / dqkv
+  const float* rs[4] = {mapped ? nullptr : a->s2, nullptr, mapped ? nullptr : a->s1, nullptr};
+  const int* perms[4] = {a->perm2, a->perm2, a->perm1, a->perm1};
+  const int kept[4] = {a->Bk2 * rps, a->Bk2 * rps, a->Bk1 * rps, a->Bk1 * rps};
+  const float scl[4] = {a->scale_const, 1.f, a->scale_const, 1.f};
   const int ncol = a->attn_kind == VTX_ATTN_WINDOW ? 3 : 2;
   const float* cpart[4] = {(const float*)a->ln2_ws, (const float*)a->ln1_ws, (const float*)a->attn_ws, nullptr};
   float* cout0[4] = {a->dg2, a->dg1, a->drel, nullptr};
@@ -199,8 +201,9 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
                       ncol == 3 ? vtx_wattn_bwd_parts(mapped ? a->Bk1 : a->B, a->nH, a->H, a->W, a->win) : 0, 0};
   const int cC[4] = {C, C, ncol == 3 ? ntab * a->nH : 0, 0};
   const int cld[4] = {2 * C, 2 * C, ncol == 3 ? vtx_wattn_bwd_part_ld(a->nH) : 0, 0};
-  return vtx_wgrad_group_live(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, mapped ? live_only : nullptr, rps, a->scale_const, M,
-                              a->wgrad_ws, a->wgrad_ws_bytes, ncol, cpart, cout0, cout1, cnb, cC, cld, a->accumulate, ws);
+  return vtx_wgrad_group_mapped(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, mapped ? perms : nullptr, kept, scl, rps,
+                                a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes, ncol, cpart, cout0, cout1, cnb, cC, cld,
+                                a->accumulate, ws);
 }
 
 }  // extern "C"
