@@ -150,7 +150,7 @@ __device__ __forceinline__ void wg_mma12(const s16x4 (&r)[12], f32x4 (&acc)[2][4
 // NW waves per workgroup: 4 (2 x 2 waves of 64 x 64) or 8 (4 x 2 waves of 32 x 64 -- half the DMA requests and MFMAs per
 // wave and k-tile, twice the waves per SIMD to interleave them).
 template <int BKT, int NS, int NW>
-__global__ __launch_bounds__(64 * NW) void wgrad_glds_kernel(WgradArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wgrad_glds_kernel(WgradArgs p) {   // two 64-KB workgroups per CU: at most 128 registers with 8 waves
   constexpr int BT = 128, ROWB = 256, OPB = BKT * ROWB;   // operand tile bytes
   constexpr int STAGE = 2 * OPB;
   constexpr int NT = 64 * NW;                              // threads
