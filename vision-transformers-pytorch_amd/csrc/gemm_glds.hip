@@ -497,7 +497,14 @@ static int glds_pick_bm(const GemmArgs& a, int bn) {
   const int force = vtx_opt(VTX_OPT_GLDS_BM);
   if (force == 64 || force == 128) return force;
   if (bn != 128 || a.K % 64 != 0) return 64;                 // the 2 x 4-wave tiles exist for 128 columns, 64-deep k-tiles
-  const long tiles128 = (long)((a.N + 127) / 128) * ((a.M + 127) / 128);
+  // (a mapped launch computes Mk rows; the copy-only tiles behind them cost ~nothing)
+  const long rows = a.perm != nullptr ? a.Mk : a.M;
+  const long tiles128 = (long)((a.N + 127) / 128) * ((rows + 127) / 128);
+  // ONE round of 128-row tiles (two 64-KB workgroups per CU = 512 resident) beats the 1.3-2 rounds of 64-row tiles the same
+  // rows need: measured on the N = 384 stage-3 shapes at the row counts stochastic-depth compaction leaves (21 756 rows =
+  // 510 tiles: fc2 forward 40.0 -> 31.4 us, fc1 dgrad 40.0 -> 30.1, qkv dgrad 31.0 -> 24.7, proj 15.5 -> 13.7; at 23 128
+  // rows = 543 tiles the 64-row tile still wins: tools/probe/bm_probe.py).  Below ~half a round the 64-row tile fills more CUs.
+  if (tiles128 > 256 && tiles128 <= 512) return 128;
   return tiles128 >= 800 ? 128 : 64;
 }
 
