@@ -503,8 +503,9 @@ static int glds_pick_bm(const GemmArgs& a, int bn) {
   // ONE round of 128-row tiles (two 64-KB workgroups per CU = 512 resident) beats the 1.3-2 rounds of 64-row tiles the same
   // rows need: measured on the N = 384 stage-3 shapes at the row counts stochastic-depth compaction leaves (21 756 rows =
   // 510 tiles: fc2 forward 40.0 -> 31.4 us, fc1 dgrad 40.0 -> 30.1, qkv dgrad 31.0 -> 24.7, proj 15.5 -> 13.7; at 23 128
-  // rows = 543 tiles the 64-row tile still wins: tools/probe/bm_probe.py).  Below ~half a round the 64-row tile fills more CUs.
-  if (tiles128 > 256 && tiles128 <= 512) return 128;
+  // rows = 543 tiles the 64-row tile still wins: tools/probe/bm_probe.py).  Up to 384 tiles the 64-row tiles (768 resident)
+  // fit one round themselves and are as fast or faster (Swin stage 4, 294 tiles: 17.1 vs 17.9, 49.6 vs 54.0 us: bm_probe2.py).
+  if (tiles128 > 384 && tiles128 <= 512) return 128;
   return tiles128 >= 800 ? 128 : 64;
 }
 

@@ -238,7 +238,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
             bm = 64
         else:
             t128 = ((N + 127) // 128) * ((M + 127) // 128)
-            bm = 128 if (t128 >= 800 or 256 < t128 <= 512) else 64
+            bm = 128 if (t128 >= 800 or 384 < t128 <= 512) else 64
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
         if bn == 128 and options.get("GLDS_EPI") == 1:                     # mirrors glds_launch_t: wave-private epilogue
