@@ -152,6 +152,11 @@ int vtx_relpos_bias(const float* rel_pos, const int64_t* pos, float* bias, int L
 int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
                       int nH, int D, int swin, int H, int W, int win, int shift, int dtype, void* stream);
 size_t vtx_attention_bwd_workspace(int B, int L, int nH, int swin, int H, int W, int win);
+/* global attention over Bk <= B images only (the b-th one is image perm[b]; lse indexed by b): bf16, D = 64, L <= 224 */
+int vtx_attention_fwd_mapped(const void* qkv, void* o, float* lse, const int* perm, int Bk, int L, int nH, int D, int dtype,
+                             void* stream);
+int vtx_attention_bwd_mapped(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const int* perm,
+                             int Bk, int L, int nH, int D, int dtype, void* stream);
 /* dqkv [rows, 3*nH*D] (fully overwritten).  With bias: drel_pos [ntab, nH] fp32 = dense gradient of
  * the rel_pos embedding (models/swin_transformer.py:46,135), scattered through the CSR (order[L*L],
  * offsets[ntab+1]) of the pos table; deterministic (no atomics). */
@@ -227,7 +232,8 @@ typedef struct VtxLayerFwd {
   float *mean1, *rstd1, *mean2, *rstd2, *lse;
   /* stochastic-depth compaction (both NULL: off): perm1 / perm2 [B] int32 on the device list the samples of the attention /
    * MLP branch, kept ones (s? != 0) first, Bk1 / Bk2 >= 1 of them -- each branch is computed for its kept samples only, the
-   * others pass through (bf16, VTX_ATTN_WINDOW, C and ff multiples of 128, rows_per_scale = tokens per sample) */
+   * others pass through (bf16; window attention, or global attention with head dim 64 and L <= 224; C and ff multiples of
+   * 128; rows_per_scale = tokens per sample) */
   const int *perm1, *perm2;
   int Bk1, Bk2;
 } VtxLayerFwd;

@@ -340,8 +340,8 @@ def test_one_call_layer_under_no_grad_and_shared_param_backward():
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("p", [0.45, 0.1])
-def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(p, monkeypatch):
+@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3)])
+def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, p, monkeypatch):
     """Round 3: with host-drawn DropPath masks every branch of a Swin layer runs over its KEPT samples only (row-mapped
     LayerNorm / LDS-DMA GEMMs / window attention, copy-only tiles for the dropped samples, weight gradients skipping their
     rows: csrc/layer.hip) instead of being computed for all samples and multiplied by 0.  Same masks, same per-row math:
@@ -349,16 +349,24 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(p, monke
     rel_pos gradients are summed over a different partition of the rows
     (1e-5).  Also: some branch must actually have been compacted, and nothing may be NaN although the dropped samples'
     activations are never written."""
-    from models import SwinTransformer
+    from models import SwinTransformer, VisionTransformer
     from vtx import functional as VF
+    from vtx.nn import Linear
     d = dev()
     torch.manual_seed(41)
-    model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=(64, 128, 384, 768), dim_head=32,
-                            n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=p).to(d).train()
-    for m in model.modules():
-        if hasattr(m, "rel_pos"):
-            torch.nn.init.normal_(m.rel_pos.weight, std=0.3)
-    x = torch.randn(10, 3, 224, 224, device=d)
+    if family == "swin":
+        model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=(64, 128, 384, 768), dim_head=32,
+                                n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=p).to(d).train()
+        for m in model.modules():
+            if hasattr(m, "rel_pos"):
+                torch.nn.init.normal_(m.rel_pos.weight, std=0.3)
+        x = torch.randn(10, 3, 224, 224, device=d)
+    else:                                                    # global attention (the bf16 fast path takes the sample order too)
+        model = VisionTransformer(Linear(384, 16), 224, 16, 4, 384, 6, 1536, 0.0, 0.0, 0.0, p).to(d).train()
+        x = torch.randn(10, 3, 224, 224, device=d)
+        if family == "vit_multicrop":
+            x = [x, torch.randn(10, 3, 96, 96, device=d)]
+    side = family != "vit_multicrop"
     used = []
     real = VF._layer_perms
     monkeypatch.setattr(VF, "_layer_perms", lambda *a: (used.append(real(*a)), used[-1])[1])
@@ -366,10 +374,10 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(p, monke
     # poison the allocator's free memory: what compaction leaves unwritten must never be read
     junk = torch.full((1 << 28,), float("nan"), device=d, dtype=torch.bfloat16)
     del junk
-    out_a, g_a = _layer_io(model, x, True, 91)
+    out_a, g_a = _layer_io(model, x, True, 91, side)
     assert sum(u is not None and (u[0][1] < 10 or u[1][1] < 10) for u in used) >= 2, "no branch was compacted"
     monkeypatch.setattr(VF, "_LAYER_CALL", False)                      # call-by-call: every sample computed, then scaled
-    out_b, g_b = _layer_io(model, x, True, 91)
+    out_b, g_b = _layer_io(model, x, True, 91, side)
     assert torch.isfinite(out_a).all() and all(torch.isfinite(v).all() for v in g_a.values())
     assert torch.equal(out_a, out_b)
     exact = 0

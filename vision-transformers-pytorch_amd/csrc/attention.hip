@@ -500,9 +500,9 @@ static int attn_bwd_launch(const void* qkv, const void* oin, const void* dout, c
 
 // bf16 / head-dim-64 / 64 < L <= 224 global attention: LDS-DMA + transpose-read kernels (attention_seq.hip)
 bool sattn_ok(int dtype, int L, int D, int swin, const void* bias);
-int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st);
+int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st, const int* perm = nullptr);
 int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int L, int nH,
-                     hipStream_t st);
+                     hipStream_t st, const int* perm = nullptr);
 
 // global attention of any length (attention_long.hip): blocks of 64 keys, online softmax
 bool lattn_ok(int dtype, int D);
@@ -585,6 +585,21 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
     rc = vtx_check_launch();
   }
   return rc;
+}
+
+/* Global attention over Bk <= B images only (stochastic-depth compaction, csrc/layer.hip): the b-th image worked on is image
+ * perm[b]; lse is indexed by b.  Only where the bf16 fast path applies (head dim 64, L <= 224): VTX_ERR_SHAPE otherwise. */
+int vtx_attention_fwd_mapped(const void* qkv, void* o, float* lse, const int* perm, int Bk, int L, int nH, int D, int dtype,
+                             void* stream) {
+  if (!qkv || !o || !lse || !perm) return VTX_ERR_NULL;
+  if (Bk <= 0 || !sattn_ok(dtype, L, D, 0, nullptr)) return VTX_ERR_SHAPE;
+  return sattn_fwd_launch(qkv, o, lse, Bk, L, nH, (hipStream_t)stream, perm);
+}
+int vtx_attention_bwd_mapped(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, const int* perm,
+                             int Bk, int L, int nH, int D, int dtype, void* stream) {
+  if (!qkv || !o || !dout || !lse || !dqkv || !perm) return VTX_ERR_NULL;
+  if (Bk <= 0 || !sattn_ok(dtype, L, D, 0, nullptr)) return VTX_ERR_SHAPE;
+  return sattn_bwd_launch(qkv, o, dout, lse, dqkv, Bk, L, nH, (hipStream_t)stream, perm);
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __attribute__((aligned(256))) unsigned int sa_zero_row[64];   // 256 zero bytes
 
-struct SeqGeom { int L, nH, hd; float scale; };
+struct SeqGeom { int L, nH, hd; float scale; const int* perm; };   // perm: the b-th image worked on is image perm[b] (null: identity)
 
 // DMA `rows` rows x 64 bf16 of one head (token rows base .. ) into a swizzled row-major LDS image
 template <int LP, int NW>
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_fwd_kernel(const bf16* __res
   unsigned char* ks = sa_smem;            // K image
   unsigned char* vs = sa_smem + IMG;      // V image
   const int prob = blockIdx.x;
-  const int h = prob % g.nH, b = prob / g.nH;
+  const int h = prob % g.nH, b = g.perm ? g.perm[prob / g.nH] : prob / g.nH;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c_ = lane & 15, g_ = lane >> 4;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_bwd_kernel(const bf16* __res
   float* dq_s = reinterpret_cast<float*>(sa_smem + 2 * IMG);   // D[q]
   float* lse_s = dq_s + LP;
   const int prob = blockIdx.x;
-  const int h = prob % g.nH, b = prob / g.nH;
+  const int h = prob % g.nH, b = g.perm ? g.perm[prob / g.nH] : prob / g.nH;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c_ = lane & 15, g_ = lane >> 4;
@@ -429,16 +429,16 @@ template <int NKT> static int sattn_bwd_t(const void* qkv, const void* o, const 
 
 // key-tile count of the instantiation: 14 (L <= 224: ViT-S/16 at 224^2, L = 197), 8 (L <= 128), 4 (L <= 64: the 96^2 DINO
 // crops, L = 37)
-int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st) {
-  SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D);
+int sattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, hipStream_t st, const int* perm) {
+  SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D); g.perm = perm;
   if (L <= 64) return sattn_fwd_t<4>(qkv, o, lse, B, g, st);
   if (L <= 128) return sattn_fwd_t<8>(qkv, o, lse, B, g, st);
   return sattn_fwd_t<14>(qkv, o, lse, B, g, st);
 }
 
 int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int L, int nH,
-                     hipStream_t st) {
-  SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D);
+                     hipStream_t st, const int* perm) {
+  SeqGeom g; g.L = L; g.nH = nH; g.hd = nH * SA_D; g.scale = 1.0f / sqrtf((float)SA_D); g.perm = perm;
   if (L <= 64) return sattn_bwd_t<4>(qkv, o, dout, lse, dqkv, B, g, st);
   if (L <= 128) return sattn_bwd_t<8>(qkv, o, dout, lse, dqkv, B, g, st);
   return sattn_bwd_t<14>(qkv, o, dout, lse, dqkv, B, g, st);

@@ -70,7 +70,7 @@ int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
     //      rows of dropped samples pass through (x1 = x, y = x1: copy-only tiles of the residual GEMMs), their saved
     //      activations are never written and never read.  bf16, window attention, N % 128 == 0, K % 64 == 0.
     const int T = a->rows_per_scale;
-    if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || a->attn_kind != VTX_ATTN_WINDOW || T <= 0 || M != a->B * T ||
+    if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || T <= 0 || M != a->B * T ||
         a->Bk1 <= 0 || a->Bk1 > a->B || a->Bk2 <= 0 || a->Bk2 > a->B)
       return VTX_ERR_SHAPE;
     const int M1 = a->Bk1 * T, M2 = a->Bk2 * T;
@@ -78,8 +78,11 @@ int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
     if (rc) return rc;
     rc = layer_gemm_mapped(a->ln1, a->wq, a->qkv, M1, M1, 3 * C, C, a->bq, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream);
     if (rc) return rc;
-    rc = vtx_wattn_fwd_mapped(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W,
-                              a->win, a->shift, dt, stream);
+    if (a->attn_kind == VTX_ATTN_WINDOW)
+      rc = vtx_wattn_fwd_mapped(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W,
+                                a->win, a->shift, dt, stream);
+    else
+      rc = vtx_attention_fwd_mapped(a->qkv, a->o, a->lse, a->perm1, a->Bk1, a->L, a->nH, C / a->nH, dt, stream);
     if (rc) return rc;
     rc = layer_gemm_mapped(a->o, a->wo, a->x1, M, M1, C, C, a->bo, a->x, a->s1, T, nullptr, nullptr, 0, a->perm1, stream);
     if (rc) return rc;
@@ -120,7 +123,7 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
   const bool mapped = a->perm1 != nullptr || a->perm2 != nullptr;
   if (mapped) {
     const int T = rps;
-    if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || a->attn_kind != VTX_ATTN_WINDOW || T <= 0 || M != (int64_t)a->B * T ||
+    if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || T <= 0 || M != (int64_t)a->B * T ||
         a->Bk1 <= 0 || a->Bk1 > a->B || a->Bk2 <= 0 || a->Bk2 > a->B || !a->w2t || !a->w1t || !a->wot || !a->wqt ||
         !a->s1 || !a->s2)
       return VTX_ERR_SHAPE;
@@ -134,8 +137,11 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
     if (rc) return rc;
     rc = layer_gemm_mapped(a->dx1, a->wot, a->dout, M1, M1, C, C, nullptr, nullptr, a->s1, T, nullptr, nullptr, 0, a->perm1, stream);
     if (rc) return rc;
-    rc = vtx_wattn_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, a->attn_ws, a->attn_ws_bytes,
-                              a->inv_cells, a->inv_count, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+    if (a->attn_kind == VTX_ATTN_WINDOW)
+      rc = vtx_wattn_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, a->attn_ws, a->attn_ws_bytes,
+                                a->inv_cells, a->inv_count, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+    else
+      rc = vtx_attention_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->dqkv, a->perm1, a->Bk1, a->L, a->nH, C / a->nH, dt, stream);
     if (rc) return rc;
     rc = layer_gemm_mapped(a->dqkv, a->wqt, a->dln1, M1, M1, C, 3 * C, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream);
     if (rc) return rc;

@@ -118,6 +118,8 @@ class VisionTransformer(nn.Module):
         for table in (self.pos_embed, self.cls_token):
             nn.init.normal_(table, std=0.02)
         self.head = head                                     # registered last (state_dict order), not re-initialised
+        # DropPath masks drawn on the host (vtx.nn.drop_path_scope): each branch runs over its kept samples only (csrc/layer.hip)
+        self._vtx_dp_compaction = dim % 128 == 0 and dim_ff % 128 == 0 and dim // n_head == 64
 
     init_weights = staticmethod(reset_transformer_parameters)
 

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "vtx_layer_desc_bytes": (c_int, [c_int]),
     "vtx_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     "vtx_layernorm_bwd_mapped": (c_int, [c_void_p] * 8 + [c_size_t, c_int64, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "vtx_attention_fwd_mapped": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "vtx_attention_bwd_mapped": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "vtx_wattn_fwd_mapped": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_void_p]),
     "vtx_wattn_bwd_mapped": (c_int, [c_void_p] * 9 + [c_size_t, c_void_p, c_int, c_void_p] + [c_int] * 9 + [c_void_p]),
     "vtx_wgrad_group_mapped": (c_int, [c_int, c_int] + [c_void_p] * 12 + [c_int, c_float, c_int64, c_void_p, c_size_t, c_int] +

@@ -387,14 +387,17 @@ def _layer_plan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c):
     return pl
 
 
-def _layer_perms(kind, T, C, ff, s1, s2):
+def _layer_perms(kind, T, C, ff, s1, s2, head_dim=64, L=0):
     """((perm1, Bk1), (perm2, Bk2)) when this layer can run its two branches over their kept samples only (stochastic-depth
     compaction, csrc/layer.hip): the DropPath scales carry the host-drawn sample orders (vtx.nn.drop_path_scope), bf16,
-    window attention, and every GEMM of the layer on the wave-private LDS-DMA kernel (N % 128 == 0, K % 64 == 0)."""
+    window attention or the bf16 global-attention fast path, and every GEMM of the layer on the wave-private LDS-DMA kernel
+    (N % 128 == 0, K % 64 == 0)."""
     p1 = getattr(s1, "_vtx_perm", None) if s1 is not None else None
     p2 = getattr(s2, "_vtx_perm", None) if s2 is not None else None
-    if p1 is None or p2 is None or kind != _lib.ATTN_WINDOW or T != torch.bfloat16 or C % 128 or ff % 128:
+    if p1 is None or p2 is None or T != torch.bfloat16 or C % 128 or ff % 128:
         return None
+    if kind == _lib.ATTN_GLOBAL and (head_dim != 64 or L > 224 or not options.get("SATTN")):
+        return None                      # (the bf16 fast-path attention kernels take the sample order; the others do not)
     if options.get("GLDS_EPI") != 1 or not options.get("GEMM_GLDS"):
         return None
     return p1, p2
@@ -680,7 +683,7 @@ class TransformerLayerFn(Function):
         if kind == _lib.ATTN_WINDOW:
             d.rel_pos, d.pos, d.region = rel_pos.data_ptr(), meta.pos.data_ptr(), _dp(meta.region)
         d.s1, d.s2 = _dp(s1), _dp(s2)
-        ctx.perms = _layer_perms(kind, T, C, ff, s1, s2)
+        ctx.perms = _layer_perms(kind, T, C, ff, s1, s2, meta.dim_head, meta.L)
         if ctx.perms is not None:
             (p1, d.Bk1), (p2, d.Bk2) = ctx.perms
             d.perm1, d.perm2 = p1.data_ptr(), p2.data_ptr()
