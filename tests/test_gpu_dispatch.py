@@ -30,7 +30,7 @@ def _mm64(a, b_t):
     return a.double() @ b_t.double().t()
 
 
-BIG128 = "gemm_glds_pv_kernel<128, 2>"            # 128 x 128 tiles, 4 x 2 waves, wave-private epilogue (the benchmark default)
+BIG128 = "gemm_glds_pv_kernel<128, 2, false>"            # 128 x 128 tiles, 4 x 2 waves, wave-private epilogue (the benchmark default)
 
 
 # ------------------------------------------------------------------ the 128-row LDS-DMA GEMM with every fused epilogue
@@ -125,7 +125,7 @@ def test_wgrad_through_droppath_at_benchmark_size(B, T, N, Kin):
     c = 1.0 / 0.7
     keep = (torch.rand(B, generator=torch.Generator().manual_seed(133)) < 0.7).float() * c
     use = None if N == 1536 else keep
-    assert ops.wgrad_kernel_name(BF, N, Kin, True) == "wgrad_glds_kernel<64, 2, 8>"
+    assert ops.wgrad_kernel_name(BF, N, Kin, True) == "wgrad_glds_kernel<64, 2, 8, false>"
     dW, db = ops.wgrad(dy.to(d), x.to(d), rowscale=None if use is None else use.to(d), rows_per_scale=T,
                        scale_const=c if use is not None else 0.0)
     rW, rb = _wgrad_ref(dy, x, use, T, c)

@@ -37,8 +37,10 @@ struct GemmArgs {
   const int* perm;          // [samples] int32 or null (no map: logical row == row, Mk == M)
   int map_T;                // rows per sample
   int Mk;
+  unsigned map_magic;       // ceil(2^32 / map_T): r / map_T == __umulhi(r, map_magic) for r * map_T < 2^32 (no runtime division)
 };
-__host__ __device__ inline void gemm_args_nomap(GemmArgs& a) { a.perm = nullptr; a.map_T = 1; a.Mk = a.M; }
+inline void gemm_args_nomap(GemmArgs& a) { a.perm = nullptr; a.map_T = 1; a.Mk = a.M; a.map_magic = 0; }
+inline unsigned vtx_div_magic(int T) { return (unsigned)((0x100000000ull + (unsigned)T - 1) / (unsigned)T); }
 
 
 // Global operands of the epilogue, requested ahead of it (EpiOperands::load) -- by the LDS-DMA kernel before its main

@@ -157,13 +157,13 @@ __global__ __launch_bounds__(128 * NWN) void gemm_glds_kernel(GemmArgs p) {
 // staging passes, mostly waiting at their three barriers for the slowest wave.  Element values are those of
 // gemm_epilogue (same expression per element), so the two variants are bitwise interchangeable.
 // logical row -> row of the operands (GemmArgs::perm: stochastic-depth compaction; identity without a map)
-__device__ __forceinline__ int glds_orow(const GemmArgs& p, int row) {
-  if (p.perm == nullptr) return row;
-  const int s = row / p.map_T;
+template <bool MAPPED> __device__ __forceinline__ int glds_orow(const GemmArgs& p, int row) {
+  if constexpr (!MAPPED) return row;
+  const int s = (int)__umulhi((unsigned)row, p.map_magic);
   return p.perm[s] * p.map_T + (row - s * p.map_T);
 }
 
-template <int BM, int NWN> struct PvEpiOperands {
+template <int BM, int NWN, bool MAPPED = false> struct PvEpiOperands {
   static constexpr int WN = 128 / (16 * NWN);          // 16-column tiles per wave: 4 | 2
   static constexpr int VROW = 2 * WN;                  // 8-element vectors per staged row of the wave tile
   static constexpr int NIT = 16 * VROW / 64;           // store iterations per 16-row pass: 2 | 1
@@ -178,12 +178,12 @@ template <int BM, int NWN> struct PvEpiOperands {
     const int lrow = m0 + wm * 32 + i * 16 + lr;
     col = n0 + wn * (16 * WN) + cv * 8;
     const bool ok = lrow < p.M && col < p.N;
-    if (p.perm == nullptr) {
+    if constexpr (!MAPPED) {
       row = lrow;
       if (srow) *srow = lrow / p.rows_per_scale;
     } else {
       const int lc = ok ? lrow : 0;
-      const int s = lc / p.map_T, smp = p.perm[s];
+      const int s = (int)__umulhi((unsigned)lc, p.map_magic), smp = p.perm[s];
       row = smp * p.map_T + (lc - s * p.map_T);
       if (srow) *srow = smp;
     }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void glds_wave_sync() {      // orders this wave's ow
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int BM, int NWN>
+template <int BM, int NWN, bool MAPPED = false>
 __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   constexpr int BN = 128, BK = 64, NS = 2;
   constexpr int ROWB = BK * 2, CPR = BK / 8, PR = 1024 / ROWB, KS = BK / 32, NWV = 8;
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
-  const int live_rows = p.perm != nullptr ? p.Mk : p.M;
-  if (m0 >= live_rows) {
+  const int live_rows = MAPPED ? p.Mk : p.M;
+  if (MAPPED && m0 >= live_rows) {
     // copy-only tile of a mapped launch: the rows of DROPPED samples (DropPath scale 0): C = resid, no operands touched
     const bf16* __restrict__ rs = (const bf16*)p.resid;
     bf16* __restrict__ cd = (bf16*)p.C;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
       for (int v = threadIdx.x; v < BM * 16; v += 512) {
         const int lrow = m0 + (v >> 4), col = n0 + (v & 15) * 8;
         if (lrow < p.M && col < p.N) {
-          const int64_t off = (int64_t)glds_orow(p, lrow) * p.ldc + col;
+          const int64_t off = (int64_t)glds_orow<MAPPED>(p, lrow) * p.ldc + col;
           store8<bf16>(cd + off, load8<bf16>(rs + off));
         }
       }
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   }
 
   VTX_TRACE(0);
-  PvEpiOperands<BM, NWN> eo;
+  PvEpiOperands<BM, NWN, MAPPED> eo;
   eo.load_small(p, m0, n0, wm, wn, lane);
-  const bool has_vec = PvEpiOperands<BM, NWN>::vec_src(p) != nullptr && !(GLDS_ABLATE & 8);
-  constexpr int NVEC = PvEpiOperands<BM, NWN>::NVEC;
+  const bool has_vec = PvEpiOperands<BM, NWN, MAPPED>::vec_src(p) != nullptr && !(GLDS_ABLATE & 8);
+  constexpr int NVEC = PvEpiOperands<BM, NWN, MAPPED>::NVEC;
 
   const int lr = lane / CPR, slot = lane % CPR;
   constexpr int APW = BM / (NWV * PR), BPW = BN / (NWV * PR);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
     const int r = wave * (BM / NWV) + j * PR + lr;
     // rows past the computed ones (past M; past Mk in a tile that straddles the kept / dropped boundary of a mapped
     // launch) are never stored or are scaled by an exact 0: any valid, FINITE row will do -- the last computed one
-    asrc[j] = A + (int64_t)glds_orow(p, min(m0 + r, live_rows - 1)) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
+    asrc[j] = A + (int64_t)glds_orow<MAPPED>(p, min(m0 + r, live_rows - 1)) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   VTX_TRACE(2);
 
   // ---------------- wave-private epilogue: acc[i][j][r] = C[m0 + 32 wm + 16 i + 4 g + r][n0 + 16 WN wn + 16 j + c]
-  using EO = PvEpiOperands<BM, NWN>;
+  using EO = PvEpiOperands<BM, NWN, MAPPED>;
   constexpr int VROW = EO::VROW, NIT = EO::NIT;
   float* cbuf = reinterpret_cast<float*>(glds_smem + wave * PVB);
   bf16* __restrict__ Cout = (bf16*)p.C;
@@ -441,15 +441,19 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   VTX_TRACE(7);
 }
 
-template <int BM, int NWN> static int glds_launch_pv(const GemmArgs& a, hipStream_t st) {
+template <int BM, int NWN, bool MAPPED> static int glds_launch_pv_m(const GemmArgs& a, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * (BM + 128) * 128;
-  auto kern = gemm_glds_pv_kernel<BM, NWN>;
+  auto kern = gemm_glds_pv_kernel<BM, NWN, MAPPED>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
   dim3 grid((a.N + 127) / 128, (a.M + BM - 1) / BM, 1);
   hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
   return vtx_check_launch();
+}
+// (the row map of stochastic-depth compaction is a compile-time variant: the unmapped kernels carry none of its code)
+template <int BM, int NWN> static int glds_launch_pv(const GemmArgs& a, hipStream_t st) {
+  return a.perm != nullptr ? glds_launch_pv_m<BM, NWN, true>(a, st) : glds_launch_pv_m<BM, NWN, false>(a, st);
 }
 
 template <int BM, int BN, int BK, int NS, int NWN = 2> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {

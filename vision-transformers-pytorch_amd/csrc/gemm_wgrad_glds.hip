@@ -149,8 +149,8 @@ __device__ __forceinline__ void wg_mma12(const s16x4 (&r)[12], f32x4 (&acc)[2][4
 // read-back burst at the end of every launch: profiles/round2_wgrad_phase_ablation.txt) and removed in round 3.
 // NW waves per workgroup: 4 (2 x 2 waves of 64 x 64) or 8 (4 x 2 waves of 32 x 64 -- half the DMA requests and MFMAs per
 // wave and k-tile, twice the waves per SIMD to interleave them).
-template <int BKT, int NS, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wgrad_glds_kernel(WgradArgs p) {   // two 64-KB workgroups per CU: at most 128 registers with 8 waves
+template <int BKT, int NS, int NW, bool MAPPED = false>
+__global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_glds_kernel(WgradArgs p) {   // (mapped: two 64-KB workgroups per CU need <= 128 registers)
   constexpr int BT = 128, ROWB = 256, OPB = BKT * ROWB;   // operand tile bytes
   constexpr int STAGE = 2 * OPB;
   constexpr int NT = 64 * NW;                              // threads
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wgrad_glds_kernel(Wg
   // DropPath liveness of the samples this slice touches (host guarantees they fit the table)
   const int s0 = mbeg / p.rows_per_scale;
   const int* __restrict__ gperm = q.perm;
-  const bool mapped = gperm != nullptr;                     // wave-uniform
+  constexpr bool mapped = MAPPED;                           // compile-time variant: the plain kernel carries none of this
   if (mapped && nkt > 0) {
     const int ns = (mend - 1) / p.rows_per_scale - s0 + 1;
     for (int i = threadIdx.x; i < ns; i += NT) perm_tab[i] = gperm[s0 + i] * p.rows_per_scale;
@@ -490,9 +490,9 @@ bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale
   return on && dtype == VTX_BF16 && shape_ok && (rowscale == nullptr || scale_const > 0.f);
 }
 
-template <int BKT, int NS, int NW> static int wgrad_glds_launch_cfg(const WgradArgs& a, hipStream_t st) {
-  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES + WG_MAXSAMPLES * 4;
-  auto kern = wgrad_glds_kernel<BKT, NS, NW>;
+template <int BKT, int NS, int NW, bool MAPPED = false> static int wgrad_glds_launch_cfg(const WgradArgs& a, hipStream_t st) {
+  constexpr int smem = NS * 2 * BKT * 256 + WG_MAXSAMPLES + (MAPPED ? WG_MAXSAMPLES * 4 : 0);
+  auto kern = wgrad_glds_kernel<BKT, NS, NW, MAPPED>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
@@ -543,5 +543,12 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
   if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
   // (ring geometries measured in round 2 and removed: 64 tokens x 3 stages, 32 x 3 / 4 / 5 -- all slower than 64 x 2,
   //  profiles/round2_wgrad_ring_variants.txt)
+  bool mapped = false;
+  for (int i = 0; i < nprob; ++i) mapped = mapped || hp[i].perm != nullptr;
+  if (mapped) {
+    for (int i = 0; i < nprob; ++i)
+      if (hp[i].perm == nullptr) return VTX_ERR_SHAPE;        // all problems of a launch are mapped, or none
+    return wgrad_glds_launch_cfg<64, 2, 8, true>(a, st);
+  }
   return wgrad_glds_launch_cfg<64, 2, 8>(a, st);
 }

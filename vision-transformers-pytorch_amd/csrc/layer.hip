@@ -48,7 +48,7 @@ int layer_gemm_mapped(const void* A, const void* W, void* Cc, int M, int Mk, int
   a.A = A; a.B = W; a.C = Cc; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.bias = bias; a.resid = resid; a.rowscale = rowscale; a.rows_per_scale = T; a.aux_out = aux_out; a.aux_in = aux_in;
   a.act = act; a.kscale = nullptr; a.k_per_scale = 1; a.kscale_const = 0.f; a.kchunk = ((K + 127) / 128) * 128;
-  a.ksum_out = nullptr; a.perm = perm; a.map_T = T; a.Mk = Mk;
+  a.ksum_out = nullptr; a.perm = perm; a.map_T = T; a.Mk = Mk; a.map_magic = vtx_div_magic(T);
   if (!A || !W || !Cc || !perm) return VTX_ERR_NULL;
   if ((act == 2 || act == 4) && !aux_in) return VTX_ERR_NULL;
   return gemm_glds_launch_mapped(a, (hipStream_t)st);

@@ -19,11 +19,12 @@ struct LnAddr {
   const int* perm;
   int T;
   int64_t live;
+  unsigned magic;    // ceil(2^32 / T): r / T == __umulhi(r, magic) (rows x T < 2^32, checked by the entry points)
 };
-__device__ __forceinline__ int64_t ln_orow(const LnAddr& a, int64_t row) {
-  if (a.perm == nullptr) return row;
-  const int64_t s = row / a.T;
-  return (int64_t)a.perm[s] * a.T + (row - s * a.T);
+template <bool MAPPED> __device__ __forceinline__ int64_t ln_orow(const LnAddr& a, int64_t row) {
+  if constexpr (!MAPPED) return row;
+  const int s = (int)__umulhi((unsigned)row, a.magic);
+  return (int64_t)a.perm[s] * a.T + ((int)row - s * a.T);
 }
 
 __device__ __forceinline__ int64_t ln_src_offset(const LnAddr& a, int64_t row, int col, int C) {
@@ -38,7 +39,7 @@ __device__ __forceinline__ int64_t ln_src_offset(const LnAddr& a, int64_t row, i
   return ((b * a.H + 2 * i + py) * a.W + 2 * j + px) * (int64_t)a.Cs + c;
 }
 
-template <typename T, int G, int NV>
+template <typename T, int G, int NV, bool MAPPED = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, T* __restrict__ y,
                                                     float* __restrict__ mean, float* __restrict__ rstd,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const int64_t row = row0 + rr * stride;
-      orow[rr] = row < rows ? ln_orow(addr, row) : 0;
+      orow[rr] = row < rows ? ln_orow<MAPPED>(addr, row) : 0;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int v = lig + k * G;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // gradient that bypasses the norm, fused so the stream gradient is written once).
 // dgamma / dbeta: per-lane register accumulation over the block's rows, LDS reduce across the
 // block's groups, one deterministic partial row per block; ln_colreduce_kernel sums the partials.
-template <typename T, int G, int NV>
+template <typename T, int G, int NV, bool MAPPED = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const T* __restrict__ dres,
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
   const float invC = 1.f / (float)C;
   for (int64_t lrow = (int64_t)blockIdx.x * GPB + grp; lrow < rows; lrow += (int64_t)gridDim.x * GPB) {
-    const int64_t row = ln_orow(addr, lrow);
-    if (addr.perm != nullptr && lrow >= addr.live) {           // a dropped sample's row: dx = dres (uniform within the group)
+    const int64_t row = ln_orow<MAPPED>(addr, lrow);
+    if (MAPPED && lrow >= addr.live) {           // a dropped sample's row: dx = dres (uniform within the group)
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int v = lig + k * G;
@@ -235,8 +236,13 @@ template <typename T, int G, int NV>
 static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int64_t rows, int C, float eps, LnAddr a, hipStream_t st) {
   const int nb = ln_grid(rows, 256 / G, 1024);
-  hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
-                     rstd, rows, C, eps, a);
+  // (the row map of stochastic-depth compaction is a compile-time variant: the plain kernels carry none of its code)
+  if (a.perm != nullptr)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV, true>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
+                       rstd, rows, C, eps, a);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV, false>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
+                       rstd, rows, C, eps, a);
   return vtx_check_launch();
 }
 
@@ -246,8 +252,12 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
                          LnAddr a, hipStream_t st) {
   const int nb = ln_grid(rows, 256 / G, 1024);
   const size_t smem = (size_t)2 * (256 / G) * C * sizeof(float);
-  hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
-                     gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+  if (a.perm != nullptr)
+    hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, true>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                       gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, false>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                       gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
   int rc = vtx_check_launch();
   if (rc || dgamma == nullptr) return rc;                // deferred: the partials stay in ws ([nb][2C]), see vtx_colreduce_multi
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(2 * C), dim3(1024), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
@@ -274,7 +284,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
 
 static int ln_make_addr(LnAddr& a, int64_t rows, int C, int merge, int H, int W) {
   a.merge = merge; a.H = H; a.W = W; a.Cs = C / 4;
-  a.perm = nullptr; a.T = 1; a.live = rows;
+  a.perm = nullptr; a.T = 1; a.live = rows; a.magic = 0;
   if (C <= 0 || (C & 7)) return VTX_ERR_SHAPE;
   if (merge) {
     if ((C & 31) || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return VTX_ERR_SHAPE;
@@ -308,7 +318,8 @@ int vtx_layernorm_fwd_mapped(const void* x, const float* gamma, const float* bet
   LnAddr a;
   int rc = ln_make_addr(a, rows, C, 0, 0, 0);
   if (rc) return rc;
-  a.perm = perm; a.T = T;
+  a.perm = perm; a.T = T; a.magic = (unsigned)((0x100000000ull + (unsigned)T - 1) / (unsigned)T);
+  if ((uint64_t)rows * (uint64_t)T >= 0x100000000ull) return VTX_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VTX_BF16) LN_DISPATCH(ln_fwd_launch, bf16, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
   if (dtype == VTX_F32) LN_DISPATCH(ln_fwd_launch, float, 1, x, gamma, beta, y, mean, rstd, rows, C, eps, a, st);
@@ -362,7 +373,8 @@ int vtx_layernorm_bwd_mapped(const void* dy, const void* x, const float* mean, c
   LnAddr a;
   int rc = ln_make_addr(a, rows, C, 0, 0, 0);
   if (rc) return rc;
-  a.perm = perm; a.T = T; a.live = live;
+  a.perm = perm; a.T = T; a.live = live; a.magic = (unsigned)((0x100000000ull + (unsigned)T - 1) / (unsigned)T);
+  if ((uint64_t)rows * (uint64_t)T >= 0x100000000ull) return VTX_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   float* nul = nullptr;

@@ -314,6 +314,8 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
 # attention fast path; global attention without bias / mask); everything else, and bench.py's event-sampled steps (which
 # bracket each launch), take the call-by-call path.  VTX_LAYER_CALL=0 disables.
 _LAYER_CALL = os.environ.get("VTX_LAYER_CALL", "1") != "0"
+# a layer's branches are compacted when at least this percentage of its (sample, branch) pairs is dropped
+_COMPACT_MIN_PCT = int(os.environ.get("VTX_DP_COMPACT_MIN", "6"))
 _ALIGN = 256
 
 
@@ -398,6 +400,10 @@ def _layer_perms(kind, T, C, ff, s1, s2, head_dim=64, L=0):
         return None
     if kind == _lib.ATTN_GLOBAL and (head_dim != 64 or L > 224 or not options.get("SATTN")):
         return None                      # (the bf16 fast-path attention kernels take the sample order; the others do not)
+    # the row map costs a little in every kernel (address arithmetic, copy-only tiles): only where enough samples are dropped
+    B = p1[0].numel()
+    if 100 * (2 * B - p1[1] - p2[1]) < _COMPACT_MIN_PCT * 2 * B:
+        return None
     if options.get("GLDS_EPI") != 1 or not options.get("GEMM_GLDS"):
         return None
     return p1, p2

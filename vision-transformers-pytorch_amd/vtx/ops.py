@@ -242,7 +242,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
         if bn == 128 and options.get("GLDS_EPI") == 1:                     # mirrors glds_launch_t: wave-private epilogue
-            return f"gemm_glds_pv_kernel<{bm}, {2 if bm == 128 else 4}>"
+            return f"gemm_glds_pv_kernel<{bm}, {2 if bm == 128 else 4}, false>"
         nwn = 4 if (bn == 128 and options.get("GLDS_WAVES") != 4) else 2
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2, {nwn}>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
@@ -287,7 +287,7 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
 
 def wgrad_kernel_name(dtype, N, Kin, glds):
     if glds:
-        return f"wgrad_glds_kernel<64, 2, {4 if options.get('WG_WAVES') == 4 else 8}>"
+        return f"wgrad_glds_kernel<64, 2, {4 if options.get('WG_WAVES') == 4 else 8}, false>"
     t = "__bf16" if dtype == torch.bfloat16 else "float"
     bn = 128 if Kin % 128 == 0 else (96 if Kin % 96 == 0 else (64 if Kin <= 64 else 128))
     return f"gemm_kernel<{t}, float, 128, {bn}, true, true>"
