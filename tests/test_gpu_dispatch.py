@@ -371,6 +371,8 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
     real = VF._layer_perms
     monkeypatch.setattr(VF, "_layer_perms", lambda *a: (used.append(real(*a)), used[-1])[1])
     monkeypatch.setattr(VF, "_LAYER_CALL", True)
+    monkeypatch.setattr(VF, "_COMPACT_MIN_PCT", 0)             # (compact whenever anything is dropped: the mechanism is under test)
+    model._vtx_dp_compaction = True
     # poison the allocator's free memory: what compaction leaves unwritten must never be read
     junk = torch.full((1 << 28,), float("nan"), device=d, dtype=torch.bfloat16)
     del junk

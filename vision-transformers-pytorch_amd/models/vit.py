@@ -118,8 +118,9 @@ class VisionTransformer(nn.Module):
         for table in (self.pos_embed, self.cls_token):
             nn.init.normal_(table, std=0.02)
         self.head = head                                     # registered last (state_dict order), not re-initialised
-        # DropPath masks drawn on the host (vtx.nn.drop_path_scope): each branch runs over its kept samples only (csrc/layer.hip)
-        self._vtx_dp_compaction = dim % 128 == 0 and dim_ff % 128 == 0 and dim // n_head == 64
+        # Stochastic-depth compaction (host-drawn DropPath masks, each branch over its kept samples only: csrc/layer.hip) pays
+        # from ~14 % dropped samples per layer on (measured: Swin-S -1.5 %, ViT-S/16 at its rates <= 0.1 +1 %): opt-in by rate
+        self._vtx_dp_compaction = (dim % 128 == 0 and dim_ff % 128 == 0 and dim // n_head == 64 and drop_path >= 0.2)
 
     init_weights = staticmethod(reset_transformer_parameters)
 

@@ -315,7 +315,7 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
 # bracket each launch), take the call-by-call path.  VTX_LAYER_CALL=0 disables.
 _LAYER_CALL = os.environ.get("VTX_LAYER_CALL", "1") != "0"
 # a layer's branches are compacted when at least this percentage of its (sample, branch) pairs is dropped
-_COMPACT_MIN_PCT = int(os.environ.get("VTX_DP_COMPACT_MIN", "6"))
+_COMPACT_MIN_PCT = int(os.environ.get("VTX_DP_COMPACT_MIN", "14"))
 _ALIGN = 256
 
 
