@@ -133,8 +133,6 @@ class PatchEmbedding(nn.Module):
     def forward(self, input, grid=None, skip=0):
         """input: the NCHW image / feature map as in the reference, or token-major features (B, skip + H*W, C) with
         ``grid = (H, W)`` (what PyramidVisionTransformer passes between stages).  Returns (tokens, (height, width))."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("vtx: dropout > 0 is not supported by the fused HIP path")
         T = VF.compute_dtype(input)
         if input.dim() == 4 and input.shape[1] != 3:                  # NCHW feature map: go through the token layout
             B, C, H, W = input.shape
@@ -146,7 +144,7 @@ class PatchEmbedding(nn.Module):
             input = input.to(T)
         out = VF.PvtPatchEmbedFn.apply(input, self.conv.weight, self.conv.bias, self.norm.weight, self.norm.bias,
                                        self.cls_token, self.pos, self.patch, grid, skip, self.norm.eps, T)
-        return out, (height, width)
+        return self.dropout(out), (height, width)         # (identity at the configured rate 0; reference pvt.py:138)
 
 
 class PyramidVisionTransformer(nn.Module):

@@ -48,7 +48,8 @@ class MultiHeadedAttention(nn.Module):
 
     def check(self):
         if self.training and self.dropout.p > 0:
-            raise NotImplementedError("vtx: attention dropout > 0 is not supported by the fused HIP path")
+            raise NotImplementedError("vtx: attention-probability dropout > 0 is not supported: the probabilities never leave the "
+                                      "fused attention kernel (residual / feed-forward / positional dropout are)")
 
     def forward(self, input):
         self.check()
@@ -70,11 +71,11 @@ class TransformerLayer(nn.Module):
 
     def forward(self, input):
         self.attn.check()
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("vtx: residual dropout > 0 is not supported by the fused HIP path")
-        if self.attn.qkv.bias is None or not self.ff.fused_ok():
-            out = input + self.drop_path(self.attn(self.norm_attn(input)))
-            return out + self.drop_path(self.ff(self.norm_ff(out)))
+        if self.attn.qkv.bias is None or not self.ff.fused_ok() or (self.training and self.dropout.p > 0):
+            # reference composition (vit.py:59-63) from the HIP modules: residual / feed-forward dropout > 0 (nn.Dropout on
+            # the device tensors), a bias-free qkv or another activation -- none of the BASELINE configurations
+            out = input + self.drop_path(self.dropout(self.attn(self.norm_attn(input))))
+            return out + self.drop_path(self.dropout(self.ff(self.norm_ff(out))))
         T = VF.compute_dtype(input)
         B = input.shape[0]
         s1 = drop_path_scale(self.drop_path.p, self.training, B, input.device)   # reference vit.py:60
@@ -129,10 +130,9 @@ class VisionTransformer(nn.Module):
             layer.set_drop_path(rate)
 
     def forward_feature(self, input):
-        if self.training and self.pos_drop.p > 0:
-            raise NotImplementedError("vtx: positional dropout > 0 is not supported by the fused HIP path")
         tokens = self.patch_embedding(input)
         tokens = VF.VitAssembleFn.apply(tokens, self.cls_token, resize_position_grid(self.pos_embed, tokens.shape[1]))
+        tokens = self.pos_drop(tokens)                       # (identity at the configured rate 0; reference vit.py:144)
         with drop_path_scope(self, tokens.shape[0], tokens.device):    # one mask draw per crop group
             for layer in self.layers:
                 tokens = layer(tokens)
