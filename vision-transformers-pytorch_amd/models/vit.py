@@ -169,13 +169,14 @@ class DINOHead(nn.Module):
 
     def forward(self, input):
         linears = [self.mlp] if isinstance(self.mlp, nn.Linear) else list(self.mlp)
+        T = VF.compute_dtype(input)
         if not all(isinstance(m, (nn.Linear, nn.GELU)) for m in linears):
-            # use_bn=True puts BatchNorm1d between the projection layers (reference vit.py:226-229); the reference's own
-            # DINO configuration (config/dino_deit-s-16.conf) runs without it and there is no HIP BatchNorm here
-            raise NotImplementedError("vtx: DINOHead(use_bn=True) is not supported on the HIP path (no torch fallback)")
+            # use_bn=True puts BatchNorm1d between the projection layers (reference vit.py:226-229; the reference's own DINO
+            # configuration runs without it): the HIP linears composed around torch's BatchNorm1d / GELU on the device tensors
+            out = VF.L2NormFn.apply(self.mlp(input.to(T)), 1e-12)
+            return self.last(out)
         # Linear / GELU chain with the activation in the GEMM epilogues, then the L2-normalisation kernel (no fallback:
         # CPU tensors raise inside the HIP ops)
-        T = VF.compute_dtype(input)
         wb = [t for m in linears if isinstance(m, nn.Linear) for t in (m.weight, m.bias)]
         out = VF.MlpChainFn.apply(input.to(T), VF.ACT_GELU, *wb)
         out = VF.L2NormFn.apply(out, 1e-12)
