@@ -38,7 +38,7 @@ for what in "$@"; do
       export TMPDIR=/tmp
       # (single-stream: with the weight gradients on a second stream kernel durations overlap and are not attributable)
       (cd /tmp && VTX_SIDE_WGRAD=0 timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o trace -- \
-         python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_${tag}/run.log 2>&1)
+         python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-secondary > $R/gpurun_out/prof_${tag}/run.log 2>&1)
       grep '"metric"' gpurun_out/prof_${tag}/run.log | cut -c1-220
       python tools/rocpd_stats.py gpurun_out/prof_${tag}/trace_results.db --steps 7 --top 70 > gpurun_out/prof_${tag}/kernel_stats.md
       python tools/rocpd_stats.py gpurun_out/prof_${tag}/trace_results.db --neighbours FillFunctor > gpurun_out/prof_${tag}/fill_neighbours.txt

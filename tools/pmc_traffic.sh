@@ -7,7 +7,7 @@ O=$R/gpurun_out/pmc_traffic_$M
 mkdir -p $O
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c -d $O -o $c -- python $R/bench.py --model $M --steps 3 --warmup 1 --no-cpu-baseline \
+  timeout 900 rocprofv3 --pmc $c -d $O -o $c -- python $R/bench.py --model $M --steps 3 --warmup 1 --no-cpu-baseline --no-secondary \
       --no-kernel-events > $O/$c.log 2>&1
 done
 python $R/tools/rocpd_traffic.py $O/FETCH_SIZE_results.db $O/WRITE_SIZE_results.db --model $M \
