@@ -259,7 +259,17 @@ typedef struct VtxLayerBwd {
   int Bk1, Bk2;
 } VtxLayerBwd;
 int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream);
-int vtx_layer_desc_bytes(int which);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */
+int vtx_layer_desc_bytes(int which);
+/* Per-launch HIP-event timing of what vtx_layer_* enqueues (bench.py's roofline block describes the kernels of the timed
+ * path): between vtx_timer_start() and vtx_timer_stop() every launch of a layer call is bracketed by two events on its
+ * stream; _stop synchronises and returns up to `cap` records.  tag: VTX_T_*; rows = rows / tokens the launch computes;
+ * GEMM: C[rows, n] over k; attention: n heads, k tokens per problem; flags: 1 residual, 2 z written, 4 z read, 8 row-mapped
+ * (compacted branch), 16 shifted-window mask. */
+enum { VTX_T_LN_FWD = 1, VTX_T_GEMM = 2, VTX_T_WATTN_FWD = 3, VTX_T_ATTN_FWD = 4, VTX_T_LN_BWD = 5, VTX_T_WATTN_BWD = 6,
+       VTX_T_ATTN_BWD = 7, VTX_T_WGRAD = 8 };
+typedef struct VtxTimerRec { int tag, n, k, flags; int64_t rows; float ms; } VtxTimerRec;
+int vtx_timer_start(void);
+int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */
 
 /* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66):
  * head dim 64, Lq queries against Lk <= 64 reduced keys per (image, head).

@@ -51,6 +51,6 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 11; }
+int vtx_abi_version(void) { return 12; }
 
 }  // extern "C"

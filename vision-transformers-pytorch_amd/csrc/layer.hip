@@ -10,6 +10,8 @@
 // models/vit.py:59-63 and models/swin_transformer.py:193-197 (window attention: :103-160), DropPath models/layer.py:172-180.
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "gemm_common.h"
 #include "../../include/vtx.h"    // (after the internal header: its VTX_* macros shadow the internal enum of the same values)
 
@@ -29,6 +31,27 @@ struct EventRing {                       // fork events for the side stream (nev
   }
 };
 thread_local EventRing g_events;
+
+// Per-launch HIP-event timing of the launches a vtx_layer_* call enqueues (bench.py's event-sampled steps: the roofline
+// block must describe the kernels of the TIMED path -- one call per layer, compacted branches -- not a call-by-call replay of
+// it).  Between vtx_timer_start() and vtx_timer_stop() every launch of a layer call is bracketed by two events on the stream
+// it is enqueued on; vtx_timer_stop() synchronises and returns (what was launched, milliseconds) records.
+struct TimerEntry { int tag, n, k, flags; int64_t rows; hipEvent_t e0, e1; };
+std::vector<TimerEntry>* g_timer = nullptr;
+int g_timer_base = 0;                     // dtype / head-dim bits of the layer call being recorded
+struct TimerScope {
+  TimerEntry e; hipStream_t st; bool on;
+  TimerScope(int tag, int64_t rows, int n, int k, int flags, void* stream) : st((hipStream_t)stream), on(g_timer != nullptr) {
+    if (!on) return;
+    e.tag = tag; e.rows = rows; e.n = n; e.k = k; e.flags = flags | g_timer_base;
+    on = hipEventCreate(&e.e0) == hipSuccess && hipEventCreate(&e.e1) == hipSuccess && hipEventRecord(e.e0, st) == hipSuccess;
+  }
+  ~TimerScope() {
+    if (on && hipEventRecord(e.e1, st) == hipSuccess) g_timer->push_back(e);
+  }
+};
+#define TCALL(tag, rows, n, k, flags, st, expr) ([&]() -> int { TimerScope ts_(tag, rows, n, k, flags, st); return (expr); }())
+enum { F_RESID = 1, F_AUXOUT = 2, F_AUXIN = 4, F_MAPPED = 8, F_MASKED = 16, F_BF16 = 32 };   // | head dim << 8 (attention)
 
 // dx = epi(dy @ W): the LDS-DMA kernel on the transposed weight copy where it applies (K = out-features, N =
 // in-features), else the register-staged NN kernel on W itself -- the rule of vtx.functional.dgrad
@@ -61,10 +84,33 @@ extern "C" {
 /* sizeof the descriptors (0: VtxLayerFwd, 1: VtxLayerBwd): the bindings check their mirror structures against it */
 int vtx_layer_desc_bytes(int which) { return which == 0 ? (int)sizeof(VtxLayerFwd) : (which == 1 ? (int)sizeof(VtxLayerBwd) : 0); }
 
+int vtx_timer_start(void) {
+  if (g_timer == nullptr) g_timer = new std::vector<TimerEntry>();
+  g_timer->clear();
+  return VTX_OK;
+}
+/* -> number of records written (<= cap); synchronises on the recorded events, frees them and switches the timer off */
+int vtx_timer_stop(VtxTimerRec* out, int cap) {
+  if (g_timer == nullptr) return 0;
+  int n = 0;
+  for (TimerEntry& e : *g_timer) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.e1) == hipSuccess && hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess && out && n < cap) {
+      out[n].tag = e.tag; out[n].n = e.n; out[n].k = e.k; out[n].flags = e.flags; out[n].rows = e.rows; out[n].ms = ms;
+      ++n;
+    }
+    hipEventDestroy(e.e0); hipEventDestroy(e.e1);
+  }
+  delete g_timer;
+  g_timer = nullptr;
+  return n;
+}
+
 int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
   if (!a || !a->x || !a->y || !a->ln1 || !a->qkv || !a->o || !a->x1 || !a->ln2 || !a->h) return VTX_ERR_NULL;
   if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0) return VTX_ERR_SHAPE;
   const int dt = a->dtype, M = (int)a->M, C = a->C, ff = a->ff;
+  g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
   if (a->perm1 != nullptr || a->perm2 != nullptr) {
     // ---- stochastic-depth compaction: each branch runs over ITS kept samples only (perm?: kept first, Bk? of them); the
     //      rows of dropped samples pass through (x1 = x, y = x1: copy-only tiles of the residual GEMMs), their saved
@@ -74,44 +120,47 @@ int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
         a->Bk1 <= 0 || a->Bk1 > a->B || a->Bk2 <= 0 || a->Bk2 > a->B)
       return VTX_ERR_SHAPE;
     const int M1 = a->Bk1 * T, M2 = a->Bk2 * T;
-    int rc = vtx_layernorm_fwd_mapped(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, M1, C, a->eps, dt, a->perm1, T, stream);
+    int rc = TCALL(VTX_T_LN_FWD, M1, C, 0, F_MAPPED, stream, vtx_layernorm_fwd_mapped(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, M1, C, a->eps, dt, a->perm1, T, stream));
     if (rc) return rc;
-    rc = layer_gemm_mapped(a->ln1, a->wq, a->qkv, M1, M1, 3 * C, C, a->bq, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream);
+    rc = TCALL(VTX_T_GEMM, M1, 3 * C, C, F_MAPPED, stream, layer_gemm_mapped(a->ln1, a->wq, a->qkv, M1, M1, 3 * C, C, a->bq, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream));
     if (rc) return rc;
     if (a->attn_kind == VTX_ATTN_WINDOW)
-      rc = vtx_wattn_fwd_mapped(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W,
-                                a->win, a->shift, dt, stream);
+      rc = TCALL(VTX_T_WATTN_FWD, M1, a->nH, a->L, F_MAPPED | (a->region ? F_MASKED : 0), stream,
+                 vtx_wattn_fwd_mapped(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W,
+                                      a->win, a->shift, dt, stream));
     else
-      rc = vtx_attention_fwd_mapped(a->qkv, a->o, a->lse, a->perm1, a->Bk1, a->L, a->nH, C / a->nH, dt, stream);
+      rc = TCALL(VTX_T_ATTN_FWD, M1, a->nH, a->L, F_MAPPED, stream,
+                 vtx_attention_fwd_mapped(a->qkv, a->o, a->lse, a->perm1, a->Bk1, a->L, a->nH, C / a->nH, dt, stream));
     if (rc) return rc;
-    rc = layer_gemm_mapped(a->o, a->wo, a->x1, M, M1, C, C, a->bo, a->x, a->s1, T, nullptr, nullptr, 0, a->perm1, stream);
+    rc = TCALL(VTX_T_GEMM, M1, C, C, F_MAPPED | F_RESID, stream, layer_gemm_mapped(a->o, a->wo, a->x1, M, M1, C, C, a->bo, a->x, a->s1, T, nullptr, nullptr, 0, a->perm1, stream));
     if (rc) return rc;
-    rc = vtx_layernorm_fwd_mapped(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, M2, C, a->eps, dt, a->perm2, T, stream);
+    rc = TCALL(VTX_T_LN_FWD, M2, C, 0, F_MAPPED, stream, vtx_layernorm_fwd_mapped(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, M2, C, a->eps, dt, a->perm2, T, stream));
     if (rc) return rc;
-    rc = layer_gemm_mapped(a->ln2, a->w1, a->h, M2, M2, ff, C, a->b1, nullptr, nullptr, T, a->z, nullptr, 1, a->perm2, stream);
+    rc = TCALL(VTX_T_GEMM, M2, ff, C, F_MAPPED | (a->z ? F_AUXOUT : 0), stream, layer_gemm_mapped(a->ln2, a->w1, a->h, M2, M2, ff, C, a->b1, nullptr, nullptr, T, a->z, nullptr, 1, a->perm2, stream));
     if (rc) return rc;
-    return layer_gemm_mapped(a->h, a->w2, a->y, M, M2, C, ff, a->b2, a->x1, a->s2, T, nullptr, nullptr, 0, a->perm2, stream);
+    return TCALL(VTX_T_GEMM, M2, C, ff, F_MAPPED | F_RESID, stream, layer_gemm_mapped(a->h, a->w2, a->y, M, M2, C, ff, a->b2, a->x1, a->s2, T, nullptr, nullptr, 0, a->perm2, stream));
   }
-  int rc = vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream);
+  int rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream));
   if (rc) return rc;
-  rc = vtx_gemm(0, dt, a->ln1, a->wq, a->qkv, M, 3 * C, C, C, C, 3 * C, a->bq, nullptr, nullptr, 1, nullptr, nullptr, 0, stream);
+  rc = TCALL(VTX_T_GEMM, M, 3 * C, C, 0, stream, vtx_gemm(0, dt, a->ln1, a->wq, a->qkv, M, 3 * C, C, C, C, 3 * C, a->bq, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
   if (rc) return rc;
   if (a->attn_kind == VTX_ATTN_WINDOW)
-    rc = vtx_wattn_fwd(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift,
-                       dt, stream);
+    rc = TCALL(VTX_T_WATTN_FWD, M, a->nH, a->L, a->region ? F_MASKED : 0, stream,
+               vtx_wattn_fwd(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream));
   else if (a->attn_kind == VTX_ATTN_GLOBAL)
-    rc = vtx_attention_fwd(a->qkv, a->o, a->lse, nullptr, nullptr, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream);
+    rc = TCALL(VTX_T_ATTN_FWD, M, a->nH, a->L, 0, stream,
+               vtx_attention_fwd(a->qkv, a->o, a->lse, nullptr, nullptr, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream));
   else
     return VTX_ERR_SHAPE;
   if (rc) return rc;
-  rc = vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream);
+  rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream));
   if (rc) return rc;
-  rc = vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream);
+  rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream));
   if (rc) return rc;
-  rc = vtx_gemm(0, dt, a->ln2, a->w1, a->h, M, ff, C, C, C, ff, a->b1, nullptr, nullptr, 1, a->z, nullptr, 1, stream);
+  rc = TCALL(VTX_T_GEMM, M, ff, C, a->z ? F_AUXOUT : 0, stream, vtx_gemm(0, dt, a->ln2, a->w1, a->h, M, ff, C, C, C, ff, a->b1, nullptr, nullptr, 1, a->z, nullptr, 1, stream));
   if (rc) return rc;
-  return vtx_gemm(0, dt, a->h, a->w2, a->y, M, C, ff, ff, ff, C, a->b2, a->x1, a->s2, a->rows_per_scale, nullptr, nullptr, 0,
-                  stream);
+  return TCALL(VTX_T_GEMM, M, C, ff, F_RESID, stream,
+               vtx_gemm(0, dt, a->h, a->w2, a->y, M, C, ff, ff, ff, C, a->b2, a->x1, a->s2, a->rows_per_scale, nullptr, nullptr, 0, stream));
 }
 
 int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
@@ -121,6 +170,7 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
   const int dt = a->dtype, C = a->C, ff = a->ff, rps = a->rows_per_scale;
   const int64_t M = a->M;
   const bool mapped = a->perm1 != nullptr || a->perm2 != nullptr;
+  g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
   if (mapped) {
     const int T = rps;
     if (!a->perm1 || !a->perm2 || dt != VTX_BF16 || T <= 0 || M != (int64_t)a->B * T ||
@@ -128,52 +178,60 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
         !a->s1 || !a->s2)
       return VTX_ERR_SHAPE;
     const int M1 = a->Bk1 * T, M2 = a->Bk2 * T;
-    int rc = layer_gemm_mapped(a->dy, a->w2t, a->dz, M2, M2, ff, C, nullptr, nullptr, a->s2, T, nullptr, a->z, 2, a->perm2, stream);
+    int rc = TCALL(VTX_T_GEMM, M2, ff, C, F_MAPPED | F_AUXIN, stream, layer_gemm_mapped(a->dy, a->w2t, a->dz, M2, M2, ff, C, nullptr, nullptr, a->s2, T, nullptr, a->z, 2, a->perm2, stream));
     if (rc) return rc;
-    rc = layer_gemm_mapped(a->dz, a->w1t, a->dln2, M2, M2, C, ff, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm2, stream);
+    rc = TCALL(VTX_T_GEMM, M2, C, ff, F_MAPPED, stream, layer_gemm_mapped(a->dz, a->w1t, a->dln2, M2, M2, C, ff, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm2, stream));
     if (rc) return rc;
-    rc = vtx_layernorm_bwd_mapped(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, a->ln2_ws, a->ln_ws_bytes, M, M2, C, dt,
-                                  a->perm2, T, stream);
+    rc = TCALL(VTX_T_LN_BWD, M, C, 0, F_MAPPED, stream,
+               vtx_layernorm_bwd_mapped(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, a->ln2_ws, a->ln_ws_bytes, M, M2, C, dt,
+                                        a->perm2, T, stream));
     if (rc) return rc;
-    rc = layer_gemm_mapped(a->dx1, a->wot, a->dout, M1, M1, C, C, nullptr, nullptr, a->s1, T, nullptr, nullptr, 0, a->perm1, stream);
+    rc = TCALL(VTX_T_GEMM, M1, C, C, F_MAPPED, stream, layer_gemm_mapped(a->dx1, a->wot, a->dout, M1, M1, C, C, nullptr, nullptr, a->s1, T, nullptr, nullptr, 0, a->perm1, stream));
     if (rc) return rc;
     if (a->attn_kind == VTX_ATTN_WINDOW)
-      rc = vtx_wattn_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, a->attn_ws, a->attn_ws_bytes,
-                                a->inv_cells, a->inv_count, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+      rc = TCALL(VTX_T_WATTN_BWD, M1, a->nH, a->L, F_MAPPED | (a->region ? F_MASKED : 0), stream,
+                 vtx_wattn_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, a->attn_ws, a->attn_ws_bytes,
+                                      a->inv_cells, a->inv_count, a->perm1, a->Bk1, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream));
     else
-      rc = vtx_attention_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->dqkv, a->perm1, a->Bk1, a->L, a->nH, C / a->nH, dt, stream);
+      rc = TCALL(VTX_T_ATTN_BWD, M1, a->nH, a->L, F_MAPPED, stream,
+                 vtx_attention_bwd_mapped(a->qkv, a->o, a->dout, a->lse, a->dqkv, a->perm1, a->Bk1, a->L, a->nH, C / a->nH, dt, stream));
     if (rc) return rc;
-    rc = layer_gemm_mapped(a->dqkv, a->wqt, a->dln1, M1, M1, C, 3 * C, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream);
+    rc = TCALL(VTX_T_GEMM, M1, C, 3 * C, F_MAPPED, stream, layer_gemm_mapped(a->dqkv, a->wqt, a->dln1, M1, M1, C, 3 * C, nullptr, nullptr, nullptr, T, nullptr, nullptr, 0, a->perm1, stream));
     if (rc) return rc;
-    rc = vtx_layernorm_bwd_mapped(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, a->ln1_ws, a->ln_ws_bytes, M, M1, C, dt,
-                                  a->perm1, T, stream);
+    rc = TCALL(VTX_T_LN_BWD, M, C, 0, F_MAPPED, stream,
+               vtx_layernorm_bwd_mapped(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, a->ln1_ws, a->ln_ws_bytes, M, M1, C, dt,
+                                        a->perm1, T, stream));
     if (rc) return rc;
   }
   if (!mapped) {
     // ---- MLP branch
-    int rc = layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream);
+    int rc = TCALL(VTX_T_GEMM, M, ff, C, F_AUXIN, stream, layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream));
     if (rc) return rc;
-    rc = layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream);
+    rc = TCALL(VTX_T_GEMM, M, C, ff, 0, stream, layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream));
     if (rc) return rc;
-    rc = vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
-                           M, C, dt, 0, 0, 0, stream);
+    rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+               vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
+                                 M, C, dt, 0, 0, 0, stream));
     if (rc) return rc;
     // ---- attention branch
-    rc = layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream);
+    rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream));
     if (rc) return rc;
     if (a->attn_kind == VTX_ATTN_WINDOW)
-      rc = vtx_wattn_bwd(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, nullptr, a->attn_ws, a->attn_ws_bytes,
-                         a->inv_cells, a->inv_count, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream);
+      rc = TCALL(VTX_T_WATTN_BWD, M, a->nH, a->L, a->region ? F_MASKED : 0, stream,
+                 vtx_wattn_bwd(a->qkv, a->o, a->dout, a->lse, a->rel_pos, a->pos, a->region, a->dqkv, nullptr, a->attn_ws, a->attn_ws_bytes,
+                               a->inv_cells, a->inv_count, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream));
     else if (a->attn_kind == VTX_ATTN_GLOBAL)
-      rc = vtx_attention_bwd(a->qkv, a->o, a->dout, a->lse, nullptr, nullptr, nullptr, nullptr, a->dqkv, nullptr, 0, a->attn_ws,
-                             a->attn_ws_bytes, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream);
+      rc = TCALL(VTX_T_ATTN_BWD, M, a->nH, a->L, 0, stream,
+                 vtx_attention_bwd(a->qkv, a->o, a->dout, a->lse, nullptr, nullptr, nullptr, nullptr, a->dqkv, nullptr, 0, a->attn_ws,
+                                   a->attn_ws_bytes, a->B, a->L, a->nH, C / a->nH, 0, 0, 0, 0, 0, dt, stream));
     else
       return VTX_ERR_SHAPE;
     if (rc) return rc;
-    rc = layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream);
+    rc = TCALL(VTX_T_GEMM, M, C, 3 * C, 0, stream, layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream));
     if (rc) return rc;
-    rc = vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
-                           M, C, dt, 0, 0, 0, stream);
+    rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+               vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
+                                 M, C, dt, 0, 0, 0, stream));
     if (rc) return rc;
   }
   // ---- the four weight gradients + the layer's column reductions: one grouped launch + one reduce launch, on the side
@@ -207,9 +265,10 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
                       ncol == 3 ? vtx_wattn_bwd_parts(mapped ? a->Bk1 : a->B, a->nH, a->H, a->W, a->win) : 0, 0};
   const int cC[4] = {C, C, ncol == 3 ? ntab * a->nH : 0, 0};
   const int cld[4] = {2 * C, 2 * C, ncol == 3 ? vtx_wattn_bwd_part_ld(a->nH) : 0, 0};
-  return vtx_wgrad_group_mapped(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, mapped ? perms : nullptr, kept, scl, rps,
-                                a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes, ncol, cpart, cout0, cout1, cnb, cC, cld,
-                                a->accumulate, ws);
+  return TCALL(VTX_T_WGRAD, mapped ? (int64_t)(kept[0] > kept[2] ? kept[0] : kept[2]) : M, C, ff, mapped ? F_MAPPED : 0, ws,
+               vtx_wgrad_group_mapped(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, mapped ? perms : nullptr, kept, scl, rps,
+                                      a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes, ncol, cpart, cout0, cout1, cnb, cC, cld,
+                                      a->accumulate, ws));
 }
 
 }  // extern "C"

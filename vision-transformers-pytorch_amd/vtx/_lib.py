@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class VtxError(RuntimeError):
@@ -47,10 +47,17 @@ class LayerBwd(ctypes.Structure):
 ATTN_WINDOW, ATTN_GLOBAL = 1, 2
 
 
+class TimerRec(ctypes.Structure):
+    """include/vtx.h VtxTimerRec."""
+    _fields_ = [("tag", _I), ("n", _I), ("k", _I), ("flags", _I), ("rows", _L), ("ms", _F)]
+
+
 _SIGNATURES = {
     "vtx_layer_fwd": (c_int, [c_void_p, c_void_p]),
     "vtx_layer_bwd": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vtx_layer_desc_bytes": (c_int, [c_int]),
+    "vtx_timer_start": (c_int, []),
+    "vtx_timer_stop": (c_int, [c_void_p, c_int]),
     "vtx_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     "vtx_layernorm_bwd_mapped": (c_int, [c_void_p] * 8 + [c_size_t, c_int64, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "vtx_attention_fwd_mapped": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),

@@ -311,8 +311,8 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
 # entry points in the same order as the call-by-call code below (bit-identical), but one ctypes call and one activation
 # buffer per layer instead of ~19 calls and ~28 tensor allocations -- the Python host path was 13.9 ms per Swin-S step
 # against 17.9 ms of GPU time (tools/probe/host_time.py).  Taken for the two layer kinds the benchmarks run (window
-# attention fast path; global attention without bias / mask); everything else, and bench.py's event-sampled steps (which
-# bracket each launch), take the call-by-call path.  VTX_LAYER_CALL=0 disables.
+# attention fast path; global attention without bias / mask); everything else takes the call-by-call path.  In bench.py's
+# event-sampled steps the launches of a layer call are timed inside the library (vtx_timer_*).  VTX_LAYER_CALL=0 disables.
 _LAYER_CALL = os.environ.get("VTX_LAYER_CALL", "1") != "0"
 # a layer's branches are compacted when at least this percentage of its (sample, branch) pairs is dropped
 _COMPACT_MIN_PCT = int(os.environ.get("VTX_DP_COMPACT_MIN", "14"))
@@ -320,7 +320,7 @@ _ALIGN = 256
 
 
 def _layer_kind(x, rel_pos, meta):
-    if not (_LAYER_CALL and _DEFER_REDUCE and x.is_cuda and not ops.timing()):
+    if not (_LAYER_CALL and _DEFER_REDUCE and x.is_cuda):
         return 0
     if _wattn_ok(rel_pos, meta):
         return _lib.ATTN_WINDOW
@@ -763,7 +763,7 @@ class TransformerLayerFn(Function):
         d.attn_ws = sb + bo["attn_ws"] if bo["attn_ws"] is not None else None
         (d.dg1, d.dbe1, d.dWq, d.dbq, d.dWo, d.dbo, d.dg2, d.dbe2, d.dW1, d.db1, d.dW2, d.db2) = gp
         side = None
-        if _deferred:
+        if _deferred and not ops.timing():          # (bench.py's event-sampled steps stay single-stream: attributable durations)
             st = _side_states.get(dev)
             if st is None:
                 st = _side_states[dev] = _SideState(dev)

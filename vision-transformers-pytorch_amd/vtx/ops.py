@@ -145,6 +145,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.extra = []            # (name, flops, bytes, ms): launches timed inside libvtx (vtx_timer_*: the one-call layers)
 
     def bracket(self, name, flops, nbytes=0.0):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -162,6 +163,12 @@ class KernelTimer:
             d["flops"] += flops
             d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
+        for name, flops, nbytes, ms in self.extra:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            d["ms"] += ms
         return out
 
 
@@ -216,8 +223,58 @@ def _attn_bracket(name, nprob, L, D, rows, hd, es, bwd):
 
 
 def set_kernel_timer(timer):
+    """Install / remove the per-launch timer.  The launches of the one-call layers (vtx_layer_fwd / _bwd) are timed inside
+    libvtx (vtx_timer_start / _stop: HIP events on the launch stream around every launch of a layer call); removing the
+    timer waits for those events and files them under the names rocprofv3 prints for the kernels."""
     global _timer
+    lib = _lib.load()
+    if _timer is not None and timer is not _timer:
+        cap = 16384
+        buf = (_lib.TimerRec * cap)()
+        n = lib.vtx_timer_stop(buf, cap)
+        _timer.extra.extend(_describe_timer_rec(buf[i]) for i in range(n))
+    if timer is not None and timer is not _timer:
+        lib.vtx_timer_start()
     _timer = timer
+
+
+def _describe_timer_rec(r):
+    """(kernel name as rocprofv3 prints it, algorithmic FLOPs, algorithmic HBM bytes, ms) of one libvtx timer record."""
+    fl, rows, n, k = r.flags, r.rows, r.n, r.k
+    bf = bool(fl & 32)
+    es = 2 if bf else 4
+    dt = torch.bfloat16 if bf else torch.float32
+    tn = "__bf16" if bf else "float"
+    mapped = "true" if fl & 8 else "false"
+    D = fl >> 8
+    if r.tag == 2:                                                      # GEMM: C[rows, n] over k
+        name = gemm_kernel_name(dt, n, 0, K=k, M=rows, mapped=bool(fl & 8))
+        nb = es * (rows * k + n * k + rows * n * (1 + bool(fl & 1) + bool(fl & 2) + bool(fl & 4)))
+        return name, 2.0 * rows * n * k, float(nb), r.ms
+    if r.tag == 1:
+        return "ln_fwd_kernel", 0.0, 2.0 * rows * n * es + 8.0 * rows, r.ms
+    if r.tag == 5:
+        return "ln_bwd_kernel", 0.0, 4.0 * rows * n * es + 8.0 * rows, r.ms
+    if r.tag in (3, 6):                                                 # window attention: n heads of 32, k tokens per window
+        bwd = r.tag == 6
+        nprob = rows // k * n
+        name = f"wattn_{'bwd' if bwd else 'fwd'}_kernel<{tn}, {'true' if fl & 16 else 'false'}>"
+        return name, (10.0 if bwd else 4.0) * nprob * k * k * 32, (8.0 if bwd else 4.0) * rows * n * 32 * es, r.ms
+    if r.tag in (4, 7):                                                 # global attention: n heads of D, k tokens per image
+        bwd = r.tag == 7
+        nprob = rows // k * n
+        nkt = 4 if k <= 64 else (8 if k <= 128 else 14)
+        fast = bf and D == 64 and k <= 224 and options.get("SATTN")
+        name = (f"sattn_{'bwd' if bwd else 'fwd'}_kernel<{nkt}, {_sattn_cfg()}>" if fast else
+                ("lattn_*_kernel" if k > 224 else f"attn_{'bwd' if bwd else 'fwd'}_kernel"))
+        return name, (10.0 if bwd else 4.0) * nprob * k * k * D, (8.0 if bwd else 4.0) * rows * n * D * es, r.ms
+    if r.tag == 8:                                                      # the layer's grouped weight gradient: n = C, k = ff
+        C, ff = n, k
+        pairs = ((C, ff), (ff, C), (C, C), (3 * C, C))
+        name = f"wgrad_glds_kernel<64, 2, 8, {mapped}> (+split-K and column reduce)"
+        return (name, sum(2.0 * rows * a * b for a, b in pairs),
+                sum(2.0 * rows * (a + b) + 4.0 * a * b for a, b in pairs), r.ms)
+    return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
 
 
 def glds_ok(N, K):
@@ -225,8 +282,9 @@ def glds_ok(N, K):
     return K % 64 == 0 or (K % 32 == 0 and N % 128 == 0)
 
 
-def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
-    """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip)."""
+def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False):
+    """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip); ``mapped``: the
+    row-mapped variant of a compacted branch (M = the rows it computes)."""
     t = "__bf16" if dtype == torch.bfloat16 else "float"
     to = "float" if out_f32 else t
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
@@ -242,7 +300,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0):
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
         if bn == 128 and options.get("GLDS_EPI") == 1:                     # mirrors glds_launch_t: wave-private epilogue
-            return f"gemm_glds_pv_kernel<{bm}, {2 if bm == 128 else 4}, false>"
+            return f"gemm_glds_pv_kernel<{bm}, {2 if bm == 128 else 4}, {'true' if mapped else 'false'}>"
         nwn = 4 if (bn == 128 and options.get("GLDS_WAVES") != 4) else 2
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2, {nwn}>"
     ta, tb = {0: ("false", "false"), 1: ("false", "true"), 2: ("true", "true")}[mode]
