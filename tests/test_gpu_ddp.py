@@ -100,3 +100,46 @@ def test_two_ranks_match_single_process_full_batch(grad_accum, ddp_sync):
     den = sum((b.double().norm() ** 2).item() for b in ref)
     assert report(f"2 ranks x {grad_accum} micro-batches ({ddp_sync}) vs 1 process x full batch: parameters after 2 steps "
                   "(rel-L2)", (num / den) ** 0.5, 2e-5)
+
+
+def test_grad_allreduce_with_droppath_compaction_matches_the_plain_step():
+    """GradAllReduce (bucket sinks, hooks, finish) on top of the round-3 layer path -- one C call per layer, DropPath masks drawn
+    on the host, compacted branches whose weight gradients land in the bucket slots -- with the machinery forced on for a
+    1-rank gloo group (mean over one rank = identity): parameters after two optimizer steps must equal the step without it."""
+    import torch.distributed as dist
+    from gpu_util import dev, report
+    from models import SwinTransformer
+    from vtx import functional as VF
+    from vtx.ddp import GradAllReduce
+    cfg = dict(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 1), dims=(64, 128, 384, 768), dim_head=32,
+               n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7)
+    x, l1, l2, r = (t.to(dev()) for t in _data(12))
+    used = []
+    real = VF._layer_perms
+    VF._layer_perms = lambda *a, **k: (used.append(real(*a, **k)), used[-1])[1]
+    old_min, VF._COMPACT_MIN_PCT = VF._COMPACT_MIN_PCT, 0
+    try:
+        def run(with_ddp):
+            torch.manual_seed(71)
+            model = SwinTransformer(**cfg, drop_path=0.4).to(dev()).train()
+            ddp = GradAllReduce(model, bucket_bytes=1 << 22, first_bucket_bytes=1 << 18, force=True) if with_ddp else None
+            torch.manual_seed(72)                              # the host-drawn DropPath masks of the two steps
+            out = _train(model, (x, l1, l2, r), 2, ddp)
+            if ddp is not None:
+                ddp.remove()
+            return out
+
+        plain = run(False)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            bucketed = run(True)
+        finally:
+            dist.destroy_process_group()
+    finally:
+        VF._layer_perms, VF._COMPACT_MIN_PCT = real, old_min
+    assert sum(u is not None for u in used) >= 4, "no layer ran compacted"
+    num = sum(((a.double() - b.double()).norm() ** 2).item() for a, b in zip(bucketed, plain))
+    den = sum((b.double().norm() ** 2).item() for b in plain)
+    assert report("GradAllReduce forced on + compacted layers vs plain: parameters after 2 steps (rel-L2)", (num / den) ** 0.5, 1e-6)
