@@ -32,7 +32,7 @@ def _data(n):
     return x, l1, l1.roll(1), torch.rand(n, generator=g)
 
 
-def _train(model, data, steps, ddp=None, grad_accum=1, ddp_sync="boundary"):
+def _train(model, data, steps, ddp=None, grad_accum=1, ddp_sync="boundary", autocast_dtype=None):
     """``grad_accum`` > 1: every optimizer step consumes grad_accum micro-batches = equal slices of ``data``."""
     from vtx.optim import FusedAdamW
     from vtx.train_step import MixLoss, make_param_groups, train_step
@@ -42,7 +42,7 @@ def _train(model, data, steps, ddp=None, grad_accum=1, ddp_sync="boundary"):
     for _ in range(steps):
         for a in range(grad_accum):
             micro = tuple(t[a * n:(a + 1) * n] for t in data)
-            train_step(model, MixLoss(0.1), opt, micro, clip_grad_norm=5.0, autocast_dtype=None, ddp=ddp,
+            train_step(model, MixLoss(0.1), opt, micro, clip_grad_norm=5.0, autocast_dtype=autocast_dtype, ddp=ddp,
                        grad_accum=grad_accum, micro_step=i, ddp_sync=ddp_sync)
             i += 1
     return [p.detach().cpu() for p in model.parameters()]
@@ -124,7 +124,7 @@ def test_grad_allreduce_with_droppath_compaction_matches_the_plain_step():
             model = SwinTransformer(**cfg, drop_path=0.4).to(dev()).train()
             ddp = GradAllReduce(model, bucket_bytes=1 << 22, first_bucket_bytes=1 << 18, force=True) if with_ddp else None
             torch.manual_seed(72)                              # the host-drawn DropPath masks of the two steps
-            out = _train(model, (x, l1, l2, r), 2, ddp)
+            out = _train(model, (x, l1, l2, r), 2, ddp, autocast_dtype=torch.bfloat16)   # (compaction is a bf16 path)
             if ddp is not None:
                 ddp.remove()
             return out
