@@ -250,11 +250,18 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   const int wm = wave / NWN, wn = wave % NWN;
   const int c_ = lane & 15, g_ = lane >> 4;
 
+  const int live_rows = MAPPED ? p.Mk : p.M;
   const int ntn = gridDim.x, ntm = gridDim.y;
-  const int nblk = ntn * ntm;
+  // Dispatch order -> tile: workgroup `did` lands on XCD did & 7; each XCD gets a contiguous chunk of the tile order (its
+  // L2 then holds a band of A rows).  In a mapped launch only the tiles of the kept rows COMPUTE and the chunking runs over
+  // those alone: chunked over all tiles, the copy-only tiles (last in tile order) would all fall to the last XCDs and the
+  // others would hold ntiles / 8 compute tiles each -- 73 on 64 resident slots for the 588-tile N = 384 launches, a second
+  // round for a launch whose compute tiles (~480) fit one (measured in the model: 42 us where the row count predicts 25).
+  const int nblk = ntn * (MAPPED ? (live_rows + BM - 1) / BM : ntm);
   const int did = blockIdx.y * ntn + blockIdx.x;
   const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
-  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int lid = (MAPPED && did >= nblk) ? did
+                                          : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
   const int tn = lid % ntn, tm = lid / ntn;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = p.K / BK;
@@ -262,7 +269,6 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
-  const int live_rows = MAPPED ? p.Mk : p.M;
   if (MAPPED && m0 >= live_rows) {
     // copy-only tile of a mapped launch: the rows of DROPPED samples (DropPath scale 0): C = resid, no operands touched
     const bf16* __restrict__ rs = (const bf16*)p.resid;
