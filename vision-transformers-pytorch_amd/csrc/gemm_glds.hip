@@ -162,6 +162,40 @@ template <bool MAPPED> __device__ __forceinline__ int glds_orow(const GemmArgs& 
   const int s = (int)__umulhi((unsigned)row, p.map_magic);
   return p.perm[s] * p.map_T + (row - s * p.map_T);
 }
+// The same for the rows of ONE tile (rows m0 .. m0 + BM - 1): they span at most four samples when 3 T >= BM - 2 (a condition
+// of the mapped launch; every compacted geometry of these models has T = 196 / 49 tokens per sample), whose perm entries are
+// fetched with four SCALAR loads at kernel entry -- a per-lane perm[s] is a dependent vector load in front of the first DMA
+// request and again in front of the epilogue's stores (in-model the mapped launches ran ~10 % over what their row count
+// predicts).
+template <bool MAPPED, int BM> struct TileRowMap {
+  int s0, sp0, sp1, sp2, sp3;             // (four scalars, not an array: indexed by a lane value an array goes to scratch)
+  __device__ __forceinline__ void init(const GemmArgs& p, int m0) {
+    if constexpr (MAPPED) {
+      s0 = (int)__umulhi((unsigned)m0, p.map_magic);
+      const int last = p.M / p.map_T - 1;
+      sp0 = __builtin_amdgcn_readfirstlane(p.perm[min(s0, last)]);
+      sp1 = __builtin_amdgcn_readfirstlane(p.perm[min(s0 + 1, last)]);
+      sp2 = __builtin_amdgcn_readfirstlane(p.perm[min(s0 + 2, last)]);
+      sp3 = __builtin_amdgcn_readfirstlane(p.perm[min(s0 + 3, last)]);
+    }
+  }
+  // sample (perm applied) of the s-th sample in compacted order, s0 <= s <= s0 + 3
+  __device__ __forceinline__ int sample_of(int s) const {
+    const int d = s - s0;
+    const int lo = d <= 0 ? sp0 : sp1, hi = d == 2 ? sp2 : sp3;
+    return d <= 1 ? lo : hi;
+  }
+  __device__ __forceinline__ int orow(const GemmArgs& p, int row, int* smp = nullptr) const {
+    if constexpr (!MAPPED) {
+      if (smp) *smp = row / p.rows_per_scale;
+      return row;
+    } else {
+      const int s = (int)__umulhi((unsigned)row, p.map_magic), sm = sample_of(s);
+      if (smp) *smp = sm;
+      return sm * p.map_T + (row - s * p.map_T);
+    }
+  }
+};
 
 template <int BM, int NWN, bool MAPPED = false> struct PvEpiOperands {
   static constexpr int WN = 128 / (16 * NWN);          // 16-column tiles per wave: 4 | 2
@@ -172,25 +206,18 @@ template <int BM, int NWN, bool MAPPED = false> struct PvEpiOperands {
   Vec8<bf16> ein[2 * NIT];
   // (row, col) of the 8-vector this lane stores in iteration it of pass i; clamped in range, `ok` says whether it exists
   // `row` is the row of the operands (mapped: GemmArgs::perm); `srow` the sample whose DropPath scale applies
-  static __device__ __forceinline__ bool where(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane, int i, int it,
-                                               int& row, int& col, int* srow = nullptr) {
+  using Map = TileRowMap<MAPPED, BM>;
+  static __device__ __forceinline__ bool where(const GemmArgs& p, const Map& tmap, int m0, int n0, int wm, int wn, int lane,
+                                               int i, int it, int& row, int& col, int* srow = nullptr) {
     const int v = lane + 64 * it, lr = v / VROW, cv = v - lr * VROW;
     const int lrow = m0 + wm * 32 + i * 16 + lr;
     col = n0 + wn * (16 * WN) + cv * 8;
     const bool ok = lrow < p.M && col < p.N;
-    if constexpr (!MAPPED) {
-      row = lrow;
-      if (srow) *srow = lrow / p.rows_per_scale;
-    } else {
-      const int lc = ok ? lrow : 0;
-      const int s = (int)__umulhi((unsigned)lc, p.map_magic), smp = p.perm[s];
-      row = smp * p.map_T + (lc - s * p.map_T);
-      if (srow) *srow = smp;
-    }
+    row = tmap.orow(p, (MAPPED && !ok) ? m0 : lrow, srow);
     return ok;
   }
   // bias per accumulator column and the DropPath scale per stored row: small, L2-resident; requested before the first DMA
-  __device__ __forceinline__ void load_small(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+  __device__ __forceinline__ void load_small(const GemmArgs& p, const Map& tmap, int m0, int n0, int wm, int wn, int lane) {
     const int c_ = lane & 15;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -200,7 +227,7 @@ template <int BM, int NWN, bool MAPPED = false> struct PvEpiOperands {
 #pragma unroll
     for (int q = 0; q < 2 * NIT; ++q) {
       int row, col, srow;
-      const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col, &srow);
+      const bool ok = where(p, tmap, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col, &srow);
       ein[q] = vec8_zero<bf16>();
       rsc[q] = (ok && p.rowscale) ? p.rowscale[srow] : 1.f;
     }
@@ -214,13 +241,13 @@ template <int BM, int NWN, bool MAPPED = false> struct PvEpiOperands {
   static __device__ __forceinline__ const bf16* vec_src(const GemmArgs& p) {
     return (p.act == 2 || p.act == 4) ? (const bf16*)p.aux_in : (const bf16*)p.resid;
   }
-  __device__ __forceinline__ void load_vec(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+  __device__ __forceinline__ void load_vec(const GemmArgs& p, const Map& tmap, int m0, int n0, int wm, int wn, int lane) {
     const bf16* __restrict__ esrc = vec_src(p);
     if (!esrc || (GLDS_ABLATE & 8)) return;
 #pragma unroll
     for (int q = 0; q < 2 * NIT; ++q) {
       int row, col;
-      const bool ok = where(p, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col);
+      const bool ok = where(p, tmap, m0, n0, wm, wn, lane, q / NIT, q % NIT, row, col);
       ein[q] = load8<bf16>(esrc + (ok ? (int64_t)row * p.ldc + col : (int64_t)0));
     }
   }
@@ -269,6 +296,8 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   const bf16* A = (const bf16*)p.A;
   const bf16* B = (const bf16*)p.B;
 
+  TileRowMap<MAPPED, BM> tmap;
+  tmap.init(p, m0);
   if (MAPPED && m0 >= live_rows) {
     // copy-only tile of a mapped launch: the rows of DROPPED samples (DropPath scale 0): C = resid, no operands touched
     const bf16* __restrict__ rs = (const bf16*)p.resid;
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
       for (int v = threadIdx.x; v < BM * 16; v += 512) {
         const int lrow = m0 + (v >> 4), col = n0 + (v & 15) * 8;
         if (lrow < p.M && col < p.N) {
-          const int64_t off = (int64_t)glds_orow<MAPPED>(p, lrow) * p.ldc + col;
+          const int64_t off = (int64_t)tmap.orow(p, lrow) * p.ldc + col;
           store8<bf16>(cd + off, load8<bf16>(rs + off));
         }
       }
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
 
   VTX_TRACE(0);
   PvEpiOperands<BM, NWN, MAPPED> eo;
-  eo.load_small(p, m0, n0, wm, wn, lane);
+  eo.load_small(p, tmap, m0, n0, wm, wn, lane);
   const bool has_vec = PvEpiOperands<BM, NWN, MAPPED>::vec_src(p) != nullptr && !(GLDS_ABLATE & 8);
   constexpr int NVEC = PvEpiOperands<BM, NWN, MAPPED>::NVEC;
 
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
     const int r = wave * (BM / NWV) + j * PR + lr;
     // rows past the computed ones (past M; past Mk in a tile that straddles the kept / dropped boundary of a mapped
     // launch) are never stored or are scaled by an exact 0: any valid, FINITE row will do -- the last computed one
-    asrc[j] = A + (int64_t)glds_orow<MAPPED>(p, min(m0 + r, live_rows - 1)) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
+    asrc[j] = A + (int64_t)tmap.orow(p, min(m0 + r, live_rows - 1)) * p.lda + ((slot ^ glds_swz<BK>(r)) << 3);
   }
 #pragma unroll
   for (int j = 0; j < BPW; ++j) {
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   issue(0, 0);
   if (nk >= 2) issue(1, 1);
   const bool vec_early = nk <= 2;
-  if (vec_early) eo.load_vec(p, m0, n0, wm, wn, lane);
+  if (vec_early) eo.load_vec(p, tmap, m0, n0, wm, wn, lane);
   if (nk >= 2) {
     if (vec_early && has_vec) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPT + NVEC) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPT) : "memory");
@@ -348,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
     const bool refill = kt + 1 < nk;
     if (refill && kt >= 1) issue(kt + 1, buf ^ 1);         // (k-tile 1 is already on its way)
     if (kt >= 1 && kt + 2 == nk) {                        // k-tile nk - 1 was just requested: the vectors go behind it
-      eo.load_vec(p, m0, n0, wm, wn, lane);
+      eo.load_vec(p, tmap, m0, n0, wm, wn, lane);
       vec_pending = true;
     }
     const unsigned char* la = glds_smem + buf * STAGE;
@@ -408,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
     for (int it = 0; it < NIT; ++it) {
       const int q = i * NIT + it;
       int row, col;
-      if (!EO::where(p, m0, n0, wm, wn, lane, i, it, row, col)) continue;
+      if (!EO::where(p, tmap, m0, n0, wm, wn, lane, i, it, row, col)) continue;
       const int64_t off = (int64_t)row * p.ldc + col;
       const int v = lane + 64 * it, lrow = v / VROW, cv = v - lrow * VROW;
       const float* cp = cbuf + lrow * CSTR + cv * 8;
@@ -531,6 +560,7 @@ int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st) {
   if (a.perm == nullptr || a.map_T <= 0 || a.Mk <= 0 || a.Mk > a.M) return VTX_ERR_SHAPE;
   if (a.N % 128 != 0 || a.K % 64 != 0 || vtx_opt(VTX_OPT_GLDS_EPI) != 1) return VTX_ERR_SHAPE;   // wave-private epilogue kernels only
   if (a.rowscale != nullptr && a.rows_per_scale != a.map_T) return VTX_ERR_SHAPE;
+  if (3 * a.map_T < 126) return VTX_ERR_SHAPE;                      // TileRowMap: a 128-row tile spans at most four samples
   if (a.Mk < a.M && a.resid == nullptr) return VTX_ERR_SHAPE;       // copy-only rows need something to copy
   return glds_launch_bn<128>(a, st);
 }

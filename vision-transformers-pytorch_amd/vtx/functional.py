@@ -389,7 +389,7 @@ def _layer_plan(kind, meta, B, M, C, ff, T, want_z, has_rs, rps, dp_c):
     return pl
 
 
-def _layer_perms(kind, T, C, ff, s1, s2, head_dim=64, L=0):
+def _layer_perms(kind, T, C, ff, s1, s2, head_dim=64, L=0, rps=196):
     """((perm1, Bk1), (perm2, Bk2)) when this layer can run its two branches over their kept samples only (stochastic-depth
     compaction, csrc/layer.hip): the DropPath scales carry the host-drawn sample orders (vtx.nn.drop_path_scope), bf16,
     window attention or the bf16 global-attention fast path, and every GEMM of the layer on the wave-private LDS-DMA kernel
@@ -398,6 +398,8 @@ def _layer_perms(kind, T, C, ff, s1, s2, head_dim=64, L=0):
     p2 = getattr(s2, "_vtx_perm", None) if s2 is not None else None
     if p1 is None or p2 is None or T != torch.bfloat16 or C % 128 or ff % 128:
         return None
+    if 3 * rps < 126:
+        return None                      # (the mapped GEMM keeps a tile's sample order in four scalars: <= 4 samples per 128 rows)
     if kind == _lib.ATTN_GLOBAL and (head_dim != 64 or L > 224 or not options.get("SATTN")):
         return None                      # (the bf16 fast-path attention kernels take the sample order; the others do not)
     # the row map costs a little in every kernel (address arithmetic, copy-only tiles): only where enough samples are dropped
@@ -689,7 +691,7 @@ class TransformerLayerFn(Function):
         if kind == _lib.ATTN_WINDOW:
             d.rel_pos, d.pos, d.region = rel_pos.data_ptr(), meta.pos.data_ptr(), _dp(meta.region)
         d.s1, d.s2 = _dp(s1), _dp(s2)
-        ctx.perms = _layer_perms(kind, T, C, ff, s1, s2, meta.dim_head, meta.L)
+        ctx.perms = _layer_perms(kind, T, C, ff, s1, s2, meta.dim_head, meta.L, M // B)
         if ctx.perms is not None:
             (p1, d.Bk1), (p2, d.Bk2) = ctx.perms
             d.perm1, d.perm2 = p1.data_ptr(), p2.data_ptr()
