@@ -314,8 +314,9 @@ def layer_wgrads(jobs, rows_per_scale=1, scale_const=0.0, post=None, params=None
 # attention fast path; global attention without bias / mask); everything else takes the call-by-call path.  In bench.py's
 # event-sampled steps the launches of a layer call are timed inside the library (vtx_timer_*).  VTX_LAYER_CALL=0 disables.
 _LAYER_CALL = os.environ.get("VTX_LAYER_CALL", "1") != "0"
-# a layer's branches are compacted when at least this percentage of its (sample, branch) pairs is dropped
-_COMPACT_MIN_PCT = int(os.environ.get("VTX_DP_COMPACT_MIN", "14"))
+# a layer's branches are compacted when at least this percentage of its (sample, branch) pairs is dropped (Swin-S B = 128,
+# same box, tools/probe/ab_thresh.sh: 2 % 16.90 | 6 % 16.87 | 10 % 16.88 | 14 % 16.97 | never 17.87 ms per step)
+_COMPACT_MIN_PCT = int(os.environ.get("VTX_DP_COMPACT_MIN", "8"))
 _ALIGN = 256
 
 
