@@ -280,6 +280,45 @@ def test_dino_multicrop_under_grad_allreduce_matches_the_plain_step(grad_accum):
                   (num / den) ** 0.5, 1e-6)
 
 
+def test_teacher_forward_on_its_own_stream_is_bitwise_the_one_stream_step(monkeypatch):
+    """Round 3: the teacher's no_grad forward runs on a second HIP stream next to the student's (vtx.dino._TEACHER_STREAM).
+    Same kernels on the same data, ordered by stream waits: student AND teacher parameters (momentum update) and the loss
+    centre after three steps must equal the one-stream run bit for bit."""
+    from models.vit import dino
+    from vtx import dino as VD
+    from vtx.dino import DINOLoss, dino_train_step
+    from vtx.optim import FusedAdamW
+    d = dev()
+    kw = dict(image_size=224, window_size=16, depth=3, dim=128, n_head=2, dim_ff=512, dropout=0.0, drop_attn=0.0, drop_ff=0.0,
+              drop_path=0.1, dim_head_out=2048, use_bn=False, norm_last_layer=True, depth_head=3, dim_head_ff=256,
+              dim_head_bottleneck=64)
+    gen = torch.Generator().manual_seed(23)
+    steps = [[torch.randn(8, 3, 224, 224, generator=gen).to(d) for _ in range(2)] +
+             [torch.randn(8, 3, 96, 96, generator=gen).to(d) for _ in range(4)] for _ in range(3)]
+
+    def run(two_streams):
+        monkeypatch.setattr(VD, "_TEACHER_STREAM", two_streams)
+        torch.manual_seed(24)
+        student = dino(**kw).to(d).train()
+        teacher = dino(**kw).to(d).train()
+        teacher.load_state_dict(student.state_dict())
+        for p in teacher.parameters():
+            p.requires_grad = False
+        crit = DINOLoss(2048, 6, 0.04, 0.07, 30, 100).to(d)
+        opt = FusedAdamW(student.parameters(), lr=1e-3, weight_decay=0.04)
+        torch.manual_seed(25)
+        for crops in steps:
+            loss = dino_train_step(student, teacher, crit, opt, crops, epoch=2, momentum=0.9, clip_grad_norm=3.0,
+                                   freeze_last_layer=1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).item()
+        out = [p.detach().clone() for p in student.parameters()] + [p.detach().clone() for p in teacher.parameters()]
+        return out + [crit.center.clone(), loss.detach().clone()]
+
+    one, two = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(one, two))
+
+
 def test_second_gradient_added_inside_the_reduce_launch_is_bitwise_autograds_sum():
     """Round 3: inside functional.shared_param_backward() a layer's second gradient of one backward (the other crop
     resolution's pass) is ADDED onto the first by the reduce launch (out + sum) instead of reaching autograd as a second tensor.

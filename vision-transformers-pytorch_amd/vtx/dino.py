@@ -8,12 +8,26 @@ and the train step of the reference's train_dino.py:188-288, for the multi-crop 
   cancel_last_layer_grad   reference train_util.py:25-31
   dino_train_step          train_dino.py:229-263 for one batch of crops
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
 from torch.autograd import Function
 
 from . import ops
+
+# The teacher's forward (no_grad, 2 global crops) does not depend on the student's: it runs on its own HIP stream next to the
+# student's forward, whose small local-crop launches leave most of the chip idle.  VTX_DINO_TEACHER_STREAM=0: one stream.
+_TEACHER_STREAM = os.environ.get("VTX_DINO_TEACHER_STREAM", "1") != "0"
+_teacher_streams = {}
+
+
+def _teacher_stream(device):
+    st = _teacher_streams.get(device)
+    if st is None:
+        st = _teacher_streams[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 class _DinoLossFn(Function):
@@ -93,10 +107,22 @@ def dino_train_step(student, teacher, criterion, optimizer, crops, epoch, moment
     from .optim import FusedAdamW
     from .train_step import accumulation_boundary, backward_ddp
     boundary = accumulation_boundary(grad_accum, micro_step)
+    side = None
+    if _TEACHER_STREAM and crops[0].is_cuda and not ops.timing():
+        main = torch.cuda.current_stream(crops[0].device)
+        side = _teacher_stream(crops[0].device)
+        side.wait_stream(main)            # the crops and last step's momentum update of the teacher are main-stream work
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
-        with torch.no_grad():
-            teacher_out = teacher(crops[:2])
+        if side is not None:
+            with torch.cuda.stream(side), torch.no_grad():
+                teacher_out = teacher(crops[:2])
+        else:
+            with torch.no_grad():
+                teacher_out = teacher(crops[:2])
         student_out = student(crops)
+        if side is not None:
+            main.wait_stream(side)
+            teacher_out.record_stream(main)
         loss = criterion(student_out, teacher_out, epoch) / grad_accum
     # (multi-crop: the backbone's parameters get one gradient per resolution -- no side stream)
     from . import functional as VF
