@@ -126,7 +126,8 @@ __device__ __forceinline__ void wa_wave_sync() {
 // Column h of rel_pos goes to LDS first (relh, WA_NBIN floats) while the 16 pos loads of every thread are in flight,
 // so the build pays ONE global round trip.
 __device__ __forceinline__ void wa_build_bias(float* bias_s, float* relh, const float* __restrict__ rel_pos,
-                                              const int64_t* __restrict__ pos, int L, int nH, int h, int ntab) {
+                                              const int64_t* __restrict__ pos, int L, int nH, int h, int ntab,
+                                              int qrows = 64) {
   constexpr int PER = 64 * 64 / (64 * WA_WAVES);
   if (WA_ABLATE & 16) return;
   int pidx[PER];
@@ -142,7 +143,7 @@ __device__ __forceinline__ void wa_build_bias(float* bias_s, float* relh, const 
   for (int i = 0; i < PER; ++i) {
     const int idx = threadIdx.x + i * 64 * WA_WAVES;
     const int k = idx & 63, q = idx >> 6;
-    bias_s[q * WA_BSTR + k] = k >= L ? -INFINITY : (pidx[i] >= 0 ? relh[pidx[i]] : 0.f);
+    if (q < qrows) bias_s[q * WA_BSTR + k] = k >= L ? -INFINITY : (pidx[i] >= 0 ? relh[pidx[i]] : 0.f);
   }
 }
 
@@ -490,6 +491,262 @@ __global__ __launch_bounds__(64 * WA_WAVES, 2) void wattn_bwd_kernel(
     for (int i = lane; i < WA_NBIN; i += 64) out[(int64_t)i * g.nH] = bins[i];
 }
 
+// --------------------------------------------------------------------------------------------- backward, 4 waves per problem
+// Round 3 (bf16, inverse pos map present).  The one-wave-per-problem backward above holds a problem's Q / K / V / dO fragments
+// (64 registers) and the 64-register dS sum: 256 registers, 2 waves per SIMD, and a wave pays its problem's 20 global loads,
+// ~2 300 instructions and the stores one after the other -- loads + stores alone take 25 us of the 65-us stage-3 launch, the two
+// phases 32 us, the gather 8 us, and they ADD (profiles/round2_wattn_bwd_phase_ablation.txt).  Here the four waves of the
+// persistent workgroup share ONE problem: wave w owns token tile w (16 tokens) -- it loads only those rows (5 x 16 B per lane),
+// runs phase A for query tile w and phase B for key tile w, and stores dQ / dK / dV of its tokens.  What the phases need of the
+// OTHER tiles comes from LDS: plain [token][d] images of K, V, Q, dO, read with ds_read_b128 for the MFMA operands contracted
+// over d and with the transposing ds_read_b64_tr_b16 for those contracted over tokens (no transposed copies, no 2-byte stores).  A wave's share of the NEXT problem (20 registers) is requested right
+// after the staging barrier, so global latency runs under the phases; the dS sum is 16 registers per wave; ~150 registers ->
+// 3 workgroups (12 waves) per CU.  Arithmetic per element is that of the one-wave kernel (same products in the same order).
+#define WA4_PSTR 40      // plain image row stride (elements): 80 B
+#ifndef WA4_OCC
+#define WA4_OCC 3        // workgroups per CU the backward is compiled for (168 registers)
+#endif
+#define WA4_BROWS 50     // bias table rows kept (queries < L <= 49; padded queries read row 0: their lse is +inf)
+#define WA4_MSTR 72      // P / dS matrix row stride (elements)
+struct Wa4Smem {
+  static constexpr int kBias = WA4_BROWS * WA_BSTR * 4;
+  static constexpr int kPlain = WA_LP * WA4_PSTR * 2;          // one plain image (bf16)
+  static constexpr int kMat = WA_LP * WA4_MSTR * 2;            // P or dS of the problem, [q][key] bf16
+  static constexpr int kSmall = 64;                            // region ids
+  static constexpr int kTotal = kBias + 4 * kPlain + 2 * kMat + kSmall;
+};
+static_assert((WA_LP + 1) * 64 * 4 <= 4 * Wa4Smem::kPlain, "the dS spill must fit the images");
+static_assert(3 * Wa4Smem::kTotal <= 160 * 1024, "three workgroups per CU");
+
+typedef __attribute__((ext_vector_type(4))) short wa_s16x4;
+typedef __attribute__((ext_vector_type(8))) short wa_s16x8;
+typedef __attribute__((address_space(3))) wa_s16x4 wa_lds_s16x4;
+// Fragment contracted over TOKENS straight from a plain [token][d] image (ds_read_b64_tr_b16; cf. sa_frag_trp in
+// attention_seq.hip): k-slots j < 4 <-> tokens t0 + 4 g + j, j >= 4 <-> t0 + 16 + 4 g + (j - 4); the A row of lane c is the
+// head channel d = 8 (c >> 2) + 4 dt + (c & 3) -- the row permutation of wa_store_t, so that accumulator dt register r of
+// lane (c, g) is the output of token c for d = 8 g + 4 dt + r (8 contiguous channels per lane: one 16-byte store).
+__device__ __forceinline__ Vec8<bf16> wa4_frag_trp(const bf16* img, int t0, int dt, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int n = ((p & 3) << 3) + 4 * dt;
+  wa_s16x4 v[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = t0 + half * 16 + g * 4 + (p >> 2);
+    v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wa_lds_s16x4*)(img + r * WA4_PSTR + n));
+  }
+  wa_s16x8 wv = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);   // whole-vector cast only (gemm_wgrad_glds.hip)
+  Vec8<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, wv);
+  return f;
+}
+
+__device__ __forceinline__ void wa_wg_sync() {      // workgroup barrier that leaves global loads / stores in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Fragment contracted over QUERIES from a [q][key] matrix: k-slots as above (rows t0 ...), column key0 + c for lane c
+__device__ __forceinline__ Vec8<bf16> wa4_frag_tr(const bf16* mat, int t0, int key0, int lane) {
+  const int p = lane & 15, g = lane >> 4;
+  const int n = key0 + ((p & 3) << 2);
+  wa_s16x4 v[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r = t0 + half * 16 + g * 4 + (p >> 2);
+    v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wa_lds_s16x4*)(mat + r * WA4_MSTR + n));
+  }
+  wa_s16x8 wv = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  Vec8<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, wv);
+  return f;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(64 * WA_WAVES, WA4_OCC) void wattn_bwd4_kernel(
+    const bf16* __restrict__ qkv, const bf16* __restrict__ oin, const bf16* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ rel_pos, const int64_t* __restrict__ pos, const uint8_t* __restrict__ region,
+    bf16* __restrict__ dqkv, float* __restrict__ bins_part, const int* __restrict__ inv_cells, int inv_count, int nbn,
+    int nblk, int rows_total, int xcd_major, WinGeom g) {
+  using T = bf16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
+  float* bias_s = reinterpret_cast<float*>(wa_smem);
+  unsigned char* base = wa_smem + Wa4Smem::kBias;
+  T* pk = reinterpret_cast<T*>(base);                               // K [token][d]
+  T* pv = reinterpret_cast<T*>(base + Wa4Smem::kPlain);
+  T* pq = reinterpret_cast<T*>(base + 2 * Wa4Smem::kPlain);
+  T* pdo = reinterpret_cast<T*>(base + 3 * Wa4Smem::kPlain);
+  T* pm_s = reinterpret_cast<T*>(base + 4 * Wa4Smem::kPlain);        // P [q][key] of the problem (phase A -> phase B)
+  T* dm_s = reinterpret_cast<T*>(base + 4 * Wa4Smem::kPlain + Wa4Smem::kMat);   // dS[q][key]
+  uint8_t* reg_s = base + 4 * Wa4Smem::kPlain + 2 * Wa4Smem::kMat;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's token tile
+  const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
+  int blk, h;
+  wa_block_map(nblk, g.nH, xcd_major, blk, h);
+  const int64_t ld = 3 * (int64_t)g.hd;
+  const int ntab = (2 * g.win - 1) * (2 * g.win - 1);
+  wa_build_bias(bias_s, reinterpret_cast<float*>(base), rel_pos, pos, g.L, g.nH, h, ntab, WA4_BROWS);
+  __syncthreads();                                    // table complete; the relh scratch (the K image) is free again
+
+  // this lane's token 16 w + c: (ay, ax) inside its window, once per kernel (see WaTok)
+  const int tok = 16 * w + c_;
+  const bool val = tok < g.L;
+  const int tcl = val ? tok : 0;
+  const int ay = tcl / g.win, ax = tcl - ay * g.win;
+  const bool tile_live = 16 * w < g.L;
+
+  f32x4 dsacc[4];                                     // sum over this workgroup's problems of dS[q = 16 w + c][key = 16 kt + 4 g + r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dsacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Vec8<T> nq, nk, nv, ndo, no;                        // this wave's rows of the NEXT problem
+  float nl = 0.f;
+  int nrow = 0;
+  auto request = [&](int bn) {
+    const int n = bn % g.nW, b = g.perm ? g.perm[bn / g.nW] : bn / g.nW;
+    const int wi = n / g.nWx, wj = n - wi * g.nWx;
+    int y = wi * g.win + ay + g.shift;
+    y -= y >= g.H ? g.H : 0;
+    int x = wj * g.win + ax + g.shift;
+    x -= x >= g.W ? g.W : 0;
+    nrow = (b * g.H + y) * g.W + x;
+    const T* p = qkv + (int64_t)nrow * ld + h * WA_D + g_ * 8;
+    const int64_t ro = (int64_t)nrow * g.hd + h * WA_D + g_ * 8;
+    nq = load8<T>(p);
+    nk = load8<T>(p + g.hd);
+    nv = load8<T>(p + 2 * g.hd);
+    ndo = load8<T>(dout + ro);
+    no = load8<T>(oin + ro);
+    nl = lse[((int64_t)bn * g.nH + h) * g.L + tcl];
+  };
+  if (blk < nbn) request(blk);
+
+  for (int bn = blk; bn < nbn; bn += nblk) {
+    const Vec8<T> qf = nq, kf = nk, vf = nv, dof = ndo;
+    const int row = nrow;
+    const float lq = val ? nl : INFINITY;             // padded query rows: exp(. - inf) = 0
+    float dsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsum += no.get(e) * dof.get(e);
+    dsum += shfl_xor_f(dsum, 16);
+    dsum += shfl_xor_f(dsum, 32);                     // D[q = 16 w + c]
+    uint8_t myreg = 0;
+    if (MASKED && w == 0) myreg = region[(int64_t)(bn % g.nW) * 64 + lane];
+    if (bn != blk) wa_wg_sync();                      // every wave is done reading the previous problem's images
+    *reinterpret_cast<Vec8<T>*>(pk + tok * WA4_PSTR + g_ * 8) = kf;
+    *reinterpret_cast<Vec8<T>*>(pv + tok * WA4_PSTR + g_ * 8) = vf;
+    *reinterpret_cast<Vec8<T>*>(pq + tok * WA4_PSTR + g_ * 8) = qf;
+    *reinterpret_cast<Vec8<T>*>(pdo + tok * WA4_PSTR + g_ * 8) = dof;
+    if (MASKED && w == 0) reg_s[lane] = myreg;
+    wa_wg_sync();
+    if (bn + nblk < nbn) request(bn + nblk);          // global latency of the next problem runs under the two phases
+
+    constexpr bool MK = MASKED;
+    // ---------------- phase A (swapped layout), query tile w: P, dS of the tile (-> LDS for phase B), dQ = scale * dS K
+    if (tile_live) {
+      const int q = tok;
+      const unsigned rq = MK ? reg_s[q] * 0x01010101u : 0u;
+      f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 dsv[2], pv2[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int kt = 2 * ks + half;
+          const Vec8<T> kk = *reinterpret_cast<const Vec8<T>*>(pk + (16 * kt + c_) * WA4_PSTR + g_ * 8);
+          const Vec8<T> vv = *reinterpret_cast<const Vec8<T>*>(pv + (16 * kt + c_) * WA4_PSTR + g_ * 8);
+          f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+          mma16(kk, qf, pt);                  // S [q = 16 w + c][key = 16 kt + 4 g + r]
+          mma16(vv, dof, dpt);                // dP[same]
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + tcl * WA_BSTR + kt * 16 + g_ * 4);
+          unsigned rx = 0u;                         // byte r == 0  <=>  key r is in the query's region
+          if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __expf(pt[r] * g.scale + bb[r] - lq);       // padded q: lse = +inf, padded key: bias = -inf
+            if (MK && (rx & (0xffu << (8 * r))) != 0u) p = 0.f;
+            pv2[half][r] = p;
+            dsv[half][r] = p * (dpt[r] - dsum);
+          }
+          dsacc[kt] += dsv[half];
+        }
+        const Vec8<T> pf = wa_frag_acc<T>(pv2[0], pv2[1]);
+        const Vec8<T> dsf = wa_frag_acc<T>(dsv[0], dsv[1]);
+        // rows q of P / dS: keys 16 (2 ks) + 4 g .. + 3 and 16 (2 ks + 1) + 4 g .. + 3 (8 bytes each)
+        bf16x4 plo, phi, dlo, dhi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { plo[j] = pf.v[j]; phi[j] = pf.v[4 + j]; dlo[j] = dsf.v[j]; dhi[j] = dsf.v[4 + j]; }
+        *reinterpret_cast<bf16x4*>(pm_s + q * WA4_MSTR + 32 * ks + 4 * g_) = plo;
+        *reinterpret_cast<bf16x4*>(pm_s + q * WA4_MSTR + 32 * ks + 16 + 4 * g_) = phi;
+        *reinterpret_cast<bf16x4*>(dm_s + q * WA4_MSTR + 32 * ks + 4 * g_) = dlo;
+        *reinterpret_cast<bf16x4*>(dm_s + q * WA4_MSTR + 32 * ks + 16 + 4 * g_) = dhi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma16(wa4_frag_trp(pk, ks * 32, dt, lane), dsf, dqacc[dt]);
+      }
+      // dqacc[dt][r] = dQ[q = 16 w + c][d = 8 g + 4 dt + r] / scale
+      if (val) store8<T>(dqkv + (int64_t)row * ld + h * WA_D + g_ * 8, wa_out8<T>(dqacc[0], dqacc[1], g.scale));
+    } else {
+      // a tile of padding only (16 w >= L): its rows of P / dS are exact zeros
+      const bf16x4 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<bf16x4*>(pm_s + tok * WA4_MSTR + 16 * j + 4 * g_) = z;
+        *reinterpret_cast<bf16x4*>(dm_s + tok * WA4_MSTR + 16 * j + 4 * g_) = z;
+      }
+    }
+    wa_wg_sync();                                       // P and dS of the whole problem are in LDS
+    // ---------------- phase B, key tile w: dV = P^T dO, dK = scale * dS^T Q (P, dS: the bf16 values phase A used)
+    if (tile_live) {
+      f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const Vec8<T> pf = wa4_frag_tr(pm_s, qs * 32, 16 * w, lane);
+        const Vec8<T> dsf = wa4_frag_tr(dm_s, qs * 32, 16 * w, lane);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          mma16(wa4_frag_trp(pdo, qs * 32, dt, lane), pf, dvacc[dt]);
+          mma16(wa4_frag_trp(pq, qs * 32, dt, lane), dsf, dkacc[dt]);
+        }
+      }
+      // d{k,v}acc[dt][r] = d{K,V}[key = 16 w + c][d = 8 g + 4 dt + r]
+      if (val) {
+        T* p = dqkv + (int64_t)row * ld + h * WA_D + g_ * 8;
+        store8<T>(p + g.hd, wa_out8<T>(dkacc[0], dkacc[1], g.scale));
+        store8<T>(p + 2 * g.hd, wa_out8<T>(dvacc[0], dvacc[1], 1.f));
+      }
+    }
+  }
+
+  // rel_pos gradient: the workgroup's dS sum goes to LDS ([q][64] fp32 over the images) and thread b gathers bin b over the
+  // inverse map of pos in a fixed order (see the one-wave kernel) -- ONE partial row per workgroup
+  wa_wg_sync();
+  float* ds_s = reinterpret_cast<float*>(base);
+  {
+    const int q = tok;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + g_ * 4 + r;
+        if (key < g.L && q < g.L) ds_s[q * 64 + key] = dsacc[kt][r];
+      }
+    if (threadIdx.x == 0) ds_s[g.L * 64] = 0.f;             // the padding cell
+  }
+  wa_wg_sync();
+  for (int b = threadIdx.x; b < WA_NBIN; b += 64 * WA_WAVES) {
+    float sum = 0.f;
+    if (b < ntab) {
+      const int* __restrict__ ic = inv_cells + b;
+#pragma unroll 7
+      for (int t = 0; t < inv_count; ++t) sum += ds_s[ic[t * ntab]];
+    }
+    // partial layout [row][bin][head]; rows past this kernel's nblk (the one-wave kernel writes 4 per workgroup) are zero
+    bins_part[((int64_t)blk * WA_NBIN + b) * g.nH + h] = sum;
+    for (int r = nblk + blk; r < rows_total; r += nblk) bins_part[((int64_t)r * WA_NBIN + b) * g.nH + h] = 0.f;
+  }
+}
+
 static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift) {
   if (win <= 0 || H % win || W % win || L != win * win || L > WA_LP) return VTX_ERR_SHAPE;
   if ((2 * win - 1) * (2 * win - 1) > WA_NBIN) return VTX_ERR_SHAPE;
@@ -523,6 +780,20 @@ static int wattn_bwd_blocks(int nbn, int nH) {
   const int cap = vtx_opt(VTX_OPT_WATTN_BWD_WAVES);
   return wattn_blocks(nbn, nH, cap > 0 ? cap : 2048);
 }
+// the four-wave backward: workgroups per head = problems in flight per head (3 workgroups per CU resident)
+static int wattn_bwd4_blocks(int nbn, int nH) {
+  int per_head = 256 * WA4_OCC / nH;
+  if (per_head < 1) per_head = 1;
+  const int ppw = (nbn + per_head - 1) / per_head;            // problems per workgroup
+  int blocks = (nbn + ppw - 1) / ppw;
+  if (blocks >= 8 && vtx_opt(VTX_OPT_WATTN_XCD_MAJOR)) blocks = (blocks + 7) / 8 * 8;
+  return blocks;
+}
+// rows of rel_pos-gradient partials a backward launch leaves ([rows][172 * nH]): whichever kernel runs fills them all
+static int wattn_bwd_rows(int nbn, int nH) {
+  const int a = wattn_bwd_blocks(nbn, nH) * WA_WAVES, b = wattn_bwd4_blocks(nbn, nH);
+  return a > b ? a : b;
+}
 
 template <typename K> static int wa_smem_attr(K kern, int bytes) {
   if (bytes > 64 * 1024 &&
@@ -547,10 +818,27 @@ template <typename T, bool MASKED>
 static int wattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, const float* rel_pos,
                             const int64_t* pos, const uint8_t* region, void* dqkv, float* part, const int* inv_cells,
                             int inv_count, int nbn, const WinGeom& g, hipStream_t st) {
+  const int rows = wattn_bwd_rows(nbn, g.nH);
+  if constexpr (sizeof(T) == 2) {
+    if (inv_cells != nullptr && vtx_opt(VTX_OPT_WATTN_BWD4) != 0) {   // four waves per problem
+      auto kern4 = wattn_bwd4_kernel<MASKED>;
+      int rc4 = wa_smem_attr(kern4, Wa4Smem::kTotal);
+      if (rc4) return rc4;
+      const int nb4 = wattn_bwd4_blocks(nbn, g.nH);
+      hipLaunchKernelGGL(kern4, dim3(nb4 * g.nH), dim3(64 * WA_WAVES), Wa4Smem::kTotal, st,
+                         (const bf16*)qkv, (const bf16*)o, (const bf16*)dout, lse, rel_pos, pos, region, (bf16*)dqkv, part,
+                         inv_cells, inv_count, nbn, nb4, rows, wattn_xcd_major(nb4), g);
+      return vtx_check_launch();
+    }
+  }
   auto kern = wattn_bwd_kernel<T, MASKED>;
   int rc = wa_smem_attr(kern, WaSmem<T>::kBwd);
   if (rc) return rc;
   const int nblk = wattn_bwd_blocks(nbn, g.nH);
+  if (rows > nblk * WA_WAVES &&
+      hipMemsetAsync(part + (size_t)nblk * WA_WAVES * WA_NBIN * g.nH, 0,
+                     (size_t)(rows - nblk * WA_WAVES) * WA_NBIN * g.nH * sizeof(float), st) != hipSuccess)
+    return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(nblk * g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kBwd, st,
                      (const T*)qkv, (const T*)o, (const T*)dout, lse, rel_pos, pos, region, (T*)dqkv, part, inv_cells,
                      inv_count, nbn, nblk, wattn_xcd_major(nblk), g);
@@ -608,13 +896,13 @@ int vtx_wattn_fwd_mapped(const void* qkv, void* o, float* lse, const float* rel_
  * drel_pos == NULL (the caller reduces them with vtx_colreduce_multi: C = (2 win - 1)^2 * nH, ld = 172 * nH) */
 int vtx_wattn_bwd_parts(int B, int nH, int H, int W, int win) {
   if (win <= 0 || H % win || W % win) return 0;
-  return wattn_bwd_blocks(B * (H / win) * (W / win), nH) * WA_WAVES;
+  return wattn_bwd_rows(B * (H / win) * (W / win), nH);
 }
 int vtx_wattn_bwd_part_ld(int nH) { return WA_NBIN * nH; }
 
 size_t vtx_wattn_bwd_workspace(int B, int nH, int H, int W, int win) {
   const int nbn = B * (H / win) * (W / win);
-  return (size_t)wattn_bwd_blocks(nbn, nH) * WA_WAVES * nH * WA_NBIN * sizeof(float);
+  return (size_t)wattn_bwd_rows(nbn, nH) * nH * WA_NBIN * sizeof(float);
 }
 
 /* inv_cells [inv_count][(2 win - 1)^2] int32 (device) or NULL: the inverse of pos -- inv_cells[t][b] = the t-th cell
@@ -644,7 +932,7 @@ int vtx_wattn_bwd(const void* qkv, const void* o, const void* dout, const float*
   else return VTX_ERR_DTYPE;
   if (rc || drel_pos == nullptr) return rc;              // deferred: partials stay in the workspace
   const int ntab = (2 * win - 1) * (2 * win - 1);
-  const int nwaves = wattn_bwd_blocks(nbn, nH) * WA_WAVES;
+  const int nwaves = wattn_bwd_rows(nbn, nH);
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(ntab * nH), dim3(1024), 0, st, (const float*)part, drel_pos,
                      (float*)nullptr, nwaves, ntab * nH, WA_NBIN * nH);
   return vtx_check_launch();
