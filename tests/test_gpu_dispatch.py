@@ -106,6 +106,37 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
             assert torch.equal(a, g), f"{name} differs under {kw}"
 
 
+@pytest.mark.parametrize("H,nH", [(14, 12), (56, 3)])
+def test_wattn_backward_four_waves_per_problem_matches_the_one_wave_kernel_at_bench_size(H, nH):
+    """Round 3: the bf16 window-attention backward shares a problem between the four waves of its workgroup
+    (wattn_bwd4_kernel; option WATTN_BWD4).  Same products in the same order: dqkv must equal the one-wave kernel's bit for
+    bit at the Swin-S B = 128 geometry (stage 3 and stage 1, shifted windows), the rel_pos gradient up to fp32 summation
+    order, and two launches must agree bit for bit (fixed-order gather and reduce)."""
+    from oracle import tables
+    from vtx import ops, options
+    from vtx.tables import mask_regions
+    d = dev()
+    B, win, L, ntab = 128, 7, 49, 169
+    pos_np, mask_np = tables.make_pos_mask((H, H), win, True)
+    pos = torch.from_numpy(pos_np).to(d)
+    region, ok = mask_regions(torch.from_numpy(mask_np).to(d))
+    assert ok
+    qkv = _mk((B * H * H, 3 * nH * 32), 141, BF, device=d)
+    do = _mk((B * H * H, nH * 32), 142, BF, device=d)
+    rel = _mk((ntab, nH), 143, torch.float32, 0.5, device=d)
+    swin = (H, H, win, True)
+    o, lse = ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin)
+    assert ops.wattn_bwd_kernel_name(BF, True) == "wattn_bwd4_kernel<true>"
+    a = ops.wattn_bwd(qkv, o, do, lse, rel, pos, region, B, L, nH, swin, ntab)
+    b = ops.wattn_bwd(qkv, o, do, lse, rel, pos, region, B, L, nH, swin, ntab)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "the four-wave backward is not deterministic"
+    with options.override(WATTN_BWD4=0):
+        assert ops.wattn_bwd_kernel_name(BF, True) == "wattn_bwd_kernel<__bf16, true>"
+        c = ops.wattn_bwd(qkv, o, do, lse, rel, pos, region, B, L, nH, swin, ntab)
+    assert torch.equal(a[0], c[0]), "dqkv of the four-wave kernel differs from the one-wave kernel"
+    check(f"wattn drel_pos, four waves vs one wave per problem (H {H})", a[1], c[1].double(), 2e-5)
+
+
 # ------------------------------------------------------------------ weight gradients at the real token counts
 def _wgrad_ref(dy, x, keep, T, c):
     m = None if keep is None else (keep > 0).double().repeat_interleave(T)[:, None]

@@ -258,7 +258,8 @@ def _describe_timer_rec(r):
     if r.tag in (3, 6):                                                 # window attention: n heads of 32, k tokens per window
         bwd = r.tag == 6
         nprob = rows // k * n
-        name = f"wattn_{'bwd' if bwd else 'fwd'}_kernel<{tn}, {'true' if fl & 16 else 'false'}>"
+        name = (wattn_bwd_kernel_name(dt, bool(fl & 16)) if bwd else
+                f"wattn_fwd_kernel<{tn}, {'true' if fl & 16 else 'false'}>")
         return name, (10.0 if bwd else 4.0) * nprob * k * k * 32, (8.0 if bwd else 4.0) * rows * n * 32 * es, r.ms
     if r.tag in (4, 7):                                                 # global attention: n heads of D, k tokens per image
         bwd = r.tag == 7
@@ -275,6 +276,14 @@ def _describe_timer_rec(r):
         return (name, sum(2.0 * rows * a * b for a, b in pairs),
                 sum(2.0 * rows * (a + b) + 4.0 * a * b for a, b in pairs), r.ms)
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
+
+
+def wattn_bwd_kernel_name(dtype, masked, inverse_map=True):
+    """Mirrors wattn_bwd_launch (attention_win.hip): bf16 with the inverse pos map takes the four-wave kernel."""
+    m = "true" if masked else "false"
+    if dtype == torch.bfloat16 and inverse_map and options.get("WATTN_BWD4"):
+        return f"wattn_bwd4_kernel<{m}>"
+    return f"wattn_bwd_kernel<{'__bf16' if dtype == torch.bfloat16 else 'float'}, {m}>"
 
 
 def glds_ok(N, K):
@@ -927,7 +936,7 @@ def wattn_bwd(qkv, o, dout, lse, rel_pos, pos, region, B, L, n_head, swin, ntab,
     ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
     nW = (H // win) * (W // win)
     tn = "__bf16" if qkv.dtype == torch.bfloat16 else "float"
-    ev = _attn_bracket(f"wattn_bwd_kernel<{tn}, {'true' if region is not None else 'false'}>", B * nW * n_head, L, 32,
+    ev = _attn_bracket(wattn_bwd_kernel_name(qkv.dtype, region is not None, use_inverse), B * nW * n_head, L, 32,
                        B * nW * L, n_head * 32, qkv.element_size(), True)     # (+ the small drel_pos column reduce)
     check(lib.vtx_wattn_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(rel_pos), _p(pos), _p(region), _p(dqkv), _p(drel),
                             _p(ws), wsb, _p(inv_cells), inv_count, B, L, n_head, H, W, win, int(bool(shift)), _dt(qkv),
