@@ -259,15 +259,8 @@ __device__ __forceinline__ void glds_wave_sync() {      // orders this wave's ow
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// chunked dispatch order -> tile order: workgroup `did` runs on XCD did & 7; XCD x gets the x-th contiguous eighth of `nblk`
-__device__ __forceinline__ int glds_xcd_chunk(int did, int nblk) {
-  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
-  return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
-}
-
-// one BM x 128 output tile at (m0, n0) on the 8 waves of the workgroup
-template <int BM, int NWN, bool MAPPED>
-__device__ __forceinline__ void glds_pv_tile(const GemmArgs& p, const int m0, const int n0) {
+template <int BM, int NWN, bool MAPPED = false>
+__global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
   constexpr int BN = 128, BK = 64, NS = 2;
   constexpr int ROWB = BK * 2, CPR = BK / 8, PR = 1024 / ROWB, KS = BK / 32, NWV = 8;
   constexpr int NWM = NWV / NWN;
@@ -285,6 +278,19 @@ __device__ __forceinline__ void glds_pv_tile(const GemmArgs& p, const int m0, co
   const int c_ = lane & 15, g_ = lane >> 4;
 
   const int live_rows = MAPPED ? p.Mk : p.M;
+  const int ntn = gridDim.x, ntm = gridDim.y;
+  // Dispatch order -> tile: workgroup `did` lands on XCD did & 7; each XCD gets a contiguous chunk of the tile order (its
+  // L2 then holds a band of A rows).  In a mapped launch only the tiles of the kept rows COMPUTE and the chunking runs over
+  // those alone: chunked over all tiles, the copy-only tiles (last in tile order) would all fall to the last XCDs and the
+  // others would hold ntiles / 8 compute tiles each -- 73 on 64 resident slots for the 588-tile N = 384 launches, a second
+  // round for a launch whose compute tiles (~480) fit one (measured in the model: 42 us where the row count predicts 25).
+  const int nblk = ntn * (MAPPED ? (live_rows + BM - 1) / BM : ntm);
+  const int did = blockIdx.y * ntn + blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
+  const int lid = (MAPPED && did >= nblk) ? did
+                                          : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int tn = lid % ntn, tm = lid / ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int nk = p.K / BK;
 
   const bf16* A = (const bf16*)p.A;
@@ -470,38 +476,6 @@ __device__ __forceinline__ void glds_pv_tile(const GemmArgs& p, const int m0, co
   VTX_TRACE(7);
 }
 
-template <int BM, int NWN, bool MAPPED = false>
-__global__ __launch_bounds__(512) void gemm_glds_pv_kernel(GemmArgs p) {
-  const int ntn = gridDim.x, ntm = gridDim.y;
-  // Dispatch order -> tile: workgroup `did` lands on XCD did & 7; each XCD gets a contiguous chunk of the tile order (its
-  // L2 then holds a band of A rows).  In a mapped launch only the tiles of the kept rows COMPUTE and the chunking runs over
-  // those alone: chunked over all tiles, the copy-only tiles (last in tile order) would all fall to the last XCDs and the
-  // others would hold ntiles / 8 compute tiles each -- 73 on 64 resident slots for the 588-tile N = 384 launches, a second
-  // round for a launch whose compute tiles (~480) fit one (measured in the model: 42 us where the row count predicts 25).
-  const int nblk = ntn * (MAPPED ? (p.Mk + BM - 1) / BM : ntm);
-  const int did = blockIdx.y * ntn + blockIdx.x;
-  const int lid = (MAPPED && did >= nblk) ? did : glds_xcd_chunk(did, nblk);
-  const int tn = lid % ntn, tm = lid / ntn;
-  glds_pv_tile<BM, NWN, MAPPED>(p, tm * BM, tn * 128);
-}
-
-// Mixed tile heights in ONE launch (unmapped): the first n128 workgroups compute 128-row tiles over rows [0, row_split), the
-// others 64-row tiles over the rest.  A launch of t 128-row tiles runs ceil(t / 512) resident rounds (two 64-KB workgroups on
-// each of the 256 CUs); with t mod 512 small, the last round leaves most of the chip idle for a whole tile time -- ViT-S/16's
-// N = 384 GEMMs (1 182 tiles = 2.31 rounds, 60 launches per step) pay 3 tile times for 2.31 of work.  With the rows of that
-// last partial round cut into 64-row tiles (twice as many, half the time each, still one round) it ends after half a tile time.
-__global__ __launch_bounds__(512) void gemm_glds_pv_mixed_kernel(GemmArgs p, int n128, int row_split) {
-  const int ntn = (p.N + 127) >> 7;
-  const int did = blockIdx.x;                             // n128 % 8 == 0: did & 7 is the XCD in both parts
-  if (did < n128) {
-    const int lid = glds_xcd_chunk(did, n128);
-    glds_pv_tile<128, 2, false>(p, (lid / ntn) * 128, (lid % ntn) * 128);
-  } else {
-    const int lid = glds_xcd_chunk(did - n128, (int)gridDim.x - n128);
-    glds_pv_tile<64, 4, false>(p, row_split + (lid / ntn) * 64, (lid % ntn) * 128);
-  }
-}
-
 template <int BM, int NWN, bool MAPPED> static int glds_launch_pv_m(const GemmArgs& a, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * (BM + 128) * 128;
   auto kern = gemm_glds_pv_kernel<BM, NWN, MAPPED>;
@@ -515,29 +489,6 @@ template <int BM, int NWN, bool MAPPED> static int glds_launch_pv_m(const GemmAr
 // (the row map of stochastic-depth compaction is a compile-time variant: the unmapped kernels carry none of its code)
 template <int BM, int NWN> static int glds_launch_pv(const GemmArgs& a, hipStream_t st) {
   return a.perm != nullptr ? glds_launch_pv_m<BM, NWN, true>(a, st) : glds_launch_pv_m<BM, NWN, false>(a, st);
-}
-
-// 128-row tiles for the full resident rounds + 64-row tiles for the rows of the last partial round, when that round is
-// at most half full (gemm_glds_pv_mixed_kernel); returns -1 when the launch does not qualify
-static int glds_launch_pv_mixed(const GemmArgs& a, hipStream_t st) {
-  if (a.perm != nullptr || a.K % 64 != 0 || a.N % 128 != 0 || vtx_opt(VTX_OPT_GLDS_EPI) != 1) return -1;
-  const int force = vtx_opt(VTX_OPT_GLDS_BM);
-  if (force == 64 || force == 128) return -1;
-  const long ntn = a.N / 128, rb = ((long)a.M + 127) / 128, t128 = ntn * rb;
-  const long tail = t128 % 512;
-  if (t128 < 800 || tail == 0 || tail > 256) return -1;
-  long rb128 = (t128 - tail) / ntn;                       // whole 128-row blocks inside the full rounds
-  while (rb128 > 0 && (rb128 * ntn) % 8 != 0) --rb128;
-  if (rb128 <= 0) return -1;
-  const long row_split = rb128 * 128, n128 = rb128 * ntn;
-  const long n64 = (((long)a.M - row_split + 63) / 64) * ntn;
-  if (n64 <= 0 || n64 > 640) return -1;
-  constexpr size_t smem = (size_t)2 * (128 + 128) * 128;
-  auto kern = gemm_glds_pv_mixed_kernel;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return VTX_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n128 + n64)), dim3(512), smem, st, a, (int)n128, (int)row_split);
-  return vtx_check_launch();
 }
 
 template <int BM, int BN, int BK, int NS, int NWN = 2> static int glds_launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -598,12 +549,6 @@ static int glds_pick_bm(const GemmArgs& a, int bn) {
 }
 
 template <int BN> static int glds_launch_bn(const GemmArgs& a, hipStream_t st) {
-  if constexpr (BN == 128) {
-    if (vtx_opt(VTX_OPT_GLDS_MIXED) != 0) {
-      const int rc = glds_launch_pv_mixed(a, st);
-      if (rc >= 0) return rc;
-    }
-  }
   return glds_pick_bm(a, BN) == 64 ? glds_launch_t<64, BN>(a, st) : glds_launch_t<128, BN>(a, st);
 }
 

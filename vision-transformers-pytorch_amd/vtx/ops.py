@@ -291,29 +291,6 @@ def glds_ok(N, K):
     return K % 64 == 0 or (K % 32 == 0 and N % 128 == 0)
 
 
-def gemm_mixed_tiles(N, K, M, mapped=False):
-    """Mirrors glds_launch_pv_mixed (gemm_glds.hip): (n128 workgroups, row_split, n64 workgroups) when the launch takes 128-row
-    tiles for its full resident rounds and 64-row tiles for the rows of the last, at most half-full one; else None."""
-    if mapped or K % 64 or N % 128 or options.get("GLDS_EPI") != 1 or not options.get("GLDS_MIXED"):
-        return None
-    if options.get("GLDS_BM") in (64, 128):
-        return None
-    ntn, rb = N // 128, (M + 127) // 128
-    t128 = ntn * rb
-    tail = t128 % 512
-    if t128 < 800 or tail == 0 or tail > 256:
-        return None
-    rb128 = (t128 - tail) // ntn
-    while rb128 > 0 and (rb128 * ntn) % 8:
-        rb128 -= 1
-    if rb128 <= 0:
-        return None
-    n64 = ((M - rb128 * 128 + 63) // 64) * ntn
-    if n64 <= 0 or n64 > 640:
-        return None
-    return rb128 * ntn, rb128 * 128, n64
-
-
 def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False):
     """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip); ``mapped``: the
     row-mapped variant of a compacted branch (M = the rows it computes)."""
@@ -332,8 +309,6 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False):
         if K % 64 != 0:
             return f"gemm_glds_kernel<{bm}, {bn}, 32, 3, 2>"
         if bn == 128 and options.get("GLDS_EPI") == 1:                     # mirrors glds_launch_t: wave-private epilogue
-            if gemm_mixed_tiles(N, K, M, mapped):
-                return "gemm_glds_pv_mixed_kernel"
             return f"gemm_glds_pv_kernel<{bm}, {2 if bm == 128 else 4}, {'true' if mapped else 'false'}>"
         nwn = 4 if (bn == 128 and options.get("GLDS_WAVES") != 4) else 2
         return f"gemm_glds_kernel<{bm}, {bn}, 64, 2, {nwn}>"
