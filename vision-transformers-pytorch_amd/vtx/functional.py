@@ -1068,7 +1068,12 @@ class PvtLayerFn(Function):
         # ---- MLP branch
         dz = dgrad(dy, w2, T, act=ACT_DSILU, aux_in=z, rowscale=s2, rows_per_scale=rps)
         dln2 = dgrad(dz, w1, T)
-        dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
+        # (round 3: the layer's column reductions -- LayerNorm dgamma / dbeta of LN2, LN1 and the reduction's LayerNorm -- ride in
+        #  the reduce launch of the grouped weight gradients, like the Swin / ViT layers: -3 launches per layer, off the main stream)
+        if _DEFER_REDUCE:
+            dx1, part2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy, defer=True)
+        else:
+            dx1, dg2, dbe2 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, ln2_w.detach(), dres=dy)
         # ---- attention branch
         do = dgrad(dx1, wo, T, rowscale=s1, rows_per_scale=rps)
         dq, dkv = ops.srattn_bwd(q, kv, o, do, lse, B, L, Lk, m.n_head)
@@ -1076,7 +1081,10 @@ class PvtLayerFn(Function):
         jobs = [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dq, ln1, False, None)]
         if r > 1:
             dkvin = dgrad(dkv, wkv, T)
-            dred, dgs, dbs = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach())
+            if _DEFER_REDUCE:
+                dred, part_s = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach(), defer=True)
+            else:
+                dred, dgs, dbs = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach())
             dpatches = dgrad(dred, wsr, T)
             dln1 = dgrad(dq, wq, T)
             ops.patchify_bwd(dpatches, dln1, B, m.height, m.width, C, r, m.skip, accumulate=True)
@@ -1090,8 +1098,16 @@ class PvtLayerFn(Function):
             jobs.append((dkv, ln1, False, None))
             dkvin = dgrad(dkv, wkv, T)
             dln1 = dgrad(dq, wq, T, resid=dkvin)                       # both consumers of LN1's output
-        dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
-        res = layer_wgrads(jobs, rps, dp_c)
+        if _DEFER_REDUCE:
+            dx, part1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1, defer=True)
+            parts = [part2, part1] + ([part_s] if r > 1 else [])
+            res, red_out = layer_wgrads(jobs, rps, dp_c, colparts=parts)
+            (dg2, dbe2), (dg1, dbe1) = red_out[0], red_out[1]
+            if r > 1:
+                dgs, dbs = red_out[2]
+        else:
+            dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
+            res = layer_wgrads(jobs, rps, dp_c)
         (dW2, db2), (dW1, db1), (dWo, dbo), (dWq, _) = res[:4]
         if r == 1:
             dWkv = res[4][0]
