@@ -106,6 +106,52 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
             assert torch.equal(a, g), f"{name} differs under {kw}"
 
 
+@pytest.mark.parametrize("M,N,K,T", [(66395, 288, 96, 49), (66395, 96, 96, 49), (66395, 384, 96, 49),
+                                     (40100, 128, 64, 100), (33100, 256, 128, 100), (36100, 512, 64, 100)])
+def test_weight_resident_streaming_gemm_vs_oracle_and_the_tiled_kernels(M, N, K, T):
+    """Round 3: bf16 GEMMs with a short contraction (K = 64 / 96 / 128: Swin-S stage 1, PVT stages 1-2) over >= 32 768 rows
+    take gemm_skinny_kernel (whole weight resident in LDS, A streamed into MFMA registers, transposed product, 16-byte
+    epilogue vectors).  Every fused epilogue vs the fp64 oracle, and bit for bit against the tiled kernels (same products,
+    same k order inside the MFMA) -- at row counts that are no multiple of the 32-row wave block."""
+    from vtx import ops, options
+    d = dev()
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == f"gemm_skinny_kernel<{K // 32}>"
+    assert "skinny" not in ops.gemm_kernel_name(BF, N, 0, K=K, M=M, vec=True)      # (residual / z epilogues: tiled by default)
+    x = _mk((M, K), 151, BF)
+    w = _mk((N, K), 152, BF, 0.1)
+    b = _mk((N,), 153, torch.float32, 0.1)
+    res = _mk((M, N), 154, BF)
+    zin = _mk((M, N), 155, BF)
+    keep = (torch.rand(M // T, generator=torch.Generator().manual_seed(156)) < 0.8).float() / 0.8
+    xd, wd, bd, rd, zd, kd = (t.to(d) for t in (x, w, b, res, zin, keep))
+
+    def run():
+        y0 = ops.gemm(xd, wd, 0, bias=bd)
+        h, z = ops.gemm(xd, wd, 0, bias=bd, act=ops.ACT_SILU, want_aux=True)
+        dz = ops.gemm(xd, wd, 0, act=ops.ACT_DSILU, aux_in=zd, rowscale=kd, rows_per_scale=T)
+        y = ops.gemm(xd, wd, 0, bias=bd, resid=rd, rowscale=kd, rows_per_scale=T)
+        g, zg = ops.gemm(xd, wd, 0, bias=bd, act=ops.ACT_GELU, want_aux=True)
+        return y0, h, z, dz, y, g, zg
+
+    with options.override(GEMM_SKINNY=2):              # every epilogue on the streaming kernel
+        got = run()
+    acc = _mm64(x, w)
+    ks = keep.double().repeat_interleave(T)[:, None]
+    zr = acc + b.double()
+    check(f"skinny bias {M}x{N}x{K}", got[0], zr, TOL[BF]["out"])
+    check(f"skinny z {M}x{N}x{K}", got[2], zr, TOL[BF]["out"])
+    check(f"skinny silu(z) {M}x{N}x{K}", got[1], R.silu(got[2].cpu().double()), TOL[BF]["out"])
+    sz = torch.sigmoid(zin.double())
+    check(f"skinny dsilu+droppath {M}x{N}x{K}", got[3], ks * acc * (sz * (1 + zin.double() * (1 - sz))), TOL[BF]["out"])
+    check(f"skinny bias+droppath+residual {M}x{N}x{K}", got[4], res.double() + ks * zr, TOL[BF]["out"])
+    check(f"skinny gelu(z) {M}x{N}x{K}", got[5], torch.nn.functional.gelu(got[6].cpu().double()), TOL[BF]["out"])
+    with options.override(GEMM_SKINNY=0):
+        assert "skinny" not in ops.gemm_kernel_name(BF, N, 0, K=K, M=M)
+        tiled = run()
+    for a, t_, name in zip(got, tiled, ("bias", "silu", "z", "dsilu", "resid", "gelu", "z(gelu)")):
+        assert torch.equal(a, t_), f"{name}: the streaming kernel differs from the tiled kernel at {(M, N, K)}"
+
+
 @pytest.mark.parametrize("H,nH", [(14, 12), (56, 3)])
 def test_wattn_backward_four_waves_per_problem_matches_the_one_wave_kernel_at_bench_size(H, nH):
     """Round 3: the bf16 window-attention backward shares a problem between the four waves of its workgroup

@@ -281,6 +281,7 @@ int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, 
   int rc = gemm_validate(a, mode);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16 && mode == 0 && gemm_skinny_ok(a)) return gemm_skinny_launch(a, st);
   if (dtype == VTX_BF16 && mode == 0 && gemm_glds_ok(N, K) && gemm_glds_enabled()) {
     return gemm_glds_launch(a, st);
   }

@@ -172,6 +172,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[BM
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st);
 bool gemm_glds_enabled();
 bool gemm_glds_ok(int N, int K);
+// gemm_skinny.hip: weight-resident streaming kernel for K = 64 / 96 / 128 over >= 32 768 rows (bf16, A . W^T)
+bool gemm_skinny_ok(const GemmArgs& a);
+int gemm_skinny_launch(const GemmArgs& a, hipStream_t st);
 // mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE
 int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st);
 

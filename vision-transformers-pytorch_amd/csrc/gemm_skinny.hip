@@ -1,0 +1,199 @@
+// Weight-resident streaming GEMM for gfx950 (bf16): C[M,N] = epilogue(A[M,K] . W[N,K]^T) with a SHORT contraction
+// (K = 64 / 96 / 128: Swin-S stage 1, PVT stages 1-2) over MANY rows (M >= 32 768).
+//
+// These launches are pure HBM streams (Swin stage 1, M = 401 408, K = 96: qkv forward reads 77 MB and writes 231 MB; fc1
+// forward writes its 308-MB output twice), yet the tiled kernels ran them at 0.4-0.6 of the stream rate: a 128 x 128 (or 64 x
+// 128) tile has a 1-3 k-tile main loop, i.e. it is all prologue and epilogue, the A panel is fetched once per column tile, and
+// the register-staged kernel that takes N = 96 / 288 pays ds_write for every operand byte.  Here
+//   * the WHOLE weight (N x K bf16, <= 139 KB) is copied into LDS once per persistent workgroup (one per CU, 4 waves);
+//   * a wave streams 32-row blocks of A straight from global memory into MFMA operand registers (16 B per lane and k-step,
+//     the next block's fragments requested before the current block is multiplied) -- no LDS traffic for A at all;
+//   * the product is taken TRANSPOSED, D[n][m] with W rows as the MFMA A operand in the row order n(8 g + e) <-> operand row
+//     16 (e >> 2) + 4 g + (e & 3) (the permutation of attention_win.hip's wa_store_t): after two 16 x 16 tiles a lane holds 8
+//     CONSECUTIVE output columns of one row -> the epilogue works on 16-byte vectors in the layout of its operands (residual,
+//     z) with no staging pass, and every output byte is written once;
+//   * same element-wise epilogue expressions as gemm_glds.hip (bias, SiLU / GELU + z, silu' / gelu' x z, DropPath scale,
+//     residual), same k order inside the MFMA: bit-identical to the tiled kernels.
+// Measured (tools/probe/skinny_gemm.hip, M = 401 408, K = 96): N = 288 74 us (tiled 117), N = 384 with two outputs 168 us
+// (217), N = 96 26 us; floors at 6.3 TB/s: 49 / 110 / 24.5 us.
+#include "gemm_common.h"
+#include "options.h"
+
+constexpr int SK_ROWS = 32;        // rows of A per wave iteration (two 16-row MFMA tiles)
+constexpr int SK_WAVES = 4;
+
+// K = 32 KS; ACT = GemmArgs::act, VEC = the epilogue reads a vector per output vector (z for act', else the residual) --
+// both compile-time: the per-pair loop of a plain / activation forward carries no loads, no selects, no dead operands
+template <int KS, int ACT, bool VEC>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p) {
+  constexpr int K = 32 * KS, WSTR = K + 8;             // LDS row stride of W (elements): 16 B of padding per row
+  extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+  bf16* ws = reinterpret_cast<bf16*>(sk_smem);
+  float* bs = reinterpret_cast<float*>(sk_smem + (size_t)p.N * WSTR * 2);
+  const bf16* __restrict__ A = (const bf16*)p.A;
+  const bf16* __restrict__ W = (const bf16*)p.B;
+  const int N = p.N, M = p.M;
+  for (int i = threadIdx.x; i < N * (K / 8); i += 64 * SK_WAVES) {
+    const int n = i / (K / 8), q = i - n * (K / 8);
+    *reinterpret_cast<bf16x8*>(ws + n * WSTR + q * 8) = *reinterpret_cast<const bf16x8*>(W + (int64_t)n * p.ldb + q * 8);
+  }
+  for (int i = threadIdx.x; i < N; i += 64 * SK_WAVES) bs[i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int nrb = (M + SK_ROWS - 1) / SK_ROWS;
+  const int stride = gridDim.x * SK_WAVES;
+  bf16* __restrict__ Cout = (bf16*)p.C;
+  bf16* __restrict__ aux_out = (bf16*)p.aux_out;
+  const bf16* __restrict__ resid = (const bf16*)p.resid;
+  const bf16* __restrict__ aux_in = (const bf16*)p.aux_in;
+  constexpr int act = ACT;
+  constexpr bool act_fwd = act == 1 || act == 3, act_bwd = act == 2 || act == 4;
+  const int npairs = N >> 5;
+
+  bf16x8 an[2][KS];
+  auto load_a = [&](int rb) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = min(rb * SK_ROWS + mt * 16 + c, M - 1);   // (rows past M are never stored)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) an[mt][ks] = *reinterpret_cast<const bf16x8*>(A + (int64_t)row * p.lda + ks * 32 + g * 8);
+    }
+  };
+  int rb = blockIdx.x * SK_WAVES + wave;
+  if (rb < nrb) load_a(rb);
+  for (; rb < nrb; rb += stride) {
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[mt][ks] = an[mt][ks];
+    if (rb + stride < nrb) load_a(rb + stride);
+    int row[2];
+    float rsc[2];
+    bool ok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      row[mt] = rb * SK_ROWS + mt * 16 + c;
+      ok[mt] = row[mt] < M;
+      rsc[mt] = (ok[mt] && p.rowscale) ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+    }
+    // epilogue vectors of the first column pair (z for act', else the residual); the next pair's are requested one pair ahead
+    const bf16* __restrict__ vsrc = act_bwd ? aux_in : resid;
+    Vec8<bf16> ev[2], evn[2];
+    if constexpr (VEC) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) evn[mt] = load8<bf16>(vsrc + (int64_t)min(row[mt], M - 1) * p.ldc + 8 * g);
+    }
+#pragma unroll 3
+    for (int np = 0; np < npairs; ++np) {
+      if constexpr (VEC) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ev[mt] = evn[mt];
+        const int npn = min(np + 1, npairs - 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) evn[mt] = load8<bf16>(vsrc + (int64_t)min(row[mt], M - 1) * p.ldc + npn * 32 + 8 * g);
+      } else {
+        ev[0] = vec8_zero<bf16>(); ev[1] = ev[0];
+      }
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = np * 32 + 8 * (c >> 2) + 4 * j + (c & 3);       // the W row this lane supplies as MFMA A-operand row c
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Vec8<bf16> wf;
+          wf.v = *reinterpret_cast<const bf16x8*>(ws + n * WSTR + ks * 32 + g * 8);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            Vec8<bf16> af;
+            af.v = a[mt][ks];
+            mma16(wf, af, acc[mt][j]);
+          }
+        }
+      }
+      // acc[mt][j][r] = (A . W^T)[row = 32 rb + 16 mt + c][col = 32 np + 8 g + 4 j + r]
+      const int col = np * 32 + 8 * g;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + col), b1 = *reinterpret_cast<const f32x4*>(bs + col + 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (!ok[mt]) continue;
+        const int64_t off = (int64_t)row[mt] * p.ldc + col;
+        float val[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { val[r] = acc[mt][0][r] + b0[r]; val[4 + r] = acc[mt][1][r] + b1[r]; }
+        if (act_fwd) {
+          Vec8<bf16> z;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z.set(e, val[e]);
+          if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = silu_f(z.get(e));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = gelu_f(z.get(e));
+          }
+          if (aux_out) store8<bf16>(aux_out + off, z);
+        } else if (act_bwd) {
+          if (act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(ev[mt].get(e));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] *= dgelu_f(ev[mt].get(e));
+          }
+        }
+        Vec8<bf16> rv = ev[mt];
+        if (act_bwd) rv = resid ? load8<bf16>(resid + off) : vec8_zero<bf16>();
+        Vec8<bf16> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, val[e] * rsc[mt] + rv.get(e));
+        store8<bf16>(Cout + off, o);
+      }
+    }
+  }
+}
+
+static size_t skinny_smem(int N, int K) { return (size_t)N * (K + 8) * 2 + (size_t)N * 4; }
+
+bool gemm_skinny_ok(const GemmArgs& a) {
+  if (vtx_opt(VTX_OPT_GEMM_SKINNY) == 0 || a.perm != nullptr) return false;
+  // (launches whose epilogue READS a vector per output vector -- residual, z of act' -- stay on the tiled kernels unless option
+  //  GEMM_SKINNY = 2: with 4 waves per CU the loads are exposed; measured fc2 dgrad 160 -> 215 us, proj forward 44 -> 47 us)
+  if ((a.resid != nullptr || a.act == 2 || a.act == 4) && vtx_opt(VTX_OPT_GEMM_SKINNY) != 2) return false;
+  if (a.K != 64 && a.K != 96 && a.K != 128) return false;
+  if (a.N % 32 != 0 || a.N < 32 || a.M < 32768) return false;
+  if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
+  return skinny_smem(a.N, a.K) <= 150 * 1024;
+}
+
+template <int KS, int ACT, bool VEC> static int skinny_launch_kav(const GemmArgs& a, hipStream_t st) {
+  const size_t smem = skinny_smem(a.N, a.K);
+  auto kern = gemm_skinny_kernel<KS, ACT, VEC>;
+  if (smem > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return VTX_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(64 * SK_WAVES), smem, st, a);   // one persistent workgroup per CU
+  return vtx_check_launch();
+}
+
+template <int KS> static int skinny_launch_k(const GemmArgs& a, hipStream_t st) {
+  const bool vec = a.resid != nullptr;
+  switch (a.act) {
+    case 0: return vec ? skinny_launch_kav<KS, 0, true>(a, st) : skinny_launch_kav<KS, 0, false>(a, st);
+    case 1: return vec ? skinny_launch_kav<KS, 1, true>(a, st) : skinny_launch_kav<KS, 1, false>(a, st);
+    case 3: return vec ? skinny_launch_kav<KS, 3, true>(a, st) : skinny_launch_kav<KS, 3, false>(a, st);
+    case 2: return skinny_launch_kav<KS, 2, true>(a, st);           // (act': z is always read)
+    default: return skinny_launch_kav<KS, 4, true>(a, st);
+  }
+}
+
+int gemm_skinny_launch(const GemmArgs& a, hipStream_t st) {
+  if (a.K == 64) return skinny_launch_k<2>(a, st);
+  if (a.K == 96) return skinny_launch_k<3>(a, st);
+  return skinny_launch_k<4>(a, st);
+}

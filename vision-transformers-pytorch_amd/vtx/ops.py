@@ -248,7 +248,7 @@ def _describe_timer_rec(r):
     mapped = "true" if fl & 8 else "false"
     D = fl >> 8
     if r.tag == 2:                                                      # GEMM: C[rows, n] over k
-        name = gemm_kernel_name(dt, n, 0, K=k, M=rows, mapped=bool(fl & 8))
+        name = gemm_kernel_name(dt, n, 0, K=k, M=rows, mapped=bool(fl & 8), vec=bool(fl & 5))
         nb = es * (rows * k + n * k + rows * n * (1 + bool(fl & 1) + bool(fl & 2) + bool(fl & 4)))
         return name, 2.0 * rows * n * k, float(nb), r.ms
     if r.tag == 1:
@@ -286,17 +286,27 @@ def wattn_bwd_kernel_name(dtype, masked, inverse_map=True):
     return f"wattn_bwd_kernel<{'__bf16' if dtype == torch.bfloat16 else 'float'}, {m}>"
 
 
+def skinny_ok(N, K, M, vec=False):
+    """Mirrors gemm_skinny_ok (gemm_skinny.hip): the weight-resident streaming kernel (contiguous operands assumed);
+    ``vec``: the epilogue reads a residual or z (those launches stay on the tiled kernels unless GEMM_SKINNY = 2)."""
+    opt = options.get("GEMM_SKINNY")
+    return (bool(opt) and (not vec or opt == 2) and K in (64, 96, 128) and N % 32 == 0 and N >= 32 and M >= 32768
+            and N * (K + 8) * 2 + N * 4 <= 150 * 1024)
+
+
 def glds_ok(N, K):
     """Shapes the LDS-DMA GEMM takes (mirrors gemm_glds_ok in gemm_glds.hip)."""
     return K % 64 == 0 or (K % 32 == 0 and N % 128 == 0)
 
 
-def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False):
+def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False):
     """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip); ``mapped``: the
     row-mapped variant of a compacted branch (M = the rows it computes)."""
     t = "__bf16" if dtype == torch.bfloat16 else "float"
     to = "float" if out_f32 else t
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
+    if dtype == torch.bfloat16 and mode == 0 and skinny_ok(N, K, M, vec) and not mapped:
+        return f"gemm_skinny_kernel<{K // 32}>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
         force = options.get("GLDS_BM")                                     # mirrors glds_pick_bm in gemm_glds.hip
         if force in (64, 128):
@@ -342,7 +352,8 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     if _timer is not None:
         es = a.element_size()
         nb = es * (M * K + N * K + M * N * (1 + (resid is not None) + bool(want_aux) + (aux_in is not None)))
-        ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M), 2.0 * M * N * K, float(nb))
+        ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M, vec=resid is not None or act in (ACT_DSILU, ACT_DGELU)),
+                            2.0 * M * N * K, float(nb))
     if ev:
         ev[0].record()
     check(lib.vtx_gemm(mode, _dt(a), _p(a), _p(w), _p(c), M, N, K, K, w.shape[1], N, _p(bias), _p(resid),
