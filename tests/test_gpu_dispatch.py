@@ -107,7 +107,8 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
 
 
 @pytest.mark.parametrize("M,N,K,T", [(66395, 288, 96, 49), (66395, 96, 96, 49), (66395, 384, 96, 49),
-                                     (40100, 128, 64, 100), (33100, 256, 128, 100), (36100, 512, 64, 100)])
+                                     (40100, 128, 64, 100), (33100, 256, 128, 100), (36100, 512, 64, 100),
+                                     (33100, 1024, 128, 100), (33100, 2048, 64, 100)])   # (column chunks: 2, 4)
 def test_weight_resident_streaming_gemm_vs_oracle_and_the_tiled_kernels(M, N, K, T):
     """Round 3: bf16 GEMMs with a short contraction (K = 64 / 96 / 128: Swin-S stage 1, PVT stages 1-2) over >= 32 768 rows
     take gemm_skinny_kernel (whole weight resident in LDS, A streamed into MFMA registers, transposed product, 16-byte

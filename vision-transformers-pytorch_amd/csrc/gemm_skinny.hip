@@ -25,28 +25,32 @@ constexpr int SK_WAVES = 4;
 // K = 32 KS; ACT = GemmArgs::act, VEC = the epilogue reads a vector per output vector (z for act', else the residual) --
 // both compile-time: the per-pair loop of a plain / activation forward carries no loads, no selects, no dead operands
 template <int KS, int ACT, bool VEC>
-__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, int nchunk) {
   constexpr int K = 32 * KS, WSTR = K + 8;             // LDS row stride of W (elements): 16 B of padding per row
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
   bf16* ws = reinterpret_cast<bf16*>(sk_smem);
-  float* bs = reinterpret_cast<float*>(sk_smem + (size_t)p.N * WSTR * 2);
+  // A weight too large for LDS is split into `nchunk` (1, 2 or 4) column chunks: workgroup b keeps chunk b % nchunk and streams
+  // every nchunk-th share of the row blocks (A is then read nchunk times -- it is the small operand of these launches)
+  const int chunk = blockIdx.x % nchunk, wgc = blockIdx.x / nchunk, nwgc = gridDim.x / nchunk;
+  const int N = p.N / nchunk, M = p.M;                  // columns of this workgroup
+  const int ncol0 = chunk * N;
   const bf16* __restrict__ A = (const bf16*)p.A;
-  const bf16* __restrict__ W = (const bf16*)p.B;
-  const int N = p.N, M = p.M;
+  const bf16* __restrict__ W = (const bf16*)p.B + (int64_t)ncol0 * p.ldb;
+  float* bs = reinterpret_cast<float*>(sk_smem + (size_t)N * WSTR * 2);
   for (int i = threadIdx.x; i < N * (K / 8); i += 64 * SK_WAVES) {
     const int n = i / (K / 8), q = i - n * (K / 8);
     *reinterpret_cast<bf16x8*>(ws + n * WSTR + q * 8) = *reinterpret_cast<const bf16x8*>(W + (int64_t)n * p.ldb + q * 8);
   }
-  for (int i = threadIdx.x; i < N; i += 64 * SK_WAVES) bs[i] = p.bias ? p.bias[i] : 0.f;
+  for (int i = threadIdx.x; i < N; i += 64 * SK_WAVES) bs[i] = p.bias ? p.bias[ncol0 + i] : 0.f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int nrb = (M + SK_ROWS - 1) / SK_ROWS;
-  const int stride = gridDim.x * SK_WAVES;
-  bf16* __restrict__ Cout = (bf16*)p.C;
-  bf16* __restrict__ aux_out = (bf16*)p.aux_out;
-  const bf16* __restrict__ resid = (const bf16*)p.resid;
-  const bf16* __restrict__ aux_in = (const bf16*)p.aux_in;
+  const int stride = nwgc * SK_WAVES;
+  bf16* __restrict__ Cout = (bf16*)p.C + ncol0;
+  bf16* __restrict__ aux_out = p.aux_out ? (bf16*)p.aux_out + ncol0 : nullptr;
+  const bf16* __restrict__ resid = p.resid ? (const bf16*)p.resid + ncol0 : nullptr;
+  const bf16* __restrict__ aux_in = p.aux_in ? (const bf16*)p.aux_in + ncol0 : nullptr;
   constexpr int act = ACT;
   constexpr bool act_fwd = act == 1 || act == 3, act_bwd = act == 2 || act == 4;
   const int npairs = N >> 5;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p) 
       for (int ks = 0; ks < KS; ++ks) an[mt][ks] = *reinterpret_cast<const bf16x8*>(A + (int64_t)row * p.lda + ks * 32 + g * 8);
     }
   };
-  int rb = blockIdx.x * SK_WAVES + wave;
+  int rb = wgc * SK_WAVES + wave;
   if (rb < nrb) load_a(rb);
   for (; rb < nrb; rb += stride) {
     bf16x8 a[2][KS];
@@ -159,25 +163,34 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p) 
 }
 
 static size_t skinny_smem(int N, int K) { return (size_t)N * (K + 8) * 2 + (size_t)N * 4; }
+// column chunks (1, 2, 4) so that a chunk of the weight fits LDS; 0: none does
+static int skinny_chunks(int N, int K) {
+  for (int nc = 1; nc <= 4; nc *= 2)
+    if (N % (32 * nc) == 0 && skinny_smem(N / nc, K) <= 150 * 1024) return nc;
+  return 0;
+}
 
 bool gemm_skinny_ok(const GemmArgs& a) {
   if (vtx_opt(VTX_OPT_GEMM_SKINNY) == 0 || a.perm != nullptr) return false;
   // (launches whose epilogue READS a vector per output vector -- residual, z of act' -- stay on the tiled kernels unless option
   //  GEMM_SKINNY = 2: with 4 waves per CU the loads are exposed; measured fc2 dgrad 160 -> 215 us, proj forward 44 -> 47 us)
   if ((a.resid != nullptr || a.act == 2 || a.act == 4) && vtx_opt(VTX_OPT_GEMM_SKINNY) != 2) return false;
+  // (K = 192, Swin stage 2, was built and measured: 6 k-steps per output pair on 4 waves per CU -- qkv forward 56.4 -> 54.5 us, fc1
+  //  forward 125 -> 121 us: within noise of the tiled kernels, not routed here)
   if (a.K != 64 && a.K != 96 && a.K != 128) return false;
-  if (a.N % 32 != 0 || a.N < 32 || a.M < 32768) return false;
+  if (a.N < 32 || a.M < 32768) return false;
   if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
-  return skinny_smem(a.N, a.K) <= 150 * 1024;
+  return skinny_chunks(a.N, a.K) != 0;
 }
 
 template <int KS, int ACT, bool VEC> static int skinny_launch_kav(const GemmArgs& a, hipStream_t st) {
-  const size_t smem = skinny_smem(a.N, a.K);
+  const int nc = skinny_chunks(a.N, a.K);
+  const size_t smem = skinny_smem(a.N / nc, a.K);
   auto kern = gemm_skinny_kernel<KS, ACT, VEC>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(256), dim3(64 * SK_WAVES), smem, st, a);   // one persistent workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(256), dim3(64 * SK_WAVES), smem, st, a, nc);   // one persistent workgroup per CU
   return vtx_check_launch();
 }
 

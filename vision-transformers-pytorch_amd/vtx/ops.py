@@ -290,8 +290,8 @@ def skinny_ok(N, K, M, vec=False):
     """Mirrors gemm_skinny_ok (gemm_skinny.hip): the weight-resident streaming kernel (contiguous operands assumed);
     ``vec``: the epilogue reads a residual or z (those launches stay on the tiled kernels unless GEMM_SKINNY = 2)."""
     opt = options.get("GEMM_SKINNY")
-    return (bool(opt) and (not vec or opt == 2) and K in (64, 96, 128) and N % 32 == 0 and N >= 32 and M >= 32768
-            and N * (K + 8) * 2 + N * 4 <= 150 * 1024)
+    fits = any(N % (32 * nc) == 0 and (N // nc) * (K + 8) * 2 + (N // nc) * 4 <= 150 * 1024 for nc in (1, 2, 4))
+    return bool(opt) and (not vec or opt == 2) and K in (64, 96, 128) and N >= 32 and M >= 32768 and fits
 
 
 def glds_ok(N, K):
