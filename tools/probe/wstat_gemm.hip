@@ -15,7 +15,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int K = 384, KS = 12, WSTR = K + 8;
+constexpr int K = 384, KS = 12, WSTR = K;          // no padding: 16-byte chunk q of LDS row r sits at chunk (q & ~15) | ((q & 15) ^ (r & 15))
 
 template <int CN, int NW, int DB>
 __global__ __launch_bounds__(64 * NW) void wstat_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
@@ -24,11 +24,18 @@ __global__ __launch_bounds__(64 * NW) void wstat_kernel(const bf16* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* ws = reinterpret_cast<bf16*>(smem);
   float* bs = reinterpret_cast<float*>(smem + CN * WSTR * 2);
-  const int chunk = blockIdx.x % nchunk, wgc = blockIdx.x / nchunk, nwgc = gridDim.x / nchunk;
+  // XCD-aware groups: workgroup b runs on XCD b & 7 (observed dispatch rule); the nchunk workgroups that need the SAME rows of A
+  // (one per column chunk) sit on one XCD and walk the row blocks in the same order -- the first to ask brings a row block into
+  // that XCD's L2, the others hit it (A from beyond L2 arrives at ~10 B/clk/CU: 12 re-reads of A were the whole run time)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gpx = (int)(gridDim.x >> 3) / nchunk;   // groups per XCD
+  if (slot >= gpx * nchunk) return;
+  const int chunk = slot % nchunk, wgc = xcd * gpx + slot / nchunk, nwgc = 8 * gpx;
   const int n0 = chunk * CN;
   for (int i = threadIdx.x; i < CN * (K / 8); i += 64 * NW) {
-    const int n = i / (K / 8), q = i % (K / 8);
-    *reinterpret_cast<bf16x8*>(ws + n * WSTR + q * 8) = *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + n) * K + q * 8);
+    const int r = i / (K / 8), q = i % (K / 8);         // LDS row r = 32 np + 16 j + c holds W row 32 np + 8 (c >> 2) + 4 j + (c & 3):
+    const int np_ = r >> 5, j_ = (r >> 4) & 1, c_ = r & 15;   // the 16 rows one fragment read touches are CONSECUTIVE in LDS (conflict-free)
+    const int n = np_ * 32 + 8 * (c_ >> 2) + 4 * j_ + (c_ & 3);
+    *reinterpret_cast<bf16x8*>(ws + r * WSTR + (((q & ~15) | ((q & 15) ^ (r & 15))) << 3)) = *reinterpret_cast<const bf16x8*>(W + (size_t)(n0 + n) * K + q * 8);
   }
   for (int i = threadIdx.x; i < CN; i += 64 * NW) bs[i] = bias[n0 + i];
   __syncthreads();
@@ -52,16 +59,21 @@ __global__ __launch_bounds__(64 * NW) void wstat_kernel(const bf16* __restrict__
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 wf[KS][2];                                 // every weight fragment of the pair requested before the first MFMA
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int n = np * 32 + 8 * (c >> 2) + 4 * j + (c & 3);
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + n * WSTR + ks * 32 + g * 8);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a[buf][mt][ks], acc[mt][j], 0, 0, 0);
+          wf[ks][j] = *reinterpret_cast<const bf16x8*>(ws + (np * 32 + 16 * j + c) * WSTR + ((((ks * 4 + g) & ~15) | (((ks * 4 + g) & 15) ^ c)) << 3));
         }
-      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], a[buf][mt][ks], acc[mt][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + np * 32 + 8 * g), b1 = *reinterpret_cast<const f32x4*>(bs + np * 32 + 8 * g + 4);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -108,7 +120,7 @@ template <int CN, int NW, int DB> static void run(int M, int N) {
   const int nchunk = N / CN;
   auto kern = wstat_kernel<CN, NW, DB>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  const int wgs = (256 / nchunk) * nchunk;
+  const int wgs = 256;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * NW), smem, 0, a, w, b, c, M, N, nchunk);
   hipEventRecord(e0);
@@ -132,12 +144,12 @@ template <int CN, int NW, int DB> static void run(int M, int N) {
   hipFree(a); hipFree(w); hipFree(b); hipFree(c);
 }
 
-int main() {
-  run<128, 8, 1>(50432, 1536);
+int main(int argc, char** argv) {
+  if (argc > 1) { run<128, 8, 0>(50432, 1536); return 0; }      // (one configuration: counter passes)
+  run<128, 4, 1>(50432, 1536);
   run<128, 8, 0>(50432, 1536);
-  run<128, 12, 0>(50432, 1536);
-  run<128, 16, 0>(50432, 1536);
+  run<128, 4, 1>(25088, 1152);
   run<128, 8, 0>(25088, 1152);
-  run<128, 16, 0>(25088, 1152);
+  run<128, 8, 0>(25088, 384);
   return 0;
 }
