@@ -162,7 +162,7 @@ def _img(x):
 #     before it reduces a bucket.  Operands are kept alive until the join (the caching allocator would otherwise hand
 #     their memory to the main stream while the side stream still reads it).  Bitwise identical either way.
 _SIDE_ENABLED = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
-_SIDE_FENCE = os.environ.get("VTX_SIDE_FENCE", "1") != "0"      # (0: measurement only -- see side_fence)
+_SIDE_FENCE_MODE = os.environ.get("VTX_SIDE_FENCE", "1")        # (0 / merge: measurement only -- see side_fence)
 # one column-reduce launch per layer (LayerNorm dgamma / dbeta x 2 + rel_pos gradient) instead of three; 0: each kernel reduces its own
 _DEFER_REDUCE = os.environ.get("VTX_DEFER_REDUCE", "1") != "0"
 _deferred = False
@@ -204,7 +204,7 @@ def side_stream_after_current(dev):
     return st.stream
 
 
-def side_fence(dev):
+def side_fence(dev, merge=False):
     """The current stream waits for the side-stream weight gradients enqueued so far (they stay pending: no join).
 
     Called at the start of every backward OUTSIDE the transformer layers (patch merge / embed, head, pooling ...).  Measured
@@ -212,9 +212,11 @@ def side_fence(dev):
     grouped weight gradient is still on the side stream, its dx differs in the last bf16 bit on a few rows in ~1 of 15 train
     steps (inputs, statistics and dgamma bit-identical; the kernels are bit-reproducible on their own and under an unrelated
     concurrent launch: tools/probe/concurrent_bitwise.py, concurrent_stale.py) -- not understood, so these few nodes do not
-    overlap with the side stream; the 24 layers, where the overlap pays, do."""
+    overlap with the side stream; the 24 layers, where the overlap pays, do.  (VTX_SIDE_FENCE=merge fences the PatchMerge
+    LayerNorm backward only: also 0 differing trials of 1 146 -- that launch is the only one seen to misbehave; the default
+    keeps every non-layer node fenced, the cost is ~0.05 ms per Swin-S step.)"""
     st = _side_states.get(dev)
-    if st is not None and st.pending and _SIDE_FENCE:
+    if st is not None and st.pending and (_SIDE_FENCE_MODE == "1" or (_SIDE_FENCE_MODE == "merge" and merge)):
         torch.cuda.current_stream(dev).wait_stream(st.stream)
 
 
@@ -876,7 +878,7 @@ class PatchMergeFn(Function):
         dy = _c(dy)
         dW, _ = ops.wgrad(dy, ln, want_bias=False)
         dln = dgrad(dy, ctx.wp, x.dtype)
-        side_fence(dy.device)            # (the LayerNorm backward is the launch that must not overlap: see side_fence)
+        side_fence(dy.device, merge=True)   # (the LayerNorm backward is the launch that must not overlap: see side_fence)
         dx, dg, db = ops.layernorm_bwd(dln, x, mean, rstd, ln_w.detach(), merge_hw=(x.shape[1], x.shape[2]))
         return dx, dg, db, dW, None
 
