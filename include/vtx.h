@@ -271,19 +271,41 @@ typedef struct VtxTimerRec { int tag, n, k, flags; int64_t rows; float ms; } Vtx
 int vtx_timer_start(void);
 int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */
 
-/* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66):
- * head dim 64, Lq queries against Lk <= 64 reduced keys per (image, head).
- *   q [B*Lq, nH*64] (= linear_q output), kv [B*Lk, 2*nH*64] (= linear_kv output: k | v halves, pvt.py:51),
- *   o [B*Lq, nH*64], lse [B*nH*Lq] fp32 (saved for the backward).
+/* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66) and the global
+ * sub-sampled attention of Twins-SVT (models/twins.py:56-93): head dim D = 64 | 32, Lq queries against Lk <= 64 reduced keys
+ * per (image, head).
+ *   q [B*Lq, nH*D] (= linear_q output), kv [B*Lk, 2*nH*D] (= linear_kv output: k | v halves, pvt.py:51, twins.py:74),
+ *   o [B*Lq, nH*D], lse [B*nH*Lq] fp32 (saved for the backward).
  * The backward writes dq and dkv fully; key-side partials are summed in fixed order (deterministic). */
-int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int dtype,
+int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
                    void* stream);
-/* score [B, nH, Lq, Lk] = q k^T / sqrt(64) before the softmax: the second value pvt.MultiHeadedAttention.forward returns
+/* score [B, nH, Lq, Lk] = q k^T / sqrt(D) before the softmax: the second value pvt.MultiHeadedAttention.forward returns
  * (models/pvt.py:53, 69; the PVT layers discard it).  Inference-side helper: no backward. */
-int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int dtype, void* stream);
-size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH);
+int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int D, int dtype,
+                      void* stream);
+size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH, int D);
 int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
-                   void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int dtype, void* stream);
+                   void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, void* stream);
+
+/* ---- Positional-encoding generator of Twins-SVT (csrc/twins_misc.hip; reference models/twins.py:25-37):
+ * y = x + DepthwiseConv3x3(x) on channels-last features x, y [B, H, W, C] (C % 8 == 0, C <= 1024), w = the
+ * Conv2d(C, C, 3, padding=1, bias=False, groups=C) weight [C, 1, 3, 3] fp32.  The reference permutes to NCHW, convolves and
+ * permutes back (twins.py:32-35); here the taps are read in place.  adjoint != 0 mirrors the taps: vtx_dwconv3_fwd(dy, w, dx,
+ * ..., 1, ...) is the input gradient.  _wgrad writes dw [C, 1, 3, 3] fp32 = sum over pixels of dy * shifted x (deterministic:
+ * fixed-order partial sums in the workspace). */
+int vtx_dwconv3_fwd(const void* x, const float* w, void* y, int B, int H, int W, int C, int adjoint, int dtype, void* stream);
+size_t vtx_dwconv3_wgrad_workspace(int B, int H, int W, int C);
+int vtx_dwconv3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t ws_bytes, int B, int H, int W, int C,
+                      int dtype, void* stream);
+
+/* ---- Operand of the sub-sampling convolution of Twins-SVT's global attention (csrc/twins_misc.hip; reference
+ * models/twins.py:69-71).  The reference reshapes its 4-D input as ``input.transpose(1, 2).reshape(B, C, H, W)``: the "image"
+ * the Conv2d(C, C, r, stride r) sees is a fixed permutation of the feature map's elements (flat index f = c' H W + y W + x of
+ * the (W, H, C)-ordered map), kept here as written.  x [B, H, W, C] -> out [B*(H/r)*(W/r), r*r*C], columns (py, px, c');
+ * _bwd is the inverse scatter (accumulate != 0 adds into dx). */
+int vtx_twins_subsample_fwd(const void* x, void* out, int B, int H, int W, int C, int r, int dtype, void* stream);
+int vtx_twins_subsample_bwd(const void* dout, void* dx, int B, int H, int W, int C, int r, int accumulate, int dtype,
+                            void* stream);
 
 /* ---- Non-overlapping patch gather on token-major (NHWC) features: the im2col of Conv2d(C, C', p, stride = p)
  * (PVT patch embeddings of stages 2-4 and the spatial-reduction conv, pvt.py:26-29, 44-46, 112, 129-131).

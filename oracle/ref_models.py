@@ -155,3 +155,47 @@ def pvt_forward(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
             li += 1
     out = R.layer_norm(out[:, 0], sd["norm.weight"], sd["norm.bias"], 1e-6)   # pvt.py:283
     return R.linear(R._q(out, q), sd["classifier.weight"], sd["classifier.bias"])
+
+
+# Twins-SVT-S of the paper (Chu et al. 2021, table 2) in the reference's formulation: one TransformerLayer = one locally-grouped
+# + one globally sub-sampled block (twins.py:154-203), so depths (1, 1, 5, 2) are the paper's (2, 2, 10, 4) blocks.  The
+# hyper-parameters are not in the reference repository (no .conf for the class).
+TWINS_SVT_S = dict(n_class=1000, depths=(1, 1, 5, 2), dims=(64, 128, 256, 512), dim_head=32, n_heads=(2, 4, 8, 16),
+                   dim_ffs=(256, 512, 1024, 2048), window_size=7)
+TWINS_PATCH = (4, 2, 2, 2)                                              # twins.py:263-266
+
+
+def twins_forward(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
+    """TwinsSVT.forward (twins.py:347-356).  ``drop_masks``: one entry per transformer layer (network order) of FOUR per-sample
+    keep masks (local attention, local MLP, global attention, global MLP: twins.py:198-201); rates dp * i / n_layers
+    (twins.py:275-277).  Block layout (twins.py:327-345): [PatchEmbedding, layer 0, PEG, layer 1, ...]."""
+    depths, w = cfg["depths"], cfg["window_size"]
+    rates = swin_drop_path_rates(depths, drop_path)
+    x = x_nchw.permute(0, 2, 3, 1)
+    li = 0
+    for s in range(4):
+        blk = f"block{s + 1}."
+        x = R._q(R.twins_patch_embedding(x, sd[blk + "0.linear.weight"], sd[blk + "0.linear.bias"], sd[blk + "0.norm.weight"],
+                                         sd[blk + "0.norm.bias"], TWINS_PATCH[s], q), q)
+        j = 1
+        for i in range(depths[s]):
+            pre = f"{blk}{j}."
+            sub = lambda name: {k[len(pre + name + "."):]: v for k, v in sd.items() if k.startswith(pre + name + ".")}
+            ln = lambda name, t: R._q(R.layer_norm(t, sd[pre + name + ".weight"], sd[pre + name + ".bias"], 1e-6), q)
+            ff = lambda name, t: R.feed_forward(t, sd[pre + name + ".0.weight"], sd[pre + name + ".0.bias"],
+                                                sd[pre + name + ".3.weight"], sd[pre + name + ".3.bias"], q)
+            m = drop_masks[li] if drop_masks is not None else (None,) * 4
+            a = R.twins_local_attention(ln("norm_attn_local", x), sub("attn_local"), cfg["n_heads"][s], cfg["dim_head"], w, q)
+            x = R._q(x + R.drop_path_apply(a, m[0], rates[li]), q)
+            x = R._q(x + R.drop_path_apply(ff("ff_local", ln("norm_ff_local", x)), m[1], rates[li]), q)
+            a = R.twins_global_attention(ln("norm_attn_global", x), sub("attn_global"), cfg["n_heads"][s], w, q)
+            x = R._q(x + R.drop_path_apply(a, m[2], rates[li]), q)
+            x = R._q(x + R.drop_path_apply(ff("ff_global", ln("norm_ff_global", x)), m[3], rates[li]), q)
+            li += 1
+            j += 1
+            if i == 0:                                                  # twins.py:342-343
+                x = R.twins_peg(x, sd[f"{blk}{j}.proj.weight"], q)
+                j += 1
+    x = R.layer_norm(x, sd["final_linear.0.weight"], sd["final_linear.0.bias"], 1e-5)
+    pooled = R._q(x.mean(dim=(1, 2)), q)
+    return R.linear(pooled, sd["classifier.2.weight"], sd["classifier.2.bias"])

@@ -273,6 +273,55 @@ def pvt_patch_embedding(x_nchw, w_conv, b_conv, g_norm, b_norm, pos, cls_token, 
     return out + pos.unsqueeze(0), (height, width)
 
 
+# ------------------------------------------------------------------------------------------ Twins-SVT (twins.py:25-220)
+def twins_peg(x, w, qf=None):
+    """PositionalEncodingGenerator.forward (twins.py:32-37): NHWC -> NCHW, depthwise Conv2d(dim, dim, 3, padding 1, no bias,
+    groups = dim), + the input, back to NHWC."""
+    img = x.permute(0, 3, 1, 2)
+    out = torch.nn.functional.conv2d(img, w, None, padding=1, groups=w.shape[0]) + img
+    return _q(out.permute(0, 2, 3, 1), qf)
+
+
+def twins_local_attention(x, p, n_head, dim_head, window, qf=None):
+    """twins.MultiHeadedLocalAttention.forward (twins.py:109-151): qkv Linear, window partition (row-major windows,
+    row-major tokens inside), softmax(q k^T / sqrt(d)) v per window and head -- no position bias, no mask, no shift --
+    inverse partition, output Linear.  The partition is the un-shifted one of swin (window_attention_core with a zero table)."""
+    qkv = _q(linear(x, p["weight.weight"], p["weight.bias"]), qf)
+    zero = qkv.new_zeros((2 * window - 1) ** 2, n_head)
+    o = _q(window_attention_core(qkv, zero, n_head, dim_head, window, False, qf), qf)
+    return linear(o, p["linear.weight"], p["linear.bias"])
+
+
+def twins_global_attention(x, p, n_head, reduction, qf=None):
+    """twins.MultiHeadedAttention.forward (twins.py:56-93) on NHWC x: q = linear_q(tokens); the key / value tokens are the
+    Conv2d(dim, dim, r, stride r) sub-sampled "image" of twins.py:69-72 (see the comment below; NO LayerNorm after it,
+    unlike pvt.py:47); k | v =
+    linear_kv(.).chunk(2) (twins.py:77); heads = contiguous channel blocks of dim // n_head (twins.py:60-63)."""
+    B, H, W, C = x.shape
+    tok = x.reshape(B, H * W, C)
+    qq = _q(linear(tok, p["linear_q.weight"], None), qf)
+    if reduction <= 1:
+        # twins.py:74-77 would chunk a 4-D (B, H, W, 2 dim) tensor along dim 2 (the WIDTH); TransformerLayer never builds
+        # the module that way (reduction = window_size, twins.py:182)
+        raise ValueError("twins.MultiHeadedAttention with reduction 1 is not a meaningful configuration of the reference")
+    # twins.py:69-70, kept as written: the module's input is 4-D (B, H, W, dim), so ``input.transpose(1, 2)`` swaps H and W
+    # (it does NOT bring the channels forward as in pvt.py:44, where the input is (B, L, dim)) and the following
+    # ``reshape(B, dim, H, W)`` reinterprets the (B, W, H, dim) memory as an NCHW image: the "image" the reduction conv sees is
+    # a fixed permutation of the feature map's elements, not the feature map
+    img = x.transpose(1, 2).reshape(B, C, H, W)
+    red = torch.nn.functional.conv2d(img, p["reduce_conv.weight"], p["reduce_conv.bias"], stride=reduction)
+    kvin = _q(red.reshape(B, C, -1).transpose(1, 2), qf)
+    kv = _q(linear(kvin, p["linear_kv.weight"], None), qf)
+    out = _q(sr_attention_core(qq, kv, n_head, qf), qf)
+    return linear(out, p["linear.weight"], p["linear.bias"]).reshape(B, H, W, C)
+
+
+def twins_patch_embedding(x, w, b, ln_w, ln_b, size, qf=None):
+    """twins.PatchEmbedding.forward (twins.py:214-220): patchify(size) -> Linear -> LayerNorm(eps 1e-5) on NHWC x."""
+    t = _q(linear(patchify(x, size), w, b), qf)
+    return layer_norm(t, ln_w, ln_b, 1e-5)
+
+
 # ------------------------------------------------------------------------------------------ DINO (loss.py:89-152, vit.py:206-262)
 def dino_head(x, p, depth=3, qf=None):
     """vit.DINOHead.forward (vit.py:255-262) without BatchNorm: mlp (Linear, exact-erf GELU, ...) -> L2 normalise ->

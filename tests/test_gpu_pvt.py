@@ -22,11 +22,16 @@ def _mk(shape, seed, dtype, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,Lq,Lk,nH", [(2, 784, 49, 2), (3, 50, 50, 8), (1, 3136, 49, 1), (2, 196, 49, 5), (2, 70, 17, 1)])
-def test_sr_attention_core(dtype, B, Lq, Lk, nH):
+@pytest.mark.parametrize("B,Lq,Lk,nH,D", [(2, 784, 49, 2, 64), (3, 50, 50, 8, 64), (1, 3136, 49, 1, 64), (2, 196, 49, 5, 64),
+                                         (2, 70, 17, 1, 64),
+                                         # head dim 32: the global sub-sampled attention of Twins-SVT (twins.py:56-93) at
+                                         # its four stage geometries (7 x 7 sub-sampling of 56^2 / 28^2 / 14^2 / 7^2 tokens)
+                                         (2, 3136, 64, 2, 32), (2, 784, 16, 4, 32), (3, 196, 4, 8, 32), (2, 49, 1, 16, 32),
+                                         (1, 70, 17, 3, 32)])
+def test_sr_attention_core(dtype, B, Lq, Lk, nH, D):
     from vtx import ops
     d = dev()
-    C = nH * 64
+    C = nH * D
     # random (not formula) data: the key-side gradients are sums over up to 3136 queries, and the smooth sin-hash fill
     # cancels almost exactly there -- the bf16 rounding of P / dS would then be measured against a vanishing signal
     gen = torch.Generator().manual_seed(401)
@@ -41,7 +46,7 @@ def test_sr_attention_core(dtype, B, Lq, Lk, nH):
     orf = R.sr_attention_core(qr, kvr, nH)
     dqr, dkvr = torch.autograd.grad(orf, [qr, kvr], do.double())
     t = TOL[dtype]
-    tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH}"
+    tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH} d{D}"
     check(f"srattn fwd {tag}", o, orf, t["out"] * 1.5)
     check(f"srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"srattn dkv {tag}", dkv, dkvr, 2e-5 if dtype == torch.float32 else 1e-2)

@@ -206,21 +206,21 @@ def test_sweep_window_attention(dtype, case):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", _cases(606, 8))
 def test_sweep_sr_attention(dtype, case):
-    """PVT cross attention: Lq queries against Lk <= 64 reduced keys, head dim 64."""
+    """PVT / Twins cross attention: Lq queries against Lk <= 64 reduced keys, head dim 64 or 32."""
     from vtx import ops
     rng = random.Random(case)
     g = torch.Generator().manual_seed(case)
     d = dev()
     B, nH = rng.randint(1, 4), rng.randint(1, 8)
     Lq, Lk = rng.choice([1, 7, 49, 50, 196, 197, 784, 1000]), rng.choice([1, 5, 16, 49, 50, 64])
-    C = nH * 64
+    C = nH * rng.choice([64, 32])
     q, kv, do = _mk((B, Lq, C), g, dtype), _mk((B, Lk, 2 * C), g, dtype), _mk((B, Lq, C), g, dtype)
     o, lse = ops.srattn_fwd(q.to(d), kv.to(d), B, Lq, Lk, nH)
     dq, dkv = ops.srattn_bwd(q.to(d), kv.to(d), o, do.to(d), lse, B, Lq, Lk, nH)
     qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
     orf = R.sr_attention_core(qr, kvr, nH)
     dqr, dkvr = torch.autograd.grad(orf, [qr, kvr], do.double())
-    tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH}"
+    tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH} d{C // nH}"
     check(f"sweep srattn fwd {tag}", o, orf, TOL[dtype]["out"] * 1.5)
     check(f"sweep srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"sweep srattn dkv {tag}", dkv, dkvr, 2e-5 if dtype == torch.float32 else 1.5e-2)

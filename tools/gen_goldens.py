@@ -8,7 +8,7 @@ travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
 
 Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
 fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1), G8 DINO head + loss (F2),
-G9 mixup / cutmix / RandomErasing outputs (F4).
+G9 mixup / cutmix / RandomErasing outputs (F4), G10 Twins-SVT (the row after F1-F4).
 """
 import os
 import sys
@@ -38,10 +38,11 @@ from models import swin_transformer as ref_swin   # noqa: E402  (reference)
 from models import vit as ref_vit                 # noqa: E402  (reference)
 from models import layer as ref_layer             # noqa: E402  (reference)
 from models import pvt as ref_pvt                 # noqa: E402  (reference)
+from models import twins as ref_twins             # noqa: E402  (reference)
 import loss as ref_loss                           # noqa: E402  (reference)
 
 from oracle.formula import fill, fill_state_dict, summarize, name_seed  # noqa: E402
-from oracle.ref_models import PVT_SMALL, SWIN_S, VIT_S16     # noqa: E402
+from oracle.ref_models import PVT_SMALL, SWIN_S, TWINS_SVT_S, VIT_S16     # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -417,8 +418,77 @@ def gen_train_step():
     save("g6_train_step", rec)
 
 
+# ------------------------------------------------------------------ G10 (Twins-SVT: the row after F1-F4)
+def gen_twins():
+    rec = {}
+    # positional-encoding generator (depthwise 3 x 3 + residual) on a 14 x 14 map
+    peg = load_formula(ref_twins.PositionalEncodingGenerator(64)).double()
+    x = fill((2, 14, 14, 64), 81, 1.0).double().requires_grad_(True)
+    out = peg(x)
+    (out * fill(out.shape, 82, 1.0).double()).sum().backward()
+    rec["peg.out"] = summarize(out)
+    rec["peg.dx"] = summarize(x.grad)
+    rec["peg.grad.proj.weight"] = summarize(peg.proj.weight.grad)
+    # locally-grouped attention: dim 64, 2 heads x 32, window 7 on 14 x 14
+    lsa = load_formula(ref_twins.MultiHeadedLocalAttention(64, 2, 32, 7)).double()
+    x = fill((2, 14, 14, 64), 83, 1.0).double().requires_grad_(True)
+    out = lsa(x)
+    (out * fill(out.shape, 84, 1.0).double()).sum().backward()
+    rec["lsa.out"] = summarize(out)
+    rec["lsa.dx"] = summarize(x.grad)
+    for n, p in lsa.named_parameters():
+        rec[f"lsa.grad.{n}"] = summarize(p.grad)
+    # global sub-sampled attention: dim 128, 4 heads (head dim 32), reduction 7 on 28 x 28 (16 keys)
+    gsa = load_formula(ref_twins.MultiHeadedAttention(128, 4, reduction=7)).double()
+    x = fill((2, 28, 28, 128), 85, 1.0).double().requires_grad_(True)
+    out = gsa(x)
+    (out * fill(out.shape, 86, 1.0).double()).sum().backward()
+    rec["gsa.out"] = summarize(out)
+    rec["gsa.dx"] = summarize(x.grad)
+    for n, p in gsa.named_parameters():
+        rec[f"gsa.grad.{n}"] = summarize(p.grad)
+    # patch embedding of a later stage: 2 x 2 tokens of a 28 x 28 x 64 map
+    pe = load_formula(ref_twins.PatchEmbedding(64, 128, 2)).double()
+    x = fill((2, 28, 28, 64), 87, 1.0).double().requires_grad_(True)
+    out = pe(x)
+    (out * fill(out.shape, 88, 1.0).double()).sum().backward()
+    rec["patch_embed.out"] = summarize(out)
+    rec["patch_embed.dx"] = summarize(x.grad)
+    for n, p in pe.named_parameters():
+        rec[f"patch_embed.grad.{n}"] = summarize(p.grad)
+    # full model
+    x = fill((2, 3, 224, 224), 21, 1.0)
+    tw = load_formula(ref_twins.TwinsSVT(**TWINS_SVT_S, drop_path=0.0))
+    rec["twins_svt_s.n_params"] = np.array(sum(p.numel() for p in tw.parameters()))
+    rec["twins_svt_s.state_keys"] = np.array(list(tw.state_dict().keys()))
+    rec["twins_svt_s.state_shapes"] = np.array([str(tuple(v.shape)) for v in tw.state_dict().values()])
+    model_record(tw, x, "twins_svt_s.eval", rec, False)
+    model_record(tw, x, "twins_svt_s.train", rec, True)
+    tw64 = load_formula(ref_twins.TwinsSVT(**TWINS_SVT_S, drop_path=0.0)).double()
+    model_record(tw64, x.double(), "twins_svt_s.train64", rec, True)
+    for n, p in tw64.named_parameters():
+        if any(s in n for s in ("block1.0.linear.weight", "block1.2.proj.weight", "block3.1.attn_global.reduce_conv.weight",
+                                "block2.1.attn_local.weight.weight", "block4.3.attn_global.linear_kv.weight",
+                                "block3.4.ff_global.0.weight", "classifier.2.weight")):
+            rec[f"twins_svt_s.train64.grad.{n}"] = summarize(p.grad)
+    # stochastic depth: the masks the reference draws (4 per layer with p > 0) and the logits they give
+    torch.manual_seed(7)
+    twd = load_formula(ref_twins.TwinsSVT(**TWINS_SVT_S, drop_path=0.3))
+    twd.train()
+    xb = fill((4, 3, 224, 224), 22, 1.0)
+    masks, restore = capture_bernoulli()
+    try:
+        outd = twd(xb)
+    finally:
+        restore()
+    rec["twins_svt_s.dp.logits"] = summarize(outd)
+    rec["twins_svt_s.dp.masks"] = torch.stack(masks).numpy().astype(np.uint8)
+    print("captured", len(masks), "drop-path masks")
+    save("g10_twins", rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input"]
+    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input", "twins"]
     if "tables" in which:
         gen_tables()
     if "modules" in which:
@@ -433,5 +503,7 @@ if __name__ == "__main__":
         gen_dino()
     if "input" in which:
         gen_input_pipeline()
+    if "twins" in which:
+        gen_twins()
     # make sure nothing was written into the reference tree
     assert not os.path.exists(os.path.join(REF, "models", "__pycache__")), "pycache leaked into reference"

@@ -1,4 +1,5 @@
-// Spatial-reduction (cross) attention of PVT for gfx950: head dim 64, Lq queries against Lk <= 64 reduced keys.
+// Spatial-reduction (cross) attention of PVT (and of Twins-SVT's global sub-sampled attention) for gfx950: head dim D = 64
+// or 32 (template parameter), Lq queries against Lk <= 64 reduced keys.
 //
 // Replaces reference models/pvt.py:38-66 per (image, head): q = linear_q(x) [B, Lq, h*64],
 // k | v = linear_kv(reduced).chunk(2) [B, Lk, 2*h*64]; S = q k^T / sqrt(64), softmax over the Lk keys, O = P v --
@@ -23,7 +24,6 @@
 #include "options.h"
 #include "vtx_common.h"
 
-#define SR_D 64
 #define SR_LK 64         // padded key count
 #define SR_STR 72        // transposed LDS row stride (elements)
 #define SR_QB 64         // queries per sub-chunk (4 waves x 16)
@@ -58,9 +58,9 @@ template <typename T> __device__ __forceinline__ Vec8<T> sr_frag_t(const T* p, i
 // One 16-token tile (lane (c, g): token t0 + c, channels 32 ds + 8 g ..+7) -> transposed image Xt[pi(d)][token]
 // with pi(32 ds + 8 g + e) = 16 (2 ds + (e >> 2)) + 4 g + (e & 3): image rows 16 j .. 16 j + 15 (j = 2 dp + dtl) used as
 // an MFMA A operand leave lane (c, g) with the outputs of token c for d = 32 dp + 8 g + 4 dtl + r.
-template <typename T> __device__ __forceinline__ void sr_store_t(T* xt, const Vec8<T> (&f)[2], int t0, int c, int g) {
+template <typename T, int DS> __device__ __forceinline__ void sr_store_t(T* xt, const Vec8<T> (&f)[DS], int t0, int c, int g) {
 #pragma unroll
-  for (int ds = 0; ds < 2; ++ds)
+  for (int ds = 0; ds < DS; ++ds)
 #pragma unroll
     for (int e = 0; e < 8; ++e) xt[(16 * (2 * ds + (e >> 2)) + 4 * g + (e & 3)) * SR_STR + t0 + c] = f[ds].v[e];
 }
@@ -73,31 +73,32 @@ template <typename T> __device__ __forceinline__ Vec8<T> sr_out8(const f32x4& a0
 
 // --------------------------------------------------------------------------------------------- forward
 // grid = (workgroups per (image, head), B * nH)
-template <typename T>
+template <typename T, int D>
 __global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                         T* __restrict__ o, float* __restrict__ lse, SrGeom g) {
-  __shared__ __attribute__((aligned(16))) T vt[SR_D * SR_STR];          // Vt[pi(d)][key], shared by the 4 waves
+  constexpr int DS = D / 32, DJ = D / 16;                               // 32-channel k-steps, 16-channel output tiles
+  __shared__ __attribute__((aligned(16))) T vt[D * SR_STR];             // Vt[pi(d)][key], shared by the 4 waves
   const int bh = blockIdx.y, h = bh % g.nH, b = bh / g.nH;
   const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ldkv = 2 * (int64_t)g.hd;
-  const T* kb = kv + (int64_t)b * g.Lk * ldkv + h * SR_D;
+  const T* kb = kv + (int64_t)b * g.Lk * ldkv + h * D;
 
-  Vec8<T> kf[4][2];
+  Vec8<T> kf[4][DS];
   f32x4 kmask[4];                                 // 0 on real keys, -inf on padded ones (lane: keys 16 kt + 4 g + r)
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     const int key = 16 * kt + c_;
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) kf[kt][ds] = sr_load<T>(kb + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
+    for (int ds = 0; ds < DS; ++ds) kf[kt][ds] = sr_load<T>(kb + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
 #pragma unroll
     for (int r = 0; r < 4; ++r) kmask[kt][r] = (16 * kt + 4 * g_ + r) < g.Lk ? 0.f : -INFINITY;
   }
   {
     const int key = 16 * wave + c_;               // wave w transposes V tile w for everybody
-    Vec8<T> vf[2];
+    Vec8<T> vf[DS];
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) vf[ds] = sr_load<T>(kb + g.hd + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
+    for (int ds = 0; ds < DS; ++ds) vf[ds] = sr_load<T>(kb + g.hd + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
     sr_store_t<T>(vt, vf, 16 * wave, c_, g_);
   }
   __syncthreads();
@@ -108,16 +109,16 @@ __global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q
     const int qi = sub * SR_QB + 16 * wave + c_;
     const bool qv = qi < g.Lq;
     const int64_t qrow = (int64_t)b * g.Lq + (qv ? qi : 0);
-    Vec8<T> qf[2];
+    Vec8<T> qf[DS];
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[ds] = sr_load<T>(q + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = sr_load<T>(q + qrow * g.hd + h * D + 32 * ds + 8 * g_, qv);
     f32x4 st[4];
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ds = 0; ds < 2; ++ds) mma16(kf[kt][ds], qf[ds], st[kt]);   // S[q = c][key = 16 kt + 4 g + r]
+      for (int ds = 0; ds < DS; ++ds) mma16(kf[kt][ds], qf[ds], st[kt]);   // S[q = c][key = 16 kt + 4 g + r]
 #pragma unroll
       for (int r = 0; r < 4; ++r) { st[kt][r] = st[kt][r] * g.scale + kmask[kt][r]; m = fmaxf(m, st[kt][r]); }
     }
@@ -132,33 +133,35 @@ __global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q
     l += shfl_xor_f(l, 32);
     const float inv = 1.f / l;
     if (qv && g_ == 0) lse[(int64_t)bh * g.Lq + qi] = m + __logf(l);
-    f32x4 oacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
-                     f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 oacc[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       Vec8<T> pf = sr_frag_acc<T>(st[2 * ks] * inv, st[2 * ks + 1] * inv);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mma16(sr_frag_t<T>(vt + (16 * j + c_) * SR_STR + 32 * ks, g_), pf, oacc[j]);
+      for (int j = 0; j < DJ; ++j) mma16(sr_frag_t<T>(vt + (16 * j + c_) * SR_STR + 32 * ks, g_), pf, oacc[j]);
     }
     // oacc[2 dp + dtl][r] = O[q = c][d = 32 dp + 8 g + 4 dtl + r]
     if (qv) {
-      T* op = o + qrow * g.hd + h * SR_D + 8 * g_;
-      store8<T>(op, sr_out8<T>(oacc[0], oacc[1], 1.f));
-      store8<T>(op + 32, sr_out8<T>(oacc[2], oacc[3], 1.f));
+      T* op = o + qrow * g.hd + h * D + 8 * g_;
+#pragma unroll
+      for (int dp = 0; dp < DS; ++dp) store8<T>(op + 32 * dp, sr_out8<T>(oacc[2 * dp], oacc[2 * dp + 1], 1.f));
     }
   }
 }
 
 // --------------------------------------------------------------------------------------------- backward
-// same grid; part: fp32 [B * nH][workgroups][64 keys][128] (dK channels 0..63, dV channels 64..127 of the head)
-template <typename T>
+// same grid; part: fp32 [B * nH][workgroups][64 keys][2 D] (dK channels 0..D-1, dV channels D..2D-1 of the head)
+template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                            const T* __restrict__ oin, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, T* __restrict__ dq,
                                                            float* __restrict__ part, SrGeom g) {
-  __shared__ __attribute__((aligned(16))) T kt_s[SR_D * SR_STR];        // Kt[pi(d)][key]
-  __shared__ __attribute__((aligned(16))) T qt_s[SR_D * SR_STR];        // Qt[pi(d)][q of the sub-chunk]
-  __shared__ __attribute__((aligned(16))) T dot_s[SR_D * SR_STR];       // dOt[pi(d)][q]
+  constexpr int DS = D / 32, DJ = D / 16;
+  __shared__ __attribute__((aligned(16))) T kt_s[D * SR_STR];           // Kt[pi(d)][key]
+  __shared__ __attribute__((aligned(16))) T qt_s[D * SR_STR];           // Qt[pi(d)][q of the sub-chunk]
+  __shared__ __attribute__((aligned(16))) T dot_s[D * SR_STR];          // dOt[pi(d)][q]
   __shared__ __attribute__((aligned(16))) T qr_s[SR_QB * SR_STR];       // Q [q][d] row-major (phase B row fragments)
   __shared__ __attribute__((aligned(16))) T dor_s[SR_QB * SR_STR];      // dO[q][d]
   __shared__ __attribute__((aligned(16))) float dq_s[SR_QB];            // D[q] = rowsum(dO o O)
@@ -167,15 +170,15 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
   const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ldkv = 2 * (int64_t)g.hd;
-  const T* kb = kv + (int64_t)b * g.Lk * ldkv + h * SR_D;
+  const T* kb = kv + (int64_t)b * g.Lk * ldkv + h * D;
 
-  Vec8<T> kf[4][2], vf[4][2];
+  Vec8<T> kf[4][DS], vf[4][DS];
   f32x4 kmask[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     const int key = 16 * kt + c_;
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) {
+    for (int ds = 0; ds < DS; ++ds) {
       kf[kt][ds] = sr_load<T>(kb + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
       vf[kt][ds] = sr_load<T>(kb + g.hd + (int64_t)key * ldkv + 32 * ds + 8 * g_, key < g.Lk);
     }
@@ -183,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
     for (int r = 0; r < 4; ++r) kmask[kt][r] = (16 * kt + 4 * g_ + r) < g.Lk ? 0.f : -INFINITY;
   }
   // wave w: its own key tile as the B operands of phase B, and the transposed K tile for everybody
-  Vec8<T> kw[2], vw[2];
+  Vec8<T> kw[DS], vw[DS];
 #pragma unroll
-  for (int ds = 0; ds < 2; ++ds) {
+  for (int ds = 0; ds < DS; ++ds) {
     kw[ds] = kf[0][ds]; vw[ds] = vf[0][ds];
 #pragma unroll
     for (int kt = 1; kt < 4; ++kt)
@@ -193,26 +196,26 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
   }
   sr_store_t<T>(kt_s, kw, 16 * wave, c_, g_);
   const float kbias = (16 * wave + c_) < g.Lk ? 0.f : -INFINITY;         // phase B: this lane's key
-  f32x4 dkacc[4], dvacc[4];                        // [2 dp + dtl][r]: key = 16 w + c, d = 32 dp + 8 g + 4 dtl + r
+  f32x4 dkacc[DJ], dvacc[DJ];                      // [2 dp + dtl][r]: key = 16 w + c, d = 32 dp + 8 g + 4 dtl + r
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { dkacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int j = 0; j < DJ; ++j) { dkacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   // Every wave fetches only ITS query tile of a sub-chunk (Q, dO, O rows) -- one sub-chunk ahead of the one being
   // computed, so the loads fly under the MFMAs -- and publishes it to the other waves through LDS: transposed images
   // (token-contracted operands) and row-major images (the Q / dO row fragments of phase B).
-  auto fetch = [&](int sub, Vec8<T> (&qm)[2], Vec8<T> (&dom)[2], Vec8<T> (&om)[2], float& lq) {
+  auto fetch = [&](int sub, Vec8<T> (&qm)[DS], Vec8<T> (&dom)[DS], Vec8<T> (&om)[DS], float& lq) {
     const int qi = sub * SR_QB + 16 * wave + c_;
     const bool qv = sub < g.nsub && qi < g.Lq;
     const int64_t qrow = (int64_t)b * g.Lq + (qv ? qi : 0);
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) {
-      qm[ds] = sr_load<T>(q + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
-      dom[ds] = sr_load<T>(dout + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
-      om[ds] = sr_load<T>(oin + qrow * g.hd + h * SR_D + 32 * ds + 8 * g_, qv);
+    for (int ds = 0; ds < DS; ++ds) {
+      qm[ds] = sr_load<T>(q + qrow * g.hd + h * D + 32 * ds + 8 * g_, qv);
+      dom[ds] = sr_load<T>(dout + qrow * g.hd + h * D + 32 * ds + 8 * g_, qv);
+      om[ds] = sr_load<T>(oin + qrow * g.hd + h * D + 32 * ds + 8 * g_, qv);
     }
     lq = qv ? lse[(int64_t)bh * g.Lq + qi] : INFINITY;             // padded queries: exp(. - inf) = 0
   };
-  Vec8<T> qn[2], don[2], on[2];
+  Vec8<T> qn[DS], don[DS], on[DS];
   float lqn;
   fetch(blockIdx.x * g.qc, qn, don, on, lqn);
 
@@ -220,11 +223,13 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
     const int sub = blockIdx.x * g.qc + sc;
     if (sub >= g.nsub) break;
     const int q0 = sub * SR_QB;
-    Vec8<T> qm[2] = {qn[0], qn[1]}, dom[2] = {don[0], don[1]};
+    Vec8<T> qm[DS], dom[DS];
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) { qm[ds] = qn[ds]; dom[ds] = don[ds]; }
     const float lq = lqn;
     float dsum = 0.f;
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds)
+    for (int ds = 0; ds < DS; ++ds)
 #pragma unroll
       for (int e = 0; e < 8; ++e) dsum += on[ds].get(e) * dom[ds].get(e);
     dsum += shfl_xor_f(dsum, 16);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
     sr_store_t<T>(qt_s, qm, 16 * wave, c_, g_);
     sr_store_t<T>(dot_s, dom, 16 * wave, c_, g_);
 #pragma unroll
-    for (int ds = 0; ds < 2; ++ds) {
+    for (int ds = 0; ds < DS; ++ds) {
       store8<T>(qr_s + (16 * wave + c_) * SR_STR + 32 * ds + 8 * g_, qm[ds]);
       store8<T>(dor_s + (16 * wave + c_) * SR_STR + 32 * ds + 8 * g_, dom[ds]);
     }
@@ -246,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
 
     // ---------------- phase A (wave <-> query tile `wave`): dQ = scale * dS K
     {
-      f32x4 dqacc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
-                        f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dqacc[DJ];
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) dqacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         f32x4 dsv[2];
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
           const int kt = 2 * ks + half;
           f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ds = 0; ds < 2; ++ds) { mma16(kf[kt][ds], qm[ds], pt); mma16(vf[kt][ds], dom[ds], dpt); }
+          for (int ds = 0; ds < DS; ++ds) { mma16(kf[kt][ds], qm[ds], pt); mma16(vf[kt][ds], dom[ds], dpt); }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = __expf(pt[r] * g.scale + kmask[kt][r] - lq);
@@ -265,12 +271,12 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
         }
         Vec8<T> dsf = sr_frag_acc<T>(dsv[0], dsv[1]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mma16(sr_frag_t<T>(kt_s + (16 * j + c_) * SR_STR + 32 * ks, g_), dsf, dqacc[j]);
+        for (int j = 0; j < DJ; ++j) mma16(sr_frag_t<T>(kt_s + (16 * j + c_) * SR_STR + 32 * ks, g_), dsf, dqacc[j]);
       }
       if (qv) {
-        T* p = dq + qrow * g.hd + h * SR_D + 8 * g_;
-        store8<T>(p, sr_out8<T>(dqacc[0], dqacc[1], g.scale));
-        store8<T>(p + 32, sr_out8<T>(dqacc[2], dqacc[3], g.scale));
+        T* p = dq + qrow * g.hd + h * D + 8 * g_;
+#pragma unroll
+        for (int dp = 0; dp < DS; ++dp) store8<T>(p + 32 * dp, sr_out8<T>(dqacc[2 * dp], dqacc[2 * dp + 1], g.scale));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
         const int t = 2 * qs + half;
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds) {
+        for (int ds = 0; ds < DS; ++ds) {
           const Vec8<T> qf = load8<T>(qr_s + (16 * t + c_) * SR_STR + 32 * ds + 8 * g_);
           const Vec8<T> dof = load8<T>(dor_s + (16 * t + c_) * SR_STR + 32 * ds + 8 * g_);
           mma16(qf, kw[ds], s);
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
       Vec8<T> pf = sr_frag_acc<T>(pp[0], pp[1]);
       Vec8<T> dsf = sr_frag_acc<T>(dss[0], dss[1]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < DJ; ++j) {
         mma16(sr_frag_t<T>(dot_s + (16 * j + c_) * SR_STR + 32 * qs, g_), pf, dvacc[j]);
         mma16(sr_frag_t<T>(qt_s + (16 * j + c_) * SR_STR + 32 * qs, g_), dsf, dkacc[j]);
       }
@@ -310,35 +316,37 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
     __builtin_amdgcn_sched_barrier(0);
   }
   // partial dK | dV of this workgroup: row key = 16 w + c, 8 contiguous channels per accumulator pair
-  float* pr = part + (((int64_t)bh * gridDim.x + blockIdx.x) * SR_LK + 16 * wave + c_) * (2 * SR_D) + 8 * g_;
-  store8<float>(pr, sr_out8<float>(dkacc[0], dkacc[1], g.scale));
-  store8<float>(pr + 32, sr_out8<float>(dkacc[2], dkacc[3], g.scale));
-  store8<float>(pr + SR_D, sr_out8<float>(dvacc[0], dvacc[1], 1.f));
-  store8<float>(pr + SR_D + 32, sr_out8<float>(dvacc[2], dvacc[3], 1.f));
+  float* pr = part + (((int64_t)bh * gridDim.x + blockIdx.x) * SR_LK + 16 * wave + c_) * (2 * D) + 8 * g_;
+#pragma unroll
+  for (int dp = 0; dp < DS; ++dp) {
+    store8<float>(pr + 32 * dp, sr_out8<float>(dkacc[2 * dp], dkacc[2 * dp + 1], g.scale));
+    store8<float>(pr + D + 32 * dp, sr_out8<float>(dvacc[2 * dp], dvacc[2 * dp + 1], 1.f));
+  }
 }
 
-// dkv[b * Lk + key][(k | v) * hd + h * 64 + d] = sum over workgroups (fixed order) of the partial slabs
-template <typename T>
+// dkv[b * Lk + key][(k | v) * hd + h * D + d] = sum over workgroups (fixed order) of the partial slabs
+template <typename T, int D>
 __global__ void srattn_reduce_kernel(const float* __restrict__ part, T* __restrict__ dkv, int nwg, int Lk, int nH,
                                      int64_t total) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over (bh, key, 128 / 4)
+  constexpr int C4 = D / 2;                        // float4 groups per key row of a slab (2 D channels)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over (bh, key, 2 D / 4)
   if (idx >= total) return;
-  const int c4 = (int)(idx % 32), key = (int)((idx / 32) % Lk);
-  const int64_t bh = idx / (32 * (int64_t)Lk);
+  const int c4 = (int)(idx % C4), key = (int)((idx / C4) % Lk);
+  const int64_t bh = idx / (C4 * (int64_t)Lk);
   const int h = (int)(bh % nH);
   const int64_t b = bh / nH;
-  const float* p = part + ((bh * nwg) * SR_LK + key) * (2 * SR_D) + 4 * c4;
+  const float* p = part + ((bh * nwg) * SR_LK + key) * (2 * D) + 4 * c4;
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int w = 0; w < nwg; ++w) s += *reinterpret_cast<const f32x4*>(p + (int64_t)w * SR_LK * 2 * SR_D);
-  const int ch = 4 * c4;                           // 0..63 dK, 64..127 dV
-  T* out = dkv + (b * Lk + key) * (2 * (int64_t)nH * SR_D) + (ch >= SR_D ? (int64_t)nH * SR_D + (ch - SR_D) : ch) + h * SR_D;
+  for (int w = 0; w < nwg; ++w) s += *reinterpret_cast<const f32x4*>(p + (int64_t)w * SR_LK * 2 * D);
+  const int ch = 4 * c4;                           // 0..D-1 dK, D..2D-1 dV
+  T* out = dkv + (b * Lk + key) * (2 * (int64_t)nH * D) + (ch >= D ? (int64_t)nH * D + (ch - D) : ch) + h * D;
 #pragma unroll
   for (int e = 0; e < 4; ++e) out[e] = from_f32<T>(s[e]);
 }
 
-static int sr_geom(SrGeom& g, int Lq, int Lk, int nH, int B) {
-  if (Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0 || B <= 0) return VTX_ERR_SHAPE;
-  g.Lq = Lq; g.Lk = Lk; g.nH = nH; g.hd = nH * SR_D;
+static int sr_geom(SrGeom& g, int Lq, int Lk, int nH, int B, int D) {
+  if (Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0 || B <= 0 || (D != 64 && D != 32)) return VTX_ERR_SHAPE;
+  g.Lq = Lq; g.Lk = Lk; g.nH = nH; g.hd = nH * D;
   g.nsub = (Lq + SR_QB - 1) / SR_QB;
   // sub-chunks per workgroup: enough workgroups to fill the chip (~2048), as few partial slabs as possible
   int target = vtx_opt(VTX_OPT_SRATTN_WGS);
@@ -347,108 +355,109 @@ static int sr_geom(SrGeom& g, int Lq, int Lk, int nH, int B) {
   if (per_bh < 1) per_bh = 1;
   g.qc = (int)((g.nsub + per_bh - 1) / per_bh);
   if (g.qc < 1) g.qc = 1;
-  g.scale = 1.0f / sqrtf((float)SR_D);
+  g.scale = 1.0f / sqrtf((float)D);
   return VTX_OK;
 }
 static int sr_wgs(const SrGeom& g) { return (g.nsub + g.qc - 1) / g.qc; }
 
-// score[b][h][i][j] = <q[b, i, h, :], k[b, j, h, :]> / sqrt(64): the pre-softmax scores the reference's
+// score[b][h][i][j] = <q[b, i, h, :], k[b, j, h, :]> / sqrt(D): the pre-softmax scores the reference's
 // MultiHeadedAttention.forward RETURNS next to its output (models/pvt.py:53, 69).  Not on the training path (the PVT
 // layers discard it), so a plain kernel: one workgroup per (image, head, 64 queries), K in LDS, fp32 accumulation.
-template <typename T>
+template <typename T, int D>
 __global__ __launch_bounds__(256) void srattn_score_kernel(const T* __restrict__ q, const T* __restrict__ kv,
-                                                           T* __restrict__ score, int Lq, int Lk, int nH) {
-  __shared__ float ks[SR_LK][SR_D + 1];
+                                                           T* __restrict__ score, int Lq, int Lk, int nH, float scale) {
+  __shared__ float ks[SR_LK][D + 1];
   const int bh = blockIdx.y, b = bh / nH, h = bh - b * nH;
-  const int hd = nH * SR_D;
-  for (int i = threadIdx.x; i < Lk * SR_D; i += 256) {
-    const int j = i / SR_D, d = i - j * SR_D;
-    ks[j][d] = to_f32<T>(kv[((int64_t)b * Lk + j) * 2 * hd + h * SR_D + d]);
+  const int hd = nH * D;
+  for (int i = threadIdx.x; i < Lk * D; i += 256) {
+    const int j = i / D, d = i - j * D;
+    ks[j][d] = to_f32<T>(kv[((int64_t)b * Lk + j) * 2 * hd + h * D + d]);
   }
   __syncthreads();
   const int q0 = blockIdx.x * 64;
   for (int idx = threadIdx.x; idx < 64 * Lk; idx += 256) {
     const int qi = q0 + idx / Lk, j = idx % Lk;
     if (qi >= Lq) continue;
-    const T* qp = q + ((int64_t)b * Lq + qi) * hd + h * SR_D;
+    const T* qp = q + ((int64_t)b * Lq + qi) * hd + h * D;
     float s = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < SR_D; ++d) s += to_f32<T>(qp[d]) * ks[j][d];
-    score[(((int64_t)b * nH + h) * Lq + qi) * Lk + j] = from_f32<T>(s * 0.125f);
+    for (int d = 0; d < D; ++d) s += to_f32<T>(qp[d]) * ks[j][d];
+    score[(((int64_t)b * nH + h) * Lq + qi) * Lk + j] = from_f32<T>(s * scale);
   }
 }
 
-extern "C" {
-
-/* Pre-softmax scores q k^T / sqrt(64) [B, nH, Lq, Lk] of the same operands as vtx_srattn_fwd (reference models/pvt.py:53):
- * the second return value of pvt.MultiHeadedAttention.forward (models/pvt.py:69); no gradient flows through it here. */
-int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int dtype, void* stream) {
-  if (!q || !kv || !score) return VTX_ERR_NULL;
-  if (B <= 0 || Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0) return VTX_ERR_SHAPE;
+template <typename T, int D>
+static int sr_launch_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, hipStream_t st) {
   dim3 grid((Lq + 63) / 64, B * nH);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == VTX_BF16)
-    hipLaunchKernelGGL((srattn_score_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)kv, (bf16*)score, Lq, Lk, nH);
-  else if (dtype == VTX_F32)
-    hipLaunchKernelGGL((srattn_score_kernel<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)score, Lq, Lk, nH);
-  else return VTX_ERR_DTYPE;
+  hipLaunchKernelGGL((srattn_score_kernel<T, D>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)score, Lq, Lk, nH,
+                     1.0f / sqrtf((float)D));
   return vtx_check_launch();
 }
+template <typename T, int D>
+static int sr_launch_fwd(const void* q, const void* kv, void* o, float* lse, int B, const SrGeom& g, hipStream_t st) {
+  dim3 grid(sr_wgs(g), B * g.nH);
+  hipLaunchKernelGGL((srattn_fwd_kernel<T, D>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o, lse, g);
+  return vtx_check_launch();
+}
+template <typename T, int D>
+static int sr_launch_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                         float* part, int B, const SrGeom& g, hipStream_t st) {
+  const int nwg = sr_wgs(g);
+  dim3 grid(nwg, B * g.nH);
+  hipLaunchKernelGGL((srattn_bwd_kernel<T, D>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)o, (const T*)dout,
+                     lse, (T*)dq, part, g);
+  int rc = vtx_check_launch();
+  if (rc) return rc;
+  const int64_t total = (int64_t)B * g.nH * g.Lk * (D / 2);
+  const int rb = (int)((total + 255) / 256);
+  hipLaunchKernelGGL((srattn_reduce_kernel<T, D>), dim3(rb), dim3(256), 0, st, (const float*)part, (T*)dkv, nwg, g.Lk, g.nH,
+                     total);
+  return vtx_check_launch();
+}
+// (dtype, head dim) -> instantiation
+#define SR_DISPATCH(fn, ...)                                                              \
+  (dtype == VTX_BF16 ? (D == 64 ? fn<bf16, 64>(__VA_ARGS__) : fn<bf16, 32>(__VA_ARGS__))   \
+   : dtype == VTX_F32 ? (D == 64 ? fn<float, 64>(__VA_ARGS__) : fn<float, 32>(__VA_ARGS__)) \
+                      : VTX_ERR_DTYPE)
 
-/* Spatial-reduction attention of PVT (reference models/pvt.py:38-66), head dim 64, Lk <= 64 keys:
- * q [B*Lq, nH*64], kv [B*Lk, 2*nH*64] (k | v halves, head-major inside each), o [B*Lq, nH*64], lse [B*nH*Lq] fp32. */
-int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int dtype,
+extern "C" {
+
+/* Pre-softmax scores q k^T / sqrt(D) [B, nH, Lq, Lk] of the same operands as vtx_srattn_fwd (reference models/pvt.py:53):
+ * the second return value of pvt.MultiHeadedAttention.forward (models/pvt.py:69); no gradient flows through it here. */
+int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int D, int dtype,
+                      void* stream) {
+  if (!q || !kv || !score) return VTX_ERR_NULL;
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0 || (D != 64 && D != 32)) return VTX_ERR_SHAPE;
+  return SR_DISPATCH(sr_launch_scores, q, kv, score, B, Lq, Lk, nH, (hipStream_t)stream);
+}
+
+/* Spatial-reduction attention of PVT (reference models/pvt.py:38-66) and the global sub-sampled attention of Twins-SVT
+ * (models/twins.py:56-93), head dim D = 64 | 32, Lk <= 64 keys:
+ * q [B*Lq, nH*D], kv [B*Lk, 2*nH*D] (k | v halves, head-major inside each), o [B*Lq, nH*D], lse [B*nH*Lq] fp32. */
+int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
                    void* stream) {
   if (!q || !kv || !o || !lse) return VTX_ERR_NULL;
   SrGeom g;
-  int rc = sr_geom(g, Lq, Lk, nH, B);
+  int rc = sr_geom(g, Lq, Lk, nH, B, D);
   if (rc) return rc;
-  dim3 grid(sr_wgs(g), B * nH);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == VTX_BF16)
-    hipLaunchKernelGGL((srattn_fwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)kv, (bf16*)o, lse, g);
-  else if (dtype == VTX_F32)
-    hipLaunchKernelGGL((srattn_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)o, lse, g);
-  else return VTX_ERR_DTYPE;
-  return vtx_check_launch();
+  return SR_DISPATCH(sr_launch_fwd, q, kv, o, lse, B, g, (hipStream_t)stream);
 }
 
-size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH) {
+size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH, int D) {
   SrGeom g;
-  if (sr_geom(g, Lq, Lk, nH, B)) return 0;
-  return (size_t)B * nH * sr_wgs(g) * SR_LK * 2 * SR_D * sizeof(float);
+  if (sr_geom(g, Lq, Lk, nH, B, D)) return 0;
+  return (size_t)B * nH * sr_wgs(g) * SR_LK * 2 * D * sizeof(float);
 }
 
-/* dq [B*Lq, nH*64], dkv [B*Lk, 2*nH*64]; deterministic (fixed-order slab reduction). */
+/* dq [B*Lq, nH*D], dkv [B*Lk, 2*nH*D]; deterministic (fixed-order slab reduction). */
 int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
-                   void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int dtype, void* stream) {
+                   void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, void* stream) {
   if (!q || !kv || !o || !dout || !lse || !dq || !dkv || !workspace) return VTX_ERR_NULL;
   SrGeom g;
-  int rc = sr_geom(g, Lq, Lk, nH, B);
+  int rc = sr_geom(g, Lq, Lk, nH, B, D);
   if (rc) return rc;
-  if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH)) return VTX_ERR_WORKSPACE;
-  const int nwg = sr_wgs(g);
-  dim3 grid(nwg, B * nH);
-  hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)workspace;
-  const int64_t total = (int64_t)B * nH * Lk * 32;
-  const int rb = (int)((total + 255) / 256);
-  if (dtype == VTX_BF16) {
-    hipLaunchKernelGGL((srattn_bwd_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)q, (const bf16*)kv, (const bf16*)o,
-                       (const bf16*)dout, lse, (bf16*)dq, part, g);
-    rc = vtx_check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL((srattn_reduce_kernel<bf16>), dim3(rb), dim3(256), 0, st, (const float*)part, (bf16*)dkv, nwg, Lk,
-                       nH, total);
-  } else if (dtype == VTX_F32) {
-    hipLaunchKernelGGL((srattn_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)q, (const float*)kv,
-                       (const float*)o, (const float*)dout, lse, (float*)dq, part, g);
-    rc = vtx_check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL((srattn_reduce_kernel<float>), dim3(rb), dim3(256), 0, st, (const float*)part, (float*)dkv, nwg, Lk,
-                       nH, total);
-  } else return VTX_ERR_DTYPE;
-  return vtx_check_launch();
+  if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH, D)) return VTX_ERR_WORKSPACE;
+  return SR_DISPATCH(sr_launch_bwd, q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, g, (hipStream_t)stream);
 }
 
 }  // extern "C"

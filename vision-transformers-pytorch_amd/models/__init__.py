@@ -2,11 +2,13 @@
 
 The reference's models/__init__.py:1-7 re-exports eight names; the ones on the ViT / Swin training hot
 path are provided here (SwinTransformer, dino) plus VisionTransformer and -- SURVEY.md section 8 row F1 -- the
-PyramidVisionTransformer of models/pvt.py (the reference does not re-export it either; import models.pvt).  The
-convolutional families and the Halo / Twins models are outside this build's scope.
+PyramidVisionTransformer of models/pvt.py (the reference does not re-export it either; import models.pvt) and the TwinsSVT of
+models/twins.py (re-exported by the reference, models/__init__.py:5).  The convolutional families and the Halo model are
+outside this build's scope.
 """
 from .pvt import PyramidVisionTransformer
 from .swin_transformer import SwinTransformer
+from .twins import TwinsSVT
 from .vit import VisionTransformer, dino
 
-__all__ = ["SwinTransformer", "VisionTransformer", "dino", "PyramidVisionTransformer"]
+__all__ = ["SwinTransformer", "VisionTransformer", "dino", "PyramidVisionTransformer", "TwinsSVT"]

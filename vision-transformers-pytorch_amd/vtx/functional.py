@@ -973,8 +973,11 @@ def conv_as_rows(w):
 class PvtMeta:
     """Static description of one PVT transformer layer: heads, token grid, spatial reduction, leading cls tokens."""
 
-    def __init__(self, n_head, height, width, reduction, skip, eps=1e-6):
+    def __init__(self, n_head, height, width, reduction, skip, eps=1e-6, twins=False):
         self.n_head, self.height, self.width, self.reduction, self.skip, self.eps = n_head, height, width, reduction, skip, eps
+        # twins: the reduction conv's operand is gathered the way models/twins.py:69-70 reshapes its 4-D input
+        # (ops.twins_subsample_fwd) instead of the token-grid patch gather of pvt.py:44-46
+        self.twins = twins
 
 
 class PatchifyFn(Function):
@@ -996,6 +999,26 @@ class PatchifyFn(Function):
             torch.empty(shape, dtype=dout.dtype, device=dout.device)
         ops.patchify_bwd(_c(dout), dx, shape[0], H, W, shape[2], p, skip)
         return dx, None, None, None, None
+
+
+class TwinsSubsampleFn(Function):
+    """Channels-last features (B, H, W, C) -> the patch matrix of twins.MultiHeadedAttention's reduction conv, with the
+    reference's reshape kept as written (models/twins.py:69-70; ops.twins_subsample_fwd); backward = the inverse scatter."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        x = _c(x)
+        ctx.geom = (x.shape, r)
+        B, H, W, C = x.shape
+        return ops.twins_subsample_fwd(x, B, H, W, C, r)
+
+    @staticmethod
+    def backward(ctx, dout):
+        side_fence(dout.device)
+        shape, r = ctx.geom
+        dx = torch.empty(shape, dtype=dout.dtype, device=dout.device)
+        ops.twins_subsample_bwd(_c(dout), dx, shape[0], shape[1], shape[2], shape[3], r)
+        return dx, None
 
 
 class SrAttentionFn(Function):
@@ -1021,6 +1044,8 @@ class PvtLayerFn(Function):
     """One PVT block (reference models/pvt.py:31-68, 99-103):
          x1 = x  + s1 * proj(sr_attn(q(LN1 x), kv(reduce(LN1 x))))      y = x1 + s2 * fc2(silu(fc1(LN2 x1)))
     reduce = Conv2d(C, C, r, stride r) on the token grid + LayerNorm (reduction > 1) as patchify gather + GEMM + LN.
+    The global half of a Twins-SVT layer (reference models/twins.py:56-93, 201-202) is the same block without that LayerNorm
+    (srn_w = srn_b = None) and with head dim 32.
     Kernels forward: LN, GEMM(q), [gather, GEMM+bias, LN], GEMM(kv), attention, GEMM+residual, LN, GEMM+SiLU,
     GEMM+residual."""
 
@@ -1039,10 +1064,14 @@ class PvtLayerFn(Function):
         wsr = patches = red = means = rstds = None
         if r > 1:
             wsr = conv_as_rows(wcast(sr_w, T)[0])
-            patches = ops.patchify_fwd(ln1, B, m.height, m.width, C, r, m.skip)
+            patches = (ops.twins_subsample_fwd(ln1, B, m.height, m.width, C, r) if m.twins else
+                       ops.patchify_fwd(ln1, B, m.height, m.width, C, r, m.skip))
             Lk = (m.height // r) * (m.width // r)
             red = ops.gemm(patches, wsr[0], 0, bias=sr_b.detach())
-            kvin, means, rstds = ops.layernorm_fwd(red, srn_w.detach(), srn_b.detach(), m.eps)
+            if srn_w is not None:
+                kvin, means, rstds = ops.layernorm_fwd(red, srn_w.detach(), srn_b.detach(), m.eps)
+            else:                                                     # Twins-SVT: the sub-sampled tokens go straight to kv
+                kvin = red
         else:
             kvin, Lk = ln1, L
         kv = ops.gemm(kvin, wkv[0], 0)
@@ -1083,13 +1112,19 @@ class PvtLayerFn(Function):
         jobs = [(dy, h, True, s2), (dz, ln2, True, None), (dx1, o, True, s1), (dq, ln1, False, None)]
         if r > 1:
             dkvin = dgrad(dkv, wkv, T)
-            if _DEFER_REDUCE:
+            part_s = None
+            if srn_w is None:
+                dred = dkvin
+            elif _DEFER_REDUCE:
                 dred, part_s = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach(), defer=True)
             else:
                 dred, dgs, dbs = ops.layernorm_bwd(dkvin, red, means, rstds, srn_w.detach())
             dpatches = dgrad(dred, wsr, T)
             dln1 = dgrad(dq, wq, T)
-            ops.patchify_bwd(dpatches, dln1, B, m.height, m.width, C, r, m.skip, accumulate=True)
+            if m.twins:
+                ops.twins_subsample_bwd(dpatches, dln1, B, m.height, m.width, C, r, accumulate=True)
+            else:
+                ops.patchify_bwd(dpatches, dln1, B, m.height, m.width, C, r, m.skip, accumulate=True)
             co, _, pp, _ = ctx.sr_shape
 
             def unpermute(res):                                        # (py, px, c) columns back to (c, py, px)
@@ -1102,10 +1137,10 @@ class PvtLayerFn(Function):
             dln1 = dgrad(dq, wq, T, resid=dkvin)                       # both consumers of LN1's output
         if _DEFER_REDUCE:
             dx, part1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1, defer=True)
-            parts = [part2, part1] + ([part_s] if r > 1 else [])
+            parts = [part2, part1] + ([part_s] if r > 1 and part_s is not None else [])
             res, red_out = layer_wgrads(jobs, rps, dp_c, colparts=parts)
             (dg2, dbe2), (dg1, dbe1) = red_out[0], red_out[1]
-            if r > 1:
+            if r > 1 and part_s is not None:
                 dgs, dbs = red_out[2]
         else:
             dx, dg1, dbe1 = ops.layernorm_bwd(dln1, x, mean1, rstd1, ln1_w.detach(), dres=dx1)
@@ -1115,6 +1150,26 @@ class PvtLayerFn(Function):
             dWkv = res[4][0]
         return (dx.view(B, L, C), dg1, dbe1, dWq, dWkv, dWsr, dbsr, dgs, dbs, dWo, dbo, dg2, dbe2, dW1, db1, dW2, db2,
                 None, None, None, None)
+
+
+class PegFn(Function):
+    """Positional-encoding generator of Twins-SVT (reference models/twins.py:25-37): y = x + DepthwiseConv3x3(x) on the
+    channels-last feature map, one kernel forward; backward = the mirrored-tap kernel on dy + the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _c(x)
+        ctx.save_for_backward(x, w)
+        return ops.dwconv3_fwd(x, w.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        side_fence(dy.device)
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.dwconv3_fwd(dy, w.detach(), adjoint=True) if ctx.needs_input_grad[0] else None
+        dw = ops.dwconv3_wgrad(x, dy).view(w.shape) if ctx.needs_input_grad[1] else None
+        return dx, dw
 
 
 class PvtPatchEmbedFn(Function):

@@ -55,7 +55,8 @@ def drop_path_scope(model, batch, device):
     dps = model.__dict__.get("_vtx_dp_modules")
     if dps is None or dps[0] != len(model._modules):
         dps = model.__dict__["_vtx_dp_modules"] = (len(model._modules), [m for m in model.modules() if isinstance(m, _DropPathBase)])
-    ps = [m.p for m in dps[1] if m.p > 0 for _ in range(2)]
+    # (draws per DropPath module and forward: 2, or what the owning layer declares -- a Twins-SVT layer has 4 branches)
+    ps = [m.p for m in dps[1] if m.p > 0 for _ in range(getattr(m, "_vtx_draws", 2))]
     if not ps:
         yield
         return

@@ -492,23 +492,30 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=Non
     return (res, couts) if colparts is not None else res
 
 
-# ------------------------------------------------------------------------------- PVT: spatial-reduction attention
-def srattn_fwd(q, kv, B, Lq, Lk, n_head):
-    """o [B*Lq, h*64], lse from q [B*Lq, h*64] and kv [B*Lk, 2*h*64] (k | v) -- reference models/pvt.py:38-66."""
-    _dev(q, kv)
+# ------------------------------------------------------------------------------- PVT / Twins: spatial-reduction attention
+def _sr_head_dim(q, kv, B, Lq, Lk, n_head):
+    """Head dim of the operands (64: PVT, 32: Twins-SVT); the kernels exist for these two."""
     if q.dtype != kv.dtype:
         raise VtxError("vtx: srattn operand dtypes differ")
-    hd = n_head * 64
-    if q.numel() != B * Lq * hd or kv.numel() != B * Lk * 2 * hd:
-        raise VtxError("vtx: srattn shape mismatch (head dim must be 64)")
+    hd = q.numel() // max(B * Lq, 1)
+    D = hd // max(n_head, 1)
+    if D not in (32, 64) or D * n_head != hd or q.numel() != B * Lq * hd or kv.numel() != B * Lk * 2 * hd:
+        raise VtxError(f"vtx: srattn shape mismatch (q {tuple(q.shape)}, kv {tuple(kv.shape)}, {n_head} heads: head dim must be 32 or 64)")
+    return D, hd
+
+
+def srattn_fwd(q, kv, B, Lq, Lk, n_head):
+    """o [B*Lq, h*D], lse from q [B*Lq, h*D] and kv [B*Lk, 2*h*D] (k | v) -- reference models/pvt.py:38-66, twins.py:56-93."""
+    _dev(q, kv)
+    D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
     o = torch.empty_like(q)
     lse = torch.empty(B * n_head * Lq, dtype=torch.float32, device=q.device)
     tn = "__bf16" if q.dtype == torch.bfloat16 else "float"
-    ev = _attn_bracket(f"srattn_fwd_kernel<{tn}>", B * n_head, Lq, 64, B * Lq, hd, q.element_size(), False)
+    ev = _attn_bracket(f"srattn_fwd_kernel<{tn}, {D}>", B * n_head, Lq, D, B * Lq, hd, q.element_size(), False)
     if ev is not None:                              # Lq x Lk products, not Lq x Lq
-        _timer.records[-1] = (_timer.records[-1][0], 4.0 * B * n_head * Lq * Lk * 64,
+        _timer.records[-1] = (_timer.records[-1][0], 4.0 * B * n_head * Lq * Lk * D,
                               q.element_size() * (2.0 * B * Lq * hd + 2.0 * B * Lk * hd)) + _timer.records[-1][3:]
-    check(_lib.load().vtx_srattn_fwd(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, _dt(q), _stream()),
+    check(_lib.load().vtx_srattn_fwd(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, D, _dt(q), _stream()),
           "vtx_srattn_fwd")
     if ev:
         ev[1].record()
@@ -516,10 +523,11 @@ def srattn_fwd(q, kv, B, Lq, Lk, n_head):
 
 
 def srattn_scores(q, kv, B, Lq, Lk, n_head):
-    """Pre-softmax scores q k^T / 8 as (B, n_head, Lq, Lk) -- what pvt.MultiHeadedAttention.forward returns second."""
+    """Pre-softmax scores q k^T / sqrt(D) as (B, n_head, Lq, Lk) -- what pvt.MultiHeadedAttention.forward returns second."""
     _dev(q, kv)
+    D, _ = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
     score = torch.empty((B, n_head, Lq, Lk), dtype=q.dtype, device=q.device)
-    check(_lib.load().vtx_srattn_scores(_p(q), _p(kv), _p(score), B, Lq, Lk, n_head, _dt(q), _stream()), "vtx_srattn_scores")
+    check(_lib.load().vtx_srattn_scores(_p(q), _p(kv), _p(score), B, Lq, Lk, n_head, D, _dt(q), _stream()), "vtx_srattn_scores")
     return score
 
 
@@ -527,21 +535,65 @@ def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head):
     """dq, dkv (deterministic)."""
     _dev(q, kv, o, dout, lse)
     lib = _lib.load()
+    D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
-    wsb = lib.vtx_srattn_bwd_workspace(B, Lq, Lk, n_head)
+    wsb = lib.vtx_srattn_bwd_workspace(B, Lq, Lk, n_head, D)
     ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
-    hd = n_head * 64
     tn = "__bf16" if q.dtype == torch.bfloat16 else "float"
-    ev = _attn_bracket(f"srattn_bwd_kernel<{tn}>", B * n_head, Lq, 64, B * Lq, hd, q.element_size(), True)
+    ev = _attn_bracket(f"srattn_bwd_kernel<{tn}, {D}>", B * n_head, Lq, D, B * Lq, hd, q.element_size(), True)
     if ev is not None:
-        _timer.records[-1] = (_timer.records[-1][0], 10.0 * B * n_head * Lq * Lk * 64,
+        _timer.records[-1] = (_timer.records[-1][0], 10.0 * B * n_head * Lq * Lk * D,
                               q.element_size() * (4.0 * B * Lq * hd + 4.0 * B * Lk * hd)) + _timer.records[-1][3:]
-    check(lib.vtx_srattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head,
+    check(lib.vtx_srattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head, D,
                              _dt(q), _stream()), "vtx_srattn_bwd")
     if ev:
         ev[1].record()
     return dq, dkv
+
+
+def dwconv3_fwd(x, w, adjoint=False):
+    """y = x + DepthwiseConv3x3(x) on channels-last x (B, H, W, C), w (C, 1, 3, 3) fp32 -- twins.py:25-37; adjoint: the input
+    gradient of the same map (x := dy)."""
+    _dev(x, w)
+    _f32(w, "peg weight")
+    B, H, W, C = x.shape
+    if w.numel() != 9 * C:
+        raise VtxError(f"vtx: dwconv3 weight has {w.numel()} elements for {C} channels")
+    y = torch.empty_like(x)
+    check(_lib.load().vtx_dwconv3_fwd(_p(x), _p(w), _p(y), B, H, W, C, int(adjoint), _dt(x), _stream()), "vtx_dwconv3_fwd")
+    return y
+
+
+def dwconv3_wgrad(x, dy):
+    """dw (C, 1, 3, 3) fp32 of y = x + DepthwiseConv3x3(x) (deterministic)."""
+    _dev(x, dy)
+    if x.dtype != dy.dtype or x.shape != dy.shape:
+        raise VtxError("vtx: dwconv3_wgrad operands differ in dtype / shape")
+    lib = _lib.load()
+    B, H, W, C = x.shape
+    wsb = lib.vtx_dwconv3_wgrad_workspace(B, H, W, C)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib.vtx_dwconv3_wgrad(_p(x), _p(dy), _p(dw), _p(ws), wsb, B, H, W, C, _dt(x), _stream()), "vtx_dwconv3_wgrad")
+    return dw
+
+
+def twins_subsample_fwd(x, B, H, W, C, r):
+    """Patch matrix [B*(H/r)*(W/r), r*r*C] of twins.MultiHeadedAttention's reduction conv on x [B, H, W, C] (any view of
+    B*H*W*C contiguous elements), with the reference's reshape kept as written (twins.py:69-70; include/vtx.h)."""
+    _dev(x)
+    out = torch.empty((B * (H // r) * (W // r), r * r * C), dtype=x.dtype, device=x.device)
+    check(_lib.load().vtx_twins_subsample_fwd(_p(x), _p(out), B, H, W, C, r, _dt(x), _stream()), "vtx_twins_subsample_fwd")
+    return out
+
+
+def twins_subsample_bwd(dout, dx, B, H, W, C, r, accumulate=False):
+    """Inverse scatter of twins_subsample_fwd into dx (B*H*W*C elements; optionally accumulating)."""
+    _dev(dout, dx)
+    check(_lib.load().vtx_twins_subsample_bwd(_p(dout), _p(dx), B, H, W, C, r, int(accumulate), _dt(dx), _stream()),
+          "vtx_twins_subsample_bwd")
+    return dx
 
 
 def patchify_fwd(x, B, H, W, C, p, skip=0):
