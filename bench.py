@@ -37,7 +37,12 @@ SWIN_S = dict(image_size=(224, 224), n_class=1000, depths=(2, 2, 18, 2), dims=(9
 # / MLP GEMMs and the Lq x Lk attention products = 7.631 GFLOP forward = the PVT paper's 3.8 GMACs)
 PVT_SMALL = dict(image_size=224, n_class=1000, in_dim=3, depths=(3, 4, 6, 3), patch_embed_dims=(64, 128, 320, 512),
                  n_heads=(1, 2, 5, 8), dim_ffs=(512, 1024, 1280, 2048), reductions=(8, 4, 2, 1))
-TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59, "pvt_small": 22.89,
+# Twins-SVT-S in the reference's formulation (models/twins.py: one layer = one locally-grouped + one sub-sampled block, so depths
+# (1, 1, 5, 2) are the paper's (2, 2, 10, 4); the sub-sampling conv has kernel = stride = window_size 7, twins.py:182): the
+# hyper-parameters are the paper's, like PVT's they are not in the reference repository.  5.689 GFLOP forward per image.
+TWINS_SVT_S = dict(n_class=1000, depths=(1, 1, 5, 2), dims=(64, 128, 256, 512), dim_head=32, n_heads=(2, 4, 8, 16),
+                   dim_ffs=(256, 512, 1024, 2048), window_size=7)
+TRAIN_GFLOP_PER_IMG = {"swin_s": 52.45, "vit_s16": 27.59, "pvt_small": 22.89, "twins_svt_s": 17.07,
                        # DINO DeiT-S/16 per SOURCE image: student 2 x 224^2 + 8 x 96^2 crops fwd+bwd, teacher 2 x 224^2 fwd,
                        # heads (384-2048-2048-256-65536) on 10 + 2 feature rows: 3 x (2 x 9.197 + 8 x 1.618 + 10 x 0.0449)
                        # + (2 x 9.197 + 2 x 0.0449) = 113.8 GFLOP
@@ -80,6 +85,9 @@ def build_model(name, drop_path):
     if name == "pvt_small":
         from models.pvt import PyramidVisionTransformer
         return PyramidVisionTransformer(**PVT_SMALL, drop_path=drop_path)   # BASELINE.json cfg-4 (PVT paper hyper-parameters)
+    if name == "twins_svt_s":
+        from models.twins import TwinsSVT
+        return TwinsSVT(**TWINS_SVT_S, drop_path=drop_path)                 # not a BASELINE.json configuration: --model only
     return VisionTransformer(Linear(384, 1000), 224, 16, 12, 384, 6, 1536, 0.0, 0.0, 0.0, drop_path)
 
 
@@ -159,6 +167,8 @@ def cpu_baseline(name, batch, steps):
         fwd = lambda x: M.swin_forward(P, x, M.SWIN_S)
     elif name == "pvt_small":
         fwd = lambda x: M.pvt_forward(P, x, M.PVT_SMALL)
+    elif name == "twins_svt_s":
+        fwd = lambda x: M.twins_forward(P, x, M.TWINS_SVT_S)
     else:
         fwd = lambda x: M.vit_forward(P, x, M.VIT_S16, head=lambda f: R.linear(f, P["head.weight"], P["head.bias"]))
     torch.manual_seed(0)
@@ -360,7 +370,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small", "dino"])
+    ap.add_argument("--model", default="swin_s", choices=["swin_s", "vit_s16", "pvt_small", "dino", "twins_svt_s"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 128 swin_s / pvt_small, 256 vit_s16, 64 dino)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])

@@ -301,8 +301,9 @@ int vtx_dwconv3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
 /* ---- Operand of the sub-sampling convolution of Twins-SVT's global attention (csrc/twins_misc.hip; reference
  * models/twins.py:69-71).  The reference reshapes its 4-D input as ``input.transpose(1, 2).reshape(B, C, H, W)``: the "image"
  * the Conv2d(C, C, r, stride r) sees is a fixed permutation of the feature map's elements (flat index f = c' H W + y W + x of
- * the (W, H, C)-ordered map), kept here as written.  x [B, H, W, C] -> out [B*(H/r)*(W/r), r*r*C], columns (py, px, c');
- * _bwd is the inverse scatter (accumulate != 0 adds into dx). */
+ * the (W, H, C)-ordered map), kept here as written.  x [B, H, W, C] -> out [B*(H/r)*(W/r), C*r*r], columns (c', py, px) --
+ * the Conv2d weight's own memory layout [out][c'][py][px], so weight.view(out, C*r*r) is the GEMM operand and the weight
+ * gradient comes out in the parameter's layout; _bwd is the inverse scatter (accumulate != 0 adds into dx). */
 int vtx_twins_subsample_fwd(const void* x, void* out, int B, int H, int W, int C, int r, int dtype, void* stream);
 int vtx_twins_subsample_bwd(const void* dout, void* dx, int B, int H, int W, int C, int r, int accumulate, int dtype,
                             void* stream);

@@ -48,7 +48,13 @@ def test_sr_attention_core(dtype, B, Lq, Lk, nH, D):
     t = TOL[dtype]
     tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH} d{D}"
     check(f"srattn fwd {tag}", o, orf, t["out"] * 1.5)
-    check(f"srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+    if Lk == 1:
+        # one key: softmax = 1, dS = P (dP - sum P dP) vanishes and the true dq is exactly 0; the kernel's two sums come out of
+        # different MFMA / shuffle orders, a rounding-sized remainder survives (inputs are O(1))
+        assert float(dqr.abs().max()) == 0.0
+        assert report(f"srattn |dq| with a single key {tag}", float(dq.abs().max()), 1e-4)
+    else:
+        check(f"srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"srattn dkv {tag}", dkv, dkvr, 2e-5 if dtype == torch.float32 else 1e-2)
 
 

@@ -222,7 +222,10 @@ def test_sweep_sr_attention(dtype, case):
     dqr, dkvr = torch.autograd.grad(orf, [qr, kvr], do.double())
     tag = f"{dtype} B{B} Lq{Lq} Lk{Lk} h{nH} d{C // nH}"
     check(f"sweep srattn fwd {tag}", o, orf, TOL[dtype]["out"] * 1.5)
-    check(f"sweep srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
+    if Lk == 1:                     # a single key: the true dq is exactly 0 (see test_gpu_pvt.test_sr_attention_core)
+        assert float(dq.abs().max()) <= 1e-4
+    else:
+        check(f"sweep srattn dq {tag}", dq, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
     check(f"sweep srattn dkv {tag}", dkv, dkvr, 2e-5 if dtype == torch.float32 else 1.5e-2)
 
 

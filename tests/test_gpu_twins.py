@@ -51,13 +51,14 @@ def test_subsample_gather_is_the_reference_reshape(dtype, B, H, W, C, r):
     x = fill((B, H, W, C), 431, 1.0).to(dtype)
     out = ops.twins_subsample_fwd(x.to(d), B, H, W, C, r)
     img = x.transpose(1, 2).reshape(B, C, H, W)                               # as written in the reference
-    cols = img.reshape(B, C, H // r, r, W // r, r).permute(0, 2, 4, 3, 5, 1).reshape(-1, r * r * C)   # (py, px, c') columns
+    unfold = lambda t: torch.nn.functional.unfold(t, r, stride=r).transpose(1, 2).reshape(-1, C * r * r)   # (c', py, px) columns
+    cols = unfold(img.float()).to(dtype)
     assert torch.equal(out.cpu(), cols), "subsample gather differs from the reference's reshape"
     g = fill(tuple(out.shape), 432, 1.0).to(dtype)
     dx = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=d)
     ops.twins_subsample_bwd(g.to(d), dx, B, H, W, C, r)
     xr = x.double().requires_grad_(True)
-    colr = xr.transpose(1, 2).reshape(B, C, H, W).reshape(B, C, H // r, r, W // r, r).permute(0, 2, 4, 3, 5, 1).reshape(-1, r * r * C)
+    colr = unfold(xr.transpose(1, 2).reshape(B, C, H, W))
     (want,) = torch.autograd.grad(colr, xr, g.double())
     assert torch.equal(dx.cpu().double(), want), "subsample scatter is not the inverse permutation"
     base = fill((B, H, W, C), 433, 1.0).to(dtype)

@@ -1,10 +1,10 @@
 """MI355X-native drop-in for the transformer part of the reference's ``models`` package.
 
-The reference's models/__init__.py:1-7 re-exports eight names; the ones on the ViT / Swin training hot
-path are provided here (SwinTransformer, dino) plus VisionTransformer and -- SURVEY.md section 8 row F1 -- the
-PyramidVisionTransformer of models/pvt.py (the reference does not re-export it either; import models.pvt) and the TwinsSVT of
-models/twins.py (re-exported by the reference, models/__init__.py:5).  The convolutional families and the Halo model are
-outside this build's scope.
+The reference's models/__init__.py:1-7 re-exports eight names; the ones on the ViT / Swin training hot path are provided
+here (SwinTransformer, dino) plus VisionTransformer, the PyramidVisionTransformer of models/pvt.py (SURVEY.md section 8
+row F1; models/__init__.py:3) and the TwinsSVT of models/twins.py (the row after F1-F4; the reference does not re-export
+it -- ``from models.twins import TwinsSVT`` works in both).  The convolutional families and the Halo model are outside this
+build's scope.
 """
 from .pvt import PyramidVisionTransformer
 from .swin_transformer import SwinTransformer

@@ -94,7 +94,7 @@ class MultiHeadedAttention(nn.Module):
         q = VF.LinearFn.apply(x, self.linear_q.weight, None)
         # the reduction conv's operand exactly as twins.py:69-70 builds it from the 4-D input (a fixed permutation of the map)
         patches = VF.TwinsSubsampleFn.apply(x.view(B, H, W, C), r)
-        w_rows = self.reduce_conv.weight.permute(0, 2, 3, 1).reshape(C, -1)           # conv weight as (py, px, c) columns
+        w_rows = self.reduce_conv.weight.view(C, -1)               # (c', py, px) columns: the gather's column order
         kvin = VF.LinearFn.apply(patches, w_rows, self.reduce_conv.bias)
         Lk = (H // r) * (W // r)
         kv = VF.LinearFn.apply(kvin.reshape(B * Lk, C), self.linear_kv.weight, None)

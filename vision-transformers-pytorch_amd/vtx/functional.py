@@ -1063,9 +1063,13 @@ class PvtLayerFn(Function):
         q = ops.gemm(ln1, wq[0], 0)
         wsr = patches = red = means = rstds = None
         if r > 1:
-            wsr = conv_as_rows(wcast(sr_w, T)[0])
-            patches = (ops.twins_subsample_fwd(ln1, B, m.height, m.width, C, r) if m.twins else
-                       ops.patchify_fwd(ln1, B, m.height, m.width, C, r, m.skip))
+            if m.twins:                   # columns (c', py, px) = the weight's own layout: no permutation, the plan's transposed copy
+                wsr_p = wcast(sr_w, T)
+                wsr = (wsr_p[0].view(sr_w.shape[0], -1), wsr_p[1])
+                patches = ops.twins_subsample_fwd(ln1, B, m.height, m.width, C, r)
+            else:
+                wsr = conv_as_rows(wcast(sr_w, T)[0])
+                patches = ops.patchify_fwd(ln1, B, m.height, m.width, C, r, m.skip)
             Lk = (m.height // r) * (m.width // r)
             red = ops.gemm(patches, wsr[0], 0, bias=sr_b.detach())
             if srn_w is not None:
@@ -1129,6 +1133,8 @@ class PvtLayerFn(Function):
 
             def unpermute(res):                                        # (py, px, c) columns back to (c, py, px)
                 (a, _), (b, bb) = res
+                if m.twins:                                            # already the parameter's layout
+                    return a, b.view(co, C, pp, pp), bb
                 return a, b.view(co, pp, pp, C).permute(0, 3, 1, 2).contiguous(), bb
             dWkv, dWsr, dbsr = layer_wgrads([(dkv, kvin, False, None), (dred, patches, True, None)], post=unpermute)
         else:

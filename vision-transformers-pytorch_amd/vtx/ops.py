@@ -580,10 +580,11 @@ def dwconv3_wgrad(x, dy):
 
 
 def twins_subsample_fwd(x, B, H, W, C, r):
-    """Patch matrix [B*(H/r)*(W/r), r*r*C] of twins.MultiHeadedAttention's reduction conv on x [B, H, W, C] (any view of
-    B*H*W*C contiguous elements), with the reference's reshape kept as written (twins.py:69-70; include/vtx.h)."""
+    """Patch matrix [B*(H/r)*(W/r), C*r*r] (columns (c', py, px): the Conv2d weight's own layout) of
+    twins.MultiHeadedAttention's reduction conv on x [B, H, W, C] (any view of B*H*W*C contiguous elements), with the
+    reference's reshape kept as written (twins.py:69-70; include/vtx.h)."""
     _dev(x)
-    out = torch.empty((B * (H // r) * (W // r), r * r * C), dtype=x.dtype, device=x.device)
+    out = torch.empty((B * (H // r) * (W // r), C * r * r), dtype=x.dtype, device=x.device)
     check(_lib.load().vtx_twins_subsample_fwd(_p(x), _p(out), B, H, W, C, r, _dt(x), _stream()), "vtx_twins_subsample_fwd")
     return out
 
