@@ -303,8 +303,12 @@ int vtx_dwconv3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
  * the Conv2d(C, C, r, stride r) sees is a fixed permutation of the feature map's elements (flat index f = c' H W + y W + x of
  * the (W, H, C)-ordered map), kept here as written.  x [B, H, W, C] -> out [B*(H/r)*(W/r), C*r*r], columns (c', py, px) --
  * the Conv2d weight's own memory layout [out][c'][py][px], so weight.view(out, C*r*r) is the GEMM operand and the weight
- * gradient comes out in the parameter's layout; _bwd is the inverse scatter (accumulate != 0 adds into dx). */
-int vtx_twins_subsample_fwd(const void* x, void* out, int B, int H, int W, int C, int r, int dtype, void* stream);
+ * gradient comes out in the parameter's layout; out_t (nullable): a second, transposed copy [C*r*r, B*(H/r)*(W/r)] -- with the
+ * transposed weight copy it turns the few-row / long-K convolution of the late stages (128 rows x K = 25 088) into a vtx_wgrad
+ * call, i.e. a split-K launch that fills the chip; _bwd is the inverse scatter (accumulate != 0 adds into dx). */
+int vtx_twins_subsample_fwd(const void* x, void* out, void* out_t, int B, int H, int W, int C, int r, int dtype, void* stream);
+/* out [rows, C] (dtype) = x [rows, C] fp32 + bias [C] fp32 (nullable): fp32 split-K sums -> the compute dtype. */
+int vtx_bias_cast(const float* x, const float* bias, void* out, int64_t rows, int C, int dtype, void* stream);
 int vtx_twins_subsample_bwd(const void* dout, void* dx, int B, int H, int W, int C, int r, int accumulate, int dtype,
                             void* stream);
 

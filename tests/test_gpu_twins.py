@@ -54,6 +54,8 @@ def test_subsample_gather_is_the_reference_reshape(dtype, B, H, W, C, r):
     unfold = lambda t: torch.nn.functional.unfold(t, r, stride=r).transpose(1, 2).reshape(-1, C * r * r)   # (c', py, px) columns
     cols = unfold(img.float()).to(dtype)
     assert torch.equal(out.cpu(), cols), "subsample gather differs from the reference's reshape"
+    out2, out_t = ops.twins_subsample_fwd(x.to(d), B, H, W, C, r, transposed=True)
+    assert torch.equal(out2, out) and torch.equal(out_t, out.t()), "the transposed copy is not the transpose"
     g = fill(tuple(out.shape), 432, 1.0).to(dtype)
     dx = torch.full((B, H, W, C), float("nan"), dtype=dtype, device=d)
     ops.twins_subsample_bwd(g.to(d), dx, B, H, W, C, r)
@@ -189,3 +191,40 @@ def test_twins_svt_s_bf16_step_with_its_own_mask_draws_is_deterministic():
     assert torch.equal(res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("H,C,n_head,ff", [(7, 512, 16, 2048), (14, 256, 8, 1024)])
+def test_late_stage_reduction_conv_on_the_split_k_launch(monkeypatch, H, C, n_head, ff):
+    """Stages 3 / 4 at the benchmark's batch: the few-row / long-K reduction conv runs as a split-K (weight-gradient) launch on
+    the transposed operand copy (functional._TWINS_SPLITK).  Same layer with the switch off = the plain GEMM: outputs and all
+    gradients agree to bf16 rounding (the two paths differ in summation order only), and both match the fp32 oracle band."""
+    import models.twins as T
+    from vtx import functional as VF
+    from vtx import ops
+    torch.manual_seed(11)
+    layer = T.TransformerLayer(C, n_head, 32, ff, 7).to(dev()).train()
+    x = torch.randn(128, H, H, C, generator=torch.Generator().manual_seed(12)).to(dev())
+    cot = torch.randn(128, H, H, C, generator=torch.Generator().manual_seed(13)).to(dev())
+    res = {}
+    taken = []
+    real = ops.twins_subsample_fwd
+    monkeypatch.setattr(ops, "twins_subsample_fwd", lambda *a, transposed=False: (taken.append(transposed), real(*a, transposed=transposed))[1])
+    for on in (True, False):
+        monkeypatch.setattr(VF, "_TWINS_SPLITK", on)
+        layer.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with VF.weight_scope(layer, xi):
+                out = layer(xi)
+        (out.float() * cot).sum().backward()
+        res[on] = (out.float(), xi.grad.float(), {n: p.grad.clone() for n, p in layer.named_parameters()})
+    assert taken == [True, False], f"split-K path not taken where expected: {taken}"
+    check("twins split-K reduction conv: layer output vs the GEMM path", res[True][0], res[False][0], 4e-3)
+    check("twins split-K reduction conv: dx vs the GEMM path", res[True][1], res[False][1], 1e-2)
+    for n in res[True][2]:
+        if H == 7 and n == "attn_global.linear_q.weight":
+            # one sub-sampled key: the true gradient is exactly 0, both paths hold rounding remainders (see the fp32 model test)
+            scale = res[True][2]["attn_global.linear_kv.weight"].norm().item()
+            assert res[True][2][n].norm().item() < 1e-3 * scale and res[False][2][n].norm().item() < 1e-3 * scale
+            continue
+        check(f"twins split-K reduction conv: grad {n} vs the GEMM path", res[True][2][n], res[False][2][n], 1e-2)

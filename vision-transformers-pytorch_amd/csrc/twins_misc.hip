@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* 
 // consecutive f = r consecutive channels, 2-byte accesses that L2 merges; a thread per run of r was 1.5-6x slower: 14-byte
 // strides on both sides); grid.y = image, 32-bit arithmetic inside it.
 template <typename T, bool BWD, bool ACC>
-__global__ void twins_subsample_kernel(const T* __restrict__ src, T* __restrict__ dst, int H, int W, int C, int r) {
+__global__ void twins_subsample_kernel(const T* __restrict__ src, T* __restrict__ dst, T* __restrict__ dst_t, int H, int W, int C,
+                                       int r) {
   const int per_img = H * W * C;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;                      // element of this image's patch block
   if (e >= per_img) return;
@@ -165,12 +166,33 @@ __global__ void twins_subsample_kernel(const T* __restrict__ src, T* __restrict_
   const int64_t base = (int64_t)blockIdx.y * per_img;
   const int64_t xi = base + (h * W + w) * C + c, pi = base + e;
   if (!BWD) {
-    dst[pi] = src[xi];
+    const T v = src[xi];
+    dst[pi] = v;
+    // second copy, transposed [K][B Lk]: the operand of the split-K launch that serves the long-K / few-row reduction convs
+    if (dst_t != nullptr) dst_t[(int64_t)col * ((int64_t)gridDim.y * (per_img / K)) + (int64_t)blockIdx.y * (per_img / K) + t] = v;
   } else if (ACC) {
     dst[xi] = from_f32<T>(to_f32<T>(dst[xi]) + to_f32<T>(src[pi]));
   } else {
     dst[xi] = src[pi];
   }
+}
+
+// out[row][c] = T(x[row][c] + bias[c]): the epilogue of the split-K path of the reduction conv (fp32 partial sums -> compute dtype)
+template <typename T>
+__global__ void bias_cast_kernel(const float* __restrict__ x, const float* __restrict__ bias, T* __restrict__ out, int C,
+                                 int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over 8-element vectors
+  if (idx >= total) return;
+  const int cv = C >> 3;
+  const int v = (int)(idx % cv);
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + idx * 8), a1 = *reinterpret_cast<const f32x4*>(x + idx * 8 + 4);
+  Vec8<T> o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o.set(e, a0[e] + (bias ? bias[v * 8 + e] : 0.f));
+    o.set(4 + e, a1[e] + (bias ? bias[v * 8 + 4 + e] : 0.f));
+  }
+  store8<T>(out + idx * 8, o);
 }
 
 static int dw_groups(int nrows) {                  // workgroups of the weight-gradient pass: <= 1024 (4 per CU)
@@ -238,16 +260,16 @@ int vtx_dwconv3_wgrad(const void* x, const void* dy, float* dw, void* workspace,
 
 /* Patch matrix of the sub-sampling convolution of Twins-SVT's global attention (reference models/twins.py:69-71), with the
  * reference's reshape of the 4-D input kept as written (see csrc/twins_misc.hip): x [B, H, W, C] -> out [B*(H/r)*(W/r), C*r*r],
- * column order (c', py, px) = the Conv2d weight's own layout.  _bwd scatters the patch gradient back into dx [B, H, W, C] (a permutation; accumulate != 0 adds
+ * column order (c', py, px) = the Conv2d weight's own layout; out_t (may be null): the same matrix transposed [C*r*r, B*(H/r)*(W/r)].  _bwd scatters the patch gradient back into dx [B, H, W, C] (a permutation; accumulate != 0 adds
  * to what dx holds -- the gradient that also arrives through the query projection). */
-int vtx_twins_subsample_fwd(const void* x, void* out, int B, int H, int W, int C, int r, int dtype, void* stream) {
+int vtx_twins_subsample_fwd(const void* x, void* out, void* out_t, int B, int H, int W, int C, int r, int dtype, void* stream) {
   if (!x || !out) return VTX_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0 || H % r || W % r) return VTX_ERR_SHAPE;
   if ((int64_t)H * W * C >= (1ll << 31) || B > 65535) return VTX_ERR_SHAPE;
   dim3 grid((H * W * C + 255) / 256, B);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VTX_BF16) hipLaunchKernelGGL((twins_subsample_kernel<bf16, false, false>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)out, H, W, C, r);
-  else if (dtype == VTX_F32) hipLaunchKernelGGL((twins_subsample_kernel<float, false, false>), grid, dim3(256), 0, st, (const float*)x, (float*)out, H, W, C, r);
+  if (dtype == VTX_BF16) hipLaunchKernelGGL((twins_subsample_kernel<bf16, false, false>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)out, (bf16*)out_t, H, W, C, r);
+  else if (dtype == VTX_F32) hipLaunchKernelGGL((twins_subsample_kernel<float, false, false>), grid, dim3(256), 0, st, (const float*)x, (float*)out, (float*)out_t, H, W, C, r);
   else return VTX_ERR_DTYPE;
   return vtx_check_launch();
 }
@@ -260,12 +282,25 @@ int vtx_twins_subsample_bwd(const void* dout, void* dx, int B, int H, int W, int
   dim3 grid((H * W * C + 255) / 256, B);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VTX_BF16) {
-    if (accumulate) hipLaunchKernelGGL((twins_subsample_kernel<bf16, true, true>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, H, W, C, r);
-    else hipLaunchKernelGGL((twins_subsample_kernel<bf16, true, false>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, H, W, C, r);
+    if (accumulate) hipLaunchKernelGGL((twins_subsample_kernel<bf16, true, true>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, (bf16*)nullptr, H, W, C, r);
+    else hipLaunchKernelGGL((twins_subsample_kernel<bf16, true, false>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, (bf16*)nullptr, H, W, C, r);
   } else if (dtype == VTX_F32) {
-    if (accumulate) hipLaunchKernelGGL((twins_subsample_kernel<float, true, true>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, H, W, C, r);
-    else hipLaunchKernelGGL((twins_subsample_kernel<float, true, false>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, H, W, C, r);
+    if (accumulate) hipLaunchKernelGGL((twins_subsample_kernel<float, true, true>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, (float*)nullptr, H, W, C, r);
+    else hipLaunchKernelGGL((twins_subsample_kernel<float, true, false>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, (float*)nullptr, H, W, C, r);
   } else return VTX_ERR_DTYPE;
+  return vtx_check_launch();
+}
+
+/* out [rows, C] (dtype) = x [rows, C] fp32 + bias [C] fp32 (bias may be null); C % 8 == 0. */
+int vtx_bias_cast(const float* x, const float* bias, void* out, int64_t rows, int C, int dtype, void* stream) {
+  if (!x || !out) return VTX_ERR_NULL;
+  if (rows <= 0 || C <= 0 || (C & 7)) return VTX_ERR_SHAPE;
+  const int64_t total = rows * (C >> 3);
+  const int blocks = (int)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VTX_BF16) hipLaunchKernelGGL(bias_cast_kernel<bf16>, dim3(blocks), dim3(256), 0, st, x, bias, (bf16*)out, C, total);
+  else if (dtype == VTX_F32) hipLaunchKernelGGL(bias_cast_kernel<float>, dim3(blocks), dim3(256), 0, st, x, bias, (float*)out, C, total);
+  else return VTX_ERR_DTYPE;
   return vtx_check_launch();
 }
 

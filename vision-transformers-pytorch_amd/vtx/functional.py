@@ -162,7 +162,8 @@ def _img(x):
 #     before it reduces a bucket.  Operands are kept alive until the join (the caching allocator would otherwise hand
 #     their memory to the main stream while the side stream still reads it).  Bitwise identical either way.
 _SIDE_ENABLED = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
-_SIDE_FENCE_MODE = os.environ.get("VTX_SIDE_FENCE", "1")        # (0 / merge: measurement only -- see side_fence)
+_SIDE_FENCE_MODE = os.environ.get("VTX_SIDE_FENCE", "1")
+_TWINS_SPLITK = os.environ.get("VTX_TWINS_SPLITK", "1") != "0"   # few-row / long-K reduction convs on the split-K launch        # (0 / merge: measurement only -- see side_fence)
 # one column-reduce launch per layer (LayerNorm dgamma / dbeta x 2 + rel_pos gradient) instead of three; 0: each kernel reduces its own
 _DEFER_REDUCE = os.environ.get("VTX_DEFER_REDUCE", "1") != "0"
 _deferred = False
@@ -1066,12 +1067,26 @@ class PvtLayerFn(Function):
             if m.twins:                   # columns (c', py, px) = the weight's own layout: no permutation, the plan's transposed copy
                 wsr_p = wcast(sr_w, T)
                 wsr = (wsr_p[0].view(sr_w.shape[0], -1), wsr_p[1])
-                patches = ops.twins_subsample_fwd(ln1, B, m.height, m.width, C, r)
+                Lk = (m.height // r) * (m.width // r)
+                # few rows, long contraction (stage 3 / 4 of Twins-SVT-S: 512 / 128 rows x K = 12 544 / 25 088): as a plain GEMM
+                # that is 8-32 workgroups for 100-310 us.  With the operand ALSO gathered transposed and the weight plan's
+                # transposed copy it is dW-shaped work -- out[rows, C] = sum_k P^T[k, rows] W^T[k, C] -- for the split-K
+                # weight-gradient launch, which fills the chip
+                splitk = (_TWINS_SPLITK and T == torch.bfloat16 and wsr[1] is not None and B * Lk <= 512 and B * Lk >= 64 and
+                          B * Lk % 8 == 0 and wsr[0].shape[1] >= 4096)
+                if splitk:
+                    patches, patches_t = ops.twins_subsample_fwd(ln1, B, m.height, m.width, C, r, transposed=True)
+                    red32, _ = ops.wgrad(patches_t, wsr[1], want_bias=False)
+                    red = ops.bias_cast(red32, sr_b.detach(), T)
+                else:
+                    patches = ops.twins_subsample_fwd(ln1, B, m.height, m.width, C, r)
             else:
                 wsr = conv_as_rows(wcast(sr_w, T)[0])
                 patches = ops.patchify_fwd(ln1, B, m.height, m.width, C, r, m.skip)
+                splitk = False
             Lk = (m.height // r) * (m.width // r)
-            red = ops.gemm(patches, wsr[0], 0, bias=sr_b.detach())
+            if not splitk:
+                red = ops.gemm(patches, wsr[0], 0, bias=sr_b.detach())
             if srn_w is not None:
                 kvin, means, rstds = ops.layernorm_fwd(red, srn_w.detach(), srn_b.detach(), m.eps)
             else:                                                     # Twins-SVT: the sub-sampled tokens go straight to kv

@@ -579,13 +579,26 @@ def dwconv3_wgrad(x, dy):
     return dw
 
 
-def twins_subsample_fwd(x, B, H, W, C, r):
+def twins_subsample_fwd(x, B, H, W, C, r, transposed=False):
     """Patch matrix [B*(H/r)*(W/r), C*r*r] (columns (c', py, px): the Conv2d weight's own layout) of
     twins.MultiHeadedAttention's reduction conv on x [B, H, W, C] (any view of B*H*W*C contiguous elements), with the
-    reference's reshape kept as written (twins.py:69-70; include/vtx.h)."""
+    reference's reshape kept as written (twins.py:69-70; include/vtx.h).  ``transposed``: also the [C*r*r, rows] copy."""
     _dev(x)
     out = torch.empty((B * (H // r) * (W // r), C * r * r), dtype=x.dtype, device=x.device)
-    check(_lib.load().vtx_twins_subsample_fwd(_p(x), _p(out), B, H, W, C, r, _dt(x), _stream()), "vtx_twins_subsample_fwd")
+    out_t = torch.empty((C * r * r, B * (H // r) * (W // r)), dtype=x.dtype, device=x.device) if transposed else None
+    check(_lib.load().vtx_twins_subsample_fwd(_p(x), _p(out), _p(out_t), B, H, W, C, r, _dt(x), _stream()),
+          "vtx_twins_subsample_fwd")
+    return (out, out_t) if transposed else out
+
+
+def bias_cast(x, bias, dtype):
+    """(x [rows, C] fp32 + bias [C] fp32) as ``dtype`` -- the epilogue behind a split-K launch used as a forward GEMM."""
+    _dev(x, bias)
+    _f32(x, "bias_cast input"); _f32(bias, "bias")
+    C = x.shape[-1]
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    code = BF16 if dtype == torch.bfloat16 else F32
+    check(_lib.load().vtx_bias_cast(_p(x), _p(bias), _p(out), x.numel() // C, C, code, _stream()), "vtx_bias_cast")
     return out
 
 
