@@ -385,7 +385,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--selftest-launch", action="store_true", help="launcher plumbing only (gloo on CPU, no model)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the short ViT-S/16 / PVT-Small / DINO runs that follow the headline at --gpus 1 (`secondary`)")
+                    help="skip the short ViT-S/16 / PVT-Small / DINO / Twins-SVT-S runs that follow the headline at --gpus 1 (`secondary`)")
     ap.add_argument("--secondary-steps", type=int, default=10)
     args = ap.parse_args()
 
@@ -416,11 +416,15 @@ def main():
         # the other BASELINE.json configurations (cfg-2 / 4 / 5) in the same process, after the headline's timed region:
         # ~10 steps each, one event-sampled step; headline keys and timing untouched
         secondary = []
-        for name in ("vit_s16", "pvt_small", "dino"):
+        for name in ("vit_s16", "pvt_small", "dino", "twins_svt_s"):
             import gc
             gc.collect()
             torch.cuda.empty_cache()               # the previous workload's model / activations: start from an empty allocator
-            r = run_workload(name, default_batch(name), args.secondary_steps, 3, args, dev, rank, world)
+            try:
+                r = run_workload(name, default_batch(name), args.secondary_steps, 3, args, dev, rank, world)
+            except Exception as exc:               # a secondary workload never takes the headline line down with it
+                secondary.append({"model": name, "error": f"{type(exc).__name__}: {exc}"[:300]})
+                continue
             rf = r["roofline"] or {}
             secondary.append({"workload": r["workload"], "model": name, "value": round(r["value"], 2), "unit": "images/sec",
                               "ms_per_step": round(r["ms_per_step"], 3), "steps": args.secondary_steps, "warmup": 3,

@@ -42,7 +42,8 @@ def test_positional_encoding_generator_kernels(dtype, B, H, W, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C,r", [(2, 28, 28, 128, 7), (1, 56, 56, 64, 7), (3, 7, 7, 512, 7), (2, 8, 12, 24, 4), (2, 14, 14, 256, 7)])
+@pytest.mark.parametrize("B,H,W,C,r", [(2, 28, 28, 128, 7), (1, 56, 56, 64, 7), (3, 7, 7, 512, 7), (2, 8, 12, 24, 4), (2, 14, 14, 256, 7),
+                                       (1, 56, 56, 512, 7)])         # (the last one: beyond the reciprocal-division range)
 def test_subsample_gather_is_the_reference_reshape(dtype, B, H, W, C, r):
     """The operand gather of the reduction conv vs the reference's ``input.transpose(1, 2).reshape(B, C, H, W)`` followed by
     the unfold of a stride = kernel convolution (twins.py:69-71): a permutation, so exact; backward = inverse (+ add)."""

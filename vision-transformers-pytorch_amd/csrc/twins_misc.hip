@@ -149,32 +149,58 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* 
 // patch gradient back (optionally adding).  One thread per element in PATCH order (coalesced there; on the X side runs of r
 // consecutive f = r consecutive channels, 2-byte accesses that L2 merges; a thread per run of r was 1.5-6x slower: 14-byte
 // strides on both sides); grid.y = image, 32-bit arithmetic inside it.
-template <typename T, bool BWD, bool ACC>
-__global__ void twins_subsample_kernel(const T* __restrict__ src, T* __restrict__ dst, T* __restrict__ dst_t, int H, int W, int C,
-                                       int r) {
-  const int per_img = H * W * C;
+// divisors of the index map with their reciprocals: n / d == __umulhi(n, ceil(2^32 / d)) while n * d < 2^32 (checked on the
+// host; the plain-division instantiation serves anything larger) -- the six runtime divisions were the kernel's whole time
+struct SubGeom { int H, W, C, r, K, rr, Wr, HC; unsigned mK, mrr, mr, mWr, mHC, mC; };
+template <bool FAST> __device__ __forceinline__ int sub_div(int n, int d, unsigned magic) {
+  return FAST ? (int)__umulhi((unsigned)n, magic) : n / d;
+}
+template <typename T, bool BWD, bool ACC, bool FAST>
+__global__ void twins_subsample_kernel(const T* __restrict__ src, T* __restrict__ dst, T* __restrict__ dst_t, SubGeom g) {
+  const int per_img = g.H * g.W * g.C;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;                      // element of this image's patch block
   if (e >= per_img) return;
-  const int rr = r * r, K = rr * C, Wr = W / r;
-  const int t = e / K, col = e - t * K;
-  const int cp = col / rr, pp = col - cp * rr, py = pp / r, px = pp - py * r;
-  const int i = t / Wr, j = t - i * Wr;
-  const int f = cp * H * W + (i * r + py) * W + (j * r + px);
-  const int HC = H * C;
-  const int w = f / HC, rem = f - w * HC;
-  const int h = rem / C, c = rem - h * C;
+  const int t = sub_div<FAST>(e, g.K, g.mK), col = e - t * g.K;
+  const int cp = sub_div<FAST>(col, g.rr, g.mrr), pp = col - cp * g.rr;
+  const int py = sub_div<FAST>(pp, g.r, g.mr), px = pp - py * g.r;
+  const int i = sub_div<FAST>(t, g.Wr, g.mWr), j = t - i * g.Wr;
+  const int f = cp * g.H * g.W + (i * g.r + py) * g.W + (j * g.r + px);
+  const int w = sub_div<FAST>(f, g.HC, g.mHC), rem = f - w * g.HC;
+  const int h = sub_div<FAST>(rem, g.C, g.mC), c = rem - h * g.C;
   const int64_t base = (int64_t)blockIdx.y * per_img;
-  const int64_t xi = base + (h * W + w) * C + c, pi = base + e;
+  const int64_t xi = base + (h * g.W + w) * g.C + c, pi = base + e;
   if (!BWD) {
     const T v = src[xi];
     dst[pi] = v;
     // second copy, transposed [K][B Lk]: the operand of the split-K launch that serves the long-K / few-row reduction convs
-    if (dst_t != nullptr) dst_t[(int64_t)col * ((int64_t)gridDim.y * (per_img / K)) + (int64_t)blockIdx.y * (per_img / K) + t] = v;
+    if (dst_t != nullptr) {
+      const int Lk = per_img / g.K;
+      dst_t[(int64_t)col * ((int64_t)gridDim.y * Lk) + (int64_t)blockIdx.y * Lk + t] = v;
+    }
   } else if (ACC) {
     dst[xi] = from_f32<T>(to_f32<T>(dst[xi]) + to_f32<T>(src[pi]));
   } else {
     dst[xi] = src[pi];
   }
+}
+
+static unsigned sub_magic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+// -> geometry + whether the reciprocal form is exact for every dividend the kernel forms (all < H W C)
+static bool sub_geom(SubGeom& g, int H, int W, int C, int r) {
+  g.H = H; g.W = W; g.C = C; g.r = r; g.rr = r * r; g.K = g.rr * C; g.Wr = W / r; g.HC = H * C;
+  g.mK = sub_magic(g.K); g.mrr = sub_magic(g.rr); g.mr = sub_magic(r); g.mWr = sub_magic(g.Wr); g.mHC = sub_magic(g.HC);
+  g.mC = sub_magic(C);
+  const uint64_t n = (uint64_t)H * W * C;
+  const uint64_t dmax = (uint64_t)(g.K > g.HC ? g.K : g.HC);
+  return n * dmax < (1ull << 32);
+}
+template <typename T, bool BWD, bool ACC>
+static void sub_launch(const void* src, void* dst, void* dst_t, int B, int H, int W, int C, int r, hipStream_t st) {
+  SubGeom g;
+  const bool fast = sub_geom(g, H, W, C, r);
+  dim3 grid((H * W * C + 255) / 256, B);
+  if (fast) hipLaunchKernelGGL((twins_subsample_kernel<T, BWD, ACC, true>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, (T*)dst_t, g);
+  else hipLaunchKernelGGL((twins_subsample_kernel<T, BWD, ACC, false>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, (T*)dst_t, g);
 }
 
 // out[row][c] = T(x[row][c] + bias[c]): the epilogue of the split-K path of the reduction conv (fp32 partial sums -> compute dtype)
@@ -266,10 +292,9 @@ int vtx_twins_subsample_fwd(const void* x, void* out, void* out_t, int B, int H,
   if (!x || !out) return VTX_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0 || H % r || W % r) return VTX_ERR_SHAPE;
   if ((int64_t)H * W * C >= (1ll << 31) || B > 65535) return VTX_ERR_SHAPE;
-  dim3 grid((H * W * C + 255) / 256, B);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VTX_BF16) hipLaunchKernelGGL((twins_subsample_kernel<bf16, false, false>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)out, (bf16*)out_t, H, W, C, r);
-  else if (dtype == VTX_F32) hipLaunchKernelGGL((twins_subsample_kernel<float, false, false>), grid, dim3(256), 0, st, (const float*)x, (float*)out, (float*)out_t, H, W, C, r);
+  if (dtype == VTX_BF16) sub_launch<bf16, false, false>(x, out, out_t, B, H, W, C, r, st);
+  else if (dtype == VTX_F32) sub_launch<float, false, false>(x, out, out_t, B, H, W, C, r, st);
   else return VTX_ERR_DTYPE;
   return vtx_check_launch();
 }
@@ -279,14 +304,13 @@ int vtx_twins_subsample_bwd(const void* dout, void* dx, int B, int H, int W, int
   if (!dout || !dx) return VTX_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0 || H % r || W % r) return VTX_ERR_SHAPE;
   if ((int64_t)H * W * C >= (1ll << 31) || B > 65535) return VTX_ERR_SHAPE;
-  dim3 grid((H * W * C + 255) / 256, B);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VTX_BF16) {
-    if (accumulate) hipLaunchKernelGGL((twins_subsample_kernel<bf16, true, true>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, (bf16*)nullptr, H, W, C, r);
-    else hipLaunchKernelGGL((twins_subsample_kernel<bf16, true, false>), grid, dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, (bf16*)nullptr, H, W, C, r);
+    if (accumulate) sub_launch<bf16, true, true>(dout, dx, nullptr, B, H, W, C, r, st);
+    else sub_launch<bf16, true, false>(dout, dx, nullptr, B, H, W, C, r, st);
   } else if (dtype == VTX_F32) {
-    if (accumulate) hipLaunchKernelGGL((twins_subsample_kernel<float, true, true>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, (float*)nullptr, H, W, C, r);
-    else hipLaunchKernelGGL((twins_subsample_kernel<float, true, false>), grid, dim3(256), 0, st, (const float*)dout, (float*)dx, (float*)nullptr, H, W, C, r);
+    if (accumulate) sub_launch<float, true, true>(dout, dx, nullptr, B, H, W, C, r, st);
+    else sub_launch<float, true, false>(dout, dx, nullptr, B, H, W, C, r, st);
   } else return VTX_ERR_DTYPE;
   return vtx_check_launch();
 }
