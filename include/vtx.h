@@ -260,6 +260,47 @@ typedef struct VtxLayerBwd {
 } VtxLayerBwd;
 int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream);
 int vtx_layer_desc_bytes(int which);
+/* The same for the layers built around the spatial-reduction (sub-sampled) attention: one PVT block (reference
+ * models/pvt.py:31-68, 99-103) or the global half of a Twins-SVT layer (models/twins.py:56-93, 201-202):
+ *   x1 = x + s1 * proj(sr_attn(q(LN1 x), kv(reduce(LN1 x))))      y = x1 + s2 * fc2(silu(fc1(LN2 x1)))
+ * reduce (r > 1) = operand gather (vtx_patchify_fwd, or vtx_twins_subsample_fwd when twins != 0) + GEMM + bias [+ LayerNorm
+ * when srn_w != NULL]; splitk != 0: the reduction conv runs as vtx_wgrad on the transposed operand copy + vtx_bias_cast.
+ * r == 1: keys / values come from LN1's output directly (Lk = L).  linear_q / linear_kv have no bias.  The caller owns every
+ * buffer; the backward's weight gradients run as two grouped launches (the M-token problems with the LayerNorm column
+ * reductions; the B*Lk-token problems of the reduction branch) on `side_stream` when given, like vtx_layer_bwd. */
+typedef struct VtxSrLayerFwd {
+  int dtype, twins;
+  int64_t M;                                   /* B * L tokens */
+  int C, ff, nH, L, B, rows_per_scale, H, W, r, skip, Lk, splitk;
+  float eps;
+  const void* x;
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *srn_w, *srn_b;
+  const void *wq, *wkv, *wsr, *wsr_t, *wo, *w1, *w2;
+  const float *bsr, *bo, *b1, *b2;
+  const float *s1, *s2;
+  void *ln1, *q, *patches, *patches_t, *red32, *red, *kvin, *kv, *o, *x1, *ln2, *z, *h, *y;
+  float *mean1, *rstd1, *mean2, *rstd2, *means, *rstds, *lse;
+  void* splitk_ws;
+  size_t splitk_ws_bytes;
+} VtxSrLayerFwd;
+int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream);
+typedef struct VtxSrLayerBwd {
+  int dtype, twins;
+  int64_t M;
+  int C, ff, nH, L, B, rows_per_scale, H, W, r, skip, Lk, reserved;
+  float scale_const;
+  const void *dy, *x, *ln1, *q, *patches, *red, *kvin, *kv, *o, *x1, *ln2, *z, *h;
+  const float *mean1, *rstd1, *mean2, *rstd2, *means, *rstds, *lse;
+  const float *ln1_w, *ln2_w, *srn_w;
+  const void *wq, *wkv, *wsr, *wo, *w1, *w2, *wqt, *wkvt, *wsrt, *wot, *w1t, *w2t;
+  const float *s1, *s2;
+  void *dz, *dln2, *dx1, *dout, *dq, *dkv, *dkvin, *dred, *dpatches, *dln1, *dx;
+  void *ln1_ws, *ln2_ws, *lns_ws, *attn_ws, *wgrad_ws, *wgrad2_ws;
+  size_t ln_ws_bytes, lns_ws_bytes, attn_ws_bytes, wgrad_ws_bytes, wgrad2_ws_bytes;
+  float *dWq, *dWkv, *dWsr, *dbsr, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2, *dgs, *dbs;
+} VtxSrLayerBwd;
+int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream);
+/* sizeof the descriptors: 0 / 1 VtxLayerFwd / Bwd, 2 / 3 VtxSrLayerFwd / Bwd */
 /* Per-launch HIP-event timing of what vtx_layer_* enqueues (bench.py's roofline block describes the kernels of the timed
  * path): between vtx_timer_start() and vtx_timer_stop() every launch of a layer call is bracketed by two events on its
  * stream; _stop synchronises and returns up to `cap` records.  tag: VTX_T_*; rows = rows / tokens the launch computes;

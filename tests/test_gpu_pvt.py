@@ -204,3 +204,48 @@ def test_pvt_attention_standalone_forward_returns_out_and_score(reduction, heigh
     check(f"pvt attn standalone score r{reduction}", score, sref, 2e-5)
     with pytest.raises(NotImplementedError):
         attn(xg, height, width, prev=score)
+
+
+@pytest.mark.parametrize("family", ["pvt_small", "twins_svt_s"])
+def test_sr_layers_through_one_c_call_are_bitwise_the_call_by_call_path(monkeypatch, family):
+    """vtx_srlayer_fwd / bwd (one C call per PVT block / Twins global half) enqueue the launches of the call-by-call path in its
+    order with its arguments: logits and every gradient of a bf16 step with DropPath agree BIT FOR BIT, with and without the
+    side stream; and the one-call path really is the one taken."""
+    from vtx import functional as VF
+    if family == "pvt_small":
+        model = _pvt(0.1)
+    else:
+        from models.twins import TwinsSVT
+        model = TwinsSVT(**M.TWINS_SVT_S, drop_path=0.1)
+    model.to(dev()).train()
+    B = 16 if family == "pvt_small" else 64          # (64: the Twins late stages take their split-K path, 64 * 1 rows)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(21)).to(dev())
+    calls = []
+    real = VF.PvtLayerFn._forward_one_call
+
+    def spy(ctx, *a):
+        y = real(ctx, *a)
+        calls.append(y is not None)
+        return y
+
+    monkeypatch.setattr(VF.PvtLayerFn, "_forward_one_call", staticmethod(spy))
+    res = {}
+    for one_call in (True, False):
+        for side in (True, False):
+            monkeypatch.setattr(VF, "_LAYER_CALL", one_call)
+            torch.manual_seed(5)
+            model.zero_grad(set_to_none=True)
+            with VF.deferred_wgrad(side):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    out = model(x)
+                out.float().square().mean().backward()
+                VF.side_join()
+            res[(one_call, side)] = (out.clone(), [p.grad.clone() for p in model.parameters()])
+    n_layers = sum(M.PVT_SMALL["depths"]) if family == "pvt_small" else sum(M.TWINS_SVT_S["depths"])
+    assert calls == [True] * (2 * n_layers), f"one-call path not taken on every layer: {calls}"
+    ref = res[(False, False)]
+    assert torch.isfinite(ref[0].float()).all()
+    for key, (out, grads) in res.items():
+        assert torch.equal(out, ref[0]), f"logits differ {key}"
+        for (n, _), a, b in zip(model.named_parameters(), grads, ref[1]):
+            assert torch.equal(a, b), f"gradient of {n} differs {key}"

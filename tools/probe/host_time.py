@@ -7,7 +7,9 @@ import bench
 from vtx.optim import FusedAdamW
 from vtx.train_step import MixLoss, make_param_groups, train_step
 dev = torch.device("cuda")
-for name, B, dp in (("swin_s", 128, 0.3), ("vit_s16", 256, 0.1), ("pvt_small", 128, 0.1)):
+CASES = (("swin_s", 128, 0.3), ("vit_s16", 256, 0.1), ("pvt_small", 128, 0.1), ("twins_svt_s", 128, 0.1))
+ONLY = [m for m in os.environ.get("VTX_HOST_MODELS", "").split(",") if m]           # e.g. VTX_HOST_MODELS=pvt_small,twins_svt_s
+for name, B, dp in [c for c in CASES if not ONLY or c[0] in ONLY]:
     model = bench.build_model(name, dp).to(dev).train()
     opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3)
     x = torch.randn(B, 3, 224, 224, device=dev); l1 = torch.randint(0, 1000, (B,), device=dev)

@@ -52,6 +52,6 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 14; }
+int vtx_abi_version(void) { return 15; }
 
 }  // extern "C"

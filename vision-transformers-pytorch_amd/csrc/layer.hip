@@ -82,7 +82,15 @@ int layer_gemm_mapped(const void* A, const void* W, void* Cc, int M, int Mk, int
 extern "C" {
 
 /* sizeof the descriptors (0: VtxLayerFwd, 1: VtxLayerBwd): the bindings check their mirror structures against it */
-int vtx_layer_desc_bytes(int which) { return which == 0 ? (int)sizeof(VtxLayerFwd) : (which == 1 ? (int)sizeof(VtxLayerBwd) : 0); }
+int vtx_layer_desc_bytes(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(VtxLayerFwd);
+    case 1: return (int)sizeof(VtxLayerBwd);
+    case 2: return (int)sizeof(VtxSrLayerFwd);
+    case 3: return (int)sizeof(VtxSrLayerBwd);
+    default: return 0;
+  }
+}
 
 int vtx_timer_start(void) {
   if (g_timer == nullptr) g_timer = new std::vector<TimerEntry>();
@@ -269,6 +277,153 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
                vtx_wgrad_group_mapped(dt, 4, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, mapped ? perms : nullptr, kept, scl, rps,
                                       a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes, ncol, cpart, cout0, cout1, cnb, cC, cld,
                                       a->accumulate, ws));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One PVT block / the global half of a Twins-SVT layer per call (vtx.h VtxSrLayerFwd / Bwd): exactly the launches of
+// vtx.functional.PvtLayerFn's call-by-call path, in its order, with its arguments.
+int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream) {
+  if (!a || !a->x || !a->y || !a->ln1 || !a->q || !a->kv || !a->o || !a->x1 || !a->ln2 || !a->h) return VTX_ERR_NULL;
+  if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0 || a->B <= 0 || a->L <= 0 || a->Lk <= 0 || a->r < 1)
+    return VTX_ERR_SHAPE;
+  const int dt = a->dtype, M = (int)a->M, C = a->C, ff = a->ff, r = a->r;
+  g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
+  int rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream));
+  if (rc) return rc;
+  rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, vtx_gemm(0, dt, a->ln1, a->wq, a->q, M, C, C, C, C, C, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
+  if (rc) return rc;
+  const void* kvin = a->ln1;
+  const int rows = a->B * a->Lk;
+  if (r > 1) {
+    if (!a->patches || !a->red || !a->wsr) return VTX_ERR_NULL;
+    const int K = r * r * C;
+    if (a->twins) rc = vtx_twins_subsample_fwd(a->ln1, a->patches, a->splitk ? a->patches_t : nullptr, a->B, a->H, a->W, C, r, dt, stream);
+    else rc = vtx_patchify_fwd(a->ln1, a->patches, a->B, a->H, a->W, C, r, a->skip, dt, stream);
+    if (rc) return rc;
+    if (a->splitk) {
+      if (!a->twins || !a->patches_t || !a->wsr_t || !a->red32 || !a->splitk_ws) return VTX_ERR_NULL;
+      rc = TCALL(VTX_T_WGRAD, K, rows, C, 0, stream,
+                 vtx_wgrad(dt, a->patches_t, a->wsr_t, (float*)a->red32, nullptr, K, rows, C, rows, C, nullptr, 1, 0.f, a->splitk_ws,
+                           a->splitk_ws_bytes, stream));
+      if (rc) return rc;
+      rc = vtx_bias_cast((const float*)a->red32, a->bsr, a->red, rows, C, dt, stream);
+    } else {
+      rc = TCALL(VTX_T_GEMM, rows, C, K, 0, stream, vtx_gemm(0, dt, a->patches, a->wsr, a->red, rows, C, K, K, K, C, a->bsr, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
+    }
+    if (rc) return rc;
+    kvin = a->red;
+    if (a->srn_w != nullptr) {
+      if (!a->kvin || !a->means || !a->rstds) return VTX_ERR_NULL;
+      rc = TCALL(VTX_T_LN_FWD, rows, C, 0, 0, stream, vtx_layernorm_fwd(a->red, a->srn_w, a->srn_b, a->kvin, a->means, a->rstds, rows, C, a->eps, dt, 0, 0, 0, stream));
+      if (rc) return rc;
+      kvin = a->kvin;
+    }
+  }
+  rc = TCALL(VTX_T_GEMM, rows, 2 * C, C, 0, stream, vtx_gemm(0, dt, kvin, a->wkv, a->kv, rows, 2 * C, C, C, C, 2 * C, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
+  if (rc) return rc;
+  rc = vtx_srattn_fwd(a->q, a->kv, a->o, a->lse, a->B, a->L, a->Lk, a->nH, C / a->nH, dt, stream);
+  if (rc) return rc;
+  rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream));
+  if (rc) return rc;
+  rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream));
+  if (rc) return rc;
+  rc = TCALL(VTX_T_GEMM, M, ff, C, a->z ? F_AUXOUT : 0, stream, vtx_gemm(0, dt, a->ln2, a->w1, a->h, M, ff, C, C, C, ff, a->b1, nullptr, nullptr, 1, a->z, nullptr, 1, stream));
+  if (rc) return rc;
+  return TCALL(VTX_T_GEMM, M, C, ff, F_RESID, stream,
+               vtx_gemm(0, dt, a->h, a->w2, a->y, M, C, ff, ff, ff, C, a->b2, a->x1, a->s2, a->rows_per_scale, nullptr, nullptr, 0, stream));
+}
+
+int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
+  if (!a || !a->dy || !a->dx || !a->x || !a->z || !a->dz || !a->dln2 || !a->dx1 || !a->dout || !a->dq || !a->dkv || !a->dkvin || !a->dln1)
+    return VTX_ERR_NULL;
+  if (a->M <= 0 || a->M > 0x7fffffff || a->C <= 0 || a->ff <= 0 || a->nH <= 0 || a->r < 1) return VTX_ERR_SHAPE;
+  const int dt = a->dtype, C = a->C, ff = a->ff, rps = a->rows_per_scale, r = a->r;
+  const int64_t M = a->M;
+  const int rows = a->B * a->Lk;
+  g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
+  // ---- MLP branch
+  int rc = TCALL(VTX_T_GEMM, M, ff, C, F_AUXIN, stream, layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream));
+  if (rc) return rc;
+  rc = TCALL(VTX_T_GEMM, M, C, ff, 0, stream, layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream));
+  if (rc) return rc;
+  rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+             vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes, M, C, dt, 0, 0, 0, stream));
+  if (rc) return rc;
+  // ---- attention branch
+  rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream));
+  if (rc) return rc;
+  rc = vtx_srattn_bwd(a->q, a->kv, a->o, a->dout, a->lse, a->dq, a->dkv, a->attn_ws, a->attn_ws_bytes, a->B, a->L, a->Lk, a->nH, C / a->nH, dt, stream);
+  if (rc) return rc;
+  const bool srn = r > 1 && a->srn_w != nullptr;
+  rc = TCALL(VTX_T_GEMM, rows, C, 2 * C, 0, stream, layer_dgrad(dt, a->dkv, a->wkv, a->wkvt, a->dkvin, rows, C, 2 * C, nullptr, nullptr, 1, nullptr, 0, stream));
+  if (rc) return rc;
+  if (r > 1) {
+    if (!a->dpatches || !a->patches || !a->red) return VTX_ERR_NULL;
+    const int K = r * r * C;
+    const void* dred = a->dkvin;
+    if (srn) {
+      if (!a->dred || !a->lns_ws) return VTX_ERR_NULL;
+      rc = TCALL(VTX_T_LN_BWD, rows, C, 0, 0, stream,
+                 vtx_layernorm_bwd(a->dkvin, a->red, a->means, a->rstds, a->srn_w, nullptr, a->dred, nullptr, nullptr, a->lns_ws, a->lns_ws_bytes, rows, C, dt, 0, 0, 0, stream));
+      if (rc) return rc;
+      dred = a->dred;
+    }
+    rc = TCALL(VTX_T_GEMM, rows, K, C, 0, stream, layer_dgrad(dt, dred, a->wsr, a->wsrt, a->dpatches, rows, K, C, nullptr, nullptr, 1, nullptr, 0, stream));
+    if (rc) return rc;
+    rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dq, a->wq, a->wqt, a->dln1, M, C, C, nullptr, nullptr, 1, nullptr, 0, stream));
+    if (rc) return rc;
+    if (a->twins) rc = vtx_twins_subsample_bwd(a->dpatches, a->dln1, a->B, a->H, a->W, C, r, 1, dt, stream);
+    else rc = vtx_patchify_bwd(a->dpatches, a->dln1, a->B, a->H, a->W, C, r, a->skip, 1, dt, stream);
+    if (rc) return rc;
+  } else {
+    rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, layer_dgrad(dt, a->dq, a->wq, a->wqt, a->dln1, M, C, C, a->dkvin, nullptr, 1, nullptr, 0, stream));
+    if (rc) return rc;
+  }
+  rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+             vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes, M, C, dt, 0, 0, 0, stream));
+  if (rc) return rc;
+  // ---- weight gradients: on the side stream when given (fork after everything enqueued on `stream` so far)
+  void* ws = stream;
+  if (side_stream != nullptr && side_stream != stream) {
+    hipEvent_t e = g_events.get();
+    if (!e || hipEventRecord(e, (hipStream_t)stream) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)side_stream, e, 0) != hipSuccess)
+      return VTX_ERR_LAUNCH;
+    ws = side_stream;
+  }
+  if (r > 1) {                                   // the reduction branch's two problems over its B * Lk tokens
+    const void* dred = srn ? a->dred : a->dkvin;
+    const int K = r * r * C;
+    const void* dys[2] = {a->dkv, dred};
+    const void* xs[2] = {a->kvin, a->patches};
+    float* dWs[2] = {a->dWkv, a->dWsr};
+    float* dbs[2] = {nullptr, a->dbsr};
+    const int Ns[2] = {2 * C, C}, Ks[2] = {C, K};
+    const int64_t ldy[2] = {2 * C, C}, ldx[2] = {C, K};
+    const float* rs[2] = {nullptr, nullptr};
+    rc = TCALL(VTX_T_WGRAD, rows, C, K, 0, ws,
+               vtx_wgrad_group(dt, 2, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, 1, 0.f, rows, a->wgrad2_ws, a->wgrad2_ws_bytes, 0, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, ws));
+    if (rc) return rc;
+  }
+  const int n = r > 1 ? 4 : 5;
+  const void* dys[5] = {a->dy, a->dz, a->dx1, a->dq, a->dkv};
+  const void* xs[5] = {a->h, a->ln2, a->o, a->ln1, a->ln1};
+  float* dWs[5] = {a->dW2, a->dW1, a->dWo, a->dWq, a->dWkv};
+  float* dbs[5] = {a->db2, a->db1, a->dbo, nullptr, nullptr};
+  const int Ns[5] = {C, ff, C, C, 2 * C}, Ks[5] = {ff, C, C, C, C};
+  const int64_t ldy[5] = {C, ff, C, C, 2 * C}, ldx[5] = {ff, C, C, C, C};
+  const float* rs[5] = {a->s2, nullptr, a->s1, nullptr, nullptr};
+  const int ncol = srn ? 3 : 2;
+  const float* cpart[3] = {(const float*)a->ln2_ws, (const float*)a->ln1_ws, (const float*)a->lns_ws};
+  float* cout0[3] = {a->dg2, a->dg1, a->dgs};
+  float* cout1[3] = {a->dbe2, a->dbe1, a->dbs};
+  const int cnb[3] = {vtx_layernorm_bwd_blocks(M, C), vtx_layernorm_bwd_blocks(M, C), srn ? vtx_layernorm_bwd_blocks(rows, C) : 0};
+  const int cC[3] = {C, C, C};
+  const int cld[3] = {2 * C, 2 * C, 2 * C};
+  return TCALL(VTX_T_WGRAD, M, C, ff, 0, ws,
+               vtx_wgrad_group(dt, n, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, rps, a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes, ncol,
+                               cpart, cout0, cout1, cnb, cC, cld, 0, ws));
 }
 
 }  // extern "C"

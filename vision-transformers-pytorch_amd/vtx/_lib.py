@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class VtxError(RuntimeError):
@@ -44,6 +44,32 @@ class LayerBwd(ctypes.Structure):
                                    "perm1", "perm2")] + [("Bk1", _I), ("Bk2", _I)])
 
 
+class SrLayerFwd(ctypes.Structure):
+    """include/vtx.h VtxSrLayerFwd."""
+    _fields_ = ([("dtype", _I), ("twins", _I), ("M", _L)] +
+                [(n, _I) for n in ("C", "ff", "nH", "L", "B", "rows_per_scale", "H", "W", "r", "skip", "Lk", "splitk")] +
+                [("eps", _F)] +
+                [(n, _P) for n in ("x", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "srn_w", "srn_b", "wq", "wkv", "wsr", "wsr_t", "wo",
+                                   "w1", "w2", "bsr", "bo", "b1", "b2", "s1", "s2", "ln1", "q", "patches", "patches_t", "red32",
+                                   "red", "kvin", "kv", "o", "x1", "ln2", "z", "h", "y", "mean1", "rstd1", "mean2", "rstd2",
+                                   "means", "rstds", "lse", "splitk_ws")] + [("splitk_ws_bytes", _Z)])
+
+
+class SrLayerBwd(ctypes.Structure):
+    """include/vtx.h VtxSrLayerBwd."""
+    _fields_ = ([("dtype", _I), ("twins", _I), ("M", _L)] +
+                [(n, _I) for n in ("C", "ff", "nH", "L", "B", "rows_per_scale", "H", "W", "r", "skip", "Lk", "reserved")] +
+                [("scale_const", _F)] +
+                [(n, _P) for n in ("dy", "x", "ln1", "q", "patches", "red", "kvin", "kv", "o", "x1", "ln2", "z", "h", "mean1",
+                                   "rstd1", "mean2", "rstd2", "means", "rstds", "lse", "ln1_w", "ln2_w", "srn_w", "wq", "wkv",
+                                   "wsr", "wo", "w1", "w2", "wqt", "wkvt", "wsrt", "wot", "w1t", "w2t", "s1", "s2", "dz", "dln2",
+                                   "dx1", "dout", "dq", "dkv", "dkvin", "dred", "dpatches", "dln1", "dx", "ln1_ws", "ln2_ws",
+                                   "lns_ws", "attn_ws", "wgrad_ws", "wgrad2_ws")] +
+                [(n, _Z) for n in ("ln_ws_bytes", "lns_ws_bytes", "attn_ws_bytes", "wgrad_ws_bytes", "wgrad2_ws_bytes")] +
+                [(n, _P) for n in ("dWq", "dWkv", "dWsr", "dbsr", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2",
+                                   "dbe2", "dgs", "dbs")])
+
+
 ATTN_WINDOW, ATTN_GLOBAL = 1, 2
 
 
@@ -56,6 +82,8 @@ _SIGNATURES = {
     "vtx_layer_fwd": (c_int, [c_void_p, c_void_p]),
     "vtx_layer_bwd": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vtx_layer_desc_bytes": (c_int, [c_int]),
+    "vtx_srlayer_fwd": (c_int, [c_void_p, c_void_p]),
+    "vtx_srlayer_bwd": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vtx_timer_start": (c_int, []),
     "vtx_timer_stop": (c_int, [c_void_p, c_int]),
     "vtx_layernorm_fwd_mapped": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
@@ -174,6 +202,8 @@ def load():
         raise VtxError(f"libvtx.so ABI {lib.vtx_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     if lib.vtx_layer_desc_bytes(0) != ctypes.sizeof(LayerFwd) or lib.vtx_layer_desc_bytes(1) != ctypes.sizeof(LayerBwd):
         raise VtxError("libvtx.so layer descriptors do not match the bindings (VtxLayerFwd / VtxLayerBwd): rebuild")
+    if lib.vtx_layer_desc_bytes(2) != ctypes.sizeof(SrLayerFwd) or lib.vtx_layer_desc_bytes(3) != ctypes.sizeof(SrLayerBwd):
+        raise VtxError("libvtx.so layer descriptors do not match the bindings (VtxSrLayerFwd / VtxSrLayerBwd): rebuild")
     _lib = lib
     return lib
 

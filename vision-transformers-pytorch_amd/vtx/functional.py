@@ -1041,6 +1041,80 @@ class SrAttentionFn(Function):
         return dq, dkv, None, None, None, None
 
 
+class _SrLayerPlan:
+    """Shape-dependent part of the two descriptors of one PVT block / Twins global half (vtx_srlayer_fwd / bwd): buffer
+    layouts, workspace sizes, prefilled structures -- the counterpart of _LayerPlan for csrc/layer.hip's second pair."""
+
+    def __init__(self, m, B, L, C, ff, Lk, want_z, has_rs, rps, dp_c, has_srn, splitk):
+        lib = _lib.load()
+        es = 2
+        M, r = B * L, m.reduction
+        rows, K = B * Lk, r * r * C
+        nH = m.n_head
+        off = [0]
+
+        def carve(nbytes):
+            o = off[0]
+            off[0] = (o + nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+            return o
+        f = self.f_off = {k: carve(n * es) for k, n in (("ln1", M * C), ("q", M * C), ("kv", rows * 2 * C), ("o", M * C),
+                                                        ("x1", M * C), ("ln2", M * C), ("h", M * ff))}
+        f["z"] = carve(M * ff * es) if want_z else None
+        f["patches"] = carve(rows * K * es) if r > 1 else None
+        f["red"] = carve(rows * C * es) if r > 1 else None
+        f["kvin"] = carve(rows * C * es) if r > 1 and has_srn else None
+        f["patches_t"] = carve(rows * K * es) if splitk else None
+        f["red32"] = carve(rows * C * 4) if splitk else None
+        self.splitk_wsb = lib.vtx_wgrad_workspace(K, rows, C) if splitk else 0
+        f["splitk_ws"] = carve(self.splitk_wsb) if splitk else None
+        for k, n in (("mean1", M), ("rstd1", M), ("mean2", M), ("rstd2", M), ("lse", B * nH * L)):
+            f[k] = carve(4 * n)
+        f["means"] = carve(4 * rows) if r > 1 and has_srn else None
+        f["rstds"] = carve(4 * rows) if r > 1 and has_srn else None
+        self.f_bytes = off[0]
+        off[0] = 0
+        self.ln_wsb = lib.vtx_layernorm_bwd_workspace(M, C)
+        self.lns_wsb = lib.vtx_layernorm_bwd_workspace(rows, C) if r > 1 and has_srn else 0
+        self.attn_wsb = lib.vtx_srattn_bwd_workspace(B, L, Lk, nH, C // nH)
+        na = 4 if r > 1 else 5
+        Na, Ka = (ctypes.c_int * na)(*([C, ff, C, C] + ([2 * C] if r == 1 else []))), (ctypes.c_int * na)(*([ff, C, C, C] + ([C] if r == 1 else [])))
+        self.wgrad_wsb = lib.vtx_wgrad_group_workspace(na, Na, Ka, M)
+        ok = bool(lib.vtx_wgrad_group_ok(ops.BF16, na, Na, Ka, M, int(has_rs), int(rps), float(dp_c))) and na <= lib.vtx_wgrad_group_max()
+        self.wgrad2_wsb = 0
+        if r > 1:
+            Nb, Kb = (ctypes.c_int * 2)(2 * C, C), (ctypes.c_int * 2)(C, K)
+            self.wgrad2_wsb = lib.vtx_wgrad_group_workspace(2, Nb, Kb, rows)
+            ok = ok and bool(lib.vtx_wgrad_group_ok(ops.BF16, 2, Nb, Kb, rows, 0, 1, 0.0))
+        # both grouped weight-gradient launches of the backward must apply (bf16, LDS-DMA shapes); else: call-by-call path
+        self.ok = ok
+        b = self.b_off = {k: carve(n * es) for k, n in (("dz", M * ff), ("dln2", M * C), ("dx1", M * C), ("dout", M * C),
+                                                        ("dq", M * C), ("dkv", rows * 2 * C), ("dkvin", rows * C), ("dln1", M * C))}
+        b["dred"] = carve(rows * C * es) if r > 1 and has_srn else None
+        b["dpatches"] = carve(rows * K * es) if r > 1 else None
+        for k, n in (("ln1_ws", self.ln_wsb), ("ln2_ws", self.ln_wsb), ("lns_ws", self.lns_wsb), ("attn_ws", self.attn_wsb),
+                     ("wgrad_ws", self.wgrad_wsb), ("wgrad2_ws", self.wgrad2_wsb)):
+            b[k] = carve(n) if n else None
+        self.b_bytes = off[0]
+        common = dict(dtype=ops.BF16, twins=int(bool(m.twins)), M=M, C=C, ff=ff, nH=nH, L=L, B=B, H=m.height, W=m.width, r=r,
+                      skip=m.skip, Lk=Lk)
+        self.fwd = _lib.SrLayerFwd(eps=float(m.eps), splitk=int(bool(splitk)), splitk_ws_bytes=self.splitk_wsb, **common)
+        self.bwd = _lib.SrLayerBwd(ln_ws_bytes=self.ln_wsb, lns_ws_bytes=self.lns_wsb, attn_ws_bytes=self.attn_wsb,
+                                   wgrad_ws_bytes=self.wgrad_wsb, wgrad2_ws_bytes=self.wgrad2_wsb, **common)
+        self.K, self.rows = K, rows
+
+
+_sr_layer_plans = {}
+
+
+def _sr_layer_plan(m, B, L, C, ff, Lk, want_z, has_rs, rps, dp_c, has_srn, splitk):
+    key = (m.n_head, m.height, m.width, m.reduction, m.skip, m.eps, bool(m.twins), B, L, C, ff, Lk, want_z, has_rs, rps, dp_c,
+           has_srn, splitk)
+    pl = _sr_layer_plans.get(key)
+    if pl is None:
+        pl = _sr_layer_plans[key] = _SrLayerPlan(m, B, L, C, ff, Lk, want_z, has_rs, rps, dp_c, has_srn, splitk)
+    return pl
+
+
 class PvtLayerFn(Function):
     """One PVT block (reference models/pvt.py:31-68, 99-103):
          x1 = x  + s1 * proj(sr_attn(q(LN1 x), kv(reduce(LN1 x))))      y = x1 + s2 * fc2(silu(fc1(LN2 x1)))
@@ -1059,6 +1133,12 @@ class PvtLayerFn(Function):
         m = meta
         rps = L
         r = m.reduction
+        ctx.one_call = False
+        if _LAYER_CALL and _DEFER_REDUCE and x.is_cuda and T == torch.bfloat16 and C % m.n_head == 0 and C // m.n_head in (32, 64):
+            y = PvtLayerFn._forward_one_call(ctx, x, ln1_w, ln1_b, q_w, kv_w, sr_w, sr_b, srn_w, srn_b, proj_w, proj_b, ln2_w,
+                                             ln2_b, fc1_w, fc1_b, fc2_w, fc2_b, s1, s2, dp_c, m)
+            if y is not None:
+                return y
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, ln1_w.detach(), ln1_b.detach(), m.eps)
         wq, wkv, wo, w1, w2 = wcast(q_w, T), wcast(kv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T)
         q = ops.gemm(ln1, wq[0], 0)
@@ -1105,8 +1185,143 @@ class PvtLayerFn(Function):
         ctx.meta, ctx.rps, ctx.dp_c, ctx.Lk, ctx.sr_shape = m, rps, float(dp_c), Lk, (None if sr_w is None else sr_w.shape)
         return y.view(B, L, C)
 
+    # ---- the same block through ONE C call each way (csrc/layer.hip vtx_srlayer_fwd / bwd): the launches of the code
+    #      below in its order with its arguments (bit-identical), one ctypes call and one activation buffer per layer instead of
+    #      ~25 calls and ~40 tensor allocations: PVT-Small's host path was 14-15 ms per step against 13 ms of GPU time
+    @staticmethod
+    def _forward_one_call(ctx, x, ln1_w, ln1_b, q_w, kv_w, sr_w, sr_b, srn_w, srn_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b,
+                          fc2_w, fc2_b, s1, s2, dp_c, m):
+        T = x.dtype
+        B, L, C = x.shape
+        r, ff = m.reduction, fc1_w.shape[0]
+        Lk = (m.height // r) * (m.width // r) if r > 1 else L
+        has_srn = srn_w is not None
+        wq, wkv, wo, w1, w2 = wcast(q_w, T), wcast(kv_w, T), wcast(proj_w, T), wcast(fc1_w, T), wcast(fc2_w, T)
+        wsr = None
+        splitk = False
+        if r > 1:
+            if m.twins:
+                wsr_p = wcast(sr_w, T)
+                wsr = (wsr_p[0].view(sr_w.shape[0], -1), wsr_p[1])
+                splitk = (_TWINS_SPLITK and wsr[1] is not None and 64 <= B * Lk <= 512 and B * Lk % 8 == 0 and
+                          wsr[0].shape[1] >= 4096)
+            else:
+                wsr = conv_as_rows(wcast(sr_w, T)[0])
+        want_z = any(ctx.needs_input_grad)
+        pl = _sr_layer_plan(m, B, L, C, ff, Lk, want_z, s1 is not None or s2 is not None, L, float(dp_c), has_srn, splitk)
+        if not pl.ok:
+            return None
+        _check_layer_inputs(x, T, ln1_w, ln1_b, ln2_w, ln2_b, proj_b, fc1_b, fc2_b, sr_b, srn_w, srn_b)
+        buf = torch.empty(pl.f_bytes, dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        base, fo = buf.data_ptr(), pl.f_off
+        at = lambda k: None if fo[k] is None else base + fo[k]
+        d = _copy_desc(pl.fwd)
+        d.rows_per_scale = L
+        d.x, d.y = x.data_ptr(), y.data_ptr()
+        d.ln1_w, d.ln1_b, d.ln2_w, d.ln2_b = ln1_w.data_ptr(), ln1_b.data_ptr(), ln2_w.data_ptr(), ln2_b.data_ptr()
+        d.srn_w, d.srn_b = _dp(srn_w), _dp(srn_b)
+        d.wq, d.wkv, d.wo, d.w1, d.w2 = wq[0].data_ptr(), wkv[0].data_ptr(), wo[0].data_ptr(), w1[0].data_ptr(), w2[0].data_ptr()
+        if r > 1:
+            d.wsr, d.wsr_t, d.bsr = wsr[0].data_ptr(), _dp(wsr[1]) if splitk else None, sr_b.data_ptr()
+        d.bo, d.b1, d.b2 = proj_b.data_ptr(), fc1_b.data_ptr(), fc2_b.data_ptr()
+        d.s1, d.s2 = _dp(s1), _dp(s2)
+        for k in ("ln1", "q", "patches", "patches_t", "red32", "red", "kvin", "kv", "o", "x1", "ln2", "z", "h", "mean1", "rstd1",
+                  "mean2", "rstd2", "means", "rstds", "lse", "splitk_ws"):
+            setattr(d, k, at(k))
+        _lib.check(_lib.load().vtx_srlayer_fwd(ctypes.byref(d), ops._stream()), "vtx_srlayer_fwd")
+        ctx.save_for_backward(x, buf, ln1_w, ln2_w, srn_w, s1, s2)
+        ctx.wp = (wq, wkv, wo, w1, w2, wsr)
+        ctx.plan, ctx.one_call = pl, True
+        ctx.meta, ctx.rps, ctx.dp_c, ctx.Lk, ctx.sr_shape = m, L, float(dp_c), Lk, (None if sr_w is None else sr_w.shape)
+        ctx.shapes = (q_w.shape, kv_w.shape, proj_w.shape, fc1_w.shape, fc2_w.shape)
+        return y.view(B, L, C)
+
+    @staticmethod
+    def _backward_one_call(ctx, dy):
+        x, buf, ln1_w, ln2_w, srn_w, s1, s2 = ctx.saved_tensors
+        pl, m = ctx.plan, ctx.meta
+        if pl.f_off["z"] is None:
+            raise VtxError("vtx: this layer's forward ran without a graph (no pre-activation was kept)")
+        wq, wkv, wo, w1, w2, wsr = ctx.wp
+        dy = _c(dy)
+        dev = x.device
+        B, L, C = x.shape
+        r = m.reduction
+        T = x.dtype
+        has_srn = srn_w is not None
+        # transposed weight operands exactly where vtx.functional.dgrad would use them (LDS-DMA shapes); made now when the weight
+        # plan has none (the PVT reduction conv's permuted rows)
+        def tr(wp):
+            w2d = wp[0].view(wp[0].shape[0], -1)
+            if not ops.glds_ok(w2d.shape[1], w2d.shape[0]):
+                return None
+            return wp[1] if wp[1] is not None else w2d.t().contiguous()
+        wqt, wkvt, wot, w1t, w2t = tr(wq), tr(wkv), tr(wo), tr(w1), tr(w2)
+        wsrt = tr(wsr) if r > 1 else None
+        scratch = torch.empty(pl.b_bytes, dtype=torch.uint8, device=dev)
+        dx = torch.empty_like(x)
+        f32 = dict(dtype=torch.float32, device=dev)
+        qs, kvs, os_, f1s, f2s = ctx.shapes
+        dWq, dWkv, dWo, dW1, dW2 = (torch.empty(sh, **f32) for sh in (qs, kvs, os_, f1s, f2s))
+        ff = f1s[0]
+        small = torch.empty(6 * C + ff + (3 * C if r > 1 else 0), **f32).split((C, C, C, C, C, C, ff) + ((C, C, C) if r > 1 else ()))
+        dg1, dbe1, dbo, dg2, dbe2, db2, db1 = small[:7]
+        dbsr, dgs, dbs = (small[7], small[8], small[9]) if r > 1 else (None, None, None)
+        dWsr = torch.empty((C, pl.K), **f32) if r > 1 else None
+        base, fo, sb, bo = buf.data_ptr(), pl.f_off, scratch.data_ptr(), pl.b_off
+        fa = lambda k: None if fo[k] is None else base + fo[k]
+        ba = lambda k: None if bo[k] is None else sb + bo[k]
+        d = _copy_desc(pl.bwd)
+        d.rows_per_scale, d.scale_const = ctx.rps, ctx.dp_c
+        d.dy, d.x, d.dx = dy.data_ptr(), x.data_ptr(), dx.data_ptr()
+        for k in ("ln1", "q", "patches", "red", "kv", "o", "x1", "ln2", "z", "h", "mean1", "rstd1", "mean2", "rstd2", "means",
+                  "rstds", "lse"):
+            setattr(d, k, fa(k))
+        d.kvin = fa("kvin") if (r > 1 and has_srn) else (fa("red") if r > 1 else fa("ln1"))
+        d.ln1_w, d.ln2_w, d.srn_w = ln1_w.data_ptr(), ln2_w.data_ptr(), _dp(srn_w)
+        d.wq, d.wkv, d.wo, d.w1, d.w2 = wq[0].data_ptr(), wkv[0].data_ptr(), wo[0].data_ptr(), w1[0].data_ptr(), w2[0].data_ptr()
+        d.wqt, d.wkvt, d.wot, d.w1t, d.w2t = _dp(wqt), _dp(wkvt), _dp(wot), _dp(w1t), _dp(w2t)
+        if r > 1:
+            d.wsr, d.wsrt = wsr[0].data_ptr(), _dp(wsrt)
+        d.s1, d.s2 = _dp(s1), _dp(s2)
+        for k in ("dz", "dln2", "dx1", "dout", "dq", "dkv", "dkvin", "dred", "dpatches", "dln1", "ln1_ws", "ln2_ws", "lns_ws",
+                  "attn_ws", "wgrad_ws", "wgrad2_ws"):
+            setattr(d, k, ba(k))
+        d.dWq, d.dWkv, d.dWo, d.dbo, d.dW1, d.db1, d.dW2, d.db2 = (dWq.data_ptr(), dWkv.data_ptr(), dWo.data_ptr(), dbo.data_ptr(),
+                                                                   dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr())
+        d.dg1, d.dbe1, d.dg2, d.dbe2 = dg1.data_ptr(), dbe1.data_ptr(), dg2.data_ptr(), dbe2.data_ptr()
+        if r > 1:
+            d.dWsr, d.dbsr = dWsr.data_ptr(), dbsr.data_ptr()
+            if has_srn:
+                d.dgs, d.dbs = dgs.data_ptr(), dbs.data_ptr()
+        side = st = None
+        if _deferred and not ops.timing():
+            st = _side_states.get(dev)
+            if st is None:
+                st = _side_states[dev] = _SideState(dev)
+            side = st.stream.cuda_stream
+            st.keep.append((scratch, buf, dy, x, s1, s2, ctx.wp, (wqt, wkvt, wot, w1t, w2t, wsrt)))
+            st.pending = True
+        _lib.check(_lib.load().vtx_srlayer_bwd(ctypes.byref(d), ops._stream(), side), "vtx_srlayer_bwd")
+        dWsr_out = None
+        if r > 1:
+            co, _, pp, _ = ctx.sr_shape
+            if m.twins:
+                dWsr_out = dWsr.view(co, C, pp, pp)                            # already the parameter's layout
+            elif st is not None:                                               # (py, px, c) columns back to (c, py, px): after the
+                with torch.cuda.stream(st.stream):                             # weight-gradient launch, on its stream
+                    dWsr_out = dWsr.view(co, pp, pp, C).permute(0, 3, 1, 2).contiguous()
+                st.keep.append((dWsr,))
+            else:
+                dWsr_out = dWsr.view(co, pp, pp, C).permute(0, 3, 1, 2).contiguous()
+        return (dx.view(B, L, C), dg1, dbe1, dWq, dWkv, dWsr_out, dbsr, dgs if has_srn else None, dbs if has_srn else None, dWo,
+                dbo, dg2, dbe2, dW1, db1, dW2, db2, None, None, None, None)
+
     @staticmethod
     def backward(ctx, dy):
+        if ctx.one_call:
+            return PvtLayerFn._backward_one_call(ctx, dy)
         (x, ln1_w, ln2_w, srn_w, mean1, rstd1, ln1, q, kv, o, lse, x1, mean2, rstd2, ln2, z, h, patches, red, means,
          rstds, kvin, s1, s2) = ctx.saved_tensors
         wq, wkv, wo, w1, w2, wsr = ctx.wp
