@@ -212,6 +212,8 @@ def test_sr_layers_through_one_c_call_are_bitwise_the_call_by_call_path(monkeypa
     order with its arguments: logits and every gradient of a bf16 step with DropPath agree BIT FOR BIT, with and without the
     side stream; and the one-call path really is the one taken."""
     from vtx import functional as VF
+    if not (VF._LAYER_CALL and VF._DEFER_REDUCE):
+        pytest.skip("the one-call layers are switched off in this process (VTX_LAYER_CALL=0 / VTX_DEFER_REDUCE=0)")
     if family == "pvt_small":
         model = _pvt(0.1)
     else:

@@ -208,8 +208,10 @@ def test_late_stage_reduction_conv_on_the_split_k_launch(monkeypatch, H, C, n_he
     cot = torch.randn(128, H, H, C, generator=torch.Generator().manual_seed(13)).to(dev())
     res = {}
     taken = []
-    real = VF._sr_layer_plan            # (the layer runs through ONE C call: the plan carries the split-K decision)
+    real = VF._sr_layer_plan            # (the layer runs through ONE C call: the plan carries the split-K decision ...
     monkeypatch.setattr(VF, "_sr_layer_plan", lambda *a: (taken.append(bool(a[-1])), real(*a))[1])
+    real_g = ops.twins_subsample_fwd    #  ... or call by call under VTX_LAYER_CALL=0 / VTX_DEFER_REDUCE=0: the gather shows it)
+    monkeypatch.setattr(ops, "twins_subsample_fwd", lambda *a, transposed=False: (taken.append(transposed), real_g(*a, transposed=transposed))[1])
     for on in (True, False):
         monkeypatch.setattr(VF, "_TWINS_SPLITK", on)
         layer.zero_grad(set_to_none=True)
