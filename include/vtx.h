@@ -307,7 +307,13 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream);
  * GEMM: C[rows, n] over k; attention: n heads, k tokens per problem; flags: 1 residual, 2 z written, 4 z read, 8 row-mapped
  * (compacted branch), 16 shifted-window mask. */
 enum { VTX_T_LN_FWD = 1, VTX_T_GEMM = 2, VTX_T_WATTN_FWD = 3, VTX_T_ATTN_FWD = 4, VTX_T_LN_BWD = 5, VTX_T_WATTN_BWD = 6,
-       VTX_T_ATTN_BWD = 7, VTX_T_WGRAD = 8 };
+       VTX_T_ATTN_BWD = 7, VTX_T_WGRAD = 8,
+       /* vtx_srlayer_*: sub-sampled attention (rows = B*Lq queries, n heads, k keys); its layer's grouped weight gradients over
+        * rows tokens: _SR_A = fc2, fc1, proj, q [, kv when flags & 1] with n = C, k = ff; _SR_B = kv + reduction conv with n = C,
+        * k = r*r*C; _SPLITK = ONE problem dW[n, k] over rows tokens (the reduction conv's forward on the split-K launch);
+        * _GATHER = operand gather / scatter of rows x n elements */
+       VTX_T_SRATTN_FWD = 9, VTX_T_SRATTN_BWD = 10, VTX_T_WGRAD_SR_A = 11, VTX_T_WGRAD_SR_B = 12, VTX_T_WGRAD_SPLITK = 13,
+       VTX_T_GATHER = 14 };
 typedef struct VtxTimerRec { int tag, n, k, flags; int64_t rows; float ms; } VtxTimerRec;
 int vtx_timer_start(void);
 int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */

@@ -51,7 +51,7 @@ struct TimerScope {
   }
 };
 #define TCALL(tag, rows, n, k, flags, st, expr) ([&]() -> int { TimerScope ts_(tag, rows, n, k, flags, st); return (expr); }())
-enum { F_RESID = 1, F_AUXOUT = 2, F_AUXIN = 4, F_MAPPED = 8, F_MASKED = 16, F_BF16 = 32 };   // | head dim << 8 (attention)
+enum { F_RESID = 1, F_AUXOUT = 2, F_AUXIN = 4, F_MAPPED = 8, F_MASKED = 16, F_BF16 = 32, F_TWINS = 64 };   // | head dim << 8 (attention)
 
 // dx = epi(dy @ W): the LDS-DMA kernel on the transposed weight copy where it applies (K = out-features, N =
 // in-features), else the register-staged NN kernel on W itself -- the rule of vtx.functional.dgrad
@@ -297,12 +297,12 @@ int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream) {
   if (r > 1) {
     if (!a->patches || !a->red || !a->wsr) return VTX_ERR_NULL;
     const int K = r * r * C;
-    if (a->twins) rc = vtx_twins_subsample_fwd(a->ln1, a->patches, a->splitk ? a->patches_t : nullptr, a->B, a->H, a->W, C, r, dt, stream);
-    else rc = vtx_patchify_fwd(a->ln1, a->patches, a->B, a->H, a->W, C, r, a->skip, dt, stream);
+    if (a->twins) rc = TCALL(VTX_T_GATHER, rows, K, 0, F_TWINS, stream, vtx_twins_subsample_fwd(a->ln1, a->patches, a->splitk ? a->patches_t : nullptr, a->B, a->H, a->W, C, r, dt, stream));
+    else rc = TCALL(VTX_T_GATHER, rows, K, 0, 0, stream, vtx_patchify_fwd(a->ln1, a->patches, a->B, a->H, a->W, C, r, a->skip, dt, stream));
     if (rc) return rc;
     if (a->splitk) {
       if (!a->twins || !a->patches_t || !a->wsr_t || !a->red32 || !a->splitk_ws) return VTX_ERR_NULL;
-      rc = TCALL(VTX_T_WGRAD, K, rows, C, 0, stream,
+      rc = TCALL(VTX_T_WGRAD_SPLITK, K, rows, C, 0, stream,
                  vtx_wgrad(dt, a->patches_t, a->wsr_t, (float*)a->red32, nullptr, K, rows, C, rows, C, nullptr, 1, 0.f, a->splitk_ws,
                            a->splitk_ws_bytes, stream));
       if (rc) return rc;
@@ -321,7 +321,7 @@ int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream) {
   }
   rc = TCALL(VTX_T_GEMM, rows, 2 * C, C, 0, stream, vtx_gemm(0, dt, kvin, a->wkv, a->kv, rows, 2 * C, C, C, C, 2 * C, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
   if (rc) return rc;
-  rc = vtx_srattn_fwd(a->q, a->kv, a->o, a->lse, a->B, a->L, a->Lk, a->nH, C / a->nH, dt, stream);
+  rc = TCALL(VTX_T_SRATTN_FWD, M, a->nH, a->Lk, 0, stream, vtx_srattn_fwd(a->q, a->kv, a->o, a->lse, a->B, a->L, a->Lk, a->nH, C / a->nH, dt, stream));
   if (rc) return rc;
   rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream));
   if (rc) return rc;
@@ -352,7 +352,8 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
   // ---- attention branch
   rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream));
   if (rc) return rc;
-  rc = vtx_srattn_bwd(a->q, a->kv, a->o, a->dout, a->lse, a->dq, a->dkv, a->attn_ws, a->attn_ws_bytes, a->B, a->L, a->Lk, a->nH, C / a->nH, dt, stream);
+  rc = TCALL(VTX_T_SRATTN_BWD, M, a->nH, a->Lk, 0, stream,
+             vtx_srattn_bwd(a->q, a->kv, a->o, a->dout, a->lse, a->dq, a->dkv, a->attn_ws, a->attn_ws_bytes, a->B, a->L, a->Lk, a->nH, C / a->nH, dt, stream));
   if (rc) return rc;
   const bool srn = r > 1 && a->srn_w != nullptr;
   rc = TCALL(VTX_T_GEMM, rows, C, 2 * C, 0, stream, layer_dgrad(dt, a->dkv, a->wkv, a->wkvt, a->dkvin, rows, C, 2 * C, nullptr, nullptr, 1, nullptr, 0, stream));
@@ -372,8 +373,8 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
     if (rc) return rc;
     rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dq, a->wq, a->wqt, a->dln1, M, C, C, nullptr, nullptr, 1, nullptr, 0, stream));
     if (rc) return rc;
-    if (a->twins) rc = vtx_twins_subsample_bwd(a->dpatches, a->dln1, a->B, a->H, a->W, C, r, 1, dt, stream);
-    else rc = vtx_patchify_bwd(a->dpatches, a->dln1, a->B, a->H, a->W, C, r, a->skip, 1, dt, stream);
+    if (a->twins) rc = TCALL(VTX_T_GATHER, rows, K, 0, F_TWINS | 1, stream, vtx_twins_subsample_bwd(a->dpatches, a->dln1, a->B, a->H, a->W, C, r, 1, dt, stream));
+    else rc = TCALL(VTX_T_GATHER, rows, K, 0, 1, stream, vtx_patchify_bwd(a->dpatches, a->dln1, a->B, a->H, a->W, C, r, a->skip, 1, dt, stream));
     if (rc) return rc;
   } else {
     rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, layer_dgrad(dt, a->dq, a->wq, a->wqt, a->dln1, M, C, C, a->dkvin, nullptr, 1, nullptr, 0, stream));
@@ -401,7 +402,7 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
     const int Ns[2] = {2 * C, C}, Ks[2] = {C, K};
     const int64_t ldy[2] = {2 * C, C}, ldx[2] = {C, K};
     const float* rs[2] = {nullptr, nullptr};
-    rc = TCALL(VTX_T_WGRAD, rows, C, K, 0, ws,
+    rc = TCALL(VTX_T_WGRAD_SR_B, rows, C, K, 0, ws,
                vtx_wgrad_group(dt, 2, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, 1, 0.f, rows, a->wgrad2_ws, a->wgrad2_ws_bytes, 0, nullptr,
                                nullptr, nullptr, nullptr, nullptr, nullptr, 0, ws));
     if (rc) return rc;
@@ -421,7 +422,7 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
   const int cnb[3] = {vtx_layernorm_bwd_blocks(M, C), vtx_layernorm_bwd_blocks(M, C), srn ? vtx_layernorm_bwd_blocks(rows, C) : 0};
   const int cC[3] = {C, C, C};
   const int cld[3] = {2 * C, 2 * C, 2 * C};
-  return TCALL(VTX_T_WGRAD, M, C, ff, 0, ws,
+  return TCALL(VTX_T_WGRAD_SR_A, M, C, ff, r > 1 ? 0 : 1, ws,
                vtx_wgrad_group(dt, n, dys, xs, dWs, dbs, Ns, Ks, ldy, ldx, rs, rps, a->scale_const, M, a->wgrad_ws, a->wgrad_ws_bytes, ncol,
                                cpart, cout0, cout1, cnb, cC, cld, 0, ws));
 }

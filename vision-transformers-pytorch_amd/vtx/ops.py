@@ -275,6 +275,25 @@ def _describe_timer_rec(r):
         name = f"wgrad_glds_kernel<64, 2, 8, {mapped}> (+split-K and column reduce)"
         return (name, sum(2.0 * rows * a * b for a, b in pairs),
                 sum(2.0 * rows * (a + b) + 4.0 * a * b for a, b in pairs), r.ms)
+    if r.tag in (9, 10):                                                # sub-sampled attention: rows queries, n heads of D, k keys
+        bwd = r.tag == 10
+        return (f"srattn_{'bwd' if bwd else 'fwd'}_kernel<{tn}, {D}>", (10.0 if bwd else 4.0) * rows * n * k * D,
+                (4.0 if bwd else 2.0) * rows * n * D * es, r.ms)
+    if r.tag in (11, 12, 13):                                           # weight gradients of the PVT / Twins blocks
+        if r.tag == 11:
+            C, ff = n, k
+            pairs = ((C, ff), (ff, C), (C, C), (C, C)) + (((2 * C, C),) if fl & 1 else ())
+            name = "wgrad_glds_kernel<64, 2, 8, false> (+split-K and column reduce)"
+        elif r.tag == 12:
+            pairs = ((2 * n, n), (n, k))
+            name = "wgrad_glds_kernel<64, 2, 8, false> (+split-K reduce)"
+        else:
+            pairs = ((n, k),)
+            name = wgrad_kernel_name(dt, n, k, True) + " (+split-K reduce)"
+        return (name, sum(2.0 * rows * a * b for a, b in pairs), sum(es * rows * (a + b) + 4.0 * a * b for a, b in pairs), r.ms)
+    if r.tag == 14:                                                     # operand gather / scatter: rows x n elements in and out
+        kern = "patchify_kernel" if not fl & 64 else "twins_subsample_kernel"
+        return kern, 0.0, (3.0 if fl & 1 else 2.0) * rows * n * es, r.ms
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
 
 
