@@ -231,3 +231,42 @@ def test_late_stage_reduction_conv_on_the_split_k_launch(monkeypatch, H, C, n_he
             assert res[True][2][n].norm().item() < 1e-3 * scale and res[False][2][n].norm().item() < 1e-3 * scale
             continue
         check(f"twins split-K reduction conv: grad {n} vs the GEMM path", res[True][2][n], res[False][2][n], 1e-2)
+
+
+@pytest.mark.parametrize("cfg,size", [
+    (dict(n_class=10, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32, n_heads=(1, 2, 4, 8), dim_ffs=(64, 128, 256, 512),
+          window_size=4), 128),                        # window 4 on 32 / 16 / 8 / 4 maps: 64 / 16 / 4 / 1 sub-sampled keys
+    (dict(n_class=10, depths=(1, 1, 1, 1), dims=(64, 64, 128, 256), dim_head=64, n_heads=(1, 1, 2, 4), dim_ffs=(128, 128, 256, 512),
+          window_size=7), 224),                        # head dim 64: the locally-grouped half takes the generic attention kernels
+    (dict(n_class=10, depths=(1, 1, 1, 1), dims=(64, 128, 256, 512), dim_head=32, n_heads=(2, 4, 8, 16), dim_ffs=(64, 128, 256, 512),
+          window_size=7), (224, 448)),                 # a 56 x 112 map is 8 x 16 = 128 sub-sampled keys: refused, not mis-computed
+])
+def test_twins_other_geometries_fp32_vs_oracle(cfg, size):
+    """Other windows / head dims / widths than Twins-SVT-S through the same modules (fp32 parity mode vs the CPU oracle: logits and
+    every parameter gradient); what the kernels cannot hold raises instead of falling back."""
+    from models.twins import TwinsSVT
+    from test_gpu_models import _seeded_init
+    model = TwinsSVT(**cfg, drop_path=0.0)
+    sd = _seeded_init(model, 6)
+    model.to(dev()).train()
+    hw = (size, size) if isinstance(size, int) else size
+    x = torch.randn(2, 3, *hw, generator=torch.Generator().manual_seed(16))
+    if hw != (size, size):
+        with pytest.raises(NotImplementedError, match="at most 64"):
+            model(x.to(dev()))
+        return
+    out = model(x.to(dev()))
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = M.twins_forward(P, x, cfg)
+    check(f"twins {cfg['window_size']}/{cfg['dim_head']} fp32 logits vs oracle", out, ref, 1e-4)
+    cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(17))
+    (out * cot.to(dev())).sum().backward()
+    names = [n for n, _ in model.named_parameters()]
+    rg = torch.autograd.grad((ref * cot).sum(), [P[n] for n in names])
+    got = dict(model.named_parameters())
+    scale = max(r.norm().item() for r in rg)
+    for n, r in zip(names, rg):
+        if r.norm().item() < 1e-6 * scale:             # (a single sub-sampled key: linear_q's gradient is exactly 0)
+            assert got[n].grad.norm().item() < 1e-5 * scale, n
+            continue
+        check(f"twins {cfg['window_size']}/{cfg['dim_head']} fp32 grad {n}", got[n].grad, r, 2e-3)
