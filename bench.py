@@ -310,7 +310,7 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item(), "non-finite loss"
@@ -357,6 +357,12 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
                         launches_per_step=round(d["launches"] / nsampled, 1), event_sampled_steps=nsampled,
                         avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                         end_to_end_frac=round(value / world * TRAIN_GFLOP_PER_IMG[model_name] / 1e3 / peak, 4),
+                        # the same with the FLOPs of the rows actually LAUNCHED (the timer tags of the sampled steps):
+                        # stochastic-depth compaction skips the dropped samples' rows, so the nominal figure above counts
+                        # work that is never issued -- this one is the MFMA utilisation of the work done
+                        executed_flop_frac=round(sum(v["flops"] for v in allk.values()) / nsampled
+                                                 / (dt / steps) / 1e12 / peak, 4),
+                        executed_gflop_per_step=round(sum(v["flops"] for v in allk.values()) / nsampled / 1e9, 1),
                         # every launch class of the step (HIP events on the launch stream, sampled steps are
                         # single-stream): coverage = sum of the table / GPU time of the sampled steps
                         sampled_step_ms=round(sampled_ms, 3),
@@ -387,6 +393,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short ViT-S/16 / PVT-Small / DINO / Twins-SVT-S runs that follow the headline at --gpus 1 (`secondary`)")
     ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 run: nccl (= RCCL, the product path) | gloo (TEST ONLY: lets the "
+                         "world > 1 branch of this file run where RCCL cannot, e.g. two ranks on one GPU with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:(LOCAL_RANK mod device count) -- two ranks on the one GPU of a test box")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -398,16 +409,24 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     if args.selftest_launch:
         return selftest_launch(rank, world)
+    if args.share_gpu:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     batch = args.batch or default_batch(args.model)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.model, args.cpu_batch, args.cpu_steps)
+        if args.model == "swin_s":
+            # SURVEY.md section 8(d) / BASELINE.json cfg-1: ViT-S/16 forward + backward on 32 x 3 x 224 x 224 on the host cores too (~10 s)
+            cpu["also"] = [dict(cpu_baseline("vit_s16", args.cpu_batch, args.cpu_steps), model="vit_s16")]
 
     from vtx import functional as VF
     res = run_workload(args.model, batch, args.steps, args.warmup, args, dev, rank, world)
@@ -429,7 +448,8 @@ def main():
             secondary.append({"workload": r["workload"], "model": name, "value": round(r["value"], 2), "unit": "images/sec",
                               "ms_per_step": round(r["ms_per_step"], 3), "steps": args.secondary_steps, "warmup": 3,
                               "roofline": {k: rf.get(k) for k in ("kernel", "bound", "frac", "frac_hbm", "frac_mfma",
-                                                                  "avg_launch_us", "launches_per_step", "end_to_end_frac")}})
+                                                                  "avg_launch_us", "launches_per_step", "end_to_end_frac",
+                                                                  "executed_flop_frac")}})
     if rank == 0:
         line = {
             "metric": "images/sec training (fwd+bwd+step)", "value": round(res["value"], 2), "unit": "images/sec",
@@ -439,7 +459,8 @@ def main():
             "config": {"workload": res["workload"],
                        "global_batch": batch * world, "parallelism": f"dp{world}"},
             "world_size_observed": dist.get_world_size() if world > 1 else 1,
-            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 else None,
+            "backend": (args.backend if world > 1 else None),
+            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and args.backend == "nccl" else None,
             "side_stream_wgrad": bool(VF._SIDE_ENABLED),
             "roofline": res["roofline"], "cpu_baseline": cpu, "secondary": secondary,
         }

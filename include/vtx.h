@@ -11,8 +11,12 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator), including
  *     workspaces whose size comes from the matching vtx_*_workspace(); no ownership transfer
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise; re-entrant across
- *     streams / threads (autograd's backward thread).  The only process-global mutable state is the table of
- *     dispatch switches behind vtx_set_option (atomic ints, read once per call)
+ *     streams / threads (autograd's backward thread).  Process-global mutable state, all of it DIAGNOSTIC: (1) the table
+ *     of dispatch switches behind vtx_set_option (atomic ints, read once per call: a switch flipped while another thread
+ *     is inside an entry point takes effect at that thread's next call); (2) the launch timer of vtx_timer_start /
+ *     vtx_timer_stop (csrc/layer.hip: one unsynchronised record list -- while a timer is open, vtx_layer_* / vtx_srlayer_*
+ *     calls append to it from whichever thread enqueues them, so open it only around single-threaded, single-stream
+ *     sections: bench.py's event-sampled steps; with no timer open the layer calls touch no shared state)
  *   - dtype: VTX_F32 (parity mode, exact-fp32 MFMA) or VTX_BF16 (training mode: bf16 storage,
  *     fp32 accumulation / statistics); parameters, their gradients and all statistics are fp32
  *   - activations are row-major [rows, C] (tokens x channels) = NHWC / (B, L, C)

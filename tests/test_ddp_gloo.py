@@ -85,6 +85,52 @@ def _worker(rank, world, port, q):
         ddp.finish()
         for p, e in zip(model.parameters(), exp):
             assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+
+        # bucket-level hooks (VERDICT r3 #7a): after the first counted backward ONE hook per bucket is left -- on the parameter
+        # whose gradient arrived last
+        multi = [b for b in ddp.buckets if len(b.params) > 1]
+        assert multi and all(len(b.handles) == 1 and b.trigger is not None for b in multi)
+        # ... and if the order ever changes (here: the trigger is forced onto the FIRST-arriving parameter, so that it fires
+        # while the bucket's other gradients are still missing) the bucket is reduced late, by finish(), never wrongly;
+        # it counts per parameter again and re-learns the order in that same backward
+        b = multi[0]
+        ddp._count_hooks(b)
+        b.learned = b.params[0]
+        ddp._adopt_trigger(b)
+        assert b.trigger is b.params[0]
+        model.zero_grad(set_to_none=True)
+        local_grads(model, 0)
+        assert b.work is None and b.trigger is None            # fired early, found gradients missing, stood down
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+        assert len(b.handles) == len(b.params)
+        model.zero_grad(set_to_none=True)
+        local_grads(model, 0)
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+        assert len(b.handles) == 1 and b.trigger is not b.params[0]
+
+        # reset(): a step abandoned between backward() and finish() leaves the object usable
+        model.zero_grad(set_to_none=True)
+        local_grads(model, 1)                                   # reduced buckets, handed-out state ... and no finish()
+        ddp.reset()
+        model.zero_grad(set_to_none=True)
+        local_grads(model, 0)
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+        # per-parameter counting in every backward stays available
+        ddp.remove()
+        ddp2 = GradAllReduce(model, bucket_bytes=6000, first_bucket_bytes=1000, bucket_hooks=False)
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            local_grads(model, 0)
+            ddp2.finish()
+        assert all(len(bb.handles) == len(bb.params) for bb in ddp2.buckets)
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -295,6 +341,29 @@ def _accum_worker(rank, world, port, q, mode):
                 assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6), f"{mode} rep {rep}: {n} wrong " \
                     f"(max err {(p.grad - e).abs().max():.3e} vs max |g| {e.abs().max():.3e})"
             model.zero_grad(set_to_none=True)
+
+        # epoch tail (train.py:285 second clause): a loader of 3 micro-batches with windows of 2 steps at i = 1 AND at i = 2;
+        # the tail window holds one micro-batch (still divided by grad_accum, train.py:281) and the epoch ends on clean gradients
+        loader_len = 3
+        assert [accumulation_boundary(accum, i, loader_len) for i in range(loader_len)] == [False, True, True]
+        assert [accumulation_boundary(accum, i) for i in range(loader_len)] == [False, True, False]
+        stepped = []
+        for i in range(loader_len):
+            k = (rank * accum + i) % (world * accum)
+            loss = ((model(xs[k]) - ys[k]) ** 2).mean() / accum
+            boundary = accumulation_boundary(accum, i, loader_len)
+            backward_ddp(loss, ddp, boundary, mode, fresh=(i % accum == 0))
+            if boundary:
+                ddp.finish()
+                stepped.append(i)
+                if i == loader_len - 1:
+                    ref2 = _SharedNet()
+                    sum(((ref2(xs[(r * accum + i) % (world * accum)]) - ys[(r * accum + i) % (world * accum)]) ** 2).mean() / accum
+                        for r in range(world)).div(world).backward()
+                    for (n, p), e in zip(model.named_parameters(), [q_.grad for q_ in ref2.parameters()]):
+                        assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6), f"{mode} epoch tail: {n} wrong"
+                model.zero_grad(set_to_none=True)
+        assert stepped == [1, 2]
 
         # a forgotten finish() is reported as what it is, at the backward that trips over it
         loss = ((model(xs[0]) - ys[0]) ** 2).mean()

@@ -467,3 +467,33 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
         else:
             check(f"compaction: d {k}", g_a[k], g_b[k], 1e-5)
     assert exact >= 10, "the stages without compaction (and the stem / head) must still agree bit for bit"
+
+
+def test_forward_feature_without_a_weight_scope_runs_uncompacted_and_backward_works(monkeypatch):
+    """`VisionTransformer.forward_feature()` is a public method of the reference (vit.py:139-151).  Called directly
+    there is no weight_scope, hence no transposed bf16 weight copies, which the compacted backward needs: the layers must run
+    uncompacted (same numbers as forward(): compaction never changes a per-row result) instead of failing in backward."""
+    from models import VisionTransformer
+    from vtx import functional as VF
+    d = dev()
+    torch.manual_seed(3)
+    model = VisionTransformer(None, 224, 16, 3, 384, 6, 1536, 0.0, 0.0, 0.0, 0.45).to(d).train()
+    assert model._vtx_dp_compaction
+    monkeypatch.setattr(VF, "_COMPACT_MIN_PCT", 0)
+    monkeypatch.setattr(VF, "_LAYER_CALL", True)
+    x = torch.randn(10, 3, 224, 224, device=d)
+
+    def run(direct):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(17)                                  # same DropPath draws
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            f = model.forward_feature(x) if direct else model(x)
+        f.float().square().sum().backward()
+        return f.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    f_direct, g_direct = run(True)                             # raised VtxError("vtx_layer_bwd: ... shape") in backward before
+    f_model, g_model = run(False)
+    assert torch.isfinite(f_direct).all() and all(torch.isfinite(v).all() for v in g_direct.values())
+    assert torch.equal(f_direct, f_model)
+    for k in g_direct:
+        check(f"forward_feature vs forward: d {k}", g_direct[k], g_model[k], 1e-5)

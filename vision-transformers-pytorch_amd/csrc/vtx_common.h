@@ -90,15 +90,62 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
 }
 // Sum over groups of G = 16, 32 or 64 consecutive lanes, result in every lane of the group: the four steps inside a
 // 16-lane row are DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); only the steps across rows go through LDS.
+#ifndef VTX_GROUPSUM_MODE
+#define VTX_GROUPSUM_MODE 0      // probe builds only (tools/r4/build_variant.sh): 1 = extra wait states in front of every DPP read, 2 = no DPP
+#endif
 template <int G> __device__ __forceinline__ float group_sum(float v) {
+#if VTX_GROUPSUM_MODE == 2
+  v += shfl_xor_f(v, 1); v += shfl_xor_f(v, 2); v += shfl_xor_f(v, 4); v += shfl_xor_f(v, 8);
+#elif VTX_GROUPSUM_MODE == 1
+  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0xB1>(v);
+  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0x4E>(v);
+  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0x141>(v);
+  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0x140>(v);
+#elif VTX_GROUPSUM_MODE == 3
+  asm volatile("" : "+v"(v)); v += dpp_f<0xB1>(v);
+  asm volatile("" : "+v"(v)); v += dpp_f<0x4E>(v);
+  asm volatile("" : "+v"(v)); v += dpp_f<0x141>(v);
+  asm volatile("" : "+v"(v)); v += dpp_f<0x140>(v);
+#else
   v += dpp_f<0xB1>(v);       // quad_perm [1,0,3,2]
   v += dpp_f<0x4E>(v);       // quad_perm [2,3,0,1]
   v += dpp_f<0x141>(v);      // row_half_mirror: 8-lane sums
   v += dpp_f<0x140>(v);      // row_mirror: 16-lane sums
+#endif
+#if VTX_GROUPSUM_MODE == 3 || VTX_GROUPSUM_MODE == 5
+  if constexpr (G >= 32) { asm volatile("" : "+v"(v)); v += shfl_xor_f(v, 16); }
+  if constexpr (G >= 64) { asm volatile("" : "+v"(v)); v += shfl_xor_f(v, 32); }
+  asm volatile("" : "+v"(v));
+  return v;
+#elif VTX_GROUPSUM_MODE == 4
+  if constexpr (G >= 32) { asm volatile("s_nop 4" : "+v"(v)); v += shfl_xor_f(v, 16); }
+  if constexpr (G >= 64) { asm volatile("s_nop 4" : "+v"(v)); v += shfl_xor_f(v, 32); }
+  asm volatile("s_nop 4" : "+v"(v));
+  return v;
+#endif
   if constexpr (G >= 32) v += shfl_xor_f(v, 16);
   if constexpr (G >= 64) v += shfl_xor_f(v, 32);
   return v;
 }
+
+#if VTX_GROUPSUM_MODE >= 6
+// probe builds: the (s1, s2) pair of the LayerNorm backward reduced as ONE packed value -- what the SLP vectoriser makes of
+// two interleaved scalar chains (v_pk_add_f32 on a register pair) -- with an optional wait state between the packed add and
+// the ds_bpermute_b32 that reads its result (mode 7) or an empty barrier at the same place (mode 6: the control)
+template <int CTRL> __device__ __forceinline__ f32x2 dpp2(f32x2 v) { return f32x2{dpp_f<CTRL>(v[0]), dpp_f<CTRL>(v[1])}; }
+__device__ __forceinline__ f32x2 shfl2(f32x2 v, int m) { return f32x2{shfl_xor_f(v[0], m), shfl_xor_f(v[1], m)}; }
+template <int G> __device__ __forceinline__ f32x2 group_sum2(f32x2 v) {
+  v += dpp2<0xB1>(v); v += dpp2<0x4E>(v); v += dpp2<0x141>(v); v += dpp2<0x140>(v);
+#if VTX_GROUPSUM_MODE == 7
+  if constexpr (G >= 32) { asm volatile("s_nop 1" : "+v"(v)); v += shfl2(v, 16); }
+  if constexpr (G >= 64) { asm volatile("s_nop 1" : "+v"(v)); v += shfl2(v, 32); }
+#else
+  if constexpr (G >= 32) { asm volatile("" : "+v"(v)); v += shfl2(v, 16); }
+  if constexpr (G >= 64) { asm volatile("" : "+v"(v)); v += shfl2(v, 32); }
+#endif
+  return v;
+}
+#endif
 
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: these run once per output element in GEMM epilogues
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }

@@ -37,6 +37,9 @@ class _Bucket:
         self.views = []
         self.pending = 0
         self.work = None
+        self.handles = {}          # id(param) -> hook handle
+        self.trigger = None        # the parameter whose gradient arrived LAST in the learning backward (bucket-level hook)
+        self.learned = None        # candidate for `trigger` (set by the counting hooks, adopted in finish())
         self.offsets = []          # start of every parameter's slot in `flat` (floats, SLOT_ALIGN-aligned)
         self.flat_numel = 0
 
@@ -78,7 +81,7 @@ def assign_buckets(named_params, bucket_bytes, first_bucket_bytes, last_bucket_b
 
 class GradAllReduce:
     def __init__(self, module, process_group=None, bucket_bytes=48 * MIB, first_bucket_bytes=8 * MIB,
-                 broadcast=True, force=False, last_bucket_bytes=8 * MIB):
+                 broadcast=True, force=False, last_bucket_bytes=8 * MIB, bucket_hooks=True):
         """``force=True`` keeps the bucket / hook / collective machinery active even for a 1-rank group
         (used to exercise the RCCL path on a single GPU); by default world size 1 bypasses everything."""
         self.module = module
@@ -87,7 +90,7 @@ class GradAllReduce:
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         self.parameters = [p for _, p in named]
         self.buckets = []
-        self._handles = []
+        self.bucket_hooks = bucket_hooks       # False: a counting hook per parameter in every backward (round-3 behaviour)
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         if not self.active:
             return
@@ -113,8 +116,7 @@ class GradAllReduce:
                 b.views.append(b.flat[o:o + p.numel()].view_as(p))
                 self._slot[id(p)] = (b, o)
             b.pending = len(b.params)
-            for p in b.params:
-                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+            self._count_hooks(b)
         if self.active:
             from . import functional as VF
             VF.register_grad_sink_provider(self)
@@ -157,12 +159,27 @@ class GradAllReduce:
         finally:
             self._sync = prev
 
+    # -- hooks.  A `post_accumulate_grad` hook per parameter is 329 Python calls per Swin-S backward on the autograd thread
+    # (the reference's DDP counts in C++, train.py:103).  The order in which a model's gradients arrive is a property of its
+    # graph, so the FIRST synced backward counts every parameter of a bucket (``_count_hooks``) and remembers whose gradient
+    # arrived last; from then on only that parameter keeps a hook (``_trigger_hook``: one Python call per BUCKET per
+    # backward).  The trigger verifies that every gradient of its bucket is there before it launches; if one is missing (the
+    # graph changed: a frozen / newly trained parameter, another execution order) the bucket goes back to counting, and
+    # finish() launches what is still unreduced once backward has ended -- late, never wrong.
+    def _count_hooks(self, b):
+        for h in b.handles.values():
+            h.remove()
+        b.handles = {id(p): p.register_post_accumulate_grad_hook(self._make_hook(b)) for p in b.params}
+        b.trigger = b.learned = None
+        b.pending = len(b.params)
+
     def _make_hook(self, bucket):
         def hook(param):
             if not self._sync:
                 return
             bucket.pending -= 1
             if bucket.pending == 0:
+                bucket.learned = param
                 self._launch(bucket)
             elif bucket.pending < 0:
                 raise RuntimeError(
@@ -170,6 +187,47 @@ class GradAllReduce:
                     "accumulation either call finish() after EVERY backward (the reference's all-reduce per micro-batch) "
                     "or wrap the non-boundary backwards in no_sync()")
         return hook
+
+    def _trigger_hook(self, bucket):
+        def hook(param):
+            if not self._sync:
+                return
+            if bucket.work is not None:
+                raise RuntimeError(
+                    "GradAllReduce: a second backward() reached an already-reduced bucket before finish() -- with gradient "
+                    "accumulation either call finish() after EVERY backward (the reference's all-reduce per micro-batch) "
+                    "or wrap the non-boundary backwards in no_sync()")
+            if all(p.grad is not None for p in bucket.params):
+                bucket.pending = 0
+                self._launch(bucket)
+            else:
+                bucket.trigger = None      # order changed: finish() reduces this bucket late and re-installs the counting hooks
+        return hook
+
+    def _adopt_trigger(self, b):
+        """After a fully counted backward: keep only the last-arriving parameter's hook."""
+        if not self.bucket_hooks or b.trigger is not None or b.learned is None or len(b.params) == 1:
+            return
+        for h in b.handles.values():
+            h.remove()
+        b.trigger = b.learned
+        b.handles = {id(b.trigger): b.trigger.register_post_accumulate_grad_hook(self._trigger_hook(b))}
+
+    def reset(self):
+        """Re-arm after a step that was ABANDONED between backward() and finish() (a skipped step on a non-finite loss, an
+        exception, a bare zero_grad): waits for outstanding collectives, forgets handed-out gradient sinks and makes every
+        bucket count again.  Gradients already installed / accumulated are left as they are -- call zero_grad() as well."""
+        if not self.active:
+            return
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+            b.work = None
+            b.pending = len(b.params)
+            if b.trigger is None and len(b.handles) != len(b.params):
+                self._count_hooks(b)
+        self._sunk.clear()
+        self._sync = True
 
     def _launch(self, b):
         side = None
@@ -197,6 +255,17 @@ class GradAllReduce:
         """Wait (stream-wise) for every bucket, install the averaged gradients, re-arm for the next backward."""
         if not self.active:
             return
+        late = [b for b in self.buckets if b.work is None and b.handles and len(b.handles) != len(b.params)]
+        for b in late:
+            # a bucket on its bucket-level hook that was not reduced during backward: the trigger's parameter was not the
+            # last one this time (or received no gradient).  Backward is over: reduce now if every gradient is there, and
+            # count per parameter again until the order has been re-learned
+            if all(p.grad is not None for p in b.params):
+                b.pending = 0
+                self._launch(b)
+            self._count_hooks(b)
+            if b.work is not None:
+                b.pending = 0
         if any(b.pending != 0 for b in self.buckets):
             for b in self.buckets:                      # leave the object usable for the caller's next attempt
                 if b.work is not None:
@@ -217,9 +286,11 @@ class GradAllReduce:
                 p.grad = v
             b.work = None
             b.pending = len(b.params)
+            self._adopt_trigger(b)
         self._sunk.clear()
 
     def remove(self):
-        for h in self._handles:
-            h.remove()
-        self._handles = []
+        for b in self.buckets:
+            for h in b.handles.values():
+                h.remove()
+            b.handles = {}

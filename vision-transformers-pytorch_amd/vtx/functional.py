@@ -717,6 +717,11 @@ class TransformerLayerFn(Function):
             d.rel_pos, d.pos, d.region = rel_pos.data_ptr(), meta.pos.data_ptr(), _dp(meta.region)
         d.s1, d.s2 = _dp(s1), _dp(s2)
         ctx.perms = _layer_perms(kind, T, C, ff, s1, s2, meta.dim_head, meta.L, M // B)
+        if ctx.perms is not None and any(w[1] is None for w in (wq, wo, w1, w2)):
+            # the mapped backward (vtx_layer_bwd) multiplies by the TRANSPOSED bf16 weight copies; they only exist inside a
+            # weight_scope (a top-level model's forward).  Called without one -- VisionTransformer.forward_feature() directly,
+            # bf16 parameters -- the layer runs uncompacted instead of failing in backward
+            ctx.perms = None
         if ctx.perms is not None:
             (p1, d.Bk1), (p2, d.Bk2) = ctx.perms
             d.perm1, d.perm2 = p1.data_ptr(), p2.data_ptr()

@@ -21,6 +21,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._recs = None           # static per-parameter records (see _records)
         self._plans = {}
+        self._checked = set()       # plans validated in the current step
 
     # ---- host-side bookkeeping.  A step touches ~330 parameters; looking at each one's state dict, validating four
     # tensors per parameter, building four address arrays and bumping 330 CPU step tensors cost ~2.4 ms of host time per
@@ -61,22 +62,35 @@ class FusedAdamW(torch.optim.Optimizer):
         self._recs = None
 
     def _launch_plan(self, idx, recs):
-        """Address arrays of one multi-tensor launch over the parameters ``idx`` (a tuple), built once."""
+        """Address arrays of one multi-tensor launch over the parameters ``idx`` (a tuple), built once and VALIDATED once
+        per step against the live storage addresses of every parameter and moment tensor: ``p.data = ...``, ``module.to()``
+        / ``.float()`` after construction or a replaced ``exp_avg_sq`` change an address without changing any Python
+        object identity (and ``id()`` values are reused after garbage collection) -- the kernel would read and write freed
+        memory.  The plan also holds references to the moment tensors it addresses.  ~0.1 ms per step for 330 tensors."""
         pl = self._plans.get(idx)
+        if pl is not None and idx not in self._checked:
+            ps = [recs[i][0] for i in idx]
+            ms = [recs[i][1]["exp_avg"] for i in idx]
+            vs = [recs[i][1]["exp_avg_sq"] for i in idx]
+            if pl[6] != tuple(t.data_ptr() for t in ps + ms + vs):
+                pl = None                                # some storage moved: rebuild the address arrays
+            else:
+                self._checked.add(idx)
         if pl is None:
             import ctypes
             ps = [recs[i][0] for i in idx]
             ms = [recs[i][1]["exp_avg"] for i in idx]
             vs = [recs[i][1]["exp_avg_sq"] for i in idx]
             ops._dev(*ps, *ms, *vs)
+            for p, m, v in zip(ps, ms, vs):
+                if m.shape != p.shape or v.shape != p.shape or m.dtype != torch.float32 or v.dtype != torch.float32:
+                    raise ops.VtxError("FusedAdamW: exp_avg / exp_avg_sq must be fp32 tensors of the parameter's shape")
             chunk = ops._lib.load().vtx_opt_chunk()
             numel = (ctypes.c_int64 * len(idx))(*[p.numel() for p in ps])
             pl = self._plans[idx] = (ops._ptr_array(ps), ops._ptr_array(ms), ops._ptr_array(vs), numel,
                                      sum(p.numel() for p in ps), sum((p.numel() + chunk - 1) // chunk for p in ps),
-                                     tuple(id(m) for m in ms))
-        elif pl[6] != tuple(id(recs[i][1]["exp_avg"]) for i in idx):      # state tensors were replaced: rebuild
-            del self._plans[idx]
-            return self._launch_plan(idx, recs)
+                                     tuple(t.data_ptr() for t in ps + ms + vs), (ms, vs))
+            self._checked.add(idx)
         return pl
 
     @torch.no_grad()
@@ -89,6 +103,7 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         _, recs, flat, _, counts = self._records()
+        self._checked = set()
         live, gs = [], []
         for i, (p, _, _) in enumerate(recs):
             g = p.grad

@@ -79,14 +79,18 @@ def make_param_groups(named_parameters, weight_decay, skip_type="vit"):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
-def accumulation_boundary(grad_accum, micro_step):
-    """True when this micro-batch closes an accumulation window: ``(i + 1) % grad_accum == 0`` with the loader index
-    ``i`` (train.py:285).  With grad_accum > 1 the caller MUST pass the index -- a defaulted 0 would never step."""
+def accumulation_boundary(grad_accum, micro_step, loader_len=None):
+    """True when this micro-batch closes an accumulation window: ``(i + 1) % grad_accum == 0 or (i + 1) == len(loader)``
+    with the loader index ``i`` (train.py:285 -- the epoch's last micro-batches step even when the window is not full).
+    With grad_accum > 1 the caller MUST pass the index -- a defaulted 0 would never step; without ``loader_len`` only the
+    first clause applies (an endless / synthetic stream has no epoch tail)."""
     if grad_accum <= 1:
         return True
     if micro_step is None:
         raise ValueError("vtx: grad_accum > 1 needs micro_step (the loader index i of train.py:285)")
-    return (micro_step + 1) % grad_accum == 0
+    if loader_len is not None and micro_step >= loader_len:
+        raise ValueError("vtx: micro_step is the index INSIDE the epoch (0 <= i < loader_len, train.py:265)")
+    return (micro_step + 1) % grad_accum == 0 or (loader_len is not None and micro_step + 1 == loader_len)
 
 
 def backward_ddp(loss, ddp, boundary, ddp_sync, fresh):
@@ -114,28 +118,35 @@ def backward_ddp(loss, ddp, boundary, ddp_sync, fresh):
 
 
 def train_step(model, criterion, optimizer, batch, clip_grad_norm=5.0, autocast_dtype=torch.bfloat16,
-               grad_accum=1, ddp=None, micro_step=None, ddp_sync="boundary"):
+               grad_accum=1, ddp=None, micro_step=None, ddp_sync="boundary", loader_len=None):
     """One micro-batch of the reference's loop body (train.py:273-299).  ``batch`` = (input NCHW fp32, label1, label2,
     ratio) on the device.  Like the reference, clip + optimizer step + zero_grad run only on accumulation boundaries:
-    ``(micro_step + 1) % grad_accum == 0`` (``micro_step`` = the loader index ``i``, required when grad_accum > 1); in
-    between, gradients accumulate.
+    ``(micro_step + 1) % grad_accum == 0`` (``micro_step`` = the loader index ``i``, required when grad_accum > 1) or, with
+    ``loader_len`` = ``len(loader)``, on the epoch's last micro-batch (train.py:285's second clause: a tail shorter than
+    the window still steps, and the next epoch starts on clean gradients); in between, gradients accumulate.  The loss of
+    every micro-batch is divided by ``grad_accum`` as in the reference (train.py:281), tail included.
 
     ``ddp`` (vtx.ddp.GradAllReduce) overlaps the gradient all-reduce with backward; its ``finish()`` is the
     only synchronisation point before clipping (``ddp_sync``: see backward_ddp).  Returns the (unsynchronised) loss tensor.
     """
     x, l1, l2, ratio = batch
-    boundary = accumulation_boundary(grad_accum, micro_step)
+    boundary = accumulation_boundary(grad_accum, micro_step, loader_len)
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
         out = model(x)
         loss = criterion(out, l1, l2, ratio) / grad_accum
     # Side-stream weight gradients (functional.deferred_wgrad) need "one gradient per parameter, .grad None on entry":
     # true for the first micro-batch after zero_grad(set_to_none) of these single-pass models, not while accumulating.
     fresh = grad_accum == 1 or micro_step % grad_accum == 0
-    backward_ddp(loss, ddp, boundary, ddp_sync, fresh)
-    if not boundary:
-        return loss
-    if ddp is not None:
-        ddp.finish()
+    try:
+        backward_ddp(loss, ddp, boundary, ddp_sync, fresh)
+        if not boundary:
+            return loss
+        if ddp is not None:
+            ddp.finish()
+    except BaseException:
+        if ddp is not None:
+            ddp.reset()            # an abandoned backward must not leave reduced buckets / handed-out sinks behind (ADVICE r3)
+        raise
     if isinstance(optimizer, FusedAdamW):       # clip + AdamW in two multi-tensor HIP kernels (csrc/optim.hip)
         optimizer.step(max_grad_norm=clip_grad_norm or 0.0)
     else:
