@@ -275,3 +275,17 @@ def test_projection_mlp_layout_is_the_references(depth, use_bn):
     assert tuple(h.state_dict()[lin[0]].shape) == (48, 32) and tuple(h.state_dict()[lin[-1]].shape) == (16, 48)
     assert ("mlp.1.running_mean" in h.state_dict()) == use_bn
     assert tuple(h.last.weight_v.shape) == (64, 16) and float(h.last.weight_g.min()) == 1.0
+
+
+def test_no_packed_fp32_result_feeds_the_lds_or_memory_pipe_in_the_next_issue_slot():
+    """Round 4 (the side-stream nondeterminism of round 3, root-caused): on gfx950 `v_pk_add_f32 ; ds_bpermute_b32 <its result>` with
+    no wait state in between now and then reads the OLD register when another kernel shares the CU.  hipcc does not pad that
+    pair; csrc/vtx_common.h does (shfl_xor_f / vmem_guard).  The scanner compiles every kernel file to gfx950 assembly (hipcc
+    cross-compiles without a GPU) and must find no such site."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "probe", "scan_pk_hazard.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "0 packed-fp32" in r.stdout

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qk
     // the accumulators hold queries 4 g_ + r (not c_): fetch their rescale factors from the lanes that own them
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float a = __shfl(alpha, 4 * g_ + r, 64);
+      const float a = shfl_f(alpha, 4 * g_ + r);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) oacc[dt][r] *= a;
     }
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qk
   const float inv = 1.f / l_run;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float iv = __shfl(inv, 4 * g_ + r, 64);
+    const float iv = shfl_f(inv, 4 * g_ + r);
     const int qo = qt * 16 + g_ * 4 + r;
     if (qo < g.L) {
       T* op = o + (row0 + qo) * (int64_t)g.hd + h * D + c_;

@@ -175,6 +175,9 @@ bool gemm_glds_ok(int N, int K);
 // gemm_skinny.hip: weight-resident streaming kernel for K = 64 / 96 / 128 over >= 32 768 rows (bf16, A . W^T)
 bool gemm_skinny_ok(const GemmArgs& a);
 int gemm_skinny_launch(const GemmArgs& a, hipStream_t st);
+// gemm_astat.hip: A-stationary kernel for 128 <= K <= 384 (one workgroup per CU keeps its 128-row strip of A in LDS for all column tiles)
+bool gemm_astat_ok(const GemmArgs& a);
+int gemm_astat_launch(const GemmArgs& a, hipStream_t st);
 // mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE
 int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st);
 

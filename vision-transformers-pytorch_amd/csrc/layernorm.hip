@@ -183,12 +183,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int e = 0; e < 8; ++e) { xh[k][e] = 0.f; gv[k][e] = 0.f; }
       }
     }
-#if VTX_GROUPSUM_MODE >= 6
-    const f32x2 s12 = group_sum2<G>(f32x2{s1, s2});
-    const float c1 = s12[0] * invC, c2 = s12[1] * invC;
-#else
     const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
-#endif
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int v = lig + k * G;

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(const OptPack k, const 
         upd(pk, g[k], mk, vk);
         p[k] = pk; m[k] = mk; v[k] = vk;
       }
+      vmem_guard(p); vmem_guard(m); vmem_guard(v);
       *reinterpret_cast<f32x4*>(d.p + e) = p;
       *reinterpret_cast<f32x4*>(d.m + e) = m;
       *reinterpret_cast<f32x4*>(d.v + e) = v;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void ema_kernel(const OptPack k, float m) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(d.g + e);
 #pragma unroll
       for (int j = 0; j < 4; ++j) p[j] = p[j] * m + g[j] * w;
+      vmem_guard(p);
       *reinterpret_cast<f32x4*>(d.p + e) = p;
     } else {
       for (int64_t j = e; j < d.numel && j < e + 4; ++j) d.p[j] = d.p[j] * m + d.g[j] * w;

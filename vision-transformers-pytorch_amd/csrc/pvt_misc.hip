@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x
   for (int c = lane; c < C; c += 64) { const float v = to_f32<T>(xr[c]); s += v * v; }
   const float n = fmaxf(sqrtf(group_sum<64>(s)), eps);
   const float inv = 1.f / n;
-  for (int c = lane; c < C; c += 64) y[row * C + c] = from_f32<T>(to_f32<T>(xr[c]) * inv);
+  for (int c = lane; c < C; c += 64) {
+    float o = to_f32<T>(xr[c]) * inv;
+    vmem_guard(o);                       // (packed math in front of a store: vtx_common.h)
+    y[row * C + c] = from_f32<T>(o);
+  }
   if (lane == 0) nrm[row] = n;
 }
 
@@ -193,8 +197,11 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ d
   for (int c = lane; c < C; c += 64) s += to_f32<T>(y[row * C + c]) * to_f32<T>(dy[row * C + c]);
   s = group_sum<64>(s);
   const float inv = 1.f / nrm[row];
-  for (int c = lane; c < C; c += 64)
-    dx[row * C + c] = from_f32<T>((to_f32<T>(dy[row * C + c]) - to_f32<T>(y[row * C + c]) * s) * inv);
+  for (int c = lane; c < C; c += 64) {
+    float o = (to_f32<T>(dy[row * C + c]) - to_f32<T>(y[row * C + c]) * s) * inv;
+    vmem_guard(o);
+    dx[row * C + c] = from_f32<T>(o);
+  }
 }
 
 extern "C" {

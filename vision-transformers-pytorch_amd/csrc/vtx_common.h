@@ -20,6 +20,18 @@ enum { VTX_OK = 0, VTX_ERR_SHAPE = -1, VTX_ERR_DTYPE = -2, VTX_ERR_ALIGN = -3, V
        VTX_ERR_WORKSPACE = -5, VTX_ERR_NULL = -6 };
 enum { VTX_F32 = 0, VTX_BF16 = 1 };
 
+#ifndef VTX_PK_DS_GUARD
+#define VTX_PK_DS_GUARD 1          // see shfl_xor_f below
+#endif
+// A value that goes to the vector-memory pipe as store data right after packed-fp32 math (see the HAZARD note at shfl_xor_f:
+// no failure has been observed for stores -- they read their data registers later than a DS instruction does -- but the
+// guard costs one s_nop)
+template <typename V> __device__ __forceinline__ void vmem_guard(V& v) {
+#if VTX_PK_DS_GUARD
+  asm volatile("s_nop 0" : "+v"(v));
+#endif
+}
+
 // ---------------------------------------------------------------- 8-element vectors of T
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
@@ -59,6 +71,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const Vec8<f
   f32x4 a, b;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { a[i] = x.v[i]; b[i] = x.v[4 + i]; }
+  vmem_guard(a); vmem_guard(b);
   *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
@@ -83,69 +96,42 @@ __device__ __forceinline__ void mma16(const Vec8<float>& a, const Vec8<float>& b
 }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
-__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+// HAZARD (found in round 4, profiles/round4_nondeterminism_root_cause.md): on gfx950 a packed-fp32 VOP3P instruction
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 -- two passes over the register pair) followed IN THE NEXT ISSUE SLOT by an LDS
+// instruction that reads its result as data (ds_bpermute_b32 = __shfl_xor) now and then hands the LDS pipe the OLD register
+// contents.  hipcc (ROCm 7.2) pads a dependent VALU consumer of a VOP3P result with `s_nop 0`, not a DS consumer, and its SLP
+// vectoriser turns two interleaved scalar reduction chains (LayerNorm backward: the sums s1, s2) into exactly this pair of
+// instructions.  Seen only while another kernel shares the CU (the side-stream weight gradient): one row of a LayerNorm
+// backward's dx off by a few bf16 ulps in ~10 % of full-size train steps.  ONE wait state between the two removes it (0 of 900
+// trials); the guard below supplies it for every cross-lane exchange of the library (VTX_PK_DS_GUARD=0: the unguarded code,
+// for tools/probe/merge_bisect.py).  tools/probe/scan_pk_hazard.py scans the generated ISA for remaining sites.
+__device__ __forceinline__ float shfl_xor_f(float v, int m) {
+#if VTX_PK_DS_GUARD
+  asm volatile("s_nop 0" : "+v"(v));
+#endif
+  return __shfl_xor(v, m, 64);
+}
+__device__ __forceinline__ float shfl_f(float v, int src) {          // value of lane `src`
+#if VTX_PK_DS_GUARD
+  asm volatile("s_nop 0" : "+v"(v));
+#endif
+  return __shfl(v, src, 64);
+}
 // DPP lane exchange inside a 16-lane row (no LDS round trip, unlike __shfl_xor which lowers to ds_bpermute_b32)
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 // Sum over groups of G = 16, 32 or 64 consecutive lanes, result in every lane of the group: the four steps inside a
 // 16-lane row are DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); only the steps across rows go through LDS.
-#ifndef VTX_GROUPSUM_MODE
-#define VTX_GROUPSUM_MODE 0      // probe builds only (tools/r4/build_variant.sh): 1 = extra wait states in front of every DPP read, 2 = no DPP
-#endif
 template <int G> __device__ __forceinline__ float group_sum(float v) {
-#if VTX_GROUPSUM_MODE == 2
-  v += shfl_xor_f(v, 1); v += shfl_xor_f(v, 2); v += shfl_xor_f(v, 4); v += shfl_xor_f(v, 8);
-#elif VTX_GROUPSUM_MODE == 1
-  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0xB1>(v);
-  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0x4E>(v);
-  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0x141>(v);
-  asm volatile("s_nop 4" : "+v"(v)); v += dpp_f<0x140>(v);
-#elif VTX_GROUPSUM_MODE == 3
-  asm volatile("" : "+v"(v)); v += dpp_f<0xB1>(v);
-  asm volatile("" : "+v"(v)); v += dpp_f<0x4E>(v);
-  asm volatile("" : "+v"(v)); v += dpp_f<0x141>(v);
-  asm volatile("" : "+v"(v)); v += dpp_f<0x140>(v);
-#else
   v += dpp_f<0xB1>(v);       // quad_perm [1,0,3,2]
   v += dpp_f<0x4E>(v);       // quad_perm [2,3,0,1]
   v += dpp_f<0x141>(v);      // row_half_mirror: 8-lane sums
   v += dpp_f<0x140>(v);      // row_mirror: 16-lane sums
-#endif
-#if VTX_GROUPSUM_MODE == 3 || VTX_GROUPSUM_MODE == 5
-  if constexpr (G >= 32) { asm volatile("" : "+v"(v)); v += shfl_xor_f(v, 16); }
-  if constexpr (G >= 64) { asm volatile("" : "+v"(v)); v += shfl_xor_f(v, 32); }
-  asm volatile("" : "+v"(v));
-  return v;
-#elif VTX_GROUPSUM_MODE == 4
-  if constexpr (G >= 32) { asm volatile("s_nop 4" : "+v"(v)); v += shfl_xor_f(v, 16); }
-  if constexpr (G >= 64) { asm volatile("s_nop 4" : "+v"(v)); v += shfl_xor_f(v, 32); }
-  asm volatile("s_nop 4" : "+v"(v));
-  return v;
-#endif
   if constexpr (G >= 32) v += shfl_xor_f(v, 16);
   if constexpr (G >= 64) v += shfl_xor_f(v, 32);
   return v;
 }
-
-#if VTX_GROUPSUM_MODE >= 6
-// probe builds: the (s1, s2) pair of the LayerNorm backward reduced as ONE packed value -- what the SLP vectoriser makes of
-// two interleaved scalar chains (v_pk_add_f32 on a register pair) -- with an optional wait state between the packed add and
-// the ds_bpermute_b32 that reads its result (mode 7) or an empty barrier at the same place (mode 6: the control)
-template <int CTRL> __device__ __forceinline__ f32x2 dpp2(f32x2 v) { return f32x2{dpp_f<CTRL>(v[0]), dpp_f<CTRL>(v[1])}; }
-__device__ __forceinline__ f32x2 shfl2(f32x2 v, int m) { return f32x2{shfl_xor_f(v[0], m), shfl_xor_f(v[1], m)}; }
-template <int G> __device__ __forceinline__ f32x2 group_sum2(f32x2 v) {
-  v += dpp2<0xB1>(v); v += dpp2<0x4E>(v); v += dpp2<0x141>(v); v += dpp2<0x140>(v);
-#if VTX_GROUPSUM_MODE == 7
-  if constexpr (G >= 32) { asm volatile("s_nop 1" : "+v"(v)); v += shfl2(v, 16); }
-  if constexpr (G >= 64) { asm volatile("s_nop 1" : "+v"(v)); v += shfl2(v, 32); }
-#else
-  if constexpr (G >= 32) { asm volatile("" : "+v"(v)); v += shfl2(v, 16); }
-  if constexpr (G >= 64) { asm volatile("" : "+v"(v)); v += shfl2(v, 32); }
-#endif
-  return v;
-}
-#endif
 
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: these run once per output element in GEMM epilogues
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
@@ -261,6 +247,7 @@ static __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float
       s += a; s += b; s += c2; s += d;
     }
     for (; z < nz; ++z) s += p[(int64_t)z * n4];
+    vmem_guard(s);
     reinterpret_cast<f32x4*>(out)[i] = s;
   }
 }
@@ -301,6 +288,7 @@ static __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabReduc
     s += b0; s += b1; s += b2; s += b3;
   }
   for (; z < nz; ++z) s += p[(int64_t)z * n4];
+  vmem_guard(s);
   reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
@@ -350,6 +338,7 @@ static __global__ __launch_bounds__(1024) void layer_reduce_kernel(LayerReduce a
     }
     for (; z < nz; ++z) s += p[(int64_t)z * n4];
     if (a.accumulate) s = reinterpret_cast<const f32x4*>(out)[i] + s;      // one add of two finished sums = autograd's a + b
+    vmem_guard(s);
     reinterpret_cast<f32x4*>(out)[i] = s;
     return;
   }

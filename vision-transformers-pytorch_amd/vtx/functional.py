@@ -162,8 +162,8 @@ def _img(x):
 #     before it reduces a bucket.  Operands are kept alive until the join (the caching allocator would otherwise hand
 #     their memory to the main stream while the side stream still reads it).  Bitwise identical either way.
 _SIDE_ENABLED = os.environ.get("VTX_SIDE_WGRAD", "1") != "0"
-_SIDE_FENCE_MODE = os.environ.get("VTX_SIDE_FENCE", "1")
-_TWINS_SPLITK = os.environ.get("VTX_TWINS_SPLITK", "1") != "0"   # few-row / long-K reduction convs on the split-K launch        # (0 / merge: measurement only -- see side_fence)
+_SIDE_FENCE_MODE = os.environ.get("VTX_SIDE_FENCE", "0")
+_TWINS_SPLITK = os.environ.get("VTX_TWINS_SPLITK", "1") != "0"   # few-row / long-K reduction convs on the split-K launch
 # one column-reduce launch per layer (LayerNorm dgamma / dbeta x 2 + rel_pos gradient) instead of three; 0: each kernel reduces its own
 _DEFER_REDUCE = os.environ.get("VTX_DEFER_REDUCE", "1") != "0"
 _deferred = False
@@ -206,16 +206,16 @@ def side_stream_after_current(dev):
 
 
 def side_fence(dev, merge=False):
-    """The current stream waits for the side-stream weight gradients enqueued so far (they stay pending: no join).
+    """With VTX_SIDE_FENCE=1 (or =merge for the PatchMerge LayerNorm backward only) the current stream waits for the
+    side-stream weight gradients enqueued so far (they stay pending: no join).  OFF by default since round 4.
 
-    Called at the start of every backward OUTSIDE the transformer layers (patch merge / embed, head, pooling ...).  Measured
-    (round 3, tools/probe/determinism_stress.py): when the LayerNorm backward of a PatchMerge runs while the preceding layer's
-    grouped weight gradient is still on the side stream, its dx differs in the last bf16 bit on a few rows in ~1 of 15 train
-    steps (inputs, statistics and dgamma bit-identical; the kernels are bit-reproducible on their own and under an unrelated
-    concurrent launch: tools/probe/concurrent_bitwise.py, concurrent_stale.py) -- not understood, so these few nodes do not
-    overlap with the side stream; the 24 layers, where the overlap pays, do.  (VTX_SIDE_FENCE=merge fences the PatchMerge
-    LayerNorm backward only: also 0 differing trials of 1 146 -- that launch is the only one seen to misbehave; the default
-    keeps every non-layer node fenced, the cost is ~0.05 ms per Swin-S step.)"""
+    History: round 3 found that the full-size Swin-S step was not bit-reproducible in 10-20 % of runs when the LayerNorm
+    backward of a PatchMerge overlapped the preceding layer's side-stream weight gradient, and fenced every backward node
+    outside the transformer layers.  Round 4 found the cause (profiles/round4_nondeterminism_root_cause.md): a gfx950
+    hazard between a packed-fp32 instruction and the ds_bpermute_b32 that reads its result in the next issue slot -- the
+    code hipcc generated for the kernel's two cross-lane sums -- exposed only when another kernel's waves share the CU.
+    The fix is one wait state in csrc/vtx_common.h (shfl_xor_f); with it the unfenced step is clean over 2 000+ trials of
+    tools/probe/determinism_stress.py, so the fence is a measurement switch now."""
     st = _side_states.get(dev)
     if st is not None and st.pending and (_SIDE_FENCE_MODE == "1" or (_SIDE_FENCE_MODE == "merge" and merge)):
         torch.cuda.current_stream(dev).wait_stream(st.stream)
