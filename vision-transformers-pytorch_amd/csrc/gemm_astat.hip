@@ -1,321 +1,486 @@
-// A-STATIONARY LDS-DMA GEMM for gfx950 (bf16): C[M,N] = epilogue(A[M,K] . W[N,K]^T) with a SHORT contraction K <= 384
-// (Swin-S stage 3 / ViT-S/16: qkv, fc1, proj forward; proj and fc2 dgrad) and N a multiple of 128.
+// A-STATIONARY, PERSISTENT LDS-DMA GEMM for gfx950 (bf16): C[M,N] = epilogue(A[M,K] . W[N,K]^T) with a SHORT contraction
+// 192 <= K <= 384 (Swin-S stage 3 / ViT-S/16: qkv, fc1, proj forward; proj and fc2 dgrad) and N a multiple of 128.
 //
 // What the counters say about the tiled kernel on these shapes (profiles/round4_pmc_sq_gemm_in_model.txt): no unit is busy
 // (MFMA ~18 %, LDS ~18 %, TA ~37 %, HBM 0.3), the waves are parked -- a 128 x 128 tile with K = 384 is six k-tiles between a
 // prologue that waits for the first operands and an epilogue, every one of its k-tiles waits for the ONE k-tile of LDS-DMA the
 // 2-stage ring keeps in flight, and the A rows are fetched again for every column tile.  In the model a round of resident
 // workgroups takes 10-14 us for 2.6 us of MFMA work.  Here
-//   * ONE workgroup per CU (8 waves) owns a 128-row strip of A for ALL column tiles: the strip's K x 128 panel (<= 96 KB) is
-//     copied into LDS once (every k-tile of it requested up front: one latency) and stays there;
-//   * the weight streams through a ring of NSW 16-KB stages as ONE continuous sequence of k-tiles over all column tiles:
-//     no pipeline drain between column tiles, no per-tile prologue; counted s_waitcnt vmcnt + one raw s_barrier per k-tile;
-//   * the product is taken TRANSPOSED (W rows as the MFMA A operand, in the row order of gemm_skinny.hip, applied on the DMA
-//     SOURCE address so that the LDS image keeps the conflict-free fragment layout): after two 16 x 16 tiles a lane holds 8
-//     CONSECUTIVE output columns of one row -- the epilogue works on 16-byte vectors straight from the accumulators: no LDS
-//     staging, no epilogue barrier, bias from an LDS table, residual / z vectors by inline-asm loads (hipcc would drain the
-//     whole DMA ring with vmcnt(0) in front of the first use of an ordinary load);
-//   * the stores of column tile j drain while the k-tiles of tile j + 1 are multiplied (they retire in order behind the ring's
-//     requests: the waits in front of the next tiles' operands count them in).
+//   * ONE persistent workgroup per CU walks a contiguous RANGE of the launch's 128 x 128 output tiles in strip-major order (all
+//     column tiles of a 128-row strip, then the next strip); the ranges are equal to within one tile, so the launch has no
+//     round quantisation (196 strips x 9 column tiles on 256 CUs: 6.9 tiles each instead of 1 strip for 196 of them);
+//   * the strip's K x 128 panel of A (<= 96 KB) stays in LDS for every column tile of the strip the range covers; when the range
+//     moves on to the next strip each 16-KB k-tile slot is refilled right after its last use, NKT - 1 k-steps before its first
+//     use for the new strip;
+//   * the weight streams through a ring of three 16-KB stages as ONE continuous sequence of k-tiles over all tiles of the
+//     range: no pipeline drain between tiles, no per-tile prologue; counted s_waitcnt vmcnt + one raw s_barrier per k-step;
+//   * ten waves: waves 0-7 multiply (4 x 2 wave tiles of 32 x 64) and store, waves 8-9 only REQUEST the streams.  vmcnt retires
+//     in order per wave: a wave that stores a tile and then waits for a younger LDS-DMA request waits for the acknowledgement of
+//     its stores first (measured on the first version of this kernel, where every wave requested and stored: ~3 us per column
+//     tile).  With the requests on their own waves the multiplying waves never wait for memory inside the loop except for the
+//     residual / z vectors, which are requested one tile period ahead;
+//   * the weight rows of a wave's 64 columns go to LDS in the order n = 4 c + j (LDS row 16 j + c): after the four 16 x 16
+//     products of an accumulator row a lane holds FOUR CONSECUTIVE output columns -- one wave-wide 8-byte store covers 4 rows x
+//     128 contiguous bytes straight from the accumulators: no LDS staging, no epilogue barrier.  (v1 / v2 took the product
+//     transposed for 16-byte vectors: 16 rows x 64 bytes per instruction, 64 cache lines per store instruction through the same
+//     address path the weight stream's requests use -- the stores cost 29 of 47 us: gpurun_out/r4job8/ablate.log.)
+//   * the epilogue of tile j is spread over the first k-steps of tile j + 1 (the accumulators are copied).
 // Same element-wise epilogue expressions and the same k order inside the MFMA as gemm_glds.hip: bit-identical outputs.
-// Stochastic-depth compaction (GemmArgs::perm) as in gemm_glds_pv_kernel: the strip's rows go through the tile's four sample
-// scalars; strips of dropped samples are copy-only.
+// Stochastic-depth compaction (GemmArgs::perm): row maps from an LDS copy of perm; rows of dropped samples are copied by the
+// request waves after their last request.
+#include <type_traits>
+
 #include "gemm_common.h"
 #include "options.h"
 
+// phase ablation for timing probes (tools/r4/build_variant.sh; results are garbage, durations are what is measured):
+// 1 no MFMA | 4 no epilogue stores
+#ifndef ASTAT_ABLATE
+#define ASTAT_ABLATE 0
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 namespace {
 
 constexpr int AS_BM = 128, AS_BN = 128, AS_BK = 64;
-constexpr int AS_KT_BYTES = AS_BM * AS_BK * 2;          // 16 KB: one k-tile image of the A strip = one stage of the W ring
+constexpr int AS_KT_BYTES = AS_BM * AS_BK * 2;          // 16 KB: one k-tile slot of the A strip = one stage of the W ring
+constexpr int AS_NSW = 3;                               // stages of the weight ring
+constexpr int AS_MAXS = 512;                            // samples of the LDS copies of perm / rowscale
+constexpr int AS_NT = 640, AS_NCW = 8;                  // threads; multiplying waves
+constexpr int AS_LW = 8;                                // DMA instructions per request wave and 16-KB k-tile (2 request waves)
 
-// logical row -> row of the operands for the rows of ONE 128-row strip (GemmArgs::perm; see TileRowMap in gemm_glds.hip)
-template <bool MAPPED> struct StripRowMap {
-  int s0, sp0, sp1, sp2, sp3;
-  __device__ __forceinline__ void init(const GemmArgs& p, int m0) {
-    if constexpr (MAPPED) {
-      s0 = (int)__umulhi((unsigned)m0, p.map_magic);
-      const int last = p.M / p.map_T - 1;
-      sp0 = __builtin_amdgcn_readfirstlane(p.perm[min(s0, last)]);
-      sp1 = __builtin_amdgcn_readfirstlane(p.perm[min(s0 + 1, last)]);
-      sp2 = __builtin_amdgcn_readfirstlane(p.perm[min(s0 + 2, last)]);
-      sp3 = __builtin_amdgcn_readfirstlane(p.perm[min(s0 + 3, last)]);
-    }
-  }
-  __device__ __forceinline__ int orow(const GemmArgs& p, int row, int* smp) const {
-    if constexpr (!MAPPED) {
-      if (smp) *smp = row / p.rows_per_scale;
-      return row;
-    } else {
-      const int s = (int)__umulhi((unsigned)row, p.map_magic), d = s - s0;
-      const int lo = d <= 0 ? sp0 : sp1, hi = d == 2 ? sp2 : sp3;
-      const int sm = d <= 1 ? lo : hi;
-      if (smp) *smp = sm;
-      return sm * p.map_T + (row - s * p.map_T);
-    }
-  }
+struct AstatSched {
+  int ntn;            // column tiles per strip
+  int ntiles;         // tiles of the COMPUTED strips (rows [0, Mk) of a mapped launch)
+  int nwg;            // persistent workgroups (== gridDim.x)
+  int copy_row0;      // mapped launch with a residual: rows [copy_row0, M) are copy-only (C = resid); == M otherwise
 };
 
-}  // namespace
+// logical row -> row of the operands (GemmArgs::perm through its LDS copy; identity without a map); *smp: the sample whose
+// DropPath scale applies
+template <bool MAPPED>
+__device__ __forceinline__ int as_orow(const GemmArgs& p, const int* sperm, unsigned rs_magic, int row, int* smp) {
+  if constexpr (!MAPPED) {
+    if (smp) *smp = (int)__umulhi((unsigned)row, rs_magic);
+    return row;
+  } else {
+    const int s = (int)__umulhi((unsigned)row, p.map_magic), sm = sperm[s];
+    if (smp) *smp = sm;
+    return sm * p.map_T + (row - s * p.map_T);
+  }
+}
 
-// NKT = K / 64 k-tiles of the strip resident in LDS; NSW ring stages for the weight stream
-// VEC: the epilogue reads one 16-byte vector per output vector (the residual, or z for act'); AUX: it writes z (act forward)
-template <int NKT, int NSW, bool MAPPED, bool VEC, bool AUX>
-__global__ __launch_bounds__(512) void gemm_astat_kernel(GemmArgs p) {
-  constexpr int ROWB = 128, L = 2;                     // bytes per LDS row; DMA instructions per wave and 16-KB k-tile
-  constexpr int NST = 4 * (AUX ? 2 : 1);               // 16-byte store instructions per wave and column tile
+// The residual / z vectors of a tile land in FIXED registers v152 .. v167 that the compiler never allocates (the kernel is
+// compiled with amdgpu_num_vgpr(152); the clobber lists below make the kernel descriptor count 168 = three waves per SIMD):
+// requested by inline asm, used one tile period later behind a hand-counted s_waitcnt.  Why not compiler-visible registers:
+//   * as ordinary loads hipcc waits vmcnt(0) in front of every store of the loop (its bookkeeping gives up at the loop header:
+//     ISA of the first v3 build) -- the acknowledgement of the stores just issued, ~1 us per k-step;
+//   * as inline-asm OUTPUT operands the compiler believes the registers hold their value when the asm statement ends and is free
+//     to copy them -- it did: a v_mov of the destination pair in front of the hand-written wait (ISA of the second build).
+constexpr int AS_EV0 = 152;
+#define AS_EV_CLOBBERS "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+template <int V> __device__ __forceinline__ void as_request(int byte_off, const bf16* base) {
+  asm volatile("global_load_dwordx2 v[%2:%3], %0, %1" ::"v"(byte_off), "s"(base), "i"(AS_EV0 + 2 * V), "i"(AS_EV0 + 2 * V + 1)
+               : "memory", AS_EV_CLOBBERS);
+}
+// wait until at most N younger memory operations of this wave are outstanding, then read vector V
+template <int V, int N> __device__ __forceinline__ u32x2 as_take() {
+  unsigned lo, hi;
+  asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, v[%3]\n\tv_mov_b32 %1, v[%4]" : "=v"(lo), "=v"(hi) : "i"(N), "i"(AS_EV0 + 2 * V), "i"(AS_EV0 + 2 * V + 1) : "memory");
+  return u32x2{lo, hi};
+}
+
+// NKT = K / 64 k-tile slots of the strip resident in LDS
+// ACT = GemmArgs::act as a COMPILE-TIME value (a run-time switch is a branch per epilogue vector: the MFMAs of the next tile could not
+// be scheduled into the epilogue's basic blocks); RESID: C += resid (ACT 0 only); AUX: the activation forward also writes z
+template <int NKT, bool MAPPED, int ACT, bool RESID, bool AUX>
+__global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) void gemm_astat_kernel(GemmArgs p, AstatSched sc) {
+  constexpr bool act_fwd = ACT == 1 || ACT == 3, act_bwd = ACT == 2 || ACT == 4;
+  constexpr bool VEC = RESID || act_bwd;               // the epilogue reads one 8-byte vector per output vector (the residual, or z for act')
+  static_assert(!(RESID && ACT != 0) && !(AUX && !act_fwd), "epilogue kinds of the hot path");
+  constexpr int ROWB = 128;                            // bytes per LDS row
+  constexpr int NV = 8;                                // 8-byte vectors per lane and tile: rows (i, r), columns 4 c_ .. 4 c_ + 3
+  constexpr int NST = NV * (AUX ? 2 : 1);              // store instructions per multiplying wave and tile
+  constexpr int SPI = (NV + NKT - 1) / NKT;            // epilogue vectors per k-step
+  static_assert(NKT >= 3 && NKT <= 6, "a refilled A slot needs two k-steps to land; 6 slots + the ring fill the LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char as_smem[];
   unsigned char* const sa = as_smem;                                  // [NKT][128 rows][128 B]
-  unsigned char* const sw = as_smem + NKT * AS_KT_BYTES;              // [NSW][128 rows][128 B]
-  float* const sbias = reinterpret_cast<float*>(as_smem + (NKT + NSW) * AS_KT_BYTES);   // [N]
+  unsigned char* const sw = as_smem + NKT * AS_KT_BYTES;              // [AS_NSW][128 rows][128 B]
+  float* const sbias = reinterpret_cast<float*>(as_smem + (NKT + AS_NSW) * AS_KT_BYTES);   // [N]
+  float* const srs = sbias + p.N;                                     // [AS_MAXS] DropPath scale by sample
+  int* const sperm = reinterpret_cast<int*>(srs + AS_MAXS);           // [AS_MAXS] perm
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;             // 4 x 2 waves of 32 x 64
-  const int c_ = lane & 15, g_ = lane >> 4;
-  const int m0 = blockIdx.x * AS_BM;
   const int live_rows = MAPPED ? p.Mk : p.M;
-  const int ntn = p.N / AS_BN;
+  const int ntn = sc.ntn;
 
-  StripRowMap<MAPPED> rmap;
-  rmap.init(p, m0);
-  bf16* __restrict__ Cout = (bf16*)p.C;
-  const bf16* __restrict__ resid = (const bf16*)p.resid;
+  // ---- this workgroup's tile range.  Workgroup `did` lands on XCD did & 7: each XCD gets a contiguous band of ranges (neighbours
+  // share a strip of A through its L2)
+  const int did = blockIdx.x, nwg = sc.nwg;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = did & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int tq = sc.ntiles / nwg, trem = sc.ntiles - tq * nwg;
+  const int t0 = lid * tq + min(lid, trem), t1 = t0 + tq + (lid < trem ? 1 : 0);
+  const int Q = (t1 - t0) * NKT;                         // k-steps of this workgroup
 
-  if (MAPPED && m0 >= live_rows) {
-    // copy-only strip of a mapped launch: the rows of DROPPED samples: C = resid, no operands touched
-    if (resid != nullptr) {
-      const int vrow = p.N >> 3;
-      for (int v = threadIdx.x; v < AS_BM * vrow; v += 512) {
-        const int lr = v / vrow, cv = v - lr * vrow;
-        if (m0 + lr < p.M) {
-          const int64_t off = (int64_t)rmap.orow(p, m0 + lr, nullptr) * p.ldc + cv * 8;
-          store8<bf16>(Cout + off, load8<bf16>(resid + off));
+  // ---- small tables: bias, DropPath scales, the sample order
+  const int nsamp = MAPPED ? p.M / p.map_T : (p.rowscale ? (p.M + p.rows_per_scale - 1) / p.rows_per_scale : 1);    // (no scales: srs[0] = 1)
+  for (int i = threadIdx.x; i < p.N; i += AS_NT) sbias[i] = p.bias ? p.bias[i] : 0.f;
+  for (int i = threadIdx.x; i < nsamp; i += AS_NT) {
+    srs[i] = p.rowscale ? p.rowscale[i] : 1.f;
+    if constexpr (MAPPED) sperm[i] = p.perm[i];
+  }
+  const unsigned rs_magic = p.rowscale ? (unsigned)((0x100000000ull + (unsigned)p.rows_per_scale - 1) / (unsigned)p.rows_per_scale) : 0u;
+  __syncthreads();                                        // (nothing is in flight yet: an ordinary barrier)
+
+  const int lr = lane >> 3, slot = lane & 7;
+  int tn = t0 % ntn, strip = t0 / ntn;
+  if (wave >= AS_NCW) {
+    // =================================================================== the two request waves
+    const int lw = wave - AS_NCW;
+    if (Q > 0) {
+      // W: LDS row R of a 128-column tile <- weight row 64 (R >> 6) + 4 (R & 15) + ((R >> 4) & 3); XOR swizzle of the 16-byte chunk by
+      // the LDS row (applied on the source address: global_load_lds writes lane-linear)
+      const bf16* wsrc[AS_LW];
+#pragma unroll
+      for (int j = 0; j < AS_LW; ++j) {
+        const int r = lw * 64 + j * 8 + lr;
+        const int n = 64 * (r >> 6) + 4 * (r & 15) + ((r >> 4) & 3);
+        wsrc[j] = (const bf16*)p.B + (int64_t)n * p.ldb + ((slot ^ (r & 7)) << 3);
+      }
+      const int64_t wtile = (int64_t)AS_BN * p.ldb;       // elements between column tiles of W
+      auto issue_w = [&](int tnw, int kt, int stage) {
+#pragma unroll
+        for (int j = 0; j < AS_LW; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[j] + tnw * wtile + kt * AS_BK),
+                                           (lds_void_t*)(sw + stage * AS_KT_BYTES + (lw * 64 + j * 8) * ROWB), 16, 0, 0);
+      };
+      // A refill: LDS row r <- row r of the NEXT strip (row map applied; rows past the computed ones read the last one)
+      int aoff[AS_LW];                                    // element offsets of the next strip's rows (set when its refill starts)
+      auto issue_a = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < AS_LW; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)((const bf16*)p.A + aoff[j] + kt * AS_BK),
+                                           (lds_void_t*)(sa + kt * AS_KT_BYTES + (lw * 64 + j * 8) * ROWB), 16, 0, 0);
+      };
+      // weight k-tile q + 2 is requested in k-step q
+      int tnw = tn, ktw = 0, stw = 0;
+      auto advance_w = [&]() {
+        ktw += 1;
+        if (ktw == NKT) { ktw = 0; tnw = tnw + 1 == ntn ? 0 : tnw + 1; }
+        stw = stw + 1 == AS_NSW ? 0 : stw + 1;
+      };
+      issue_w(tnw, ktw, stw); advance_w();
+      if (Q > 1) { issue_w(tnw, ktw, stw); advance_w(); }
+      int pend = Q > 1 ? AS_LW : 0;                       // requests that may stay in flight at the next wait (younger than the k-tile it needs)
+      bool refill_prev = false;                           // the k-step before this one read its A slot for the last time
+      int q = 0;
+      for (int t = t0; t < t1; ++t) {
+        const bool last_of_strip = tn == ntn - 1 && t + 1 < t1;
+        if (last_of_strip) {
+#pragma unroll
+          for (int j = 0; j < AS_LW; ++j) {
+            const int r = lw * 64 + j * 8 + lr;
+            const int row = as_orow<MAPPED>(p, sperm, rs_magic, min((strip + 1) * AS_BM + r, live_rows - 1), nullptr);
+            aoff[j] = row * (int)p.lda + ((slot ^ (r & 7)) << 3);
+          }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt, ++q) {
+          // k-tile q has landed when at most `pend` younger requests are outstanding (nothing else is ever requested here)
+          if (pend == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (pend == AS_LW) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AS_LW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * AS_LW) : "memory");
+          __builtin_amdgcn_s_barrier();                     // barrier q: k-tile q is visible; every wave is past its reads of k-step q - 1
+          pend = 0;
+          if (refill_prev) { issue_a(kt == 0 ? NKT - 1 : kt - 1); pend += AS_LW; }
+          if (q + 2 < Q) { issue_w(tnw, ktw, stw); advance_w(); pend += AS_LW; }
+          refill_prev = last_of_strip;
+        }
+        tn += 1;
+        if (tn == ntn) { tn = 0; strip += 1; }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ---- rows of dropped samples of a mapped launch: C = resid (their strips are not in any tile range)
+    if constexpr (MAPPED) {
+      const bf16* __restrict__ rs = (const bf16*)p.resid;
+      bf16* __restrict__ cd = (bf16*)p.C;
+      if (rs != nullptr && sc.copy_row0 < p.M) {
+        const int vrow = p.N >> 3, nvec = (p.M - sc.copy_row0) * vrow;
+        for (int v = (lid * 2 + lw) * 64 + lane; v < nvec; v += nwg * 128) {
+          const int lrw = v / vrow, cv = v - lrw * vrow;
+          const int64_t off = (int64_t)as_orow<MAPPED>(p, sperm, rs_magic, sc.copy_row0 + lrw, nullptr) * p.ldc + cv * 8;
+          store8<bf16>(cd + off, load8<bf16>(rs + off));
         }
       }
     }
     return;
   }
 
-  // ---- rows this lane finishes: row(i) = m0 + 32 wm + 16 i + c_ (both 16-row tiles of the wave), columns 8 g_ .. 8 g_ + 7 of each
-  // 32-column pair.  DropPath scale per row, requested before any DMA (ordinary loads: nothing is in flight yet)
-  int orow_[2];
-  float rsc[2];
-  bool rok[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lrow = m0 + wm * 32 + i * 16 + c_;
-    rok[i] = lrow < p.M;
-    int smp;
-    orow_[i] = rmap.orow(p, rok[i] ? lrow : m0, &smp);
-    rsc[i] = (rok[i] && p.rowscale) ? p.rowscale[smp] : 1.f;
-  }
-  for (int i = threadIdx.x; i < p.N; i += 512) sbias[i] = p.bias ? p.bias[i] : 0.f;
-  // every ordinary load above must have RETURNED before the first DMA request: consumed inside the k-tile loop, hipcc would
-  // otherwise put s_waitcnt vmcnt(0) -- the whole ring -- in front of that use in every epilogue
-  asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(rsc[0]), "v"(rsc[1]), "v"(orow_[0]), "v"(orow_[1]) : "memory");
-  const bool full_strip = m0 + AS_BM <= p.M;            // every lane issues every store: the counted waits may rely on NST
+  // ======================================================================= the eight multiplying waves
+  if (Q == 0) return;
+  const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves of 32 x 64
+  const int c_ = lane & 15, g_ = lane >> 4;
 
-  // ---- DMA source pointers.  A: LDS row r <- strip row r (row map applied; rows past the computed ones read the last one).
-  // W: LDS row R of a 128-column tile <- weight row 32 (R >> 5) + 8 ((R & 15) >> 2) + 4 ((R >> 4) & 1) + (R & 3): the operand-row
-  // order of the transposed product (see the header); XOR swizzle of the 16-byte chunk by the LDS row on both.
-  const int lr = lane >> 3, slot = lane & 7;
-  const bf16* asrc[2];
-  const bf16* wsrc[2];
+  // the first strip's A panel, every k-tile now (the only requests these waves ever make besides the epilogue vectors)
+  {
+    int aoff0[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = wave * 16 + j * 8 + lr;
-    asrc[j] = (const bf16*)p.A + (int64_t)rmap.orow(p, min(m0 + r, live_rows - 1), nullptr) * p.lda + ((slot ^ (r & 7)) << 3);
-    const int n = 32 * (r >> 5) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3);
-    wsrc[j] = (const bf16*)p.B + (int64_t)n * p.ldb + ((slot ^ (r & 7)) << 3);
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave * 16 + j * 8 + lr;
+      const int row = as_orow<MAPPED>(p, sperm, rs_magic, min(strip * AS_BM + r, live_rows - 1), nullptr);
+      aoff0[j] = row * (int)p.lda + ((slot ^ (r & 7)) << 3);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)((const bf16*)p.A + aoff0[j] + kt * AS_BK),
+                                         (lds_void_t*)(sa + kt * AS_KT_BYTES + (wave * 16 + j * 8) * ROWB), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  const int64_t wtile = (int64_t)AS_BN * p.ldb;         // elements between column tiles of W
-  auto issue_a = [&](int kt) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[j] + kt * AS_BK), (lds_void_t*)(sa + kt * AS_KT_BYTES + (wave * 16 + j * 8) * ROWB), 16, 0, 0);
+
+  // ---- rows this lane finishes: row(i, r) = strip * 128 + 32 wm + 16 i + 4 g_ + r, columns n0 + 64 wn + 4 c_ .. + 3 (v = 4 i + r).
+  // Element offset of the row in C / resid / z (all share ldc), its DropPath scale and whether it exists are recomputed per
+  // vector from the strip number (a handful of VALU instructions and, in a mapped launch, one LDS read behind the MFMAs): kept in
+  // registers they are 17 per lane, and the kernel has 168 (three waves on two of the SIMDs).
+  const bf16* __restrict__ vsrc = VEC ? (act_bwd ? (const bf16*)p.aux_in : (const bf16*)p.resid) : nullptr;
+  // residual / z vectors of a tile: eight 8-byte loads per lane, ONE register pair per vector (as_request / as_take): vector v of
+  // tile j + 1 is requested right behind the store of vector v of tile j, which consumed the pair, and used one tile period later.
+  // vmcnt retires in order; between the request of a vector and its use this wave issues the (store, request) pairs of the 7 other
+  // vectors = 14 operations (second tile of a range: the first tile's vectors were requested back to back, 7 - v requests + 2 v
+  // operations; after the loop: the last period's pairs + v stores).  The waits below allow 7 + v (in the loop) and 7 (behind it)
+  // outstanding operations: exact for the second tile, a little early afterwards (operations issued >= 4 k-steps ago).
+  auto off_of = [&](int m0, int v, float* rs) {
+    const int lrow = m0 + wm * 32 + (v >> 2) * 16 + g_ * 4 + (v & 3);      // (< M: whole strips only, gemm_astat_ok)
+    int smp = 0;
+    const int row = as_orow<MAPPED>(p, sperm, rs_magic, lrow, &smp);
+    if (rs) *rs = srs[smp];
+    return row * (int)p.ldc + wn * 64 + c_ * 4;
   };
-  auto issue_w = [&](int tn, int kt, int stage) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[j] + tn * wtile + kt * AS_BK), (lds_void_t*)(sw + stage * AS_KT_BYTES + (wave * 16 + j * 8) * ROWB), 16, 0, 0);
+  auto request_vec = [&](int v, int off, int n0) {
+    const bf16* base = vsrc + n0;
+    switch (v) {
+      case 0: as_request<0>(off * 2, base); break;
+      case 1: as_request<1>(off * 2, base); break;
+      case 2: as_request<2>(off * 2, base); break;
+      case 3: as_request<3>(off * 2, base); break;
+      case 4: as_request<4>(off * 2, base); break;
+      case 5: as_request<5>(off * 2, base); break;
+      case 6: as_request<6>(off * 2, base); break;
+      default: as_request<7>(off * 2, base); break;
+    }
+  };
+  auto take_vec = [&](int v, bool in_loop) -> u32x2 {
+    if (in_loop) {
+      switch (v) {
+        case 0: return as_take<0, 7>();
+        case 1: return as_take<1, 8>();
+        case 2: return as_take<2, 9>();
+        case 3: return as_take<3, 10>();
+        case 4: return as_take<4, 11>();
+        case 5: return as_take<5, 12>();
+        case 6: return as_take<6, 13>();
+        default: return as_take<7, 14>();
+      }
+    }
+    switch (v) {
+      case 0: return as_take<0, 7>();
+      case 1: return as_take<1, 7>();
+      case 2: return as_take<2, 7>();
+      case 3: return as_take<3, 7>();
+      case 4: return as_take<4, 7>();
+      case 5: return as_take<5, 7>();
+      case 6: return as_take<6, 7>();
+      default: return as_take<7, 7>();
+    }
   };
 
-  // ---- prologue: the whole A strip and the first NSW - 1 weight k-tiles, in the order they are needed
-  const int T = ntn * NKT;                              // k-tiles of the weight stream
-  issue_a(0);
-  issue_w(0, 0, 0);
-#pragma unroll
-  for (int kt = 1; kt < NKT; ++kt) {
-    issue_a(kt);
-    if (kt < NSW - 1) issue_w(kt / NKT, kt % NKT, kt);
-  }
-#pragma unroll
-  for (int t = NKT; t < NSW - 1; ++t)                   // (NSW - 1 > NKT only for very short contractions)
-    if (t < T) issue_w(t / NKT, t % NKT, t);
-  // Requests in flight now, oldest first: A0 W0 A1 [W1] A2 [W2] ... ; k-tile t of the loop below needs A(t) (t < NKT) and W(t)
-
-  f32x4 acc[2][4];
+  f32x4 acc[2][4], accp[2][4];                          // the tile being multiplied / the finished one being stored
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accp[i][j] = acc[i][j]; }
+  bf16* __restrict__ Cout = (bf16*)p.C;
+  bf16* __restrict__ aux_out = (bf16*)p.aux_out;
 
-  int tn = 0, kt = 0, stage = 0;
-  for (int t = 0; t < T; ++t) {
-    // ---- wait for the operands of k-tile t.  vmcnt retires in order; what may stay in flight is exactly what was requested
-    // AFTER them.  First pass (t < NKT): the A k-tiles and weight k-tiles requested behind A(t) / W(t) in the prologue.
-    // Steady state: weight k-tiles t + 1 .. t + NSW - 2 (L requests each) and, in the NSW - 1 iterations after an epilogue, that
-    // epilogue's NST stores.  A partial last strip (some lanes store nothing) waits for everything instead.
-    static_assert(NSW == 3 && NKT >= 2, "the counted waits below are written out for a 3-stage ring");
-    if (t == 0) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(L * (NKT - 1) + L) : "memory");          // behind W(0): A(1..NKT-1) and W(1)
-    } else if (t == T - 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  // nothing was requested behind the last k-tile
-    } else if (full_strip && t >= NKT && kt < NSW - 1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(L + NST) : "memory");                    // W(t + 1) and the last epilogue's stores
-    } else {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(L) : "memory");                          // W(t + 1) (1 <= t < NKT: the A k-tiles too, once)
-    }
-    __builtin_amdgcn_s_barrier();
-    // the stage that k-tile t - 1 occupied is free (every wave is past its reads): request k-tile t + NSW - 1 into it
-    if (t + NSW - 1 < T) {
-      int tnq = tn, ktq = kt + NSW - 1;
-      if (ktq >= NKT) { ktq -= NKT; tnq += 1; }
-      issue_w(tnq, ktq, stage == 0 ? NSW - 1 : stage - 1);
-    }
-    const unsigned char* la = sa + kt * AS_KT_BYTES;
-    const unsigned char* lb = sw + stage * AS_KT_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Vec8<bf16> fa[2], fb[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = wm * 32 + i * 16 + c_;
-        fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wn * 64 + j * 16 + c_;
-        fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mma16(fb[j], fa[i], acc[i][j]);          // TRANSPOSED: W rows x A rows
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // the FINISHED tile (the one in accp)
+  int n0p = 0, strip_p = -1;
 
-    if (kt == NKT - 1) {
-      // ---- epilogue of column tile tn, straight from the accumulators:
-      //   acc[i][2 pr + h][r] = (A . W^T)[row(i)][n0 + 64 wn + 32 pr + 8 g_ + 4 h + r]
-      const int n0 = tn * AS_BN;
-      bf16x8 ev[2][2];
-      if constexpr (VEC) {
-        const bf16* __restrict__ vsrc = (p.act == 2 || p.act == 4) ? (const bf16*)p.aux_in : resid;
-        const bf16* q00 = vsrc + (int64_t)orow_[0] * p.ldc + n0 + wn * 64 + g_ * 8;
-        const bf16* q10 = vsrc + (int64_t)orow_[1] * p.ldc + n0 + wn * 64 + g_ * 8;
-        // four 16-byte loads hipcc does not see (it would wait vmcnt(0) for an ordinary load AND not know about it in the counted
-        // waits above) + their wait, in ONE asm block: the results are valid when it ends.  (v1: vmcnt(0) also waits for the
-        // ring's youngest request, one k-tile old.)
-        asm volatile(
-            "global_load_dwordx4 %0, %4, off\n\t"
-            "global_load_dwordx4 %1, %4, off offset:64\n\t"
-            "global_load_dwordx4 %2, %5, off\n\t"
-            "global_load_dwordx4 %3, %5, off offset:64\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(ev[0][0]), "=&v"(ev[0][1]), "=&v"(ev[1][0]), "=&v"(ev[1][1])
-            : "v"(q00), "v"(q10)
-            : "memory");
+  // ---- vector v = (i, r) of the finished tile: accp[i][j][r] = (A . W^T)[row(i, r)][n0p + 64 wn + 4 c_ + j]
+  auto finish_vec = [&](int v, bool in_loop) {
+    const int i = v >> 2, r = v & 3;
+    float val[4], rsv;
+    const int off = off_of(strip_p * AS_BM, v, &rsv);
+    const f32x4 bia = *reinterpret_cast<const f32x4*>(sbias + n0p + wn * 64 + c_ * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) val[j] = accp[i][j][r] + bia[j];
+    bf16x4 evv = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    if constexpr (VEC) evv = __builtin_bit_cast(bf16x4, take_vec(v, in_loop));
+    bf16* const dst = Cout + n0p + off;
+    if constexpr (act_fwd) {
+      bf16x4 z;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] = (bf16)val[j];
+      if constexpr (ACT == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = silu_f((float)z[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = gelu_f((float)z[j]);
       }
-      const bool act_fwd = p.act == 1 || p.act == 3, act_bwd = p.act == 2 || p.act == 4;
-      bf16* __restrict__ aux_out = (bf16*)p.aux_out;
+      if constexpr (AUX) *reinterpret_cast<bf16x4*>(aux_out + n0p + off) = z;
+    } else if constexpr (act_bwd) {
+      if constexpr (ACT == 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 4; ++j) val[j] *= dsilu_f((float)evv[j]);
+      } else {
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const int col = n0 + wn * 64 + pr * 32 + g_ * 8;
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sbias + col), b1 = *reinterpret_cast<const f32x4*>(sbias + col + 4);
-          float val[8];
+        for (int j = 0; j < 4; ++j) val[j] *= dgelu_f((float)evv[j]);
+      }
+    }
+    bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { val[r] = acc[i][2 * pr][r] + b0[r]; val[4 + r] = acc[i][2 * pr + 1][r] + b1[r]; }
-          const int64_t off = (int64_t)orow_[i] * p.ldc + col;
-          Vec8<bf16> evv;
-          if constexpr (VEC) evv.v = ev[i][pr]; else evv = vec8_zero<bf16>();
-          if (act_fwd) {
-            Vec8<bf16> z;
+    for (int j = 0; j < 4; ++j) {
+      const float rvj = (VEC && !act_bwd) ? (float)evv[j] : 0.f;      // (a residual next to act' is not routed here: gemm_astat_ok)
+      o[j] = (bf16)(val[j] * rsv + rvj);
+    }
+    if (!(ASTAT_ABLATE & 4) || (float)o[0] == 12345.678f) *reinterpret_cast<bf16x4*>(dst) = o;
+  };
+
+  if constexpr (VEC) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) z.set(e, val[e]);
-            if (p.act == 1) {
+    for (int v = 0; v < NV; ++v) request_vec(v, off_of(strip * AS_BM, v, nullptr), tn * AS_BN);
+  }
+  int stage = 0;
+  // one tile period: NKT k-steps of tile (strip, tn); EPI: with the previous tile's epilogue behind the MFMAs (a compile-time flag:
+  // as a run-time branch it splits every k-step into basic blocks and the MFMAs cannot be scheduled among the epilogue's VALU work)
+  auto tile_period = [&](auto EPI) {
+    const int n0 = tn * AS_BN;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) val[e] = silu_f(z.get(e));
-            } else {
+    for (int kt = 0; kt < NKT; ++kt) {
+      __builtin_amdgcn_s_barrier();                       // barrier q (see the request waves)
+      const unsigned char* la = sa + kt * AS_KT_BYTES;
+      const unsigned char* lb = sw + stage * AS_KT_BYTES;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) val[e] = gelu_f(z.get(e));
-            }
-            if constexpr (AUX) { if (rok[i]) store8<bf16>(aux_out + off, z); }
-          } else if (act_bwd) {
-            if (p.act == 2) {
+      for (int ks = 0; ks < 2; ++ks) {
+        Vec8<bf16> fa[2], fb[4];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) val[e] *= dsilu_f(evv.get(e));
-            } else {
+        for (int i = 0; i < 2; ++i) {
+          const int r = wm * 32 + i * 16 + c_;
+          fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
+        }
 #pragma unroll
-              for (int e = 0; e < 8; ++e) val[e] *= dgelu_f(evv.get(e));
-            }
-          }
-          Vec8<bf16> rv = evv;
-          if (act_bwd) rv = vec8_zero<bf16>();             // (a residual next to act' is not routed here: astat_ok)
-          Vec8<bf16> o;
+        for (int j = 0; j < 4; ++j) {
+          const int r = wn * 64 + j * 16 + c_;
+          fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
+        }
+        if (!(ASTAT_ABLATE & 1)) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o.set(e, val[e] * rsc[i] + rv.get(e));
-          if (rok[i]) store8<bf16>(Cout + off, o);
-          acc[i][2 * pr] = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[i][2 * pr + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
+        } else {
+          asm volatile("" ::"v"(fa[0].v), "v"(fa[1].v), "v"(fb[0].v), "v"(fb[1].v), "v"(fb[2].v), "v"(fb[3].v));
         }
       }
-      kt = 0;
-      tn += 1;
-    } else {
-      kt += 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the k-step are done before it reaches the next barrier
+
+      // ---- behind the MFMAs: this k-step's share of the PREVIOUS tile's epilogue, each vector followed by this tile's request
+      if constexpr (decltype(EPI)::value) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          if (v / SPI != kt) continue;
+          finish_vec(v, true);
+          if constexpr (VEC) request_vec(v, off_of(strip * AS_BM, v, nullptr), n0);
+        }
+      }
+      if (kt == NKT - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { accp[i][j] = acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        strip_p = strip;
+        n0p = n0;
+      }
+      stage = stage + 1 == AS_NSW ? 0 : stage + 1;
     }
-    stage = stage + 1 == NSW ? 0 : stage + 1;
-  }
+    tn += 1;
+    if (tn == ntn) { tn = 0; strip += 1; }
+  };
+  tile_period(std::false_type{});
+  for (int t = t0 + 1; t < t1; ++t) tile_period(std::true_type{});
+  // ---- the last tile's epilogue
+#pragma unroll
+  for (int v = 0; v < NV; ++v) finish_vec(v, false);
 }
 
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------------------------ host side
-static constexpr int AS_NSW = 3;
-static size_t astat_smem(int N, int K) { return (size_t)(K / 64 + AS_NSW) * AS_KT_BYTES + (size_t)N * 4; }
+static size_t astat_smem(int N, int K) { return (size_t)(K / 64 + AS_NSW) * AS_KT_BYTES + (size_t)N * 4 + (size_t)AS_MAXS * 8; }
+
+static int astat_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = v;
+  }
+  return n;
+}
 
 bool gemm_astat_ok(const GemmArgs& a) {
   const int mode = vtx_opt(VTX_OPT_GEMM_ASTAT);
   if (mode == 0) return false;
-  if (a.K % 64 != 0 || a.K < 128 || a.K > 384 || a.N % 128 != 0 || a.N > 4096) return false;
+  if (a.K % 64 != 0 || a.K < 192 || a.K > 384 || a.N % 128 != 0 || a.N < 256 || a.N > 4096) return false;
   if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
+  if ((int64_t)a.M * a.ldc >= (1ll << 30) || (int64_t)a.M * a.lda >= (1ll << 30)) return false;    // 32-bit byte offsets
   if (a.kscale != nullptr || a.ksum_out != nullptr) return false;
   if ((a.act == 2 || a.act == 4) && a.resid != nullptr) return false;     // (no hot-path launch has both)
   if ((a.act == 1 || a.act == 3) && a.resid != nullptr) return false;
   const long rows = a.perm != nullptr ? a.Mk : a.M;
-  if (rows < 128 * 96 && mode != 2) return false;                          // fewer strips than ~3/8 of the CUs: the tiled kernels' job
-  if (a.perm != nullptr && (3 * a.map_T < 126 || (a.rowscale != nullptr && a.rows_per_scale != a.map_T))) return false;
-  if (a.perm != nullptr && a.Mk < a.M && a.resid == nullptr) return false;
+  if (rows <= 0) return false;
+  const long tiles = (rows + AS_BM - 1) / AS_BM * (a.N / AS_BN);
+  if (tiles < 2L * astat_cus() && mode != 2) return false;                 // under two tiles per CU: the tiled kernels' job
+  if (a.M % AS_BM != 0) return false;                                      // whole strips: every lane stores every vector
+  if (a.rowscale != nullptr && (a.rows_per_scale <= 0 || (a.M + a.rows_per_scale - 1) / a.rows_per_scale > AS_MAXS)) return false;
+  if (a.perm != nullptr) {
+    if (a.map_T <= 0 || a.M % a.map_T != 0 || a.M / a.map_T > AS_MAXS) return false;
+    if (a.rowscale != nullptr && a.rows_per_scale != a.map_T) return false;
+    if (a.Mk < a.M && a.resid == nullptr) return false;
+  }
   return astat_smem(a.N, a.K) <= 160 * 1024;
 }
 
-template <int NKT, bool MAPPED, bool VEC, bool AUX> static int astat_launch_k(const GemmArgs& a, hipStream_t st) {
+template <int NKT, bool MAPPED, int ACT, bool RESID, bool AUX> static int astat_launch_k(const GemmArgs& a, hipStream_t st) {
   const size_t smem = astat_smem(a.N, a.K);
-  auto kern = gemm_astat_kernel<NKT, AS_NSW, MAPPED, VEC, AUX>;
+  auto kern = gemm_astat_kernel<NKT, MAPPED, ACT, RESID, AUX>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3((a.M + AS_BM - 1) / AS_BM), dim3(512), smem, st, a);
+  const int rows = MAPPED ? a.Mk : a.M;
+  const int nstrips = (rows + AS_BM - 1) / AS_BM;
+  AstatSched sc;
+  sc.ntn = a.N / AS_BN;
+  sc.ntiles = nstrips * sc.ntn;
+  sc.nwg = sc.ntiles < astat_cus() ? sc.ntiles : astat_cus();
+  sc.copy_row0 = (MAPPED && a.resid != nullptr && nstrips * AS_BM < a.M) ? nstrips * AS_BM : a.M;
+  hipLaunchKernelGGL(kern, dim3(sc.nwg), dim3(AS_NT), smem, st, a, sc);
   return vtx_check_launch();
 }
 template <int NKT, bool MAPPED> static int astat_launch_m(const GemmArgs& a, hipStream_t st) {
-  const bool vec = a.resid != nullptr || a.act == 2 || a.act == 4;
-  const bool aux = (a.act == 1 || a.act == 3) && a.aux_out != nullptr;
-  if (vec) return astat_launch_k<NKT, MAPPED, true, false>(a, st);
-  if (aux) return astat_launch_k<NKT, MAPPED, false, true>(a, st);
-  return astat_launch_k<NKT, MAPPED, false, false>(a, st);
+  const bool aux = a.aux_out != nullptr;
+  switch (a.act) {
+    case 0: return a.resid != nullptr ? astat_launch_k<NKT, MAPPED, 0, true, false>(a, st) : astat_launch_k<NKT, MAPPED, 0, false, false>(a, st);
+    case 1: return aux ? astat_launch_k<NKT, MAPPED, 1, false, true>(a, st) : astat_launch_k<NKT, MAPPED, 1, false, false>(a, st);
+    case 2: return astat_launch_k<NKT, MAPPED, 2, false, false>(a, st);
+    case 3: return aux ? astat_launch_k<NKT, MAPPED, 3, false, true>(a, st) : astat_launch_k<NKT, MAPPED, 3, false, false>(a, st);
+    case 4: return astat_launch_k<NKT, MAPPED, 4, false, false>(a, st);
+    default: return VTX_ERR_SHAPE;
+  }
 }
 template <int NKT> static int astat_launch_n(const GemmArgs& a, hipStream_t st) {
   return a.perm != nullptr ? astat_launch_m<NKT, true>(a, st) : astat_launch_m<NKT, false>(a, st);
@@ -323,7 +488,6 @@ template <int NKT> static int astat_launch_n(const GemmArgs& a, hipStream_t st) 
 
 int gemm_astat_launch(const GemmArgs& a, hipStream_t st) {
   switch (a.K / 64) {
-    case 2: return astat_launch_n<2>(a, st);
     case 3: return astat_launch_n<3>(a, st);
     case 4: return astat_launch_n<4>(a, st);
     case 5: return astat_launch_n<5>(a, st);
