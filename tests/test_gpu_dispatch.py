@@ -30,17 +30,30 @@ def _mm64(a, b_t):
     return a.double() @ b_t.double().t()
 
 
-BIG128 = "gemm_glds_pv_kernel<128, 2, false>"            # 128 x 128 tiles, 4 x 2 waves, wave-private epilogue (the benchmark default)
+BIG128 = "gemm_glds_pv_kernel<128, 2, false>"            # 128 x 128 tiles, 4 x 2 waves, wave-private epilogue (the benchmark default for K > 384)
+
+
+def _bench_kernel(K, astat):
+    """The kernel the benchmark runs these shapes on: round 4's A-stationary persistent kernel for 192 <= K <= 384 (option GEMM_ASTAT,
+    default 1), the tiled LDS-DMA kernel otherwise."""
+    return f"gemm_astat_kernel<{K // 64}, false, ...>" if (astat and 192 <= K <= 384) else BIG128
+
+
+@pytest.fixture(params=[1, 0], ids=["astat", "tiled"])
+def astat(request):
+    from vtx import options
+    with options.override(GEMM_ASTAT=request.param):
+        yield request.param
 
 
 # ------------------------------------------------------------------ the 128-row LDS-DMA GEMM with every fused epilogue
 @pytest.mark.parametrize("M,N,K,T", [(25088, 1536, 384, 196),      # Swin-S stage-3 fc1 / fc2-dgrad, B = 128
                                      (50432, 1536, 384, 197),      # ViT-S/16 fc1 / fc2-dgrad, B = 256
                                      (100352, 768, 192, 784)])     # Swin-S stage-2 fc1 / fc2-dgrad
-def test_glds128_silu_and_dsilu_epilogues_vs_oracle(M, N, K, T):
+def test_glds128_silu_and_dsilu_epilogues_vs_oracle(M, N, K, T, astat):
     from vtx import ops
     d = dev()
-    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128, "this shape must dispatch to the benchmark's kernel"
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == _bench_kernel(K, astat), "this shape must dispatch to the benchmark's kernel"
     x = _mk((M, K), 101, BF)
     w1 = _mk((N, K), 102, BF, 0.05)
     b1 = _mk((N,), 103, torch.float32, 0.1)
@@ -56,7 +69,7 @@ def test_glds128_silu_and_dsilu_epilogues_vs_oracle(M, N, K, T):
     keep = (torch.rand(B, generator=torch.Generator().manual_seed(104)) < 0.8).float() / 0.8
     dy = _mk((M, K), 105, BF)
     w2t = _mk((N, K), 106, BF, 0.05)              # the transposed weight copy [in = N][out = K] the dgrad kernel reads
-    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == _bench_kernel(K, astat)
     dz = ops.gemm(dy.to(d), w2t.to(d), 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep.to(d), rows_per_scale=T)
     s = torch.sigmoid(zq)
     dzr = keep.double().repeat_interleave(T)[:, None] * _mm64(dy, w2t) * (s * (1 + zq * (1 - s)))
@@ -65,10 +78,10 @@ def test_glds128_silu_and_dsilu_epilogues_vs_oracle(M, N, K, T):
 
 @pytest.mark.parametrize("M,N,K,T", [(50432, 384, 1536, 197),      # ViT-S/16 fc2 + DropPath + residual, B = 256
                                      (50432, 384, 384, 197)])      # ViT-S/16 attention projection
-def test_glds128_droppath_residual_epilogue_vs_oracle(M, N, K, T):
+def test_glds128_droppath_residual_epilogue_vs_oracle(M, N, K, T, astat):
     from vtx import ops
     d = dev()
-    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == _bench_kernel(K, astat)
     hh = _mk((M, K), 111, BF)
     w = _mk((N, K), 112, BF, 0.05)
     b = _mk((N,), 113, torch.float32, 0.1)
@@ -95,11 +108,16 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
         y = ops.gemm(x, w, 0, bias=b, resid=res, rowscale=keep, rows_per_scale=T)
         return h, z, dz, y
 
-    base = run()
-    assert options.get("GLDS_EPI") == 1 and ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    with options.override(GEMM_ASTAT=0):
+        base = run()
+        assert options.get("GLDS_EPI") == 1 and ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == BIG128
+    # (round 4) the A-stationary persistent kernel: plain product with permuted weight rows, epilogue straight from the accumulators
+    assert options.get("GEMM_ASTAT") == 1 and ops.gemm_kernel_name(BF, N, 0, K=K, M=M).startswith("gemm_astat_kernel<6, false")
+    for a, g, name in zip(base, run(), ("h", "z", "dz", "y")):
+        assert torch.equal(a, g), f"{name} differs between the tiled and the A-stationary kernel"
     for kw in (dict(GLDS_BM=64), dict(GLDS_BM=128), dict(GLDS_EPI=0), dict(GLDS_EPI=0, GLDS_BM=64), dict(GLDS_EPI=0, GLDS_BM=128),
                dict(GLDS_EPI=0, GLDS_BM=128, GLDS_WAVES=4), dict(GLDS_EPI=0, GLDS_BM=64, GLDS_WAVES=4)):
-        with options.override(**kw):
+        with options.override(GEMM_ASTAT=0, **kw):
             assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) != BIG128 or kw == dict(GLDS_BM=128)
             got = run()
         for a, g, name in zip(base, got, ("h", "z", "dz", "y")):
@@ -418,8 +436,8 @@ def test_one_call_layer_under_no_grad_and_shared_param_backward():
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3)])
-def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, p, monkeypatch):
+@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3), ("swin_astat", 0.45)])
+def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, p, monkeypatch, request):
     """Round 3: with host-drawn DropPath masks every branch of a Swin layer runs over its KEPT samples only (row-mapped
     LayerNorm / LDS-DMA GEMMs / window attention, copy-only tiles for the dropped samples, weight gradients skipping their
     rows: csrc/layer.hip) instead of being computed for all samples and multiplied by 0.  Same masks, same per-row math:
@@ -432,13 +450,23 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
     from vtx.nn import Linear
     d = dev()
     torch.manual_seed(41)
+    nb = 10
+    if family == "swin_astat":
+        # (round 4) batch 32: stage 3 has 49 whole 128-row strips; GEMM_ASTAT = 2 sends its K = 384 GEMMs to the A-stationary kernel at
+        # any row count -- row-mapped (sample table in LDS, copy-only rows by the request waves) in the compacted run, with
+        # DropPath scales and every row computed in the call-by-call run
+        from vtx import options
+        prev = options.get("GEMM_ASTAT")
+        request.addfinalizer(lambda: options.set("GEMM_ASTAT", prev))
+        options.set("GEMM_ASTAT", 2)
+        family, nb = "swin", 32
     if family == "swin":
         model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=(64, 128, 384, 768), dim_head=32,
                                 n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=p).to(d).train()
         for m in model.modules():
             if hasattr(m, "rel_pos"):
                 torch.nn.init.normal_(m.rel_pos.weight, std=0.3)
-        x = torch.randn(10, 3, 224, 224, device=d)
+        x = torch.randn(nb, 3, 224, 224, device=d)
     else:                                                    # global attention (the bf16 fast path takes the sample order too)
         model = VisionTransformer(Linear(384, 16), 224, 16, 4, 384, 6, 1536, 0.0, 0.0, 0.0, p).to(d).train()
         x = torch.randn(10, 3, 224, 224, device=d)
@@ -455,7 +483,7 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
     junk = torch.full((1 << 28,), float("nan"), device=d, dtype=torch.bfloat16)
     del junk
     out_a, g_a = _layer_io(model, x, True, 91, side)
-    assert sum(u is not None and (u[0][1] < 10 or u[1][1] < 10) for u in used) >= 2, "no branch was compacted"
+    assert sum(u is not None and (u[0][1] < nb or u[1][1] < nb) for u in used) >= 2, "no branch was compacted"
     monkeypatch.setattr(VF, "_LAYER_CALL", False)                      # call-by-call: every sample computed, then scaled
     out_b, g_b = _layer_io(model, x, True, 91, side)
     assert torch.isfinite(out_a).all() and all(torch.isfinite(v).all() for v in g_a.values())
@@ -467,6 +495,11 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
         else:
             check(f"compaction: d {k}", g_a[k], g_b[k], 1e-5)
     assert exact >= 10, "the stages without compaction (and the stem / head) must still agree bit for bit"
+    if nb == 32:
+        from vtx import options
+        options.set("GEMM_ASTAT", 0)                                     # ... and the tiled kernels give the same bits
+        out_c, _ = _layer_io(model, x, True, 91, side)
+        assert torch.equal(out_a, out_c)
 
 
 def test_forward_feature_without_a_weight_scope_runs_uncompacted_and_backward_works(monkeypatch):

@@ -318,6 +318,18 @@ def glds_ok(N, K):
     return K % 64 == 0 or (K % 32 == 0 and N % 128 == 0)
 
 
+_ASTAT_CUS = 256          # (MI355X; gemm_astat.hip asks the device)
+
+
+def astat_ok(N, K, M):
+    """Mirrors gemm_astat_ok (gemm_astat.hip) for contiguous bf16 operands: the A-stationary persistent kernel takes C[M, N] over
+    192 <= K <= 384 once a launch has two 128 x 128 tiles per CU (M: the rows a mapped launch computes)."""
+    mode = options.get("GEMM_ASTAT")
+    if not mode or K % 64 or K < 192 or K > 384 or N % 128 or N < 256 or N > 1536 or M <= 0:
+        return False
+    return mode == 2 or ((M + 127) // 128) * (N // 128) >= 2 * _ASTAT_CUS
+
+
 def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False):
     """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip); ``mapped``: the
     row-mapped variant of a compacted branch (M = the rows it computes)."""
@@ -326,6 +338,8 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and skinny_ok(N, K, M, vec) and not mapped:
         return f"gemm_skinny_kernel<{K // 32}>"
+    if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M):
+        return f"gemm_astat_kernel<{K // 64}, {'true' if mapped else 'false'}, ...>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
         force = options.get("GLDS_BM")                                     # mirrors glds_pick_bm in gemm_glds.hip
         if force in (64, 128):
