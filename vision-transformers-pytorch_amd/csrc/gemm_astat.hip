@@ -118,7 +118,7 @@ template <int V, int N> __device__ __forceinline__ u32x2 as_take() {
 // LDS counter costs more than s_barrier: 33.9 vs 29.8 us on the stage-3 qkv forward, 16.3 vs 9.7 us with stores and DMA compiled out.)
 
 #ifndef ASTAT_NT
-#define ASTAT_NT 0
+#define ASTAT_NT 1          // non-temporal stores of C / z: the outputs stream past the L2 that holds the weight panel and the A strips (ViT-S/16 step -2.7 %, Swin-S -0.3 %)
 #endif
 __device__ __forceinline__ void as_store4(bf16* dst, bf16x4 v) {
 #if ASTAT_NT
@@ -460,42 +460,47 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
           if constexpr (VEC) roc[v] = row_entry(strip, v).x;
         }
       }
+      // every fragment of the k-step is requested now, behind the table entries (the LDS answers in order) ...
+      Vec8<bf16> fa[2][2], fb[2][4];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        Vec8<bf16> fa[2], fb[4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int r = wm * 32 + i * 16 + c_;
-          if (!(ASTAT_ABLATE & 8)) fa[i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
-          else fa[i] = vec8_zero<bf16>();
+          if (!(ASTAT_ABLATE & 8)) fa[ks][i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
+          else fa[ks][i] = vec8_zero<bf16>();
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = wn * 64 + j * 16 + c_;
-          if (!(ASTAT_ABLATE & 8)) fb[j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
-          else fb[j] = vec8_zero<bf16>();
-        }
-        if (!(ASTAT_ABLATE & 1)) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
-        } else {
-          asm volatile("" ::"v"(fa[0].v), "v"(fa[1].v), "v"(fb[0].v), "v"(fb[1].v), "v"(fb[2].v), "v"(fb[3].v));
+          if (!(ASTAT_ABLATE & 8)) fb[ks][j] = load8<bf16>(reinterpret_cast<const bf16*>(lb + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
+          else fb[ks][j] = vec8_zero<bf16>();
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the k-step are done before it reaches the next barrier
-      AS_STAMP(1, 2, qc);
-
-      // ---- behind the MFMAs: this k-step's share of the PREVIOUS tile's epilogue, each vector followed by this tile's request
+      __builtin_amdgcn_sched_barrier(0);
+      // ... and while the 96 KB of fragments of the eight waves come out of the LDS (~400 cycles in which the matrix pipe has nothing to
+      // do: every wave left the barrier together) this k-step's share of the PREVIOUS tile's epilogue runs: it needs the table entries
+      // only.  Each vector is followed by this tile's request for the same register pair.
       if constexpr (decltype(EPI)::value && !(ASTAT_ABLATE & 32)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          if ((v * NKT) / NV != kt) continue;              // (spread over ALL k-steps of the period: the CU's store path is the slow one)
+          if ((v * NKT) / NV != kt) continue;              // (spread over ALL k-steps of the period)
           finish_vec(v, true, rep[v], bia);
           if constexpr (VEC) request_vec(v, roc[v] + colq, n0);
         }
       }
+      if (!(ASTAT_ABLATE & 1)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(fa[ks][i], fb[ks][j], acc[i][j]);
+      } else {
+        asm volatile("" ::"v"(fa[0][0].v), "v"(fa[1][1].v), "v"(fb[0][0].v), "v"(fb[0][1].v), "v"(fb[1][2].v), "v"(fb[1][3].v));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of the k-step are done before it reaches the next barrier
+      AS_STAMP(1, 2, qc);
       if (kt == NKT - 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
