@@ -120,12 +120,9 @@ template <int V, int N> __device__ __forceinline__ u32x2 as_take() {
 #ifndef ASTAT_NT
 #define ASTAT_NT 1          // non-temporal stores of C / z: the outputs stream past the L2 that holds the weight panel and the A strips (ViT-S/16 step -2.7 %, Swin-S -0.3 %)
 #endif
-__device__ __forceinline__ void as_store4(bf16* dst, bf16x4 v) {
-#if ASTAT_NT
-  __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(dst));
-#else
-  *reinterpret_cast<bf16x4*>(dst) = v;
-#endif
+template <bool NT> __device__ __forceinline__ void as_store4(bf16* dst, bf16x4 v) {
+  if constexpr (NT && ASTAT_NT != 0) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(dst));
+  else *reinterpret_cast<bf16x4*>(dst) = v;
 }
 
 // NKT = K / 64 k-tile slots of the strip resident in LDS
@@ -393,7 +390,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) val[j] = gelu_f((float)z[j]);
       }
-      if constexpr (AUX) as_store4(aux_out + n0p + off, z);
+      if constexpr (AUX) as_store4<true>(aux_out + n0p + off, z);
     } else if constexpr (act_bwd) {
       if constexpr (ACT == 2) {
 #pragma unroll
@@ -419,9 +416,9 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
         *reinterpret_cast<bf16x8*>(d8) = w8;
       }
     } else if constexpr ((ASTAT_ABLATE & 512) != 0) {  // timing probe: the stores without the epilogue arithmetic (raw accumulator bits)
-      as_store4(Cout + n0p + (strip_p * AS_BM + wm * 32 + i * 16 + g_ * 4 + r) * (int)p.ldc + wn * 64 + c_ * 4,
+      as_store4<true>(Cout + n0p + (strip_p * AS_BM + wm * 32 + i * 16 + g_ * 4 + r) * (int)p.ldc + wn * 64 + c_ * 4,
                 __builtin_bit_cast(bf16x4, u32x2{__builtin_bit_cast(unsigned, accp[i][0][r]), __builtin_bit_cast(unsigned, accp[i][1][r])}));
-    } else if (!(ASTAT_ABLATE & 4) || (float)o[0] + (float)o[1] + (float)o[2] + (float)o[3] == 12345.678f) as_store4(dst, o);
+    } else if (!(ASTAT_ABLATE & 4) || (float)o[0] + (float)o[1] + (float)o[2] + (float)o[3] == 12345.678f) as_store4<(ASTAT_NT > 1) || !RESID>(dst, o);
   };
 
   if constexpr (VEC) {
