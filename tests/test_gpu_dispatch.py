@@ -124,6 +124,34 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
             assert torch.equal(a, g), f"{name} differs under {kw}"
 
 
+@pytest.mark.parametrize("M,N,K,T", [(130 * 197, 1152, 384, 197), (83 * 196, 1536, 384, 196), (301 * 49, 768, 192, 49)])
+def test_a_stationary_gemm_with_a_partial_last_strip_is_bitwise_the_tiled_kernel(M, N, K, T):
+    """Round 4: rows past M in the last 128-row strip are computed as copies of the last row (same bits to the same address), so that
+    every lane stores every epilogue vector (the kernel's counted waits rely on that); M = the row count of a compacted branch is any
+    multiple of the tokens per sample."""
+    from vtx import ops, options
+    d = dev()
+    assert M % 128 != 0
+    x, w, b = _mk((M, K), 131, BF, device=d), _mk((N, K), 132, BF, 0.05, device=d), _mk((N,), 133, torch.float32, 0.1, device=d)
+    dy, res = _mk((M, K), 134, BF, device=d), _mk((M, N), 135, BF, device=d)
+    keep = ((torch.rand(M // T, device=d) < 0.8).float() / 0.8)
+
+    def run():
+        q = ops.gemm(x, w, 0, bias=b)
+        h, z = ops.gemm(x, w, 0, bias=b, act=ops.ACT_SILU, want_aux=True)
+        dz = ops.gemm(dy, w, 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep, rows_per_scale=T)
+        y = ops.gemm(x, w, 0, bias=b, resid=res, rowscale=keep, rows_per_scale=T)
+        return q, h, z, dz, y
+
+    with options.override(GEMM_ASTAT=0):
+        base = run()
+    with options.override(GEMM_ASTAT=2):
+        assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M).startswith("gemm_astat_kernel")
+        got = run()
+    for a, g, name in zip(base, got, ("q", "h", "z", "dz", "y")):
+        assert torch.equal(a, g), f"{name} differs"
+
+
 @pytest.mark.parametrize("M,N,K,T", [(66395, 288, 96, 49), (66395, 96, 96, 49), (66395, 384, 96, 49),
                                      (40100, 128, 64, 100), (33100, 256, 128, 100), (36100, 512, 64, 100),
                                      (33100, 1024, 128, 100), (33100, 2048, 64, 100)])   # (column chunks: 2, 4)

@@ -289,3 +289,17 @@ def test_no_packed_fp32_result_feeds_the_lds_or_memory_pipe_in_the_next_issue_sl
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "0 packed-fp32" in r.stdout
+
+
+def test_a_stationary_gemm_isa_keeps_the_invariants_its_counted_waits_rely_on():
+    """Round 4: csrc/gemm_astat.hip waits for its epilogue vectors with hand-counted `s_waitcnt vmcnt(N)` and lands them in registers
+    the compiler must never touch.  What hipcc may silently do against that -- spill (scratch traffic counts in vmcnt), emit a flat
+    access, allocate a reserved register, put `s_waitcnt vmcnt(0)` inside the k-step loops (it did all four in intermediate builds,
+    see the kernel's comments) -- is checked on the generated gfx950 assembly of all 64 instantiations."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "probe", "scan_astat_isa.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "0 violations in 64" in r.stdout

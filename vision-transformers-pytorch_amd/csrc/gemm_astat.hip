@@ -88,7 +88,7 @@ __device__ __forceinline__ int as_orow(const GemmArgs& p, const int* sperm, unsi
     return row;
   } else {
     const int s = (int)__umulhi((unsigned)row, p.map_magic), sm = sperm[s];
-    if (smp) *smp = sm;
+    if (smp) *smp = s;                                   // (the scale table is in LOGICAL sample order: see srs)
     return sm * p.map_T + (row - s * p.map_T);
   }
 }
@@ -180,14 +180,24 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
   const int nsamp = MAPPED ? p.M / p.map_T : (p.rowscale ? (p.M + p.rows_per_scale - 1) / p.rows_per_scale : 1);    // (no scales: srs[0] = 1)
   for (int i = threadIdx.x; i < p.N; i += AS_NT) sbias[i] = p.bias ? p.bias[i] : 0.f;
   for (int i = threadIdx.x; i < nsamp; i += AS_NT) {
-    srs[i] = p.rowscale ? p.rowscale[i] : 1.f;
-    if constexpr (MAPPED) sperm[i] = p.perm[i];
+    // DropPath scale of the i-th sample IN PERM ORDER (a mapped launch without copy-only rows has M = Mk: the table covers the kept
+    // samples only, while perm's values -- the physical samples rowscale is indexed by -- range over the whole batch)
+    if constexpr (MAPPED) {
+      const int sm = p.perm[i];
+      sperm[i] = sm;
+      srs[i] = p.rowscale ? p.rowscale[sm] : 1.f;
+    } else {
+      srs[i] = p.rowscale ? p.rowscale[i] : 1.f;
+    }
   }
   const unsigned rs_magic = p.rowscale ? (unsigned)((0x100000000ull + (unsigned)p.rows_per_scale - 1) / (unsigned)p.rows_per_scale) : 0u;
   __syncthreads();                                        // (nothing is in flight yet: an ordinary barrier)
   auto fill_row = [&](int strip_, int r) {
     int smp = 0;
-    const int row = as_orow<MAPPED>(p, sperm, rs_magic, strip_ * AS_BM + r, &smp);      // (< M: whole strips only, gemm_astat_ok)
+    // rows past M (a partial last strip; a mapped launch without copy-only rows has M = Mk, any multiple of T) are the LAST row again:
+    // same operand row, same weight, same scale -> the same bits stored to the same address by several lanes; every lane stores every
+    // vector, which is what the counted waits of the epilogue rely on
+    const int row = as_orow<MAPPED>(p, sperm, rs_magic, min(strip_ * AS_BM + r, p.M - 1), &smp);
     srow[(strip_ & 1) * AS_BM + r] = int2{row * (int)p.ldc, __builtin_bit_cast(int, srs[smp])};
     // (A rows past the computed ones of a mapped launch read the last computed row: finite values, scaled by an exact 0)
     srowa[(strip_ & 1) * AS_BM + r] = as_orow<MAPPED>(p, sperm, rs_magic, min(strip_ * AS_BM + r, live_rows - 1), nullptr) * (int)p.lda;
@@ -554,11 +564,11 @@ bool gemm_astat_ok(const GemmArgs& a) {
   if (a.kscale != nullptr || a.ksum_out != nullptr) return false;
   if ((a.act == 2 || a.act == 4) && a.resid != nullptr) return false;     // (no hot-path launch has both)
   if ((a.act == 1 || a.act == 3) && a.resid != nullptr) return false;
+  if (a.resid == a.C && a.M % AS_BM != 0) return false;                    // (in place + a partial strip: the last row is stored more than once)
   const long rows = a.perm != nullptr ? a.Mk : a.M;
   if (rows <= 0) return false;
   const long tiles = (rows + AS_BM - 1) / AS_BM * (a.N / AS_BN);
   if (tiles < 2L * astat_cus() && mode != 2) return false;                 // under two tiles per CU: the tiled kernels' job
-  if (a.M % AS_BM != 0) return false;                                      // whole strips: every lane stores every vector
   if (a.rowscale != nullptr && (a.rows_per_scale <= 0 || (a.M + a.rows_per_scale - 1) / a.rows_per_scale > AS_MAXS)) return false;
   if (a.perm != nullptr) {
     if (a.map_T <= 0 || a.M % a.map_T != 0 || a.M / a.map_T > AS_MAXS) return false;
