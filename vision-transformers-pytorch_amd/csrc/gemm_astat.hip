@@ -568,7 +568,7 @@ bool gemm_astat_ok(const GemmArgs& a) {
   const long rows = a.perm != nullptr ? a.Mk : a.M;
   if (rows <= 0) return false;
   const long tiles = (rows + AS_BM - 1) / AS_BM * (a.N / AS_BN);
-  if (tiles < 2L * astat_cus() && mode != 2) return false;                 // under two tiles per CU: the tiled kernels' job
+  if (mode != 2 && 4 * tiles < (mode == 3 ? 5L : 8L) * astat_cus()) return false;      // under two tiles per CU (mode 3: 1.25): the tiled kernels' job
   if (a.rowscale != nullptr && (a.rows_per_scale <= 0 || (a.M + a.rows_per_scale - 1) / a.rows_per_scale > AS_MAXS)) return false;
   if (a.perm != nullptr) {
     if (a.map_T <= 0 || a.M % a.map_T != 0 || a.M / a.map_T > AS_MAXS) return false;

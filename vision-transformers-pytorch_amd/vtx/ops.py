@@ -327,7 +327,7 @@ def astat_ok(N, K, M):
     mode = options.get("GEMM_ASTAT")
     if not mode or K % 64 or K < 192 or K > 384 or N % 128 or N < 256 or N > 1536 or M <= 0:
         return False
-    return mode == 2 or ((M + 127) // 128) * (N // 128) >= 2 * _ASTAT_CUS
+    return mode == 2 or 4 * ((M + 127) // 128) * (N // 128) >= (5 if mode == 3 else 8) * _ASTAT_CUS
 
 
 def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False):
