@@ -18,7 +18,7 @@ import os, re, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(REPO, "vision-transformers-pytorch_amd", "csrc", "gemm_astat.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-value"]
-RESERVED0 = 152
+RESERVED0 = 224 if any(a.startswith("-DAS_NCWD=4") for a in sys.argv[1:]) else 152
 
 
 def vgprs(line):
@@ -37,8 +37,8 @@ def main():
         return 1
     txt = open(out).read()
     bad = n = 0
-    for m in re.finditer(r"^(_ZN12_GLOBAL__N_117gemm_astat_kernel\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
-        name, body = m.group(1)[36:60], m.group(2).split("\n")
+    for m in re.finditer(r"^(_Z17gemm_astat_kernel\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
+        name, body = m.group(1)[22:46], m.group(2).split("\n")
         n += 1
         ta = re.match(r"ILi(\d)ELb([01])ELi(\d)ELb([01])ELb([01])E", name)
         vec = ta is not None and (ta.group(4) == "1" or ta.group(3) in ("2", "4"))

@@ -57,7 +57,6 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-namespace {
 
 constexpr int AS_BM = 128, AS_BN = 128, AS_BK = 64;
 constexpr int AS_KT_BYTES = AS_BM * AS_BK * 2;          // 16 KB: one k-tile slot of the A strip = one stage of the W ring
@@ -67,7 +66,14 @@ constexpr int AS_MAXN = 1536;                           // columns of the LDS co
 #ifndef AS_NLW
 #define AS_NLW 4
 #endif
-constexpr int AS_NCW = 8, AS_NRW = AS_NLW;              // multiplying waves; request waves
+#ifndef AS_NCWD
+#define AS_NCWD 8          // multiplying waves: 8 (4 x 2 wave tiles of 32 x 64) | 4 (2 x 2 wave tiles of 64 x 64: a third less LDS fragment traffic, one
+                           // multiplying wave per SIMD -- a TIMING PROBE: measured no faster (stage-3 qkv forward 28.9 vs 27.3 us, fc1 56.8 vs 58.4) and its
+                           // residual / act' kinds spill at 224 registers, which the counted waits do not survive)
+#endif
+constexpr int AS_NCW = AS_NCWD, AS_NRW = AS_NLW;        // multiplying waves; request waves
+constexpr int AS_WMT = 16 / AS_NCW;                     // 16-row MFMA tiles per wave tile along M: 2 | 4
+static_assert(AS_NCW == 8 || AS_NCW == 4, "wave tilings");
 constexpr int AS_NT = 64 * (AS_NCW + AS_NRW);           // threads
 constexpr int AS_LW = 16 / AS_NRW;                      // DMA instructions per request wave and 16-KB k-tile
 constexpr int AS_RPW = 128 / AS_NRW;                    // LDS rows per request wave
@@ -100,8 +106,14 @@ __device__ __forceinline__ int as_orow(const GemmArgs& p, const int* sperm, unsi
 //     ISA of the first v3 build) -- the acknowledgement of the stores just issued, ~1 us per k-step;
 //   * as inline-asm OUTPUT operands the compiler believes the registers hold their value when the asm statement ends and is free
 //     to copy them -- it did: a v_mov of the destination pair in front of the hand-written wait (ISA of the second build).
-constexpr int AS_EV0 = 152;
+#if AS_NCWD == 8
+constexpr int AS_EV0 = 152;          // 12 waves: three per SIMD, 168 registers each
 #define AS_EV_CLOBBERS "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+#else
+constexpr int AS_EV0 = 224;          // 8 waves: two per SIMD, 256 registers each; 16 vectors per lane and tile
+#define AS_EV_CLOBBERS "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", \
+                       "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#endif
 template <int V> __device__ __forceinline__ void as_request(int byte_off, const bf16* base) {
   asm volatile("global_load_dwordx2 v[%2:%3], %0, %1" ::"v"(byte_off), "s"(base), "i"(AS_EV0 + 2 * V), "i"(AS_EV0 + 2 * V + 1)
                : "memory", AS_EV_CLOBBERS);
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
   constexpr bool VEC = RESID || act_bwd;               // the epilogue reads one 8-byte vector per output vector (the residual, or z for act')
   static_assert(!(RESID && ACT != 0) && !(AUX && !act_fwd), "epilogue kinds of the hot path");
   constexpr int ROWB = 128;                            // bytes per LDS row
-  constexpr int NV = 8;                                // 8-byte vectors per lane and tile: rows (i, r), columns 4 c_ .. 4 c_ + 3
+  constexpr int NV = 4 * AS_WMT;                       // 8-byte vectors per lane and tile: rows (i, r), columns 4 c_ .. 4 c_ + 3
   constexpr int NST = NV * (AUX ? 2 : 1);              // store instructions per multiplying wave and tile
   constexpr int SPI = (NV + NKT - 1) / NKT;            // epilogue vectors per k-step
   static_assert(NKT >= 3 && NKT <= 6, "a refilled A slot needs two k-steps to land; 6 slots + the ring fill the LDS");
@@ -310,7 +322,8 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 
   // ======================================================================= the eight multiplying waves
   if (Q == 0) return;
-  const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves of 32 x 64
+  const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves of 32 x 64 | 2 x 2 waves of 64 x 64
+  constexpr int WROWS = 16 * AS_WMT;                    // rows of a wave tile
   const int c_ = lane & 15, g_ = lane >> 4;
 
   // ---- rows this lane finishes: row(i, r) = strip * 128 + 32 wm + 16 i + 4 g_ + r, columns n0 + 64 wn + 4 c_ .. + 3 (v = 4 i + r).
@@ -326,49 +339,48 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
   // outstanding operations: exact for the second tile, a little early afterwards (operations issued >= 4 k-steps ago).
   const int colq = wn * 64 + c_ * 4;                      // this lane's columns inside a tile
   auto row_entry = [&](int strip_, int v) {              // {element offset of row (i, r) of the strip, its DropPath scale}
-    return srow[(strip_ & 1) * AS_BM + wm * 32 + (v >> 2) * 16 + g_ * 4 + (v & 3)];
+    return srow[(strip_ & 1) * AS_BM + wm * WROWS + (v >> 2) * 16 + g_ * 4 + (v & 3)];
   };
+  // (v is a compile-time constant after unrolling: the switches fold)
   auto request_vec = [&](int v, int off, int n0) {
     const bf16* base = vsrc + n0;
     switch (v) {
-      case 0: as_request<0>(off * 2, base); break;
-      case 1: as_request<1>(off * 2, base); break;
-      case 2: as_request<2>(off * 2, base); break;
-      case 3: as_request<3>(off * 2, base); break;
-      case 4: as_request<4>(off * 2, base); break;
-      case 5: as_request<5>(off * 2, base); break;
-      case 6: as_request<6>(off * 2, base); break;
-      default: as_request<7>(off * 2, base); break;
+#define AS_RQ(V) case V: as_request<V>(off * 2, base); break;
+      AS_RQ(0) AS_RQ(1) AS_RQ(2) AS_RQ(3) AS_RQ(4) AS_RQ(5) AS_RQ(6) AS_RQ(7)
+#if AS_NCWD == 4
+      AS_RQ(8) AS_RQ(9) AS_RQ(10) AS_RQ(11) AS_RQ(12) AS_RQ(13) AS_RQ(14) AS_RQ(15)
+#endif
+#undef AS_RQ
+      default: break;
     }
   };
+  // in the loop NV - 1 + v younger operations may stay outstanding, behind it NV - 1 (see above)
   auto take_vec = [&](int v, bool in_loop) -> u32x2 {
     if (in_loop) {
       switch (v) {
-        case 0: return as_take<0, 7>();
-        case 1: return as_take<1, 8>();
-        case 2: return as_take<2, 9>();
-        case 3: return as_take<3, 10>();
-        case 4: return as_take<4, 11>();
-        case 5: return as_take<5, 12>();
-        case 6: return as_take<6, 13>();
-        default: return as_take<7, 14>();
+#define AS_TK(V) case V: return as_take<V, NV - 1 + V>();
+        AS_TK(0) AS_TK(1) AS_TK(2) AS_TK(3) AS_TK(4) AS_TK(5) AS_TK(6) AS_TK(7)
+#if AS_NCWD == 4
+        AS_TK(8) AS_TK(9) AS_TK(10) AS_TK(11) AS_TK(12) AS_TK(13) AS_TK(14) AS_TK(15)
+#endif
+#undef AS_TK
+        default: return u32x2{0u, 0u};
       }
     }
     switch (v) {
-      case 0: return as_take<0, 7>();
-      case 1: return as_take<1, 7>();
-      case 2: return as_take<2, 7>();
-      case 3: return as_take<3, 7>();
-      case 4: return as_take<4, 7>();
-      case 5: return as_take<5, 7>();
-      case 6: return as_take<6, 7>();
-      default: return as_take<7, 7>();
+#define AS_TK(V) case V: return as_take<V, NV - 1>();
+      AS_TK(0) AS_TK(1) AS_TK(2) AS_TK(3) AS_TK(4) AS_TK(5) AS_TK(6) AS_TK(7)
+#if AS_NCWD == 4
+      AS_TK(8) AS_TK(9) AS_TK(10) AS_TK(11) AS_TK(12) AS_TK(13) AS_TK(14) AS_TK(15)
+#endif
+#undef AS_TK
+      default: return u32x2{0u, 0u};
     }
   };
 
-  f32x4 acc[2][4], accp[2][4];                          // the tile being multiplied / the finished one being stored
+  f32x4 acc[AS_WMT][4], accp[AS_WMT][4];                // the tile being multiplied / the finished one being stored
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < AS_WMT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accp[i][j] = acc[i][j]; }
   bf16* __restrict__ Cout = (bf16*)p.C;
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
         *reinterpret_cast<bf16x8*>(d8) = w8;
       }
     } else if constexpr ((ASTAT_ABLATE & 512) != 0) {  // timing probe: the stores without the epilogue arithmetic (raw accumulator bits)
-      as_store4<true>(Cout + n0p + (strip_p * AS_BM + wm * 32 + i * 16 + g_ * 4 + r) * (int)p.ldc + wn * 64 + c_ * 4,
+      as_store4<true>(Cout + n0p + (strip_p * AS_BM + wm * WROWS + i * 16 + g_ * 4 + r) * (int)p.ldc + wn * 64 + c_ * 4,
                 __builtin_bit_cast(bf16x4, u32x2{__builtin_bit_cast(unsigned, accp[i][0][r]), __builtin_bit_cast(unsigned, accp[i][1][r])}));
     } else if (!(ASTAT_ABLATE & 4) || (float)o[0] + (float)o[1] + (float)o[2] + (float)o[3] == 12345.678f) as_store4<(ASTAT_NT > 1) || !RESID>(dst, o);
   };
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
   auto tile_period = [&](auto EPI, bool last_of_strip) {
     const int n0 = tn * AS_BN;
     if (last_of_strip) {                                    // the next strip's row tables (see srow / srowa), one row per lane
-      if (lane < 16) fill_row(strip + 1, wave * 16 + lane);
+      if (lane < AS_BM / AS_NCW) fill_row(strip + 1, wave * (AS_BM / AS_NCW) + lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (written before this wave reaches the barrier below)
     }
 #pragma unroll
@@ -468,12 +480,12 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
         }
       }
       // every fragment of the k-step is requested now, behind the table entries (the LDS answers in order) ...
-      Vec8<bf16> fa[2][2], fb[2][4];
+      Vec8<bf16> fa[2][AS_WMT], fb[2][4];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int r = wm * 32 + i * 16 + c_;
+        for (int i = 0; i < AS_WMT; ++i) {
+          const int r = wm * WROWS + i * 16 + c_;
           if (!(ASTAT_ABLATE & 8)) fa[ks][i] = load8<bf16>(reinterpret_cast<const bf16*>(la + r * ROWB + (((ks * 4 + g_) ^ (r & 7)) << 4)));
           else fa[ks][i] = vec8_zero<bf16>();
         }
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < AS_WMT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma16(fa[ks][i], fb[ks][j], acc[i][j]);
       } else {
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
       AS_STAMP(1, 2, qc);
       if (kt == NKT - 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < AS_WMT; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) { accp[i][j] = acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         strip_p = strip;
@@ -540,7 +552,6 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 #endif
 }
 
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------ host side
 static size_t astat_smem(int K) { return (size_t)(K / 64 + AS_NSW) * AS_KT_BYTES; }     // dynamic part: A slots + weight ring (the tables are static)
