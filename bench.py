@@ -58,13 +58,22 @@ def pmc_traffic(model, kernel):
     run inside the timed process, so the figure comes from profiles/ (newest round first) together with the commit
     the profile was taken at (`_meta.commit` in the file; the kernels may have changed since: compare with HEAD);
     None when no summary is committed or the kernel is not in it."""
-    for rnd in (3, 2, 1):
+    for rnd in (4, 3, 2, 1):
         path = os.path.join(REPO, "profiles", f"round{rnd}_pmc_traffic_{model}.json")
         try:
             tab = json.load(open(path))
         except OSError:
             continue
         key = kernel.split(" (+")[0].replace(" ", "")
+        if key.endswith(",...>"):
+            # a kernel family the timer names by its leading template arguments (gemm_astat_kernel<NKT, mapped, ...>: the epilogue
+            # kinds are separate instantiations): dispatch-weighted mean over the instantiations that match the prefix
+            pre = key[:-len("...>")]
+            hits = [v for k, v in tab.items() if k != "_meta" and k.replace(" ", "").startswith(pre)]
+            n = sum(v.get("dispatches", 1) for v in hits)
+            if n:
+                return (sum((v["fetch_x2_bytes"] + v["write_bytes"]) * v.get("dispatches", 1) for v in hits) / n,
+                        os.path.relpath(path, REPO), tab.get("_meta", {}).get("commit"))
         for k, v in tab.items():
             if k != "_meta" and k.replace(" ", "") == key:
                 return (v["fetch_x2_bytes"] + v["write_bytes"], os.path.relpath(path, REPO),
