@@ -125,12 +125,24 @@ def wcast(p, dtype):
     return (p.detach().to(dtype), None)
 
 
+_DGRAD_SPLITK = os.environ.get("VTX_DGRAD_SPLITK", "1") != "0"
+
+
 def dgrad(dy, wp, T, **epi):
     """dx = epi(dy @ W) for a ``wcast`` pair.  bf16 where the LDS-DMA kernel applies to the transposed problem (K =
     out-features, N = in-features; see ops.glds_ok): forward-layout kernel on the transposed copy; otherwise the
     register-staged NN kernel on W itself."""
     w, wt = wp
     w2 = w.view(w.shape[0], -1)
+    if (_DGRAD_SPLITK and T == torch.bfloat16 and not epi and dy.dim() == 2 and w2.shape[0] >= 16384 and w2.shape[1] % 8 == 0 and
+            w2.shape[1] >= 64 and dy.shape[0] % 8 == 0 and dy.shape[0] >= 64 and
+            ((dy.shape[0] + 63) // 64) * ((w2.shape[1] + 127) // 128) < 128):
+        # A very long contraction with a handful of output tiles (DINO's 65 536-way output layer: dx [640, 256] over K = 65 536 is 20
+        # tiles of 1 024 k-steps -- 571 us on 20 CUs): split-K.  Both operands are contracted over their ROWS once dy is transposed
+        # (W [out, in] already is), which is the weight-gradient kernel's problem: fp32 slabs over the out-features, fixed-order
+        # reduce (deterministic), then the cast.
+        dx32, _ = ops.wgrad(dy.t().contiguous(), w2 if w2.is_contiguous() else w2.contiguous(), want_bias=False)
+        return ops.bias_cast(dx32, None, T)
     if T == torch.bfloat16 and ops.glds_ok(w2.shape[1], w2.shape[0]):
         if wt is None:
             wt = w2.t().contiguous()
