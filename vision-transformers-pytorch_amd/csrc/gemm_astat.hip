@@ -190,7 +190,9 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 
   // ---- small tables: bias, DropPath scales, the sample order
   const int nsamp = MAPPED ? p.M / p.map_T : (p.rowscale ? (p.M + p.rows_per_scale - 1) / p.rows_per_scale : 1);    // (no scales: srs[0] = 1)
-  for (int i = threadIdx.x; i < p.N; i += AS_NT) sbias[i] = p.bias ? p.bias[i] : 0.f;
+  // (no bias: the table is zeros and is read at the lane's in-tile column only, whatever N is)
+  for (int i = threadIdx.x; i < (p.bias ? p.N : AS_BN); i += AS_NT) sbias[i] = p.bias ? p.bias[i] : 0.f;
+  const int bias_on = p.bias ? 1 : 0;
   for (int i = threadIdx.x; i < nsamp; i += AS_NT) {
     // DropPath scale of the i-th sample IN PERM ORDER (a mapped launch without copy-only rows has M = Mk: the table covers the kept
     // samples only, while perm's values -- the physical samples rowscale is indexed by -- range over the whole batch)
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
       int roc[NV];
       f32x4 bia = {0.f, 0.f, 0.f, 0.f};
       if constexpr (decltype(EPI)::value && !(ASTAT_ABLATE & 32)) {
-        bia = *reinterpret_cast<const f32x4*>(sbias + n0p + colq);
+        bia = *reinterpret_cast<const f32x4*>(sbias + n0p * bias_on + colq);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           if ((v * NKT) / NV != kt) continue;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
   for (int t = t0 + 1; t < t1; ++t) tile_period(std::true_type{}, tn == ntn - 1 && t + 1 < t1);
   // ---- the last tile's epilogue
   {
-    const f32x4 bia = *reinterpret_cast<const f32x4*>(sbias + n0p + colq);
+    const f32x4 bia = *reinterpret_cast<const f32x4*>(sbias + n0p * bias_on + colq);
     int2 rep[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) rep[v] = row_entry(strip_p, v);
@@ -569,7 +571,7 @@ static int astat_cus() {
 bool gemm_astat_ok(const GemmArgs& a) {
   const int mode = vtx_opt(VTX_OPT_GEMM_ASTAT);
   if (mode == 0) return false;
-  if (a.K % 64 != 0 || a.K < 192 || a.K > 384 || a.N % 128 != 0 || a.N < 256 || a.N > AS_MAXN) return false;
+  if (a.K % 64 != 0 || a.K < 192 || a.K > 384 || a.N % 128 != 0 || a.N < 256 || (a.N > AS_MAXN && a.bias != nullptr)) return false;
   if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
   if ((int64_t)a.M * a.ldc >= (1ll << 30) || (int64_t)a.M * a.lda >= (1ll << 30)) return false;    // 32-bit byte offsets
   if (a.kscale != nullptr || a.ksum_out != nullptr) return false;

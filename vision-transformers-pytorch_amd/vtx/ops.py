@@ -321,16 +321,16 @@ def glds_ok(N, K):
 _ASTAT_CUS = 256          # (MI355X; gemm_astat.hip asks the device)
 
 
-def astat_ok(N, K, M):
+def astat_ok(N, K, M, bias=True):
     """Mirrors gemm_astat_ok (gemm_astat.hip) for contiguous bf16 operands: the A-stationary persistent kernel takes C[M, N] over
     192 <= K <= 384 once a launch has two 128 x 128 tiles per CU (M: the rows a mapped launch computes)."""
     mode = options.get("GEMM_ASTAT")
-    if not mode or K % 64 or K < 192 or K > 384 or N % 128 or N < 256 or N > 1536 or M <= 0:
+    if not mode or K % 64 or K < 192 or K > 384 or N % 128 or N < 256 or (N > 1536 and bias) or M <= 0:
         return False
     return mode == 2 or 4 * ((M + 127) // 128) * (N // 128) >= (5 if mode == 3 else 8) * _ASTAT_CUS
 
 
-def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False):
+def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False, bias=True):
     """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip); ``mapped``: the
     row-mapped variant of a compacted branch (M = the rows it computes)."""
     t = "__bf16" if dtype == torch.bfloat16 else "float"
@@ -338,7 +338,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and skinny_ok(N, K, M, vec) and not mapped:
         return f"gemm_skinny_kernel<{K // 32}>"
-    if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M):
+    if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M, bias):
         return f"gemm_astat_kernel<{K // 64}, {'true' if mapped else 'false'}, ...>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
         force = options.get("GLDS_BM")                                     # mirrors glds_pick_bm in gemm_glds.hip
@@ -385,7 +385,8 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     if _timer is not None:
         es = a.element_size()
         nb = es * (M * K + N * K + M * N * (1 + (resid is not None) + bool(want_aux) + (aux_in is not None)))
-        ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M, vec=resid is not None or act in (ACT_DSILU, ACT_DGELU)),
+        ev = _timer.bracket(gemm_kernel_name(a.dtype, N, mode, K=K, M=M, vec=resid is not None or act in (ACT_DSILU, ACT_DGELU),
+                                             bias=bias is not None),
                             2.0 * M * N * K, float(nb))
     if ev:
         ev[0].record()
