@@ -8,6 +8,7 @@
 //   * dwconv3_wgrad_kernel: dw[c][k] = sum over pixels of dy[pixel][c] * x[pixel + offset(k)][c]: per-workgroup partial
 //     sums over a fixed run of pixels, added in fixed order (LDS, then a second kernel over the workgroups): deterministic.
 // (2) twins_subsample_kernel: the operand gather of the global attention's sub-sampling convolution (further down).
+#include "options.h"
 #include "vtx_common.h"
 
 constexpr int DW_THREADS = 256;
@@ -184,6 +185,96 @@ __global__ void twins_subsample_kernel(const T* __restrict__ src, T* __restrict_
   }
 }
 
+// ---- LDS-staged variant (round 4; VERDICT r3 #8: the element-wise kernel above reaches 0.155 of the HBM peak -- 2-byte accesses,
+// 128 bytes per wave instruction).  One workgroup per (image, row of patches i): the r Z-rows it gathers are, per Z-channel c', ONE
+// contiguous range of r W elements of Tflat (f = c' H W + i r W .. + r W), and Tflat's f-order visits X pixel by pixel (C contiguous
+// elements each).  Phase 1 copies those ranges X -> LDS in Z layout [c'][r W] with the widest vector CH the alignments allow (16 bytes at
+// 56 x 56, 8 at 28 x 28, 4 at 14 x 14: r W, H W and C must be multiples of CH); phase 2 walks the patch rows of the row block in output
+// order -- 16-byte stores of 8 (bf16) / 4 (fp32) consecutive columns, their elements picked out of LDS (runs of r).  The backward is
+// the same two phases the other way round (16-byte loads of the patch gradient scattered into LDS, CH-wide read-modify-write of dx).
+template <typename T, int CH, bool BWD, bool ACC>
+__global__ __launch_bounds__(256) void twins_subsample_lds_kernel(const T* __restrict__ src, T* __restrict__ dst, SubGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sub_smem[];
+  T* z = reinterpret_cast<T*>(sub_smem);                    // [C][r W]
+  constexpr int V = 16 / (int)sizeof(T);                    // elements per 16-byte vector on the patch side
+  const int i = blockIdx.x, b = blockIdx.y;
+  const int rW = g.r * g.W, HW = g.H * g.W;
+  const int64_t xbase = (int64_t)b * HW * g.C;              // this image in X (and in the patch matrix: same element count)
+  const int cpr = rW / CH;                                  // chunks per Z-channel
+  const int nchunk = g.C * cpr;
+  const int Lrow = g.Wr * g.K;                              // elements of this row block of the patch matrix
+  const int64_t pbase = xbase + (int64_t)i * Lrow;
+  struct alignas(sizeof(T) * CH) Chunk { T v[CH]; };
+  struct alignas(16) Vec { T v[V]; };
+  auto x_of = [&](int q, int& zoff) {                       // chunk q of the Z image -> element offset in X
+    const int cp = q / cpr, u = q - cp * cpr;
+    zoff = cp * rW + u * CH;
+    const int f = cp * HW + i * rW + u * CH;
+    const int w = f / g.HC, rem = f - w * g.HC;
+    const int h = rem / g.C, c = rem - h * g.C;
+    return (h * g.W + w) * g.C + c;
+  };
+  auto z_of = [&](int el) {                                 // element el of the row block (patch order) -> LDS index; el % V == 0 walks a run
+    const int jp = el / g.K, col = el - jp * g.K;
+    const int cp = col / g.rr, pp = col - cp * g.rr;
+    const int py = pp / g.r, px = pp - py * g.r;
+    return int4{cp * rW + py * g.W + jp * g.r + px, px, py, 0};
+  };
+  if (!BWD) {
+    for (int q = threadIdx.x; q < nchunk; q += 256) {
+      int zoff;
+      const int xo = x_of(q, zoff);
+      *reinterpret_cast<Chunk*>(z + zoff) = *reinterpret_cast<const Chunk*>(src + xbase + xo);
+    }
+    __syncthreads();
+    for (int el = threadIdx.x * V; el < Lrow; el += 256 * V) {
+      int4 zi = z_of(el);
+      int zidx = zi.x, px = zi.y, py = zi.z;
+      Vec o;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        o.v[k] = z[zidx];
+        px += 1; zidx += 1;
+        if (px == g.r) { px = 0; py += 1; zidx += g.W - g.r; if (py == g.r) { py = 0; zidx += rW - g.r * g.W; } }
+      }
+      *reinterpret_cast<Vec*>(dst + pbase + el) = o;
+    }
+  } else {
+    for (int el = threadIdx.x * V; el < Lrow; el += 256 * V) {
+      int4 zi = z_of(el);
+      int zidx = zi.x, px = zi.y, py = zi.z;
+      const Vec d = *reinterpret_cast<const Vec*>(src + pbase + el);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        z[zidx] = d.v[k];
+        px += 1; zidx += 1;
+        if (px == g.r) { px = 0; py += 1; zidx += g.W - g.r; if (py == g.r) { py = 0; zidx += rW - g.r * g.W; } }
+      }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nchunk; q += 256) {
+      int zoff;
+      const int xo = x_of(q, zoff);
+      Chunk c = *reinterpret_cast<const Chunk*>(z + zoff);
+      if (ACC) {
+        const Chunk old = *reinterpret_cast<const Chunk*>(dst + xbase + xo);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) c.v[k] = from_f32<T>(to_f32<T>(old.v[k]) + to_f32<T>(c.v[k]));
+      }
+      *reinterpret_cast<Chunk*>(dst + xbase + xo) = c;
+    }
+  }
+}
+// widest chunk (elements, <= 16 bytes) the geometry allows, 0: take the element-wise kernel
+template <typename T> static int sub_lds_chunk(int H, int W, int C, int r) {
+  const int V = 16 / (int)sizeof(T);
+  const size_t lds = (size_t)C * r * W * sizeof(T);
+  if (lds > 150 * 1024 || (C * r * r) % V != 0) return 0;
+  int ch = V;
+  while (ch > 1 && ((r * W) % ch || (H * W) % ch || C % ch)) ch >>= 1;
+  return ch >= 2 ? ch : 0;
+}
+
 static unsigned sub_magic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 // -> geometry + whether the reciprocal form is exact for every dividend the kernel forms (all < H W C)
 static bool sub_geom(SubGeom& g, int H, int W, int C, int r) {
@@ -198,6 +289,27 @@ template <typename T, bool BWD, bool ACC>
 static void sub_launch(const void* src, void* dst, void* dst_t, int B, int H, int W, int C, int r, hipStream_t st) {
   SubGeom g;
   const bool fast = sub_geom(g, H, W, C, r);
+  // measured per Twins-SVT-S stage (B = 128, r = 7, bf16; tools/r4/sub_bench.py): 56 x 56 (16-byte chunks) forward 52.5 -> 47.7 us, scatter + add
+  // 99.0 -> 31.1; 28 x 28 (8-byte) 25.2 -> 31.7 / 35.3 -> 24.4; 14 x 14 (4-byte) 13.7 -> 21.7 / 20.0 -> 31.4: the gather needs 16-byte
+  // chunks to win, the scatter 8-byte ones
+  int ch = dst_t == nullptr && vtx_opt(VTX_OPT_TWINS_SUB_LDS) ? sub_lds_chunk<T>(H, W, C, r) : 0;
+  if (ch * (int)sizeof(T) < (BWD ? 8 : 16)) ch = 0;
+  if (ch > 0) {
+    const size_t lds = (size_t)C * r * W * sizeof(T);
+    dim3 grid2(H / r, B);
+#define SUB_LDS_LAUNCH(CHV)                                                                                                         \
+    do {                                                                                                                            \
+      auto kern = twins_subsample_lds_kernel<T, CHV, BWD, ACC>;                                                                     \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {             \
+        hipLaunchKernelGGL(kern, grid2, dim3(256), lds, st, (const T*)src, (T*)dst, g);                                             \
+        return;                                                                                                                     \
+      }                                                                                                                             \
+    } while (0)
+    if constexpr (sizeof(T) == 2) { if (ch == 8) SUB_LDS_LAUNCH(8); }
+    if (ch == 4) SUB_LDS_LAUNCH(4);
+    if (ch == 2) SUB_LDS_LAUNCH(2);
+#undef SUB_LDS_LAUNCH
+  }
   dim3 grid((H * W * C + 255) / 256, B);
   if (fast) hipLaunchKernelGGL((twins_subsample_kernel<T, BWD, ACC, true>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, (T*)dst_t, g);
   else hipLaunchKernelGGL((twins_subsample_kernel<T, BWD, ACC, false>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, (T*)dst_t, g);
