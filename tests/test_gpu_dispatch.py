@@ -286,10 +286,26 @@ def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
         check(f"grouped wgrad dW {name} B{B} T{T} C{C}", dW, rW, 2e-5)
         check(f"grouped wgrad db {name} B{B} T{T} C{C}", db, rb, 2e-5)
     again = ops.wgrad_group(gpu, T, c)
-    with options.override(WG_WAVES=4):
-        w4 = ops.wgrad_group(gpu, T, c)
     for (a, ab), (g, gb) in zip(res, again):
         assert torch.equal(a, g) and torch.equal(ab, gb), "grouped wgrad differs on a rerun"
+    # C = 384 layers take the 128 x 384 tiles (one workgroup per CU, 7 slices); the 128 x 128 kernel (4 slices) sums the same
+    # products in another slice partition
+    wide = ops.wgrad_wide_tiles([(j[0].shape[1], j[1].shape[1]) for j in gpu]) > 0
+    assert wide == (C == 384)
+    with options.override(WGRAD_WIDE=0):
+        narrow = ops.wgrad_group(gpu, T, c)
+        again = ops.wgrad_group(gpu, T, c)
+        with options.override(WG_WAVES=4):
+            w4 = ops.wgrad_group(gpu, T, c)
+    for (a, ab), (g, gb), name in zip(narrow, res, ("fc2", "fc1", "proj", "qkv")):
+        if wide:
+            check(f"grouped wgrad dW {name}, 128 x 384 vs 128 x 128 tiles", g, a, 3e-6)
+            check(f"grouped wgrad db {name}, 128 x 384 vs 128 x 128 tiles", gb, ab, 3e-6)
+        else:
+            assert torch.equal(a, g) and torch.equal(ab, gb)
+    for (a, ab), (g, gb) in zip(narrow, again):
+        assert torch.equal(a, g) and torch.equal(ab, gb), "grouped wgrad (128 x 128 tiles) differs on a rerun"
+    res = narrow
     # 4 waves: every dW element is summed in the same order (bit-identical); the bias gradient's row groups are
     # 16 instead of 32 per workgroup, i.e. a different (still fixed) summation order
     for (a, ab), (g, gb) in zip(res, w4):

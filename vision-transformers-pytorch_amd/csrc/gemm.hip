@@ -386,7 +386,8 @@ int vtx_wgrad_group_ok(int dtype, int nprob, const int* N, const int* Kin, int64
     if (!wgrad_glds_ok(dtype, N[i], Kin[i], rs, scale_const)) return 0;
     tiles += wgrad_glds_tiles(N[i], Kin[i]);
   }
-  const int nz = wgrad_glds_slices(mtok, tiles);
+  const int wt = wgrad_wide_tiles(nprob, N, Kin);
+  const int nz = wt ? wgrad_glds_slices(mtok, wt, true) : wgrad_glds_slices(mtok, tiles);
   if (has_rowscale && chunk_of(mtok, nz) / (rows_per_scale > 0 ? rows_per_scale : 1) + 2 > 512) return 0;
   return 1;
 }
@@ -397,13 +398,25 @@ static int group_tiles(int nprob, const int* N, const int* Kin) {
   return tiles;
 }
 
+// slices of a group under the current options: 128 x 384 tiles (wgrad_wide_tiles) or 128 x 128
+static int group_slices(int nprob, const int* N, const int* Kin, int64_t mtok, bool* wide) {
+  const int wt = wgrad_wide_tiles(nprob, N, Kin);
+  if (wide) *wide = wt > 0;
+  return wt ? wgrad_glds_slices(mtok, wt, true) : wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+}
+
 int vtx_wgrad_group_slices(int nprob, const int* N, const int* Kin, int64_t mtok) {
   if (nprob < 1 || nprob > wgrad_glds_max_problems() || !N || !Kin || mtok <= 0) return 0;
-  return wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  return group_slices(nprob, N, Kin, mtok, nullptr);
 }
 
 size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_t mtok) {
-  const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  // (the larger of the two tilings' slice counts: a size taken under one setting of WGRAD_WIDE serves the other)
+  int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  bool w128 = true;
+  int wt = 0;
+  for (int i = 0; i < nprob; ++i) { w128 = w128 && N[i] % 128 == 0 && Kin[i] % 384 == 0; wt += (N[i] / 128) * (Kin[i] / 384); }
+  if (w128 && wt >= 1 && wt <= 256) { const int nzw = wgrad_glds_slices(mtok, wt, true); nz = nzw > nz ? nzw : nz; }
   size_t fl = 0;
   for (int i = 0; i < nprob; ++i) fl += (size_t)nz * ((size_t)N[i] * Kin[i] + (size_t)N[i]);
   return (fl + 4) * sizeof(float);
@@ -444,7 +457,8 @@ int vtx_wgrad_group_mapped(int dtype, int nprob, const void* const* dy, const vo
   if (!vtx_wgrad_group_ok(dtype, nprob, N, Kin, mtok, any_scale, rows_per_scale, scale_const)) return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_wgrad_group_workspace(nprob, N, Kin, mtok)) return VTX_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
+  bool wide = false;
+  const int nz = group_slices(nprob, N, Kin, mtok, &wide);
   if (accumulate && nz < 2) return VTX_ERR_SHAPE;          // accumulation lives in the slab reduce (vtx_wgrad_group_slices tells)
   WgradProbHost hp[8];
   float* w = (float*)workspace;
@@ -470,7 +484,7 @@ int vtx_wgrad_group_mapped(int dtype, int nprob, const void* const* dy, const vo
   int64_t mmax = 0;                                         // (mapped problems contract over their kept tokens only)
   for (int i = 0; i < nprob; ++i) mmax = hp[i].Mtok > mmax ? hp[i].Mtok : mmax;
   const int kchunk = (int)chunk_of(mmax, nz);
-  int rc = wgrad_glds_group_launch(nprob, hp, mmax, rows_per_scale, scale_const, nz, kchunk, st);
+  int rc = wgrad_glds_group_launch(nprob, hp, mmax, rows_per_scale, scale_const, nz, kchunk, st, wide);
   if (rc || (nz == 1 && ncol == 0)) return rc;
   // ONE reduction launch behind the group: all weight and bias slabs (kernel boundary = visibility: the slabs were written
   // with plain stores) and the layer's deferred column reductions (LayerNorm dgamma / dbeta, rel_pos gradient)

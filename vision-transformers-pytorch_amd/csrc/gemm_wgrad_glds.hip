@@ -473,6 +473,271 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_gl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE TILES (round 4): 128 (N) x 384 (Kin) output tiles, one workgroup per CU.
+//
+// What bounds the 128 x 128 kernel above is not HBM but what every CU pulls through its L2 port and its LDS per unit of
+// MFMA work: a layer's four weight gradients at C = 384 are 108 tiles that each stream 256 columns of the operands, 4.5x the
+// unique bytes (1.1 GB of L2 -> LDS traffic per Swin-S stage-3 layer, 2.8 GB per ViT-S/16 layer; the DMA stream is issue bound
+// at ~23 cycles per 1-KB instruction, profiles/round4_l2_dma_rate_probe.txt), 24 transpose reads per 16 MFMAs, and every
+// wave both requests and multiplies.  Here a tile is 128 columns of dy x 384 columns of x (every C = 384 layer: 9 + 3 + 12
+// + 12 = 36 whole tiles, no ragged edge), 8 multiplying waves of 64 x 96 (20 transpose reads per 24 MFMAs) and 4 waves that
+// only request: per MFMA 0.67x the L2 -> LDS bytes and 0.55x the LDS reads.  32-token k-steps through a 4-stage ring of 32 KB
+// (three k-steps = 96 KB per CU in flight: the first workgroup of an XCD to touch a line pays an HBM miss), one s_barrier per
+// k-step; the multiplying waves touch no vector memory inside the loop (their transpose reads need no hand-written waits).
+// x fragments are the MFMA's row operand: a lane ends with 4 consecutive Kin columns of one dW row -- 16-byte stores straight
+// from the accumulators, no staging.  Everything else (grouping, slices + slab reduce, DropPath liveness, compaction row map,
+// bias-gradient column sums) as above; slices fill 256 workgroups instead of 512.
+// Measured and not kept: an L2 prefetch by the multiplying waves (one dword of every line 4 / 8 / 12 k-steps ahead, into a
+// register nobody reads): ViT-S/16 layer 211 -> 278 us -- the touch pulls every line into the L1 as well and doubles the
+// L2 -> CU traffic, which is what the request path is bound by (tools/r4/rejected/wgrad_wide_l2_prefetch.log).
+// timing-only switches (results garbage): 1 no DMA requests | 2 no fragment reads + MFMA | 4 no slab / output stores
+#ifndef WW_ABLATE
+#define WW_ABLATE 0
+#endif
+constexpr int WW_BK = 32, WW_NS = 4, WW_PANEL = WW_BK * 256, WW_STAGE = 4 * WW_PANEL, WW_RING = WW_NS * WW_STAGE;
+constexpr int WW_NCW = 8, WW_NLW = 4, WW_NT = 64 * (WW_NCW + WW_NLW);
+constexpr int WW_LPT = 8;                                  // DMA instructions per request wave and k-step (2 row groups x 4 panels)
+constexpr int WW_SMEM = WW_RING + WG_MAXSAMPLES + WG_MAXSAMPLES * 4;
+
+__device__ __forceinline__ Vec8<bf16> ww_frag(const unsigned char* a) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
+  return wg_join(lo, hi);
+}
+
+template <bool MAPPED>
+__global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+  unsigned char* live_tab = wg_smem + WW_RING;
+  int* perm_tab = reinterpret_cast<int*>(wg_smem + WW_RING + WG_MAXSAMPLES);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nblk = gridDim.x, did = blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = did & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (did >> 3);
+  const int tz = lid / p.ntiles;
+  const int tile = lid - tz * p.ntiles;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAXPROB; ++i)
+    if (i < p.nprob && tile >= p.pr[i].tile0) pi = i;
+  const WgradProb& q = p.pr[pi];
+  const int lt = tile - q.tile0;
+  const int tq = lt % q.ntk, tp = lt / q.ntk;               // (ntk = Kin / 384 here)
+  const int n0 = tp * 128, k0 = tq * 384;
+  const int N = q.N, Kin = q.Kin;
+  const bf16* __restrict__ gdy = q.dy;
+  const bf16* __restrict__ gx = q.x;
+  const int64_t ld_dy = q.ld_dy, ld_x = q.ld_x;
+  const float* rowscale = q.rowscale;
+  const int mbeg = ((WW_ABLATE & 8) ? 0 : tz) * p.kchunk;   // (8: every slice streams the tokens of slice 0 -- timing only)
+  const int mend = min(q.Mtok, mbeg + p.kchunk);
+  const int nkt = mend > mbeg ? (mend - mbeg + WW_BK - 1) / WW_BK : 0;
+  const int rps = p.rows_per_scale;
+  const int s0 = mbeg / rps;
+  const bool has_rs = rowscale != nullptr;
+  if (MAPPED && nkt > 0) {
+    const int ns = (mend - 1) / rps - s0 + 1;
+    for (int i = threadIdx.x; i < ns; i += WW_NT) perm_tab[i] = q.perm[s0 + i] * rps;
+  }
+  if (has_rs && nkt > 0) {
+    const int ns = (mend - 1) / rps - s0 + 1;
+    for (int i = threadIdx.x; i < ns; i += WW_NT) live_tab[i] = rowscale[s0 + i] != 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const bool have_ksum = q.ksum_out != nullptr && tq == 0;
+  float ks8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave >= WW_NCW) {
+    // ---------------- request waves: wave lw owns token rows 8 lw .. 8 lw + 7 of the four panels (dy | x0 | x1 | x2) of a k-step
+    const int lw = wave - WW_NCW;
+    const int prow = lane >> 4, pslot = lane & 15;
+    const int qq = pslot ^ (((prow & 3) | ((lw & 1) << 2)) << 1);      // wg_swz(r): r & 3 = prow, (r >> 3) & 1 = lw & 1 for both row groups
+    const bf16* zero = reinterpret_cast<const bf16*>(vtx_zero_row);
+    const bf16* pz = zero + (qq << 3);
+    const int nfull = (mend - mbeg) / WW_BK;
+    const bf16* pa[2];
+    const bf16* pb[2];
+    int smp[2], rem[2], nlive[2];
+    const unsigned inca = MAPPED ? (unsigned)(ld_dy * 2) : (unsigned)(WW_BK * ld_dy * 2);
+    const unsigned incb = MAPPED ? (unsigned)(ld_x * 2) : (unsigned)(WW_BK * ld_x * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = lw * 8 + j * 4 + prow;
+      const int tok = mbeg + r;
+      smp[j] = tok / rps - s0;
+      rem[j] = tok % rps;
+      if (MAPPED) {
+        pa[j] = gdy + n0 + (qq << 3);
+        pb[j] = gx + k0 + (qq << 3);
+        nlive[j] = nkt > 0 ? perm_tab[min(smp[j], WG_MAXSAMPLES - 1)] + rem[j] : 0;
+      } else {
+        pa[j] = gdy + (int64_t)tok * ld_dy + n0 + (qq << 3);
+        pb[j] = gx + (int64_t)tok * ld_x + k0 + (qq << 3);
+        nlive[j] = has_rs ? live_tab[min(smp[j], WG_MAXSAMPLES - 1)] : 1;
+      }
+    }
+    auto advance = [&](int j) __attribute__((always_inline)) {
+      rem[j] += WW_BK;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool w = rem[j] >= rps;
+        rem[j] -= w ? rps : 0;
+        smp[j] += w ? 1 : 0;
+      }
+      if (rps * 2 < WW_BK) { while (rem[j] >= rps) { rem[j] -= rps; ++smp[j]; } }
+    };
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {   // called with kt = 0, 1, 2, ... in order
+      unsigned char* sa = wg_smem + stage * WW_STAGE + lw * 8 * 256;
+      if (WW_ABLATE & 1) return;
+      if (kt < nfull) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* srca;
+          const char* srcb;
+          if (MAPPED) {
+            const uint64_t ro = (uint64_t)(unsigned)nlive[j];
+            srca = reinterpret_cast<const char*>(pa[j]) + ro * inca;
+            srcb = reinterpret_cast<const char*>(pb[j]) + ro * incb;
+          } else {
+            srca = reinterpret_cast<const char*>(nlive[j] ? pa[j] : pz);
+            srcb = reinterpret_cast<const char*>(nlive[j] ? pb[j] : pz);
+          }
+          const unsigned step = (MAPPED || nlive[j]) ? 256u : 0u;        // (a dropped sample's rows: four times the zero row)
+          unsigned char* d = sa + j * 4 * 256;
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)d, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(d + WW_PANEL), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + step), (lds_void_t*)(d + 2 * WW_PANEL), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + 2 * step), (lds_void_t*)(d + 3 * WW_PANEL), 16, 0, 0);
+          if (!MAPPED) {
+            pa[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pa[j]) + inca);
+            pb[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pb[j]) + incb);
+          }
+        }
+        if (MAPPED) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { advance(j); nlive[j] = perm_tab[min(smp[j], WG_MAXSAMPLES - 1)] + rem[j]; }
+        } else if (has_rs) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { advance(j); nlive[j] = live_tab[min(smp[j], WG_MAXSAMPLES - 1)]; }
+        }
+      } else {                                                            // the slice's partial last k-step
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = lw * 8 + j * 4 + prow;
+          const int tok = mbeg + kt * WW_BK + r;
+          bool live = tok < mend;
+          if (live && has_rs) live = live_tab[tok / rps - s0] != 0;
+          int64_t ro = tok;
+          if (MAPPED && live) { const int sq = tok / rps; ro = (int64_t)perm_tab[sq - s0] + (tok - sq * rps); }
+          const bf16* srca = live ? gdy + ro * ld_dy + n0 + (qq << 3) : pz;
+          const bf16* srcb = live ? gx + ro * ld_x + k0 + (qq << 3) : pz;
+          const int step = live ? 128 : 0;
+          unsigned char* d = sa + j * 4 * 256;
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)d, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(d + WW_PANEL), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + step), (lds_void_t*)(d + 2 * WW_PANEL), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + 2 * step), (lds_void_t*)(d + 3 * WW_PANEL), 16, 0, 0);
+        }
+      }
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < WW_NS - 1; ++s2)
+      if (s2 < nkt) issue(s2, s2);
+    if (nkt >= WW_NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((WW_NS - 2) * WW_LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const bool refill = kt + WW_NS - 1 < nkt;
+      if (refill) issue(kt + WW_NS - 1, buf == 0 ? WW_NS - 1 : buf - 1);
+      // k-step kt + 1 must have landed; two younger ones stay in flight (vmcnt retires in order)
+      if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((WW_NS - 2) * WW_LPT) : "memory");
+      else if (kt + WW_NS - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((WW_NS - 3) * WW_LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      buf = buf + 1 == WW_NS ? 0 : buf + 1;
+    }
+  } else {
+    // ---------------- multiplying waves: wr = row half of the dy columns (64), wc = quarter of the x columns (96)
+    const int wr = wave >> 2, wc = wave & 3;
+    unsigned fp_off[4], fq_off[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fp_off[i] = wg_lane_off(wr * 64 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int qc = wc * 96 + j * 16;
+      fq_off[j] = (unsigned)((1 + (qc >> 7)) * WW_PANEL) + wg_lane_off(qc & 127, lane);
+    }
+    const int kch = threadIdx.x & 15, krg = threadIdx.x >> 4;             // bias-gradient sums: 16-byte chunk, token row (0..31)
+    const unsigned ks_off = (unsigned)(krg * 256 + ((kch ^ wg_swz(krg)) << 4));
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const unsigned char* st = wg_smem + buf * WW_STAGE;
+      Vec8<bf16> fp[4], fq[6];
+      if (!(WW_ABLATE & 2)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fp[i] = ww_frag(st + fp_off[i]);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fq[j] = ww_frag(st + fq_off[j]);
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma16(fq[j], fp[i], acc[i][j]);
+      }
+      if (have_ksum) {
+        Vec8<bf16> t = load8<bf16>(reinterpret_cast<const bf16*>(st + ks_off));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ks8[e] += t.get(e);
+      }
+      __builtin_amdgcn_s_barrier();
+      buf = buf + 1 == WW_NS ? 0 : buf + 1;
+    }
+  }
+
+  const float sc = MAPPED ? q.scale : ((has_rs && !q.live_only) ? p.scale_const : 1.f);
+  const bool split = p.nz > 1;
+  if (have_ksum) {
+    float* red = reinterpret_cast<float*>(wg_smem);         // [32 token rows][128 cols]
+    if (wave < WW_NCW) {
+      const int kch = threadIdx.x & 15, krg = threadIdx.x >> 4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[krg * 128 + kch * 8 + e] = ks8[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int qd = 0; qd < 32; ++qd) s += red[qd * 128 + threadIdx.x];
+      if (split) q.ksum_part[(int64_t)tz * N + n0 + threadIdx.x] = s * sc;
+      else q.ksum_out[n0 + threadIdx.x] = s * sc;
+    }
+  }
+  if (wave >= WW_NCW) return;
+  if ((WW_ABLATE & 4) && acc[0][0][0] != 12345.678f) return;
+  // acc[i][j][r] = dW[n0 + 64 wr + 16 i + c][k0 + 96 wc + 16 j + 4 g + r]
+  const int wr = wave >> 2, wc = wave & 3, c_ = lane & 15, g_ = lane >> 4;
+  float* Cout = (split ? q.slab + (int64_t)tz * N * Kin : q.out) + (int64_t)(n0 + wr * 64 + c_) * Kin + k0 + wc * 96 + g_ * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 v = acc[i][j] * sc;
+      vmem_guard(v);
+      *reinterpret_cast<f32x4*>(Cout + (int64_t)(i * 16) * Kin + j * 16) = v;
+    }
+}
+
 // workgroups the chip keeps resident (256 CUs x 2: 64 KB ring each): the split-K slices are sized to it.
 // Ring: 64-token k-tiles x 2 stages, the whole next tile requested at the top of an iteration.  Measured against it on
 // the stage-3/4 shapes (per step): 32 tokens x 4 stages 7.48 vs 6.89 ms, 32 x 3 (3 workgroups per CU, 768 slices)
@@ -502,9 +767,10 @@ template <int BKT, int NS, int NW, bool MAPPED = false> static int wgrad_glds_la
 
 // Split-K slices of a (grouped) launch: tiles x slices should just fill ONE round of resident workgroups -- a partly
 // filled second round leaves CUs idle for the whole kernel because every workgroup runs the same long k-loop.
-int wgrad_glds_slices(int64_t mtok, int ntiles) {
+int wgrad_glds_slices(int64_t mtok, int ntiles, bool wide) {
   int target = vtx_opt(VTX_OPT_WGRAD_BLOCKS);
   if (target <= 0) target = wgrad_glds_resident();
+  if (wide) target = 256;                                  // one 131-KB workgroup per CU
   int nz = target / ntiles;
   const int64_t maxz = (mtok + 255) / 256;
   if (nz > maxz) nz = (int)maxz;
@@ -515,22 +781,36 @@ int wgrad_glds_slices(int64_t mtok, int ntiles) {
 
 int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) / 128); }
 
+// A group takes the 128 x 384 tiles when every problem is made of whole ones and whole slices of them fill >= 85 % of the CUs
+// (C = 384 layers: 36 tiles x 7 slices = 252; a C = 768 layer's 144 tiles would leave 112 CUs idle: 128 x 128 tiles there).
+int wgrad_wide_tiles(int nprob, const int* N, const int* Kin) {
+  if (!vtx_opt(VTX_OPT_WGRAD_WIDE)) return 0;
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (N[i] % 128 || Kin[i] % 384) return 0;
+    tiles += (N[i] / 128) * (Kin[i] / 384);
+  }
+  if (tiles < 1 || tiles > 256) return 0;
+  return (256 / tiles) * tiles >= 218 ? tiles : 0;
+}
+
 // slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)
 int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
-                            int nz, int kchunk, hipStream_t st) {
+                            int nz, int kchunk, hipStream_t st, bool wide) {
   if (nprob < 1 || nprob > WG_MAXPROB) return VTX_ERR_SHAPE;
   WgradArgs a;
   int t0 = 0;
   bool any_scale = false;
   for (int i = 0; i < nprob; ++i) {
+    if (wide && (hp[i].N % 128 || hp[i].Kin % 384)) return VTX_ERR_SHAPE;
     WgradProb& q = a.pr[i];
     q.dy = (const bf16*)hp[i].dy; q.x = (const bf16*)hp[i].x; q.slab = hp[i].slab; q.out = hp[i].out;
     q.ksum_part = hp[i].ksum_part; q.ksum_out = hp[i].ksum_out; q.rowscale = hp[i].rowscale;
     q.ld_dy = hp[i].ld_dy; q.ld_x = hp[i].ld_x; q.N = hp[i].N; q.Kin = hp[i].Kin;
-    q.ntk = (hp[i].Kin + 127) / 128; q.tile0 = t0; q.live_only = hp[i].live_only;
+    q.ntk = wide ? hp[i].Kin / 384 : (hp[i].Kin + 127) / 128; q.tile0 = t0; q.live_only = hp[i].live_only;
     q.perm = hp[i].perm; q.Mtok = hp[i].perm ? hp[i].Mtok : (int)mtok; q.scale = hp[i].scale;
     any_scale = any_scale || hp[i].perm != nullptr;          // (the sample table of a mapped problem has the same bound)
-    t0 += wgrad_glds_tiles(hp[i].N, hp[i].Kin);
+    t0 += wide ? (hp[i].N / 128) * (hp[i].Kin / 384) : wgrad_glds_tiles(hp[i].N, hp[i].Kin);
     any_scale = any_scale || hp[i].rowscale != nullptr;
   }
   for (int i = nprob; i < WG_MAXPROB; ++i) a.pr[i] = a.pr[0];
@@ -540,6 +820,16 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
   // 8 waves per workgroup: every shape of Swin-S / ViT-S 9-11 % faster than with 4 (stage-2..4 weight gradients 5.20 ->
   // 4.72 ms, ViT-S/16 4.66 -> 4.16 ms per step); 16 waves (one workgroup per CU: 73 registers) 5.6 vs 4.25 ms.
   // option WG_WAVES = 4 keeps the 2 x 2 variant for comparison
+  if (wide) {
+    bool wmapped = false;
+    for (int i = 0; i < nprob; ++i) wmapped = wmapped || hp[i].perm != nullptr;
+    for (int i = 0; i < nprob; ++i)
+      if (wmapped && hp[i].perm == nullptr) return VTX_ERR_SHAPE;
+    auto kern = wmapped ? wgrad_wide_kernel<true> : wgrad_wide_kernel<false>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WW_SMEM) != hipSuccess) return VTX_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nz), dim3(WW_NT), WW_SMEM, st, a);
+    return vtx_check_launch();
+  }
   if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
   // (ring geometries measured in round 2 and removed: 64 tokens x 3 stages, 32 x 3 / 4 / 5 -- all slower than 64 x 2,
   //  profiles/round2_wgrad_ring_variants.txt)

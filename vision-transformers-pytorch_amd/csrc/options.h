@@ -25,7 +25,8 @@ enum VtxOptionId {
   VTX_OPT_GEMM_SKINNY = 15,         // 1: bf16 GEMMs with K = 64 / 96 / 128 over >= 32 768 rows take the weight-resident streaming kernel (gemm_skinny.hip) | 0
   VTX_OPT_GEMM_ASTAT = 16,          // 1: bf16 GEMMs with 128 <= K <= 384 (K % 64 == 0, N % 128 == 0) over >= 96 row strips take the A-stationary kernel (gemm_astat.hip) | 2: any row count | 0
   VTX_OPT_TWINS_SUB_LDS = 17,       // 1: the Twins sub-sampling gather / scatter staged through LDS (one workgroup per row of patches) where the geometry allows | 0: element-wise
-  VTX_OPT_COUNT = 18
+  VTX_OPT_WGRAD_WIDE = 18,          // 1: grouped weight gradients made of whole 128 x 384 tiles (C = 384 layers) take the wide-tile kernel, one workgroup per CU | 0: 128 x 128 tiles
+  VTX_OPT_COUNT = 19
 };
 
 int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip

@@ -272,7 +272,7 @@ def _describe_timer_rec(r):
     if r.tag == 8:                                                      # the layer's grouped weight gradient: n = C, k = ff
         C, ff = n, k
         pairs = ((C, ff), (ff, C), (C, C), (3 * C, C))
-        name = f"wgrad_glds_kernel<64, 2, 8, {mapped}> (+split-K and column reduce)"
+        name = wgrad_group_kernel_name(pairs, mapped) + " (+split-K and column reduce)"
         return (name, sum(2.0 * rows * a * b for a, b in pairs),
                 sum(2.0 * rows * (a + b) + 4.0 * a * b for a, b in pairs), r.ms)
     if r.tag in (9, 10):                                                # sub-sampled attention: rows queries, n heads of D, k keys
@@ -283,10 +283,10 @@ def _describe_timer_rec(r):
         if r.tag == 11:
             C, ff = n, k
             pairs = ((C, ff), (ff, C), (C, C), (C, C)) + (((2 * C, C),) if fl & 1 else ())
-            name = "wgrad_glds_kernel<64, 2, 8, false> (+split-K and column reduce)"
+            name = wgrad_group_kernel_name(pairs) + " (+split-K and column reduce)"
         elif r.tag == 12:
             pairs = ((2 * n, n), (n, k))
-            name = "wgrad_glds_kernel<64, 2, 8, false> (+split-K reduce)"
+            name = wgrad_group_kernel_name(pairs) + " (+split-K reduce)"
         else:
             pairs = ((n, k),)
             name = wgrad_kernel_name(dt, n, k, True) + " (+split-K reduce)"
@@ -395,6 +395,21 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     if ev:
         ev[1].record()
     return (c, aux) if want_aux else c
+
+
+def wgrad_wide_tiles(pairs):
+    """128 x 384 tiles of a grouped weight gradient [(N, Kin), ...], or 0 when the group stays on 128 x 128 tiles (mirrors
+    wgrad_wide_tiles, csrc/gemm_wgrad_glds.hip)."""
+    if not options.get("WGRAD_WIDE") or any(n % 128 or k % 384 for n, k in pairs):
+        return 0
+    tiles = sum((n // 128) * (k // 384) for n, k in pairs)
+    return tiles if 1 <= tiles <= 256 and (256 // tiles) * tiles >= 218 else 0
+
+
+def wgrad_group_kernel_name(pairs, mapped="false"):
+    if wgrad_wide_tiles(pairs):
+        return f"wgrad_wide_kernel<{mapped}>"
+    return f"wgrad_glds_kernel<64, 2, {4 if options.get('WG_WAVES') == 4 else 8}, {mapped}>"
 
 
 def wgrad_kernel_name(dtype, N, Kin, glds):
@@ -512,7 +527,7 @@ def wgrad_group(jobs, rows_per_scale=1, scale_const=0.0, outs=None, colparts=Non
     cvp = lambda ts: (ctypes.c_void_p * max(nc, 1))(*[None if t is None else t.data_ptr() for t in ts]) if nc else None
     cia = lambda xs: (ctypes.c_int * max(nc, 1))(*xs) if nc else None
     cp = colparts or []
-    with _timed(wgrad_kernel_name(torch.bfloat16, 0, 0, True) + (" (+split-K and column reduce)" if nc else " (+split-K reduce)"),
+    with _timed(wgrad_group_kernel_name(list(zip(Nl, Kl))) + (" (+split-K and column reduce)" if nc else " (+split-K reduce)"),
                 flops, nbytes + sum(4.0 * p.nb * p.ld for p in cp)):
         check(lib.vtx_wgrad_group(BF16, n, vp([j[0] for j in jobs]), vp([j[1] for j in jobs]), vp(dWs), vp(dbs), Ns, Ks,
                                   lds, ldx, vp([j[3] for j in jobs]), int(rows_per_scale), float(scale_const), M, _p(ws),
