@@ -303,3 +303,16 @@ def test_a_stationary_gemm_isa_keeps_the_invariants_its_counted_waits_rely_on():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "0 violations in 64" in r.stdout
+
+
+def test_wide_tile_weight_gradient_isa_has_no_spills_and_no_compiler_drain_in_its_loops():
+    """Round 4: wgrad_wide_kernel (csrc/gemm_wgrad_glds.hip) runs one 12-wave workgroup per CU at exactly the 168-register budget and
+    its request waves count their LDS-DMA by hand next to LDS table reads: a spill, a flat access or a compiler-inserted
+    `s_waitcnt vmcnt(0)` inside the loops would silently cost the overlap -- checked on the generated gfx950 assembly."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "probe", "scan_wgrad_isa.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "0 violations in 2" in r.stdout
