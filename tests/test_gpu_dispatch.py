@@ -272,7 +272,8 @@ def _layer_jobs(B, T, C, ff, d, seed=140):
 
 @pytest.mark.parametrize("B,T,C,ff", [(128, 196, 384, 1536),       # Swin-S stage 3 (18 of the 24 layers): 108 tiles x 4 slices
                                       (128, 3136, 96, 384),        # stage 1: ragged 96-wide tiles, 51 slices
-                                      (256, 197, 384, 1536)])      # ViT-S/16 B = 256
+                                      (256, 197, 384, 1536),       # ViT-S/16 B = 256
+                                      (37, 197, 384, 1536)])       # 7 289 tokens: slices that end inside a 32-token k-step of the wide-tile kernel
 def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
     """The grouped launch of a layer's four weight gradients (fc2 and proj through DropPath) vs fp64; the grouped launch vs
     one launch per problem; 8 vs 4 waves: dW bit-identical; rerun: bit-identical (deterministic)."""
