@@ -79,7 +79,18 @@ def _worker(rank, world, port, q):
         for p, e in zip(model.parameters(), exp2):
             assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6)
 
+        # (gradients existed at the entry of that backward: the object has gone back to per-parameter counting for good --
+        # a bucket-level trigger cannot verify arrival then)
+        assert ddp._counting_only and all(len(b.handles) == len(b.params) for b in ddp.buckets)
         # set_to_none + a fresh backward re-arms the buckets
+        model.zero_grad(set_to_none=True)
+        local_grads(model, 0)
+        ddp.finish()
+        for p, e in zip(model.parameters(), exp):
+            assert torch.allclose(p.grad, e, rtol=1e-6, atol=1e-7)
+        assert all(len(b.handles) == len(b.params) for b in ddp.buckets)
+        ddp.remove()
+        ddp = GradAllReduce(model, bucket_bytes=6000, first_bucket_bytes=1000)
         model.zero_grad(set_to_none=True)
         local_grads(model, 0)
         ddp.finish()
@@ -408,3 +419,107 @@ def test_micro_step_is_required_when_accumulating():
     assert [accumulation_boundary(2, i) for i in range(4)] == [False, True, False, True]
     with pytest.raises(ValueError, match="micro_step"):
         accumulation_boundary(2, None)
+
+
+class _TwoOrders(nn.Module):
+    """Two Linears whose ORDER in the graph is chosen per call: their gradients arrive in the opposite order."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.a = nn.Linear(8, 8)
+        self.b = nn.Linear(8, 8)
+
+    def forward(self, x, swap):
+        return self.a(self.b(x)) if swap else self.b(self.a(x))
+
+
+def _order_worker(rank, world, port, q, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vtx.ddp import GradAllReduce
+        torch.manual_seed(11)
+        xs = [torch.randn(5, 8) for _ in range(6)]
+
+        def expected(pairs):
+            m = _TwoOrders()
+            for x, swap in pairs:
+                m(x, swap).square().sum().backward()
+            return [p.grad.clone() for p in m.parameters()]
+
+        model = _TwoOrders()
+        ddp = GradAllReduce(model, bucket_bytes=1 << 20, first_bucket_bytes=1 << 20, force=True)   # one bucket, 4 parameters
+        assert len(ddp.buckets) == 1
+
+        def step(pairs, mode):
+            """one optimizer step of len(pairs) micro-batches"""
+            for i, (x, swap) in enumerate(pairs):
+                last = i == len(pairs) - 1
+                if mode == "boundary" and not last:
+                    with ddp.no_sync():
+                        model(x, swap).square().sum().backward()
+                else:
+                    model(x, swap).square().sum().backward()
+                    if mode == "every" or last:
+                        ddp.finish()
+            got = [p.grad.clone() for p in model.parameters()]
+            exp = expected(pairs)
+            for g, e, (n, _) in zip(got, exp, model.named_parameters()):
+                assert torch.allclose(g, e, atol=1e-5), f"{case}: {n} max err {(g - e).abs().max().item():.3g}"
+
+        # learn the arrival order on plain steps (bucket-level trigger adopted after the first)
+        for k in range(2):
+            step([(xs[k], False)], "plain")
+            model.zero_grad(set_to_none=True)
+        assert ddp.buckets[0].trigger is not None
+        if case == "no_sync_swapped":
+            # ADVICE r4: accumulated gradients exist at the entry of the boundary backward and the order is the other one
+            step([(xs[2], False), (xs[3], True)], "boundary")
+            model.zero_grad(set_to_none=True)
+            step([(xs[4], True), (xs[5], False)], "boundary")
+        elif case == "every_swapped":
+            step([(xs[2], False), (xs[3], True)], "every")
+        elif case == "zero_grad_in_place":
+            model.zero_grad(set_to_none=False)         # the gradients installed by finish() stay, zeroed
+            step([(xs[2], True)], "plain")
+            model.zero_grad(set_to_none=False)
+            step([(xs[3], False)], "plain")
+        elif case == "finish_twice":
+            try:
+                ddp.finish()
+            except RuntimeError as e:
+                assert "no backward() ran outside no_sync()" in str(e)
+            else:
+                raise AssertionError("a second finish() in a row must raise")
+            with ddp.no_sync():
+                model(xs[2], False).square().sum().backward()
+            try:
+                ddp.finish()
+            except RuntimeError as e:
+                assert "no backward() ran outside no_sync()" in str(e)
+            else:
+                raise AssertionError("finish() after only no_sync backwards must raise")
+            model.zero_grad(set_to_none=True)
+            step([(xs[3], False)], "plain")             # still usable
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["no_sync_swapped", "every_swapped", "zero_grad_in_place", "finish_twice"])
+def test_bucket_trigger_never_reduces_before_the_last_gradient(case):
+    """with gradients present at backward entry the bucket-level trigger's `grad is not None` check is
+    vacuous; a changed arrival order then reduced the bucket early (max error 5.2 in the advisor's reproduction)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    p = ctx.Process(target=_order_worker, args=(0, 1, port, q, case))
+    p.start()
+    rank, msg = q.get(timeout=180)
+    p.join(timeout=60)
+    assert msg == "ok", msg

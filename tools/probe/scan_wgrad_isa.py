@@ -15,7 +15,8 @@ import os, re, subprocess, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(REPO, "vision-transformers-pytorch_amd", "csrc", "gemm_wgrad_glds.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-value"]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "vision-transformers-pytorch_amd"))
+from vtx.build import FLAGS   # the flags of the shipped library: a scan validates THAT binary
 
 
 def main():

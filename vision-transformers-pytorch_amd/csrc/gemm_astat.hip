@@ -577,7 +577,9 @@ bool gemm_astat_ok(const GemmArgs& a) {
   if (a.kscale != nullptr || a.ksum_out != nullptr) return false;
   if ((a.act == 2 || a.act == 4) && a.resid != nullptr) return false;     // (no hot-path launch has both)
   if ((a.act == 1 || a.act == 3) && a.resid != nullptr) return false;
-  if (a.resid == a.C && a.M % AS_BM != 0) return false;                    // (in place + a partial strip: the last row is stored more than once)
+  // in place + a partial last strip: the duplicated last row is stored by several lanes and waves, and a duplicate in another
+  // wave may read an operand that aliases C (resid, z of act', A) after the row was already stored
+  if ((a.resid == a.C || a.aux_in == a.C || a.aux_out == a.C || a.A == a.C) && a.M % AS_BM != 0) return false;
   const long rows = a.perm != nullptr ? a.Mk : a.M;
   if (rows <= 0) return false;
   const long tiles = (rows + AS_BM - 1) / AS_BM * (a.N / AS_BN);

@@ -23,7 +23,7 @@ enum VtxOptionId {
   VTX_OPT_SATTN_WAVES = 13,         // ViT attention fast path: 4 waves on pairs of 16-token tiles | 8 waves on single tiles
   VTX_OPT_WATTN_BWD4 = 14,          // 1: bf16 window-attention backward with four waves per problem (wattn_bwd4_kernel) | 0: one wave
   VTX_OPT_GEMM_SKINNY = 15,         // 1: bf16 GEMMs with K = 64 / 96 / 128 over >= 32 768 rows take the weight-resident streaming kernel (gemm_skinny.hip) | 0
-  VTX_OPT_GEMM_ASTAT = 16,          // 1: bf16 GEMMs with 128 <= K <= 384 (K % 64 == 0, N % 128 == 0) over >= 96 row strips take the A-stationary kernel (gemm_astat.hip) | 2: any row count | 0
+  VTX_OPT_GEMM_ASTAT = 16,          // 1: bf16 GEMMs with 192 <= K <= 384 (K % 64 == 0, N % 128 == 0, N >= 256) and >= 2 tiles per CU take the A-stationary kernel (gemm_astat.hip) | 2: any row count | 3: >= 1.25 tiles per CU | 0
   VTX_OPT_TWINS_SUB_LDS = 17,       // 1: the Twins sub-sampling gather / scatter staged through LDS (one workgroup per row of patches) where the geometry allows | 0: element-wise
   VTX_OPT_WGRAD_WIDE = 18,          // 1: grouped weight gradients made of whole 128 x 384 tiles (C = 384 layers) take the wide-tile kernel, one workgroup per CU | 0: 128 x 128 tiles
   VTX_OPT_COUNT = 19

@@ -104,6 +104,14 @@ class GradAllReduce:
         self._slot = {}
         self._sunk = set()         # ids of the parameters whose bucket slot was handed out as a gradient sink since finish()
         self._sync = True          # False inside no_sync(): hooks do not count, nothing is reduced
+        self._saw_sync_hook = False   # a hook ran outside no_sync() since the last finish() (i.e. a synced backward happened)
+        # Bucket-level trigger hooks verify "every gradient of the bucket is there" by `p.grad is not None`, which only
+        # means ARRIVED IN THIS BACKWARD when every .grad was None at its entry.  Gradients that exist on entry -- an
+        # accumulation cycle (no_sync), finish() after every micro-batch, zero_grad(set_to_none=False) -- make the check
+        # vacuous: a changed arrival order would then reduce a bucket before its last gradient was accumulated, silently.
+        # Once such a cycle is seen the object stays on per-parameter counting hooks (exact in every case) for good.
+        self._counting_only = not bucket_hooks
+        self._pending_counting = False
         for b in self.buckets:
             dev = b.params[0].device
             off = 0
@@ -154,6 +162,7 @@ class GradAllReduce:
         the mean over ranks of the summed micro-batch gradients, i.e. what the reference's all-reduce-per-micro-batch
         (train.py:283-299 under DDP, no no_sync) arrives at, with 1 / grad_accum of its xGMI traffic."""
         prev, self._sync = self._sync, False
+        self._need_counting()       # gradients will exist at the entry of the boundary backward: triggers cannot verify arrival
         try:
             yield
         finally:
@@ -166,6 +175,18 @@ class GradAllReduce:
     # backward).  The trigger verifies that every gradient of its bucket is there before it launches; if one is missing (the
     # graph changed: a frozen / newly trained parameter, another execution order) the bucket goes back to counting, and
     # finish() launches what is still unreduced once backward has ended -- late, never wrong.
+    def _need_counting(self):
+        """Switch every bucket to per-parameter counting hooks, permanently (see ``_counting_only``)."""
+        if self._counting_only:
+            return
+        self._counting_only = True
+        for b in self.buckets:
+            if len(b.handles) != len(b.params):
+                pend = b.pending
+                self._count_hooks(b)
+                if b.work is not None:          # already reduced in this cycle: stays reduced until finish()
+                    b.pending = pend
+
     def _count_hooks(self, b):
         for h in b.handles.values():
             h.remove()
@@ -177,6 +198,7 @@ class GradAllReduce:
         def hook(param):
             if not self._sync:
                 return
+            self._saw_sync_hook = True
             bucket.pending -= 1
             if bucket.pending == 0:
                 bucket.learned = param
@@ -197,7 +219,14 @@ class GradAllReduce:
                     "GradAllReduce: a second backward() reached an already-reduced bucket before finish() -- with gradient "
                     "accumulation either call finish() after EVERY backward (the reference's all-reduce per micro-batch) "
                     "or wrap the non-boundary backwards in no_sync()")
-            if all(p.grad is not None for p in bucket.params):
+            self._saw_sync_hook = True
+            if any(p.grad is v for p, v in zip(bucket.params, bucket.views)):
+                # a gradient installed by the last finish() is still there (finish() after every micro-batch, or
+                # zero_grad(set_to_none=False)): gradients existed at the entry of this backward, arrival cannot be
+                # verified -> this bucket is reduced by finish(), and every bucket counts per parameter from then on
+                bucket.trigger = None
+                self._pending_counting = True
+            elif all(p.grad is not None for p in bucket.params):
                 bucket.pending = 0
                 self._launch(bucket)
             else:
@@ -206,7 +235,7 @@ class GradAllReduce:
 
     def _adopt_trigger(self, b):
         """After a fully counted backward: keep only the last-arriving parameter's hook."""
-        if not self.bucket_hooks or b.trigger is not None or b.learned is None or len(b.params) == 1:
+        if self._counting_only or b.trigger is not None or b.learned is None or len(b.params) == 1:
             return
         for h in b.handles.values():
             h.remove()
@@ -228,6 +257,7 @@ class GradAllReduce:
                 self._count_hooks(b)
         self._sunk.clear()
         self._sync = True
+        self._saw_sync_hook = False
 
     def _launch(self, b):
         side = None
@@ -256,6 +286,19 @@ class GradAllReduce:
         if not self.active:
             return
         late = [b for b in self.buckets if b.work is None and b.handles and len(b.handles) != len(b.params)]
+        if not self._saw_sync_hook and any(b.work is None for b in self.buckets):
+            # nothing ran outside no_sync() since the last finish() (a second finish() in a row, only no_sync backwards):
+            # raise BEFORE launching any collective -- ranks must never disagree on which collectives were issued
+            for b in self.buckets:
+                if b.work is not None:
+                    b.work.wait()
+                b.work, b.pending = None, len(b.params)
+            self._sunk.clear()
+            raise RuntimeError("GradAllReduce.finish(): not every bucket was reduced -- no backward() ran outside no_sync() "
+                               "since the last finish()")
+        if self._pending_counting:
+            self._pending_counting = False
+            self._counting_only = True
         for b in late:
             # a bucket on its bucket-level hook that was not reduced during backward: the trigger's parameter was not the
             # last one this time (or received no gradient).  Backward is over: reduce now if every gradient is there, and
@@ -286,8 +329,11 @@ class GradAllReduce:
                 p.grad = v
             b.work = None
             b.pending = len(b.params)
+            if self._counting_only and len(b.handles) != len(b.params):
+                self._count_hooks(b)
             self._adopt_trigger(b)
         self._sunk.clear()
+        self._saw_sync_hook = False
 
     def remove(self):
         for b in self.buckets:
