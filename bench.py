@@ -233,6 +233,69 @@ def selftest_launch(rank, world):
         print(json.dumps({"selftest_launch": True, "world_size_observed": seen, "sum": t.item()}))
 
 
+def preflight(args, dev, rank, world):
+    """N > 1 pre-flight (VERDICT r4 #5b): everything the data-parallel branch depends on is exercised and checked BEFORE a
+    model is built, so that the first real 8-GPU run is not also the first execution of that branch -- and fails loudly, with a
+    message that names the cause, instead of hanging in a collective or printing a wrong number.  Returns a dict of what was seen
+    (rank 0 prints it on stderr; ``--preflight-only`` prints it as the JSON line and stops)."""
+    info = {"world": world, "backend": dist.get_backend(), "rank0_device": str(dev)}
+    if dist.get_world_size() != world:
+        raise SystemExit(f"pre-flight: process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}")
+    nccl = dist.get_backend() == "nccl"
+    if nccl:
+        ndev = torch.cuda.device_count()
+        info["devices_visible"] = ndev
+        if ndev < world and not args.share_gpu:
+            raise SystemExit(f"pre-flight: {world} ranks but only {ndev} visible GPU(s) on this node (one process per GPU; "
+                             "--share-gpu is the test-only way to oversubscribe)")
+        info["rccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+        info["ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        if info["ipc_mode_legacy"] != "0":
+            print("pre-flight WARNING: HSA_ENABLE_IPC_MODE_LEGACY is not 0 -- RCCL's intra-node IPC may fail with "
+                  "'hipIpcGetMemHandle: invalid argument' on this driver", file=sys.stderr)
+    cdev = dev if nccl else torch.device("cpu")
+    # every rank is there and they agree on who they are: sum of ranks, max of ranks
+    t = torch.tensor([float(rank), 1.0], device=cdev)
+    dist.all_reduce(t)
+    if t[0].item() != world * (world - 1) / 2 or t[1].item() != world:
+        raise SystemExit(f"pre-flight: all_reduce(sum) of the ranks gave {t.tolist()} for world {world}")
+    # the collective GradAllReduce uses: fp32 average of a bucket-sized buffer (ncclAvg on RCCL; sum + divide elsewhere)
+    n = 1 << 20
+    buf = torch.full((n,), float(rank + 1), device=cdev)
+    if nccl:
+        try:
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+        except Exception as exc:     # noqa: BLE001
+            raise SystemExit(f"pre-flight: ReduceOp.AVG is not supported by this RCCL build ({type(exc).__name__}: {exc})")
+        info["reduce_op_avg"] = True
+    else:
+        dist.all_reduce(buf)
+        buf /= world
+        info["reduce_op_avg"] = False
+    want = (world + 1) / 2
+    if not torch.allclose(buf, torch.full_like(buf, want)):
+        raise SystemExit(f"pre-flight: averaged all_reduce returned {buf[:4].tolist()} instead of {want}")
+    # side-stream collective behind an event of the compute stream (how buckets are reduced during backward)
+    if nccl:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            w = dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True)
+        w.wait()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if not torch.allclose(buf, torch.full_like(buf, want)):
+            raise SystemExit("pre-flight: side-stream all_reduce changed the averaged buffer")
+    dist.barrier()
+    return info
+
+
+def describe_buckets(ddp):
+    """Bucket layout of a GradAllReduce (printed on stderr by rank 0 of an N > 1 run)."""
+    return [{"bucket": b.index, "params": len(b.params), "MB": round(b.flat_numel * 4 / 2**20, 2), "first": b.names[0],
+             "last": b.names[-1]} for b in ddp.buckets]
+
+
 def default_batch(name):
     """Per-GPU batch of BASELINE.json's configurations: 256 ViT-S/16 (cfg-2), 128 Swin-S / PVT-Small (cfg-3 / 4), 64 DINO (cfg-5)."""
     return 256 if name == "vit_s16" else (64 if name == "dino" else 128)
@@ -249,6 +312,8 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
     torch.manual_seed(0)                       # identical init on every rank (+ rank-0 broadcast in GradAllReduce)
     model = build_model(model_name, drop_path).to(dev).train()
     ddp = GradAllReduce(model)
+    if world > 1 and rank == 0:
+        print(f"[bench] gradient buckets ({model_name}): {json.dumps(describe_buckets(ddp))}", file=sys.stderr)
     ac = torch.bfloat16 if args.dtype == "bf16" else None
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     torch.manual_seed(4242 + rank)             # DropPath masks differ per rank from here on (the model is already built)
@@ -405,6 +470,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend of the N > 1 run: nccl (= RCCL, the product path) | gloo (TEST ONLY: lets the "
                          "world > 1 branch of this file run where RCCL cannot, e.g. two ranks on one GPU with --share-gpu)")
+    ap.add_argument("--preflight-only", action="store_true",
+                    help="N > 1: run only the pre-flight of the data-parallel branch (ranks, devices, RCCL version, ReduceOp.AVG, "
+                         "side-stream collective) and print what it saw")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: every rank uses cuda:(LOCAL_RANK mod device count) -- two ranks on the one GPU of a test box")
     args = ap.parse_args()
@@ -420,14 +488,32 @@ def main():
         return selftest_launch(rank, world)
     if args.share_gpu:
         local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    cpu_only = args.preflight_only and args.backend == "gloo" and not torch.cuda.is_available()
+    if cpu_only:
+        dev = torch.device("cpu")                              # (the pre-flight's own CPU test: gloo, no GPU)
+    else:
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} visible GPU(s) "
+                             "(one process per GPU; --share-gpu is the test-only way to oversubscribe)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        pf = preflight(args, dev, rank, world)
+        if rank == 0:
+            print(f"[bench] pre-flight ok: {json.dumps(pf)}", file=sys.stderr)
+        if args.preflight_only:
+            if rank == 0:
+                print(json.dumps({"preflight": pf}))
+            dist.destroy_process_group()
+            return
+    elif args.preflight_only:
+        print(json.dumps({"preflight": {"world": 1, "note": "single process: nothing to check"}}))
+        return
 
     batch = args.batch or default_batch(args.model)
     cpu = None

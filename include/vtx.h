@@ -45,6 +45,9 @@ extern "C" {
 const char* vtx_strerror(int code);
 /* ABI version of the library (bumped on any signature change). */
 int vtx_abi_version(void);
+/* Compute units of the current device (256 on MI355X): what the one-workgroup-per-CU kernels size their grids and the
+ * dispatch heuristics their thresholds with; the Python mirrors of those heuristics (vtx/ops.py) ask here. */
+int vtx_cu_count(void);
 
 /* ---- Dispatch switches (csrc/options.h).  Which kernel variant an entry point launches -- LDS-DMA vs register-staged
  * GEMM, tile height, waves per workgroup, split-K target, fused vs separate split-K reduction, persistent-grid sizes --

@@ -206,6 +206,27 @@ def test_bench_self_launches_its_ranks():
     assert r2.returncode != 0 and "disagree" in (r2.stderr + r2.stdout)
 
 
+def test_bench_preflight_checks_the_data_parallel_branch_before_any_model():
+    """VERDICT r4 #5b: `bench.py --gpus N` runs a pre-flight of the N > 1 branch (ranks agree, averaged all-reduce of a
+    bucket-sized buffer is right) and fails LOUDLY on a node that cannot run it.  Here: 2 gloo ranks on CPU pass; an nccl run
+    on a machine with fewer GPUs than ranks stops with a message that says so instead of hanging in a collective."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", "gloo", "--preflight-only"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["preflight"]
+    assert out["world"] == 2 and out["backend"] == "gloo" and out["reduce_op_avg"] is False
+    assert "pre-flight ok" in r.stderr
+    if torch.cuda.device_count() < 2:
+        r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--preflight-only"],
+                            capture_output=True, text=True, timeout=300, env=env)
+        assert r2.returncode != 0 and "visible GPU" in (r2.stderr + r2.stdout)
+
+
 def _sink_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -113,16 +113,28 @@ def _bf16_vs_oracle(model, oracle_fwd, sd, x, what):
     names = [n for n, _ in model.named_parameters()]
     rg = torch.autograd.grad((ref * cot).sum(), [P[n] for n in names])
     num = den = 0.0
-    per = []
-    for n, r in zip(names, rg):
+    per, tiny = [], []
+    norms = [r.double().norm().item() / max(r.numel(), 1) ** 0.5 for r in rg]           # RMS of every reference gradient
+    typical = float(np.median([v for v in norms if v > 0]))
+    for n, r, rms in zip(names, rg, norms):
         gp = dict(model.named_parameters())[n].grad.double().cpu()
         d = (gp - r.double()).norm().item()
         num += d * d
         den += r.double().norm().item() ** 2
-        per.append(d / max(r.double().norm().item(), 1e-30))
+        if rms < 1e-6 * typical:
+            # a parameter whose TRUE gradient is (numerically) zero -- Twins-SVT's stage-4 linear_q with one sub-sampled key:
+            # softmax over one key is constant -- receives bf16 rounding noise; a relative error is meaningless there (the old
+            # informational line printed 4e24).  Absolute bound instead: its RMS stays below 1e-3 of a typical gradient's RMS.
+            tiny.append((n, d / max(r.numel(), 1) ** 0.5 / typical))
+        else:
+            per.append(d / r.double().norm().item())
     assert report(f"{what} bf16 all-parameter gradient rel-L2 vs oracle", (num / den) ** 0.5, 2e-2)
     assert report(f"{what} bf16 median per-parameter gradient rel-L2", float(np.median(per)), 2e-2)
-    report(f"{what} bf16 worst per-parameter gradient rel-L2 (informational)", float(np.max(per)), float("inf"))
+    # every single parameter: 6x the whole-model tolerance (small tensors -- a 169 x h rel_pos table, a bias -- are noisier than the
+    # concatenation; measured worst 3.9e-2 Swin-S / 4.4e-2 ViT-S/16 in round 5)
+    assert report(f"{what} bf16 worst per-parameter gradient rel-L2", float(np.max(per)), 1.2e-1)
+    for n, v in tiny:
+        assert report(f"{what} bf16 zero-gradient parameter {n}: RMS / typical gradient RMS", v, 1e-3)
 
 
 def test_swin_s_bf16_autocast_vs_oracle():

@@ -13,7 +13,7 @@ const OptDef kOptDefs[VTX_OPT_COUNT] = {
     {"VTX_WATTN_WAVES", 2048}, {"VTX_SRATTN_WGS", 2048}, {"VTX_WATTN_XCD_MAJOR", 1},
     {"VTX_LN_FIT", 1},      {"VTX_GLDS_EPI", 1},    {"VTX_SATTN_WAVES", 8},
     {"VTX_WATTN_BWD4", 1},  {"VTX_GEMM_SKINNY", 1}, {"VTX_GEMM_ASTAT", 1},
-    {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1},
+    {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1}, {"VTX_GEMM_STRIP", 1},
 };
 struct OptTable {
   std::atomic<int> v[VTX_OPT_COUNT];
@@ -26,6 +26,17 @@ struct OptTable {
 };
 OptTable& opt_table() { static OptTable t; return t; }   // initialised on first use (thread-safe static)
 }  // namespace
+
+int vtx_cu_count_cached() {
+  static std::atomic<int> n{0};
+  int v = n.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 int vtx_opt(int id) { return opt_table().v[id].load(std::memory_order_relaxed); }
 
@@ -53,6 +64,8 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 15; }
+int vtx_abi_version(void) { return 16; }
+
+int vtx_cu_count(void) { return vtx_cu_count_cached(); }
 
 }  // extern "C"

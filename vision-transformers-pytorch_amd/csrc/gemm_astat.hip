@@ -558,15 +558,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 // ------------------------------------------------------------------------------------------------------------------ host side
 static size_t astat_smem(int K) { return (size_t)(K / 64 + AS_NSW) * AS_KT_BYTES; }     // dynamic part: A slots + weight ring (the tables are static)
 
-static int astat_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n = v;
-  }
-  return n;
-}
+static int astat_cus() { return vtx_cu_count_cached(); }
 
 bool gemm_astat_ok(const GemmArgs& a) {
   const int mode = vtx_opt(VTX_OPT_GEMM_ASTAT);

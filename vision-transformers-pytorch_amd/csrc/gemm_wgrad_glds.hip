@@ -770,7 +770,7 @@ template <int BKT, int NS, int NW, bool MAPPED = false> static int wgrad_glds_la
 int wgrad_glds_slices(int64_t mtok, int ntiles, bool wide) {
   int target = vtx_opt(VTX_OPT_WGRAD_BLOCKS);
   if (target <= 0) target = wgrad_glds_resident();
-  if (wide) target = 256;                                  // one 131-KB workgroup per CU
+  if (wide) target = vtx_cu_count_cached();                // one 131-KB workgroup per CU
   int nz = target / ntiles;
   const int64_t maxz = (mtok + 255) / 256;
   if (nz > maxz) nz = (int)maxz;
@@ -790,8 +790,9 @@ int wgrad_wide_tiles(int nprob, const int* N, const int* Kin) {
     if (N[i] % 128 || Kin[i] % 384) return 0;
     tiles += (N[i] / 128) * (Kin[i] / 384);
   }
-  if (tiles < 1 || tiles > 256) return 0;
-  return (256 / tiles) * tiles >= 218 ? tiles : 0;
+  const int cus = vtx_cu_count_cached();
+  if (tiles < 1 || tiles > cus) return 0;
+  return 100 * ((cus / tiles) * tiles) >= 85 * cus ? tiles : 0;
 }
 
 // slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)

@@ -318,7 +318,10 @@ def glds_ok(N, K):
     return K % 64 == 0 or (K % 32 == 0 and N % 128 == 0)
 
 
-_ASTAT_CUS = 256          # (MI355X; gemm_astat.hip asks the device)
+def cu_count():
+    """Compute units of the current device as the library's dispatch heuristics see them (vtx_cu_count)."""
+    return _lib.load().vtx_cu_count()
+
 
 
 def astat_ok(N, K, M, bias=True):
@@ -327,7 +330,7 @@ def astat_ok(N, K, M, bias=True):
     mode = options.get("GEMM_ASTAT")
     if not mode or K % 64 or K < 192 or K > 384 or N % 128 or N < 256 or (N > 1536 and bias) or M <= 0:
         return False
-    return mode == 2 or 4 * ((M + 127) // 128) * (N // 128) >= (5 if mode == 3 else 8) * _ASTAT_CUS
+    return mode == 2 or 4 * ((M + 127) // 128) * (N // 128) >= (5 if mode == 3 else 8) * cu_count()
 
 
 def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False, bias=True):
@@ -403,7 +406,8 @@ def wgrad_wide_tiles(pairs):
     if not options.get("WGRAD_WIDE") or any(n % 128 or k % 384 for n, k in pairs):
         return 0
     tiles = sum((n // 128) * (k // 384) for n, k in pairs)
-    return tiles if 1 <= tiles <= 256 and (256 // tiles) * tiles >= 218 else 0
+    cus = cu_count()
+    return tiles if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= 85 * cus else 0
 
 
 def wgrad_group_kernel_name(pairs, mapped="false"):
