@@ -33,9 +33,12 @@ def _mm64(a, b_t):
 BIG128 = "gemm_glds_pv_kernel<128, 2, false>"            # 128 x 128 tiles, 4 x 2 waves, wave-private epilogue (the benchmark default for K > 384)
 
 
-def _bench_kernel(K, astat):
-    """The kernel the benchmark runs these shapes on: round 4's A-stationary persistent kernel for 192 <= K <= 384 (option GEMM_ASTAT,
-    default 1), the tiled LDS-DMA kernel otherwise."""
+def _bench_kernel(K, astat, M=0, N=0):
+    """The kernel the benchmark runs these shapes on: round 5's two-group kernel for the long contractions (option GEMM_PP, default 1),
+    round 4's A-stationary persistent kernel for 192 <= K <= 384 (option GEMM_ASTAT, default 1), the tiled LDS-DMA kernel otherwise."""
+    from vtx import ops
+    if ops.pp_ok(N, K, M):
+        return f"gemm_pp_kernel<{ops.pp_wmf(M, N)}, false>"
     return f"gemm_astat_kernel<{K // 64}, false, ...>" if (astat and 192 <= K <= 384) else BIG128
 
 
@@ -81,7 +84,8 @@ def test_glds128_silu_and_dsilu_epilogues_vs_oracle(M, N, K, T, astat):
 def test_glds128_droppath_residual_epilogue_vs_oracle(M, N, K, T, astat):
     from vtx import ops
     d = dev()
-    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == _bench_kernel(K, astat)
+    assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M) == _bench_kernel(K, astat, M, N)
+    assert K != 1536 or "gemm_pp_kernel" in ops.gemm_kernel_name(BF, N, 0, K=K, M=M)    # (ViT-S/16 fc2: the two-group kernel)
     hh = _mk((M, K), 111, BF)
     w = _mk((N, K), 112, BF, 0.05)
     b = _mk((N,), 113, torch.float32, 0.1)
@@ -122,6 +126,42 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
             got = run()
         for a, g, name in zip(base, got, ("h", "z", "dz", "y")):
             assert torch.equal(a, g), f"{name} differs under {kw}"
+
+
+@pytest.mark.parametrize("M,N,K,T", [(25088, 384, 1536, 196),      # Swin-S stage-3 fc2 forward / fc1 dgrad, B = 128 (224 tiles of 224 x 192)
+                                     (50432, 384, 1152, 197),      # ViT-S/16 qkv dgrad, B = 256 (two rounds)
+                                     (111 * 196, 384, 1536, 196),  # a compacted stage-3 row count (192-row tiles, ragged last tile)
+                                     (6272, 768, 3072, 49),        # Swin-S stage-4 fc2 forward (128-row tiles, four column tiles per panel)
+                                     (100352, 192, 768, 784),      # Swin-S stage-2 fc2 forward (one column tile)
+                                     (1000, 576, 128, 50)])        # two k-tiles: the ring never wraps
+def test_two_group_gemm_is_bitwise_the_tiled_kernel_and_matches_the_oracle(M, N, K, T):
+    """Round 5: gemm_pp_kernel (BM x 192 tiles, one workgroup per CU, two wave groups half a k-step apart, ring of three 64-deep
+    k-tiles) accumulates the same products in the same k order and applies the same epilogue expression as the tiled kernels:
+    bit-identical for every epilogue and forced tile height; one epilogue against the fp64 oracle."""
+    from vtx import ops, options
+    d = dev()
+    x, w, b = _mk((M, K), 161, BF, device=d), _mk((N, K), 162, BF, 0.05, device=d), _mk((N,), 163, torch.float32, 0.1, device=d)
+    res, z = _mk((M, N), 164, BF, device=d), _mk((M, N), 165, BF, device=d)
+    keep = ((torch.rand((M + T - 1) // T, device=d, generator=torch.Generator(device=d).manual_seed(166)) < 0.8).float() / 0.8)
+
+    def run():
+        y = ops.gemm(x, w, 0, bias=b, resid=res, rowscale=keep, rows_per_scale=T)
+        h, zz = ops.gemm(x, w, 0, bias=b, act=ops.ACT_SILU, want_aux=True)
+        dz = ops.gemm(x, w, 0, act=ops.ACT_DSILU, aux_in=z, rowscale=keep, rows_per_scale=T)
+        return y, h, zz, dz, ops.gemm(x, w, 0)
+
+    with options.override(GEMM_PP=0):
+        assert "gemm_pp" not in ops.gemm_kernel_name(BF, N, 0, K=K, M=M)
+        base = run()
+    for wmf in (0, 4, 5, 6, 7):
+        with options.override(GEMM_PP=100 + wmf if wmf else 2):
+            assert "gemm_pp_kernel" in ops.gemm_kernel_name(BF, N, 0, K=K, M=M)
+            got = run()
+        for a, g, name in zip(base, got, ("y", "h", "z", "dz", "plain")):
+            assert torch.equal(a, g), f"{name} differs between the tiled and the two-group kernel (tile height {32 * wmf or 'auto'})"
+    if M <= 30000:
+        yr = res.cpu().double() + keep.cpu().double().repeat_interleave(T)[:M, None] * (_mm64(x.cpu(), w.cpu()) + b.cpu().double())
+        check(f"two-group gemm bias+droppath+residual {M}x{N}x{K}", base[0], yr, TOL[BF]["out"])
 
 
 @pytest.mark.parametrize("M,N,K,T", [(130 * 197, 1152, 384, 197), (83 * 196, 1536, 384, 196), (301 * 49, 768, 192, 49)])

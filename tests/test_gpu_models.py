@@ -130,9 +130,9 @@ def _bf16_vs_oracle(model, oracle_fwd, sd, x, what):
             per.append(d / r.double().norm().item())
     assert report(f"{what} bf16 all-parameter gradient rel-L2 vs oracle", (num / den) ** 0.5, 2e-2)
     assert report(f"{what} bf16 median per-parameter gradient rel-L2", float(np.median(per)), 2e-2)
-    # every single parameter: 6x the whole-model tolerance (small tensors -- a 169 x h rel_pos table, a bias -- are noisier than the
-    # concatenation; measured worst 3.9e-2 Swin-S / 4.4e-2 ViT-S/16 in round 5)
-    assert report(f"{what} bf16 worst per-parameter gradient rel-L2", float(np.max(per)), 1.2e-1)
+    # every single parameter: 3x the whole-model tolerance (small tensors -- a 169 x h rel_pos table, a bias -- are noisier than the
+    # concatenation; round-4 runs: worst 1.3e-2 ViT-S/16, 1.8e-2 Swin-S, 2.0e-2 PVT-Small, gpurun_out/parity.log)
+    assert report(f"{what} bf16 worst per-parameter gradient rel-L2", float(np.max(per)), 6e-2)
     for n, v in tiny:
         assert report(f"{what} bf16 zero-gradient parameter {n}: RMS / typical gradient RMS", v, 1e-3)
 

@@ -8,12 +8,14 @@ mkdir -p gpurun_out
 J=$1; shift
 LOG=gpurun_out/r5_$J.log
 case "$J" in
-  strip)      # strip GEMM: bitwise vs tiled, race screen, timing vs tiled / hipBLASLt; vendor kernel names
-    timeout 900 python tools/r5/strip_check.py "$@" 2>&1 | grep -v amdgpu.ids > $LOG
-    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r5_vendor -o v -- python $R/tools/r5/vendor_names.py > $R/gpurun_out/r5_vendor.log 2>&1)
-    python tools/rocpd_stats.py gpurun_out/r5_vendor/v_results.db --steps 1 --top 40 > gpurun_out/r5_vendor_kernels.md 2>&1
-    rm -f gpurun_out/r5_vendor/v_results.db
-    tail -40 $LOG ;;
+  pp)         # two-group GEMM: bitwise vs the other kernels, race screen, timing vs them and hipBLASLt; phase ablation
+    timeout 1200 python tools/r5/pp_check.py "$@" 2>&1 | grep -v amdgpu.ids > $LOG
+    VTX_LIBVTX=$R/tools/r5/ablate/libvtx_pp.so timeout 600 python tools/r5/pp_ablate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_pp_ablate.log
+    tail -50 $LOG; cat gpurun_out/r5_pp_ablate.log ;;
+  skew)       # two-group GEMM: start delay per column tile (VTX_PP_SKEW, units of ~0.43 us)
+    : > $LOG
+    for k in "$@"; do echo "== VTX_PP_SKEW=$k" >> $LOG; VTX_PP_SKEW=$k timeout 600 python tools/r5/pp_check.py --quick --no-correctness 2>&1 | grep -v "amdgpu.ids\|^CUs" >> $LOG; done
+    cat $LOG ;;
   tests)      # the GPU test suite (optionally -k expr)
     timeout 2400 python -m pytest tests -m gpu -x -q "$@" 2>&1 | tail -30 > $LOG; tail -30 $LOG ;;
   bench)      # headline + secondaries

@@ -13,7 +13,7 @@ const OptDef kOptDefs[VTX_OPT_COUNT] = {
     {"VTX_WATTN_WAVES", 2048}, {"VTX_SRATTN_WGS", 2048}, {"VTX_WATTN_XCD_MAJOR", 1},
     {"VTX_LN_FIT", 1},      {"VTX_GLDS_EPI", 1},    {"VTX_SATTN_WAVES", 8},
     {"VTX_WATTN_BWD4", 1},  {"VTX_GEMM_SKINNY", 1}, {"VTX_GEMM_ASTAT", 1},
-    {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1}, {"VTX_GEMM_STRIP", 1},
+    {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1}, {"VTX_GEMM_PP", 1},
 };
 struct OptTable {
   std::atomic<int> v[VTX_OPT_COUNT];

@@ -178,9 +178,9 @@ int gemm_skinny_launch(const GemmArgs& a, hipStream_t st);
 // gemm_astat.hip: A-stationary kernel for 128 <= K <= 384 (one workgroup per CU keeps its 128-row strip of A in LDS for all column tiles)
 bool gemm_astat_ok(const GemmArgs& a);
 int gemm_astat_launch(const GemmArgs& a, hipStream_t st);
-// gemm_strip.hip: full-width strips (N = 384), two-group main loop, for the long contractions (K >= 768)
-bool gemm_strip_ok(const GemmArgs& a);
-int gemm_strip_launch(const GemmArgs& a, hipStream_t st);
+// gemm_pp.hip: BM x 192 tiles, one workgroup per CU, two wave groups half a k-step apart (N % 192 == 0, K % 64 == 0)
+bool gemm_pp_ok(const GemmArgs& a);
+int gemm_pp_launch(const GemmArgs& a, hipStream_t st);
 // mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE
 int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st);
 

@@ -562,13 +562,13 @@ int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st) {
   if (a.rowscale != nullptr && a.rows_per_scale != a.map_T) return VTX_ERR_SHAPE;
   if (3 * a.map_T < 126) return VTX_ERR_SHAPE;                      // TileRowMap: a 128-row tile spans at most four samples
   if (a.Mk < a.M && a.resid == nullptr) return VTX_ERR_SHAPE;       // copy-only rows need something to copy
-  if (gemm_strip_ok(a)) return gemm_strip_launch(a, st);
+  if (gemm_pp_ok(a)) return gemm_pp_launch(a, st);
   if (gemm_astat_ok(a)) return gemm_astat_launch(a, st);
   return glds_launch_bn<128>(a, st);
 }
 
 int gemm_glds_launch(const GemmArgs& a, hipStream_t st) {
-  if (gemm_strip_ok(a)) return gemm_strip_launch(a, st);
+  if (gemm_pp_ok(a)) return gemm_pp_launch(a, st);
   if (gemm_astat_ok(a)) return gemm_astat_launch(a, st);
   if (a.N % 128 == 0) return glds_launch_bn<128>(a, st);
   if (a.N % 96 == 0) return glds_launch_bn<96>(a, st);

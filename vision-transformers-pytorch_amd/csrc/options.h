@@ -26,7 +26,7 @@ enum VtxOptionId {
   VTX_OPT_GEMM_ASTAT = 16,          // 1: bf16 GEMMs with 192 <= K <= 384 (K % 64 == 0, N % 128 == 0, N >= 256) and >= 2 tiles per CU take the A-stationary kernel (gemm_astat.hip) | 2: any row count | 3: >= 1.25 tiles per CU | 0
   VTX_OPT_TWINS_SUB_LDS = 17,       // 1: the Twins sub-sampling gather / scatter staged through LDS (one workgroup per row of patches) where the geometry allows | 0: element-wise
   VTX_OPT_WGRAD_WIDE = 18,          // 1: grouped weight gradients made of whole 128 x 384 tiles (C = 384 layers) take the wide-tile kernel, one workgroup per CU | 0: 128 x 128 tiles
-  VTX_OPT_GEMM_STRIP = 19,          // 1: bf16 GEMMs with N = 384, K >= 768 over >= one CU-filling round of rows take the full-width strip kernel with the two-group main loop (gemm_strip.hip) | 2: any row count, K >= 256 | 1WN: forced strip height 16 W and ring depth N | 0
+  VTX_OPT_GEMM_PP = 19,             // 1: bf16 GEMMs with N % 192 == 0, K % 64 == 0, long contractions (K >= 1152, or K >= 768 with N <= 384) and >= 3/4 of a CU-filling round of 128 x 192 tiles take the two-group kernel (gemm_pp.hip) | 2: any row count, any K | 10W: forced tile height 32 W | 0
   VTX_OPT_COUNT = 20
 };
 

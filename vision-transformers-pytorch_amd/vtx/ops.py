@@ -333,6 +333,29 @@ def astat_ok(N, K, M, bias=True):
     return mode == 2 or 4 * ((M + 127) // 128) * (N // 128) >= (5 if mode == 3 else 8) * cu_count()
 
 
+def pp_wmf(M, N):
+    """Tile height (in 32-row units) the two-group GEMM picks (mirrors pp_pick_wmf, csrc/gemm_pp.hip)."""
+    cus, ntn = cu_count(), N // 192
+    best, cost = 7, None
+    for w in (7, 6, 5, 4):
+        tiles = (M + 32 * w - 1) // (32 * w) * ntn
+        c = ((tiles + cus - 1) // cus) * (w + 2)
+        if cost is None or c < cost:
+            best, cost = w, c
+    return best
+
+
+def pp_ok(N, K, M):
+    """Mirrors gemm_pp_ok (csrc/gemm_pp.hip) for contiguous bf16 operands: the two-group kernel takes the long contractions
+    (K >= 1152, or K >= 768 with N <= 384) of N % 192 == 0 layers once a launch nearly fills a round (M: the rows it computes)."""
+    mode = options.get("GEMM_PP")
+    if not mode or N % 192 or K % 64 or M <= 0:
+        return False
+    if mode >= 2:
+        return True
+    return (K >= 1152 or (K >= 768 and N <= 384)) and 4 * ((M + 127) // 128) * (N // 192) >= 3 * cu_count()
+
+
 def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False, bias=True):
     """Name of the kernel instantiation vtx_gemm / vtx_wgrad picks (mirrors gemm.hip / gemm_glds.hip); ``mapped``: the
     row-mapped variant of a compacted branch (M = the rows it computes)."""
@@ -341,6 +364,9 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=
     bn = 128 if N % 128 == 0 else (96 if N % 96 == 0 else (64 if N <= 64 else 128))
     if dtype == torch.bfloat16 and mode == 0 and skinny_ok(N, K, M, vec) and not mapped:
         return f"gemm_skinny_kernel<{K // 32}>"
+    if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K) and pp_ok(N, K, M):
+        mode_ = options.get("GEMM_PP")
+        return f"gemm_pp_kernel<{mode_ % 10 if 100 <= mode_ < 1000 else pp_wmf(M, N)}, {'true' if mapped else 'false'}>"
     if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M, bias):
         return f"gemm_astat_kernel<{K // 64}, {'true' if mapped else 'false'}, ...>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
