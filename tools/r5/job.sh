@@ -28,5 +28,13 @@ case "$J" in
       env VTX_$O=$v timeout 600 python bench.py --model $M --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | grep '"metric"' | cut -c1-200 >> $LOG
     done; done
     cat $LOG ;;
+  ln)         # LayerNorm rows-in-flight variants (VTX_LN_ROWS bits): micro-benchmark + the LayerNorm tests under each
+    : > $LOG
+    for v in 0 1 2 3; do
+      echo "== VTX_LN_ROWS=$v" >> $LOG
+      VTX_LN_ROWS=$v timeout 300 python tools/bench_ln.py 2>&1 | grep -v amdgpu.ids >> $LOG
+    done
+    VTX_LN_ROWS=3 timeout 900 python -m pytest tests -m gpu -x -q -k "layernorm or ln_ or merge" 2>&1 | tail -3 >> $LOG
+    cat $LOG ;;
   *) echo "unknown job $J"; exit 2 ;;
 esac

@@ -20,11 +20,11 @@
 #include "options.h"
 
 constexpr int SK_ROWS = 32;        // rows of A per wave iteration (two 16-row MFMA tiles)
-constexpr int SK_WAVES = 4;
+// waves per persistent workgroup (one workgroup per CU): option SKINNY_WAVES (4 | 8 | 16)
 
 // K = 32 KS; ACT = GemmArgs::act, VEC = the epilogue reads a vector per output vector (z for act', else the residual) --
 // both compile-time: the per-pair loop of a plain / activation forward carries no loads, no selects, no dead operands
-template <int KS, int ACT, bool VEC>
+template <int KS, int ACT, bool VEC, int SK_WAVES>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, int nchunk) {
   constexpr int K = 32 * KS, WSTR = K + 8;             // LDS row stride of W (elements): 16 B of padding per row
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
@@ -183,15 +183,22 @@ bool gemm_skinny_ok(const GemmArgs& a) {
   return skinny_chunks(a.N, a.K) != 0;
 }
 
-template <int KS, int ACT, bool VEC> static int skinny_launch_kav(const GemmArgs& a, hipStream_t st) {
+template <int KS, int ACT, bool VEC, int WAVES> static int skinny_launch_kavw(const GemmArgs& a, hipStream_t st) {
   const int nc = skinny_chunks(a.N, a.K);
   const size_t smem = skinny_smem(a.N / nc, a.K);
-  auto kern = gemm_skinny_kernel<KS, ACT, VEC>;
+  auto kern = gemm_skinny_kernel<KS, ACT, VEC, WAVES>;
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(256), dim3(64 * SK_WAVES), smem, st, a, nc);   // one persistent workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a, nc);   // one persistent workgroup per CU
   return vtx_check_launch();
+}
+template <int KS, int ACT, bool VEC> static int skinny_launch_kav(const GemmArgs& a, hipStream_t st) {
+  switch (vtx_opt(VTX_OPT_SKINNY_WAVES)) {
+    case 16: return skinny_launch_kavw<KS, ACT, VEC, 16>(a, st);
+    case 8: return skinny_launch_kavw<KS, ACT, VEC, 8>(a, st);
+    default: return skinny_launch_kavw<KS, ACT, VEC, 4>(a, st);
+  }
 }
 
 template <int KS> static int skinny_launch_k(const GemmArgs& a, hipStream_t st) {

@@ -39,7 +39,7 @@ __device__ __forceinline__ int64_t ln_src_offset(const LnAddr& a, int64_t row, i
   return ((b * a.H + 2 * i + py) * a.W + 2 * j + px) * (int64_t)a.Cs + c;
 }
 
-template <typename T, int G, int NV, bool MAPPED = false>
+template <typename T, int G, int NV, bool MAPPED = false, int ROWS = (NV == 1 ? 4 : (NV == 2 ? 2 : 1))>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, T* __restrict__ y,
                                                     float* __restrict__ mean, float* __restrict__ rstd,
@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const float invC = 1.f / (float)C;
   // ROWS rows per group per iteration: their loads are issued back to back before any reduction starts, so
   // each lane keeps ROWS x NV 16-byte loads in flight (memory-level parallelism for an HBM-bound kernel)
-  constexpr int ROWS = NV == 1 ? 4 : (NV == 2 ? 2 : 1);
   const int64_t stride = (int64_t)gridDim.x * GPB;
   for (int64_t row0 = (int64_t)blockIdx.x * GPB + grp; row0 < rows; row0 += stride * ROWS) {
     float xv[ROWS][NV][8];
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // gradient that bypasses the norm, fused so the stream gradient is written once).
 // dgamma / dbeta: per-lane register accumulation over the block's rows, LDS reduce across the
 // block's groups, one deterministic partial row per block; ln_colreduce_kernel sums the partials.
-template <typename T, int G, int NV, bool MAPPED = false>
+template <typename T, int G, int NV, bool MAPPED = false, int ROWS = 1>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const T* __restrict__ dres,
@@ -146,59 +145,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int e = 0; e < 8; ++e) { dg[k][e] = 0.f; db[k][e] = 0.f; }
   }
   const float invC = 1.f / (float)C;
-  for (int64_t lrow = (int64_t)blockIdx.x * GPB + grp; lrow < rows; lrow += (int64_t)gridDim.x * GPB) {
-    const int64_t row = ln_orow<MAPPED>(addr, lrow);
-    if (MAPPED && lrow >= addr.live) {           // a dropped sample's row: dx = dres (uniform within the group)
+  // ROWS rows per group and iteration, every load of theirs (x, dy, the residual-stream gradient, the statistics) issued
+  // before the first reduction: ROWS x 3 NV 16-byte loads per lane in flight (round 5; one row and the residual gradient
+  // loaded after the reductions before).  Rows are visited in the same order by the same lanes: same bits.
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t lrow0 = (int64_t)blockIdx.x * GPB + grp; lrow0 < rows; lrow0 += stride * ROWS) {
+    Vec8<T> tx[ROWS][NV], td[ROWS][NV], tr[ROWS][NV];
+    int64_t orow[ROWS];
+    float mu[ROWS], rs[ROWS];
+    bool live[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int64_t lrow = lrow0 + rr * stride;
+      const bool in = lrow < rows;
+      orow[rr] = in ? ln_orow<MAPPED>(addr, lrow) : 0;
+      live[rr] = in && !(MAPPED && lrow >= addr.live);   // (a dropped sample's row: dx = dres; dy, x, statistics never read)
+      mu[rr] = live[rr] ? mean[orow[rr]] : 0.f;
+      rs[rr] = live[rr] ? rstd[orow[rr]] : 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = lig + k * G;
+        const int64_t off = ln_src_offset(addr, orow[rr], v * 8, C);
+        if (v < nvec && live[rr]) {
+          tx[rr][k] = load8<T>(x + off);
+          td[rr][k] = load8<T>(dy + orow[rr] * (int64_t)C + v * 8);
+        } else {
+          tx[rr][k] = vec8_zero<T>();
+          td[rr][k] = vec8_zero<T>();
+        }
+        tr[rr][k] = (v < nvec && in && dres != nullptr) ? load8<T>(dres + off) : vec8_zero<T>();
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int64_t lrow = lrow0 + rr * stride;
+      if (lrow >= rows) break;                       // uniform within the group
+      if (!live[rr]) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const int v = lig + k * G;
+          if (v < nvec) store8<T>(dx + orow[rr] * (int64_t)C + v * 8, tr[rr][k]);
+        }
+        continue;
+      }
+      float xh[NV][8], gv[NV][8];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int v = lig + k * G;
         if (v < nvec) {
-          const int64_t off = row * (int64_t)C + v * 8;
-          store8<T>(dx + off, dres != nullptr ? load8<T>(dres + off) : vec8_zero<T>());
-        }
-      }
-      continue;
-    }
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NV][8], gv[NV][8];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = lig + k * G;
-      if (v < nvec) {
-        Vec8<T> tx = load8<T>(x + ln_src_offset(addr, row, v * 8, C));
-        Vec8<T> td = load8<T>(dy + row * (int64_t)C + v * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = td.get(e);
-          xh[k][e] = (tx.get(e) - mu) * rs;
-          gv[k][e] = d * gm[k][e];
-          s1 += gv[k][e];
-          s2 += gv[k][e] * xh[k][e];
-          dg[k][e] += d * xh[k][e];
-          db[k][e] += d;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { xh[k][e] = 0.f; gv[k][e] = 0.f; }
-      }
-    }
-    const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = lig + k * G;
-      if (v < nvec) {
-        const int64_t off = ln_src_offset(addr, row, v * 8, C);
-        Vec8<T> o;
-        if (dres != nullptr) {
-          Vec8<T> r = load8<T>(dres + off);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o.set(e, r.get(e) + rs * (gv[k][e] - c1 - xh[k][e] * c2));
+          for (int e = 0; e < 8; ++e) {
+            const float d = td[rr][k].get(e);
+            xh[k][e] = (tx[rr][k].get(e) - mu[rr]) * rs[rr];
+            gv[k][e] = d * gm[k][e];
+            s1 += gv[k][e];
+            s2 += gv[k][e] * xh[k][e];
+            dg[k][e] += d * xh[k][e];
+            db[k][e] += d;
+          }
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o.set(e, rs * (gv[k][e] - c1 - xh[k][e] * c2));
+          for (int e = 0; e < 8; ++e) { xh[k][e] = 0.f; gv[k][e] = 0.f; }
         }
-        store8<T>(dx + off, o);
+      }
+      const float c1 = group_sum<G>(s1) * invC, c2 = group_sum<G>(s2) * invC;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = lig + k * G;
+        if (v < nvec) {
+          const int64_t off = ln_src_offset(addr, orow[rr], v * 8, C);
+          Vec8<T> o;
+          if (dres != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.set(e, tr[rr][k].get(e) + rs[rr] * (gv[k][e] - c1 - xh[k][e] * c2));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.set(e, rs[rr] * (gv[k][e] - c1 - xh[k][e] * c2));
+          }
+          store8<T>(dx + off, o);
+        }
       }
     }
   }
@@ -237,6 +263,18 @@ static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, v
                          int64_t rows, int C, float eps, LnAddr a, hipStream_t st) {
   const int nb = ln_grid(rows, 256 / G, 1024);
   // (the row map of stochastic-depth compaction is a compile-time variant: the plain kernels carry none of its code)
+  // LN_ROWS bit 0: two rows of the three-vector groups (C = 384 on 16 lanes, 768 on 32) in flight per iteration
+  if constexpr (NV == 3) {
+    if (vtx_opt(VTX_OPT_LN_ROWS) & 1) {
+      if (a.perm != nullptr)
+        hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV, true, 2>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
+                           rstd, rows, C, eps, a);
+      else
+        hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV, false, 2>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
+                           rstd, rows, C, eps, a);
+      return vtx_check_launch();
+    }
+  }
   if (a.perm != nullptr)
     hipLaunchKernelGGL((ln_fwd_kernel<T, G, NV, true>), dim3(nb), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean,
                        rstd, rows, C, eps, a);
@@ -252,12 +290,24 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* mean, const
                          LnAddr a, hipStream_t st) {
   const int nb = ln_grid(rows, 256 / G, 1024);
   const size_t smem = (size_t)2 * (256 / G) * C * sizeof(float);
-  if (a.perm != nullptr)
-    hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, true>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
-                       gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, false>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
-                       gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+  // LN_ROWS bit 1: two rows per group and iteration in the backward (one- and two-vector groups)
+  constexpr int R2 = NV <= 2 ? 2 : 1;
+  const bool two = (vtx_opt(VTX_OPT_LN_ROWS) & 2) != 0 && R2 == 2;
+  if (a.perm != nullptr) {
+    if (two)
+      hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, true, R2>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                         gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+    else
+      hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, true, 1>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                         gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+  } else {
+    if (two)
+      hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, false, R2>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                         gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+    else
+      hipLaunchKernelGGL((ln_bwd_kernel<T, G, NV, false, 1>), dim3(nb), dim3(256), smem, st, (const T*)dy, (const T*)x, mean, rstd,
+                         gamma, (const T*)dres, (T*)dx, ws, rows, C, a);
+  }
   int rc = vtx_check_launch();
   if (rc || dgamma == nullptr) return rc;                // deferred: the partials stay in ws ([nb][2C]), see vtx_colreduce_multi
   hipLaunchKernelGGL(colreduce_kernel, colreduce_grid(2 * C), dim3(1024), 0, st, ws, dgamma, dbeta, nb, C, 2 * C);
