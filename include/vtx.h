@@ -172,6 +172,24 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
                       float* drel_pos, int ntab, void* workspace, size_t ws_bytes, int B, int L, int nH, int D,
                       int swin, int H, int W, int win, int shift, int dtype, void* stream);
 
+/* ---- Dropout of the attention probabilities (reference models/vit.py:39, models/swin_transformer.py:144: F.dropout(attn, p,
+ * training) on the softmax output; models/pvt.py:60, models/twins.py:88,147 likewise).  Same arguments as vtx_attention_fwd / _bwd
+ * plus (drop_p, seed, keep): cell (problem, query, key) is kept when a counter-based hash of (seed, problem, query * L + key) says
+ * so -- the backward regenerates the decision from the same (drop_p, seed), no mask tensor exists in HBM -- and kept
+ * probabilities are scaled by 1 / (1 - drop_p).  problem = (image * nW + window) * nH + head.  keep != NULL replaces the hash by
+ * an explicit mask [problems][L][L] of bytes (1 = keep): the parity tests pass the mask the reference drew.  0 < drop_p < 1.
+ * Register-resident kernels only: head dim 64 with L <= 224, head dim 32 with L <= 64 (VTX_ERR_SHAPE otherwise).
+ * vtx_attn_keep_mask writes the hash's decisions [nprob][Lq][Lk] (what the kernels regenerate) for tests / an external checker. */
+int vtx_attention_fwd_drop(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
+                           int nH, int D, int swin, int H, int W, int win, int shift, int dtype, float drop_p, uint64_t seed,
+                           const uint8_t* keep, void* stream);
+int vtx_attention_bwd_drop(const void* qkv, const void* o, const void* dout, const float* lse, const float* bias,
+                           const uint8_t* mask, const int* csr_order, const int* csr_offsets, void* dqkv,
+                           float* drel_pos, int ntab, void* workspace, size_t ws_bytes, int B, int L, int nH, int D,
+                           int swin, int H, int W, int win, int shift, int dtype, float drop_p, uint64_t seed,
+                           const uint8_t* keep, void* stream);
+int vtx_attn_keep_mask(uint8_t* out, int64_t nprob, int Lq, int Lk, float drop_p, uint64_t seed, void* stream);
+
 /* ---- Window attention fast path (head dim 32, window <= 7x7): one wavefront per (image, window, head) problem,
  * persistent 4-wave workgroups per head, same semantics as vtx_attention_fwd/bwd with swin != 0
  * (reference models/swin_transformer.py:103-160: roll, partition, q k^T / sqrt(d) + rel_pos(pos) bias,
@@ -340,6 +358,14 @@ int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq,
 size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH, int D);
 int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
                    void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, void* stream);
+
+/* the same with dropout of the attention probabilities (models/pvt.py:60, models/twins.py:88): see vtx_attention_fwd_drop;
+ * problem = image * nH + head, cell = query * Lk + key, keep [B*nH][Lq][Lk] */
+int vtx_srattn_fwd_drop(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
+                        float drop_p, uint64_t seed, const uint8_t* keep, void* stream);
+int vtx_srattn_bwd_drop(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                        void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, float drop_p,
+                        uint64_t seed, const uint8_t* keep, void* stream);
 
 /* ---- Positional-encoding generator of Twins-SVT (csrc/twins_misc.hip; reference models/twins.py:25-37):
  * y = x + DepthwiseConv3x3(x) on channels-last features x, y [B, H, W, C] (C % 8 == 0, C <= 1024), w = the

@@ -66,11 +66,20 @@ def drop_path_apply(branch, keep_mask, p):
 
 
 # --------------------------------------------------------------------------- A2
-def global_attention_core(qkv, n_head, q=None):
+def attn_dropout(P, keep, drop_p):
+    """F.dropout(attn, p, training=True) with an INJECTED keep mask (vit.py:39, swin_transformer.py:144, pvt.py:60,
+    twins.py:88,147): attn * keep / (1 - p) on the softmax output.  keep None / p == 0: identity (eval mode)."""
+    if keep is None or drop_p == 0:
+        return P
+    return P * keep.to(P.dtype) / (1.0 - drop_p)
+
+
+def global_attention_core(qkv, n_head, q=None, keep=None, drop_p=0.0):
     """Attention core of vit.MultiHeadedAttention (vit.py:30-42) on the QKV projection output.
 
     qkv: (B, L, 3C) with channel order [q|k|v][head][d] (vit.py:30-34); returns O (B, L, C) in
     [head][d] channel order (vit.py:42); the 1/sqrt(d) scale is applied to the product (vit.py:37).
+    keep (B, n_head, L, L): dropout keep mask of the attention probabilities (vit.py:39).
     """
     B, L, C3 = qkv.shape
     C = C3 // 3
@@ -81,15 +90,15 @@ def global_attention_core(qkv, n_head, q=None):
         K = qkv[..., 1 * C + h * d:1 * C + (h + 1) * d]
         V = qkv[..., 2 * C + h * d:2 * C + (h + 1) * d]
         S = torch.einsum("bid,bjd->bij", Q, K) / math.sqrt(d)
-        P = _q(torch.softmax(S, -1), q)
+        P = _q(attn_dropout(torch.softmax(S, -1), None if keep is None else keep[:, h], drop_p), q)
         out[..., h * d:(h + 1) * d] = torch.einsum("bij,bjd->bid", P, V)
     return out
 
 
-def global_attention(x, w_qkv, b_qkv, w_o, b_o, n_head, q=None):
+def global_attention(x, w_qkv, b_qkv, w_o, b_o, n_head, q=None, keep=None, drop_p=0.0):
     """vit.MultiHeadedAttention.forward (vit.py:27-45)."""
     qkv = _q(linear(x, w_qkv, b_qkv), q)
-    out = _q(global_attention_core(qkv, n_head, q), q)
+    out = _q(global_attention_core(qkv, n_head, q, keep, drop_p), q)
     return linear(out, w_o, b_o)
 
 
@@ -117,13 +126,14 @@ def window_token_index(H, W, window, shift):
 
 
 # --------------------------------------------------------------------------- A9
-def window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q=None):
+def window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q=None, keep=None, drop_p=0.0):
     """Attention core of swin.MultiHeadedLocalAttention (swin:109-154), roll-free form.
 
     qkv: (B,H,W,3*h*dh) = output of the ``weight`` Linear on the UN-rolled input (roll commutes with
     per-token layers); returns O (B,H,W,h*dh) at original token positions (inverse partition + roll
     back folded in).  rel_pos: ((2w-1)^2, n_head).  pos / local_mask are rebuilt from oracle.tables
-    (bit-exact vs the reference buffers, goldens G1/G2).
+    (bit-exact vs the reference buffers, goldens G1/G2).  keep (B, nW, n_head, ww, ww): dropout keep mask of the
+    attention probabilities in the reference's (B, S, H, W^2, W^2) layout (swin:144).
     """
     B, H, W, _ = qkv.shape
     hd = n_head * dim_head
@@ -142,7 +152,7 @@ def window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q=None)
         S = S + bias[..., h]
         if shift:
             S = S.masked_fill(torch.from_numpy(mask_np)[None], float("-inf"))  # swin:138-141
-        P = _q(torch.softmax(S, -1), q)
+        P = _q(attn_dropout(torch.softmax(S, -1), None if keep is None else keep[:, :, h], drop_p), q)
         o[..., h * dim_head:(h + 1) * dim_head] = torch.einsum("bnij,bnjd->bnid", P, V)
     out_tok = qkv.new_zeros(B, H * W, hd)
     out_tok[:, idx.reshape(-1)] = o.reshape(B, nW * ww, hd)  # inverse partition + roll back
@@ -150,10 +160,10 @@ def window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q=None)
 
 
 def window_attention(x, w_qkv, b_qkv, w_o, b_o, rel_pos, n_head, dim_head,
-                     window, shift, q=None):
+                     window, shift, q=None, keep=None, drop_p=0.0):
     """swin.MultiHeadedLocalAttention.forward (swin:103-160).  x: (B,H,W,C) NHWC."""
     qkv = _q(linear(x, w_qkv, b_qkv), q)
-    o = _q(window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q), q)
+    o = _q(window_attention_core(qkv, rel_pos, n_head, dim_head, window, shift, q, keep, drop_p), q)
     return linear(o, w_o, b_o)
 
 
@@ -222,7 +232,7 @@ def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
 
 
 # ------------------------------------------------------------------------------------------ PVT (models/pvt.py)
-def sr_attention_core(q, kv, n_head, qf=None):
+def sr_attention_core(q, kv, n_head, qf=None, keep=None, drop_p=0.0):
     """Attention core of pvt.MultiHeadedAttention (pvt.py:38, 51-64): q (B, Lq, C) = linear_q output, kv (B, Lk, 2C) =
     linear_kv output whose halves are k | v (pvt.py:51), heads = contiguous channel blocks of C // n_head (pvt.py:35-37),
     score = q k^T / sqrt(d) (pvt.py:55), softmax over keys, out (B, Lq, C) in [head][d] order (pvt.py:66)."""
@@ -234,7 +244,7 @@ def sr_attention_core(q, kv, n_head, qf=None):
         K = kv[..., h * d:(h + 1) * d]
         V = kv[..., C + h * d:C + (h + 1) * d]
         S = torch.einsum("bid,bjd->bij", Q, K) / math.sqrt(d)
-        P = _q(torch.softmax(S, -1), qf)
+        P = _q(attn_dropout(torch.softmax(S, -1), None if keep is None else keep[:, h], drop_p), qf)   # keep (B, n_head, Lq, Lk), pvt.py:60
         out[..., h * d:(h + 1) * d] = torch.einsum("bij,bjd->bid", P, V)
     return out
 
@@ -249,7 +259,7 @@ def pvt_reduce(x, height, width, w_conv, b_conv, g_norm, b_norm, reduction, qf=N
     return layer_norm(red, g_norm, b_norm, 1e-6)
 
 
-def pvt_attention(x, height, width, p, n_head, reduction, qf=None):
+def pvt_attention(x, height, width, p, n_head, reduction, qf=None, keep=None, drop_p=0.0):
     """pvt.MultiHeadedAttention.forward (pvt.py:31-68) without the returned score; p = dict of the module's tensors
     (linear_q.weight, linear_kv.weight, linear.weight, linear.bias [, reduce_conv.*, reduce_norm.*])."""
     qq = _q(linear(x, p["linear_q.weight"], None), qf)
@@ -258,7 +268,7 @@ def pvt_attention(x, height, width, p, n_head, reduction, qf=None):
         kvin = _q(pvt_reduce(x, height, width, p["reduce_conv.weight"], p["reduce_conv.bias"], p["reduce_norm.weight"],
                              p["reduce_norm.bias"], reduction, qf), qf)
     kv = _q(linear(kvin, p["linear_kv.weight"], None), qf)
-    out = _q(sr_attention_core(qq, kv, n_head, qf), qf)
+    out = _q(sr_attention_core(qq, kv, n_head, qf, keep, drop_p), qf)
     return linear(out, p["linear.weight"], p["linear.bias"])
 
 
@@ -282,17 +292,17 @@ def twins_peg(x, w, qf=None):
     return _q(out.permute(0, 2, 3, 1), qf)
 
 
-def twins_local_attention(x, p, n_head, dim_head, window, qf=None):
+def twins_local_attention(x, p, n_head, dim_head, window, qf=None, keep=None, drop_p=0.0):
     """twins.MultiHeadedLocalAttention.forward (twins.py:109-151): qkv Linear, window partition (row-major windows,
     row-major tokens inside), softmax(q k^T / sqrt(d)) v per window and head -- no position bias, no mask, no shift --
     inverse partition, output Linear.  The partition is the un-shifted one of swin (window_attention_core with a zero table)."""
     qkv = _q(linear(x, p["weight.weight"], p["weight.bias"]), qf)
     zero = qkv.new_zeros((2 * window - 1) ** 2, n_head)
-    o = _q(window_attention_core(qkv, zero, n_head, dim_head, window, False, qf), qf)
+    o = _q(window_attention_core(qkv, zero, n_head, dim_head, window, False, qf, keep, drop_p), qf)
     return linear(o, p["linear.weight"], p["linear.bias"])
 
 
-def twins_global_attention(x, p, n_head, reduction, qf=None):
+def twins_global_attention(x, p, n_head, reduction, qf=None, keep=None, drop_p=0.0):
     """twins.MultiHeadedAttention.forward (twins.py:56-93) on NHWC x: q = linear_q(tokens); the key / value tokens are the
     Conv2d(dim, dim, r, stride r) sub-sampled "image" of twins.py:69-72 (see the comment below; NO LayerNorm after it,
     unlike pvt.py:47); k | v =
@@ -312,7 +322,7 @@ def twins_global_attention(x, p, n_head, reduction, qf=None):
     red = torch.nn.functional.conv2d(img, p["reduce_conv.weight"], p["reduce_conv.bias"], stride=reduction)
     kvin = _q(red.reshape(B, C, -1).transpose(1, 2), qf)
     kv = _q(linear(kvin, p["linear_kv.weight"], None), qf)
-    out = _q(sr_attention_core(qq, kv, n_head, qf), qf)
+    out = _q(sr_attention_core(qq, kv, n_head, qf, keep, drop_p), qf)
     return linear(out, p["linear.weight"], p["linear.bias"]).reshape(B, H, W, C)
 
 

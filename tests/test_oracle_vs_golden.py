@@ -150,3 +150,23 @@ def test_transformer_layers():
     h = R.layer_norm(y, P["norm_ff.weight"], P["norm_ff.bias"], 1e-6)
     out = y + R.feed_forward(h, P["ff.0.weight"], P["ff.0.bias"], P["ff.3.weight"], P["ff.3.bias"])
     _check_module(g, "vit_layer", out, x, P)
+
+
+# ------------------------------------------------------------------ G11: attention-probability dropout with the reference's keep mask
+import attn_dropout_cases as ADC
+
+
+@pytest.mark.parametrize("name", sorted(ADC.CASES))
+def test_attention_dropout_with_the_recorded_keep_mask(name):
+    """F.dropout(attn, p, training) of vit.py:39 / swin_transformer.py:144 / pvt.py:60 / twins.py:88,147: the oracle with the keep
+    mask the reference run drew reproduces that run's output and every gradient."""
+    g = Golden("g11_attn_dropout")
+    keep = ADC.keep_mask(g, name)
+    assert abs(float(keep.double().mean()) - (1 - ADC.P_DROP)) < 0.02
+    P = {k: v.requires_grad_(True) for k, v in ADC.params(name).items()}
+    x = ADC.case_input(name).requires_grad_(True)
+    out = ADC.CASES[name][3](x, P, keep)
+    _check_module(g, name, out, x, P)
+    # and the mask matters: without it the output is a different one
+    plain = ADC.CASES[name][3](x, P, None)
+    assert (plain - out).norm() / out.norm() > 1e-3

@@ -8,7 +8,8 @@ travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
 
 Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
 fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1), G8 DINO head + loss (F2),
-G9 mixup / cutmix / RandomErasing outputs (F4), G10 Twins-SVT (the row after F1-F4).
+G9 mixup / cutmix / RandomErasing outputs (F4), G10 Twins-SVT (the row after F1-F4), G11 attention-probability dropout with an
+injected keep mask (vit.py:39, swin_transformer.py:144, pvt.py:60, twins.py:88,147).
 """
 import os
 import sys
@@ -487,8 +488,70 @@ def gen_twins():
     save("g10_twins", rec)
 
 
+# ------------------------------------------------------------------ G11: attention-probability dropout
+def inject_dropout(masks, seed):
+    """Replace F.dropout (also what nn.Dropout.forward calls) by ``x * keep / (1 - p)`` with a keep mask drawn HERE from a seeded
+    numpy generator and recorded: the reference runs its own code path, only the Bernoulli draw is ours."""
+    import torch.nn.functional as F
+    orig = F.dropout
+    rng = np.random.default_rng(seed)
+
+    def fake(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0:
+            return input
+        keep = torch.from_numpy((rng.random(tuple(input.shape)) >= p).astype(np.uint8))
+        masks.append(keep)
+        return input * keep.to(input.dtype) / (1.0 - p)
+
+    F.dropout = fake
+    return lambda: setattr(F, "dropout", orig)
+
+
+def gen_attn_dropout():
+    rec = {}
+    P = 0.25
+
+    def run(name, mod, x, call, seed):
+        mod = load_formula(mod).double().train()
+        masks = []
+        restore = inject_dropout(masks, seed)
+        try:
+            xx = x.clone().requires_grad_(True)
+            out = call(mod, xx)
+            cot = fill(out.shape, name_seed(name + ".cot"), 1.0)
+            (out * cot).sum().backward()
+        finally:
+            restore()
+        assert len(masks) == 1, (name, len(masks))
+        rec[f"{name}.keepshape"] = np.array(masks[0].shape, dtype=np.int64)
+        rec[f"{name}.keep"] = np.packbits(masks[0].numpy().reshape(-1))
+        rec[f"{name}.out"] = summarize(out)
+        rec[f"{name}.dx"] = summarize(xx.grad)
+        for n, g in grads_of(mod).items():
+            rec[f"{name}.d.{n}"] = summarize(g)
+        print(name, "keep fraction", float(masks[0].double().mean()))
+
+    for L in (37, 197):
+        run(f"vit_L{L}", ref_vit.MultiHeadedAttention(128, 2, dropout=P), fill((2, L, 128), 21, 1.0, dtype=torch.float64),
+            lambda m, x: m(x), 100 + L)
+    for shift, tag in ((True, "s1"), (False, "s0")):
+        run(f"swin_{tag}", ref_swin.MultiHeadedLocalAttention(64, 2, 32, (14, 14), 7, shift, dropout=P),
+            fill((2, 14, 14, 64), 22, 1.0, dtype=torch.float64), lambda m, x: m(x), 300 + int(shift))
+    run("pvt_r2", ref_pvt.MultiHeadedAttention(128, 2, reduction=2, dropout=P), fill((2, 64, 128), 23, 1.0, dtype=torch.float64),
+        lambda m, x: m(x, 8, 8)[0], 400)
+    run("pvt_r1_cls", ref_pvt.MultiHeadedAttention(128, 2, reduction=1, dropout=P), fill((2, 17, 128), 24, 1.0, dtype=torch.float64),
+        lambda m, x: m(x, 4, 4)[0], 401)
+    run("twins_local", ref_twins.MultiHeadedLocalAttention(64, 2, 32, 7, dropout=P), fill((2, 14, 14, 64), 25, 1.0, dtype=torch.float64),
+        lambda m, x: m(x), 500)
+    run("twins_global", ref_twins.MultiHeadedAttention(64, 2, reduction=7, dropout=P), fill((2, 14, 14, 64), 26, 1.0, dtype=torch.float64),
+        lambda m, x: m(x), 501)
+    save("g11_attn_dropout", rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input", "twins"]
+    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input", "twins", "attn_dropout"]
+    if "attn_dropout" in which:
+        gen_attn_dropout()
     if "tables" in which:
         gen_tables()
     if "modules" in which:

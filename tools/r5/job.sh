@@ -17,7 +17,8 @@ case "$J" in
     for k in "$@"; do echo "== VTX_PP_SKEW=$k" >> $LOG; VTX_PP_SKEW=$k timeout 600 python tools/r5/pp_check.py --quick --no-correctness 2>&1 | grep -v "amdgpu.ids\|^CUs" >> $LOG; done
     cat $LOG ;;
   tests)      # the GPU test suite (optionally -k expr)
-    timeout 2400 python -m pytest tests -m gpu -x -q "$@" 2>&1 | tail -30 > $LOG; tail -30 $LOG ;;
+    if [ $# -gt 0 ] && [ -e "$1" ]; then T="$1"; shift; else T=tests; fi       # first argument: a test file, else the whole suite
+    timeout 2400 python -m pytest $T -m gpu -x -q "$@" 2>&1 | tail -30 > $LOG; tail -30 $LOG ;;
   bench)      # headline + secondaries
     timeout 900 python bench.py --steps 20 --warmup 5 "$@" 2>&1 | grep '"metric"' > $LOG; cut -c1-400 $LOG ;;
   ab)         # same-box A/B of one option on one model: tools/r5/job.sh ab swin_s GEMM_STRIP 0 1

@@ -95,10 +95,10 @@ __device__ __forceinline__ float attn_bias_mask(const float* __restrict__ bias, 
 
 // ------------------------------------------------------------------------------------- forward
 // grid.x = B * nW * nH problems; 256 threads; wave w handles query tiles w, w+4, ...
-template <typename T, int D, int NKT>
+template <typename T, int D, int NKT, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
                                                       float* __restrict__ lse, const float* __restrict__ bias,
-                                                      const uint8_t* __restrict__ mask, AttnGeom g) {
+                                                      const uint8_t* __restrict__ mask, AttnGeom g, DropArgs da) {
   constexpr int LP = NKT * 16, STR = LP + 8, DS = D / 32, DT = D / 16, KSN = NKT / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   T* vt = reinterpret_cast<T*>(attn_smem);                       // Vt[D][STR]
@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     l += shfl_xor_f(l, 32);
     const float inv = 1.f / l;
     if (qv && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
+    if constexpr (DROP) {
+      // dropout acts on the NORMALISED probabilities (vit.py:38-39): the row sum above is the undropped one
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] *= drop_factor(da, (unsigned)prob, q, kt * 16 + g_ * 4 + r);
+    }
     // O[q][d] = sum_key P[q][key] V[key][d]
     f32x4 oacc[DT];
 #pragma unroll
@@ -202,11 +209,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 //   phase A (wave <-> query tile, swapped layout): Dq = rowsum(dO o O), then per key-tile pair P, dP, dS,
 //           dQ = scale * dS K
 //   phase B (wave <-> key tile,   plain   layout): P, dP, dS, dV = P^T dO, dK = scale * dS^T Q, dbias += dS
-template <typename T, int D, int NKT, bool HAS_BIAS>
+template <typename T, int D, int NKT, bool HAS_BIAS, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ oin,
                                                       const T* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ bias,
                                                       const uint8_t* __restrict__ mask, T* __restrict__ dqkv,
-                                                      float* __restrict__ dbias_part, int nbn, AttnGeom g) {
+                                                      float* __restrict__ dbias_part, int nbn, AttnGeom g, DropArgs da) {
   constexpr int LP = NKT * 16, STR = LP + 8, DS = D / 32, DT = D / 16, KSN = NKT / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   T* r0 = reinterpret_cast<T*>(attn_smem);                 // Kt (phase A) then Qt (phase B): [D][STR]
@@ -290,7 +297,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             const int kk = kt * 16 + g_ * 4 + r;
             float p = 0.f;
             if (qv) p = __expf(pt[r] * g.scale + attn_bias_mask(bias_h, mask_n, g.L, q, kk) - lq);
-            dsv[half][r] = p * (dpt[r] - dsum);
+            // with dropout O = (P o F) V, F = keep / (1 - p): dP = F o (dO V^T), and rowsum(dO o O) is still rowsum(P o dP)
+            float dpv = dpt[r];
+            if constexpr (DROP) dpv *= drop_factor(da, (unsigned)prob, q, kk);
+            dsv[half][r] = p * (dpv - dsum);
           }
         }
         Vec8<T> dsf = frag_from_acc<T>(dsv[0], dsv[1]);
@@ -350,8 +360,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             const int qq = qt * 16 + g_ * 4 + r;
             float p = 0.f;
             if (qq < g.L) p = __expf(s[r] * g.scale + attn_bias_mask(bias_h, mask_n, g.L, qq, key) - lse_s[qq]);
-            pp[half][r] = p;
-            dss[half][r] = p * (dp[r] - dq_s[qq < g.L ? qq : 0]);
+            float f = 1.f;
+            if constexpr (DROP) f = drop_factor(da, (unsigned)prob, qq, key);
+            pp[half][r] = p * f;                       // dV = (P o F)^T dO
+            dss[half][r] = p * (dp[r] * f - dq_s[qq < g.L ? qq : 0]);
           }
           if (HAS_BIAS) {
             // block-level accumulation requires one key tile per wave (NKT <= 4): tile index = qt
@@ -439,14 +451,15 @@ static int attn_geom(AttnGeom& g, int L, int nH, int D, int swin, int H, int W, 
 
 template <typename T, int D, int NKT>
 static int attn_fwd_launch(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B,
-                           const AttnGeom& g, hipStream_t st) {
+                           const AttnGeom& g, hipStream_t st, const DropArgs* da = nullptr) {
   constexpr size_t smem = (size_t)D * (NKT * 16 + 8) * sizeof(T);
-  auto kern = attn_fwd_kernel<T, D, NKT>;
+  auto kern = da ? attn_fwd_kernel<T, D, NKT, true> : attn_fwd_kernel<T, D, NKT, false>;
   if (smem > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return VTX_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3(B * g.nW * g.nH), dim3(256), smem, st, (const T*)qkv, (T*)o, lse, bias, mask, g);
+  hipLaunchKernelGGL(kern, dim3(B * g.nW * g.nH), dim3(256), smem, st, (const T*)qkv, (T*)o, lse, bias, mask, g,
+                     da ? *da : DropArgs{});
   return vtx_check_launch();
 }
 
@@ -460,26 +473,37 @@ static int attn_bwd_blocks(int nbn, int nH) {
 template <typename T, int D, int NKT>
 static int attn_bwd_launch(const void* qkv, const void* oin, const void* dout, const float* lse, const float* bias,
                            const uint8_t* mask, void* dqkv, float* part, int B, int nblk, const AttnGeom& g,
-                           hipStream_t st) {
+                           hipStream_t st, const DropArgs* da = nullptr) {
   constexpr size_t smem = (size_t)2 * D * (NKT * 16 + 8) * sizeof(T) + (size_t)2 * NKT * 16 * sizeof(float);
   const int nbn = B * g.nW;
+  const DropArgs dv = da ? *da : DropArgs{};
   if (bias) {
     if (NKT > 4) return VTX_ERR_SHAPE;   // register-resident bias gradient: one key tile per wave
-    auto kern = attn_bwd_kernel<T, D, NKT, true>;
+    auto kern = da ? attn_bwd_kernel<T, D, NKT, true, true> : attn_bwd_kernel<T, D, NKT, true, false>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return VTX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(nblk, g.nH), dim3(256), smem, st, (const T*)qkv, (const T*)oin, (const T*)dout, lse, bias, mask,
-                       (T*)dqkv, part, nbn, g);
+                       (T*)dqkv, part, nbn, g, dv);
   } else {
-    auto kern = attn_bwd_kernel<T, D, NKT, false>;
+    auto kern = da ? attn_bwd_kernel<T, D, NKT, false, true> : attn_bwd_kernel<T, D, NKT, false, false>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return VTX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(nbn, g.nH), dim3(256), smem, st, (const T*)qkv, (const T*)oin, (const T*)dout, lse, bias, mask,
-                       (T*)dqkv, part, nbn, g);
+                       (T*)dqkv, part, nbn, g, dv);
   }
   return vtx_check_launch();
+}
+
+// keep[prob][q][key] = 1 where the hash keeps the cell (what the kernels regenerate): for tests and for feeding an oracle
+__global__ void attn_keep_mask_kernel(uint8_t* __restrict__ out, int64_t total, DropArgs da) {
+  const int64_t cells = (int64_t)da.Lq * da.Lk;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prob = i / cells;
+    const int cell = (int)(i - prob * cells);
+    out[i] = drop_hash(da.s0, da.s1, (unsigned)prob, (unsigned)cell) >= da.thresh ? 1 : 0;
+  }
 }
 
 #define ATTN_DISPATCH(FN, ...)                                                          \
@@ -524,17 +548,48 @@ int vtx_relpos_bias(const float* rel_pos, const int64_t* pos, float* bias, int L
   return vtx_check_launch();
 }
 
-int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
-                      int nH, int D, int swin, int H, int W, int win, int shift, int dtype, void* stream) {
+static int attention_fwd_impl(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
+                              int nH, int D, int swin, int H, int W, int win, int shift, int dtype, hipStream_t st,
+                              const DropArgs* da) {
   if (!qkv || !o || !lse) return VTX_ERR_NULL;
   AttnGeom g;
   int rc = attn_geom(g, L, nH, D, swin, H, W, win, shift);
   if (rc) return rc;
   if (B <= 0) return VTX_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (sattn_ok(dtype, L, D, swin, bias)) return sattn_fwd_launch(qkv, o, lse, B, L, nH, st);
-  if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) return lattn_fwd_launch(qkv, o, lse, B, L, nH, D, dtype, st);
-  ATTN_DISPATCH(attn_fwd_launch, qkv, o, lse, bias, mask, B, g, st);
+  if (!da) {
+    if (sattn_ok(dtype, L, D, swin, bias)) return sattn_fwd_launch(qkv, o, lse, B, L, nH, st);
+    if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) return lattn_fwd_launch(qkv, o, lse, B, L, nH, D, dtype, st);
+  }
+  ATTN_DISPATCH(attn_fwd_launch, qkv, o, lse, bias, mask, B, g, st, da);
+}
+
+int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
+                      int nH, int D, int swin, int H, int W, int win, int shift, int dtype, void* stream) {
+  return attention_fwd_impl(qkv, o, lse, bias, mask, B, L, nH, D, swin, H, W, win, shift, dtype, (hipStream_t)stream, nullptr);
+}
+
+/* The same with dropout of the attention probabilities (training mode of the reference's F.dropout(attn, p)): register-resident
+ * kernels only (L <= 224 with head dim 64, L <= 64 with head dim 32). */
+int vtx_attention_fwd_drop(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
+                           int nH, int D, int swin, int H, int W, int win, int shift, int dtype, float drop_p, uint64_t seed,
+                           const uint8_t* keep, void* stream) {
+  DropArgs da;
+  int rc = drop_args(da, drop_p, seed, keep, L, L);
+  if (rc) return rc;
+  return attention_fwd_impl(qkv, o, lse, bias, mask, B, L, nH, D, swin, H, W, win, shift, dtype, (hipStream_t)stream, &da);
+}
+
+int vtx_attn_keep_mask(uint8_t* out, int64_t nprob, int Lq, int Lk, float drop_p, uint64_t seed, void* stream) {
+  if (!out) return VTX_ERR_NULL;
+  if (nprob <= 0 || Lq <= 0 || Lk <= 0) return VTX_ERR_SHAPE;
+  DropArgs da;
+  int rc = drop_args(da, drop_p, seed, nullptr, Lq, Lk);
+  if (rc) return rc;
+  const int64_t total = nprob * Lq * Lk;
+  int64_t nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(attn_keep_mask_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, out, total, da);
+  return vtx_check_launch();
 }
 
 size_t vtx_attention_bwd_workspace(int B, int L, int nH, int swin, int H, int W, int win) {
@@ -546,19 +601,18 @@ size_t vtx_attention_bwd_workspace(int B, int L, int nH, int swin, int H, int W,
 }
 
 /* dqkv [rows, 3*h*D] (every element written); drel_pos [(2w-1)^2, nH] fp32 when bias is given. */
-int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* bias, const uint8_t* mask,
-                      const int* csr_order, const int* csr_offsets, void* dqkv, float* drel_pos, int ntab,
-                      void* workspace, size_t ws_bytes,
-                      int B, int L, int nH, int D, int swin, int H, int W, int win, int shift, int dtype,
-                      void* stream) {
+static int attention_bwd_impl(const void* qkv, const void* o, const void* dout, const float* lse, const float* bias, const uint8_t* mask,
+                              const int* csr_order, const int* csr_offsets, void* dqkv, float* drel_pos, int ntab,
+                              void* workspace, size_t ws_bytes,
+                              int B, int L, int nH, int D, int swin, int H, int W, int win, int shift, int dtype,
+                              hipStream_t st, const DropArgs* da) {
   if (!qkv || !o || !dout || !lse || !dqkv) return VTX_ERR_NULL;
   AttnGeom g;
   int rc = attn_geom(g, L, nH, D, swin, H, W, win, shift);
   if (rc) return rc;
   if (B <= 0) return VTX_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (sattn_ok(dtype, L, D, swin, bias)) return sattn_bwd_launch(qkv, o, dout, lse, dqkv, B, L, nH, st);
-  if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) {
+  if (!da && sattn_ok(dtype, L, D, swin, bias)) return sattn_bwd_launch(qkv, o, dout, lse, dqkv, B, L, nH, st);
+  if (!da && attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) {
     if (!workspace) return VTX_ERR_NULL;
     if (ws_bytes < lattn_bwd_workspace(B, L, nH)) return VTX_ERR_WORKSPACE;
     return lattn_bwd_launch(qkv, o, dout, lse, dqkv, (float*)workspace, B, L, nH, D, dtype, st);
@@ -569,7 +623,7 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
     if (!csr_order || !csr_offsets || !drel_pos || !workspace) return VTX_ERR_NULL;
     if (ws_bytes < vtx_attention_bwd_workspace(B, L, nH, swin, H, W, win)) return VTX_ERR_WORKSPACE;
   }
-  auto run = [&]() -> int { ATTN_DISPATCH(attn_bwd_launch, qkv, o, dout, lse, bias, mask, dqkv, part, B, nblk, g, st); };
+  auto run = [&]() -> int { ATTN_DISPATCH(attn_bwd_launch, qkv, o, dout, lse, bias, mask, dqkv, part, B, nblk, g, st, da); };
   rc = run();
   if (rc) return rc;
   if (bias) {
@@ -585,6 +639,28 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
     rc = vtx_check_launch();
   }
   return rc;
+}
+
+int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* bias, const uint8_t* mask,
+                      const int* csr_order, const int* csr_offsets, void* dqkv, float* drel_pos, int ntab,
+                      void* workspace, size_t ws_bytes,
+                      int B, int L, int nH, int D, int swin, int H, int W, int win, int shift, int dtype,
+                      void* stream) {
+  return attention_bwd_impl(qkv, o, dout, lse, bias, mask, csr_order, csr_offsets, dqkv, drel_pos, ntab, workspace, ws_bytes, B, L, nH,
+                            D, swin, H, W, win, shift, dtype, (hipStream_t)stream, nullptr);
+}
+
+/* Backward of vtx_attention_fwd_drop: same (drop_p, seed, keep) as the forward; workspace as vtx_attention_bwd with a bias. */
+int vtx_attention_bwd_drop(const void* qkv, const void* o, const void* dout, const float* lse, const float* bias, const uint8_t* mask,
+                           const int* csr_order, const int* csr_offsets, void* dqkv, float* drel_pos, int ntab,
+                           void* workspace, size_t ws_bytes,
+                           int B, int L, int nH, int D, int swin, int H, int W, int win, int shift, int dtype,
+                           float drop_p, uint64_t seed, const uint8_t* keep, void* stream) {
+  DropArgs da;
+  int rc = drop_args(da, drop_p, seed, keep, L, L);
+  if (rc) return rc;
+  return attention_bwd_impl(qkv, o, dout, lse, bias, mask, csr_order, csr_offsets, dqkv, drel_pos, ntab, workspace, ws_bytes, B, L, nH,
+                            D, swin, H, W, win, shift, dtype, (hipStream_t)stream, &da);
 }
 
 /* Global attention over Bk <= B images only (stochastic-depth compaction, csrc/layer.hip): the b-th image worked on is image

@@ -73,9 +73,9 @@ template <typename T> __device__ __forceinline__ Vec8<T> sr_out8(const f32x4& a0
 
 // --------------------------------------------------------------------------------------------- forward
 // grid = (workgroups per (image, head), B * nH)
-template <typename T, int D>
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
-                                                        T* __restrict__ o, float* __restrict__ lse, SrGeom g) {
+                                                        T* __restrict__ o, float* __restrict__ lse, SrGeom g, DropArgs da) {
   constexpr int DS = D / 32, DJ = D / 16;                               // 32-channel k-steps, 16-channel output tiles
   __shared__ __attribute__((aligned(16))) T vt[D * SR_STR];             // Vt[pi(d)][key], shared by the 4 waves
   const int bh = blockIdx.y, h = bh % g.nH, b = bh / g.nH;
@@ -133,6 +133,12 @@ __global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q
     l += shfl_xor_f(l, 32);
     const float inv = 1.f / l;
     if (qv && g_ == 0) lse[(int64_t)bh * g.Lq + qi] = m + __logf(l);
+    if constexpr (DROP) {                           // F.dropout on the normalised probabilities (pvt.py:60, twins.py:88)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] *= drop_factor(da, (unsigned)bh, qi, 16 * kt + 4 * g_ + r);
+    }
     f32x4 oacc[DJ];
 #pragma unroll
     for (int j = 0; j < DJ; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -153,11 +159,11 @@ __global__ __launch_bounds__(256) void srattn_fwd_kernel(const T* __restrict__ q
 
 // --------------------------------------------------------------------------------------------- backward
 // same grid; part: fp32 [B * nH][workgroups][64 keys][2 D] (dK channels 0..D-1, dV channels D..2D-1 of the head)
-template <typename T, int D>
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                            const T* __restrict__ oin, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, T* __restrict__ dq,
-                                                           float* __restrict__ part, SrGeom g) {
+                                                           float* __restrict__ part, SrGeom g, DropArgs da) {
   constexpr int DS = D / 32, DJ = D / 16;
   __shared__ __attribute__((aligned(16))) T kt_s[D * SR_STR];           // Kt[pi(d)][key]
   __shared__ __attribute__((aligned(16))) T qt_s[D * SR_STR];           // Qt[pi(d)][q of the sub-chunk]
@@ -266,7 +272,9 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = __expf(pt[r] * g.scale + kmask[kt][r] - lq);
-            dsv[half][r] = p * (dpt[r] - dsum);
+            float dpv = dpt[r];
+            if constexpr (DROP) dpv *= drop_factor(da, (unsigned)bh, qi, 16 * kt + 4 * g_ + r);
+            dsv[half][r] = p * (dpv - dsum);
           }
         }
         Vec8<T> dsf = sr_frag_acc<T>(dsv[0], dsv[1]);
@@ -301,8 +309,10 @@ __global__ __launch_bounds__(256, 2) void srattn_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __expf(s[r] * g.scale + kbias - ls[r]);
-          pp[half][r] = p;
-          dss[half][r] = p * (dp[r] - dd[r]);
+          float f = 1.f;
+          if constexpr (DROP) f = drop_factor(da, (unsigned)bh, q0 + 16 * t + 4 * g_ + r, 16 * wave + c_);
+          pp[half][r] = p * f;
+          dss[half][r] = p * (dp[r] * f - dd[r]);
         }
       }
       Vec8<T> pf = sr_frag_acc<T>(pp[0], pp[1]);
@@ -394,18 +404,26 @@ static int sr_launch_scores(const void* q, const void* kv, void* score, int B, i
   return vtx_check_launch();
 }
 template <typename T, int D>
-static int sr_launch_fwd(const void* q, const void* kv, void* o, float* lse, int B, const SrGeom& g, hipStream_t st) {
+static int sr_launch_fwd(const void* q, const void* kv, void* o, float* lse, int B, const SrGeom& g, hipStream_t st,
+                         const DropArgs* da = nullptr) {
   dim3 grid(sr_wgs(g), B * g.nH);
-  hipLaunchKernelGGL((srattn_fwd_kernel<T, D>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o, lse, g);
+  if (da)
+    hipLaunchKernelGGL((srattn_fwd_kernel<T, D, true>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o, lse, g, *da);
+  else
+    hipLaunchKernelGGL((srattn_fwd_kernel<T, D, false>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (T*)o, lse, g, DropArgs{});
   return vtx_check_launch();
 }
 template <typename T, int D>
 static int sr_launch_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
-                         float* part, int B, const SrGeom& g, hipStream_t st) {
+                         float* part, int B, const SrGeom& g, hipStream_t st, const DropArgs* da = nullptr) {
   const int nwg = sr_wgs(g);
   dim3 grid(nwg, B * g.nH);
-  hipLaunchKernelGGL((srattn_bwd_kernel<T, D>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)o, (const T*)dout,
-                     lse, (T*)dq, part, g);
+  if (da)
+    hipLaunchKernelGGL((srattn_bwd_kernel<T, D, true>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)o, (const T*)dout,
+                       lse, (T*)dq, part, g, *da);
+  else
+    hipLaunchKernelGGL((srattn_bwd_kernel<T, D, false>), grid, dim3(256), 0, st, (const T*)q, (const T*)kv, (const T*)o, (const T*)dout,
+                       lse, (T*)dq, part, g, DropArgs{});
   int rc = vtx_check_launch();
   if (rc) return rc;
   const int64_t total = (int64_t)B * g.nH * g.Lk * (D / 2);
@@ -443,6 +461,20 @@ int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, in
   return SR_DISPATCH(sr_launch_fwd, q, kv, o, lse, B, g, (hipStream_t)stream);
 }
 
+/* The same with dropout of the attention probabilities (reference models/pvt.py:60, models/twins.py:88): keep mask by hash of
+ * (seed, image * nH + head, query * Lk + key), or `keep` [B*nH][Lq][Lk] bytes when given (see vtx_attention_fwd_drop). */
+int vtx_srattn_fwd_drop(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
+                        float drop_p, uint64_t seed, const uint8_t* keep, void* stream) {
+  if (!q || !kv || !o || !lse) return VTX_ERR_NULL;
+  SrGeom g;
+  int rc = sr_geom(g, Lq, Lk, nH, B, D);
+  if (rc) return rc;
+  DropArgs da;
+  rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  if (rc) return rc;
+  return SR_DISPATCH(sr_launch_fwd, q, kv, o, lse, B, g, (hipStream_t)stream, &da);
+}
+
 size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH, int D) {
   SrGeom g;
   if (sr_geom(g, Lq, Lk, nH, B, D)) return 0;
@@ -458,6 +490,20 @@ int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dou
   if (rc) return rc;
   if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH, D)) return VTX_ERR_WORKSPACE;
   return SR_DISPATCH(sr_launch_bwd, q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, g, (hipStream_t)stream);
+}
+
+int vtx_srattn_bwd_drop(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                        void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, float drop_p,
+                        uint64_t seed, const uint8_t* keep, void* stream) {
+  if (!q || !kv || !o || !dout || !lse || !dq || !dkv || !workspace) return VTX_ERR_NULL;
+  SrGeom g;
+  int rc = sr_geom(g, Lq, Lk, nH, B, D);
+  if (rc) return rc;
+  if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH, D)) return VTX_ERR_WORKSPACE;
+  DropArgs da;
+  rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  if (rc) return rc;
+  return SR_DISPATCH(sr_launch_bwd, q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, g, (hipStream_t)stream, &da);
 }
 
 }  // extern "C"

@@ -381,6 +381,42 @@ static __global__ __launch_bounds__(1024) void layer_reduce_kernel(LayerReduce a
   }
 }
 
+// ---------------------------------------------------------------- attention-probability dropout
+// Reference: F.dropout(attn, p) on the softmax output (models/vit.py:39, swin_transformer.py:144, pvt.py:60, twins.py:88,147).
+// The keep decision of cell (problem, query, key) is a counter-based hash of (seed, problem, query * Lk + key): the backward
+// regenerates it, no mask tensor exists in HBM.  keep != NULL: an explicit keep mask [problems][Lq][Lk] (bytes, 1 = keep)
+// replaces the hash -- the parity tests feed the mask the reference drew.  scale = 1 / (1 - p).
+struct DropArgs {
+  float scale;
+  unsigned thresh, s0, s1;
+  const uint8_t* keep;
+  int Lq, Lk;
+};
+__device__ __forceinline__ unsigned drop_hash(unsigned s0, unsigned s1, unsigned prob, unsigned cell) {
+  unsigned h = s0 ^ (prob * 0x9E3779B1u);
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+  h += cell * 0xC2B2AE35u + s1;
+  h ^= h >> 16; h *= 0x27D4EB2Fu; h ^= h >> 15; h *= 0x165667B1u; h ^= h >> 16;
+  return h;
+}
+// factor of attention probability (problem, q, key): 0 (dropped) or 1 / (1 - p); cells outside [Lq) x [Lk) are never used
+__device__ __forceinline__ float drop_factor(const DropArgs& d, unsigned prob, int q, int key) {
+  if (d.keep != nullptr) {
+    if (q >= d.Lq || key >= d.Lk) return 0.f;
+    return d.keep[((int64_t)prob * d.Lq + q) * d.Lk + key] ? d.scale : 0.f;
+  }
+  return drop_hash(d.s0, d.s1, prob, (unsigned)(q * d.Lk + key)) >= d.thresh ? d.scale : 0.f;
+}
+static inline int drop_args(DropArgs& d, float p, uint64_t seed, const uint8_t* keep, int Lq, int Lk) {
+  if (!(p > 0.f) || !(p < 1.f)) return VTX_ERR_SHAPE;
+  d.scale = 1.f / (1.f - p);
+  const double t = (double)p * 4294967296.0;
+  d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  d.s0 = (unsigned)seed; d.s1 = (unsigned)(seed >> 32);
+  d.keep = keep; d.Lq = Lq; d.Lk = Lk;
+  return VTX_OK;
+}
+
 static inline dim3 slab_reduce_grid(int64_t n) {
   int64_t nb = ((n >> 2) + 255) / 256;
   return dim3((unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb)));

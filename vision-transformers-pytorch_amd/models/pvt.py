@@ -39,7 +39,11 @@ class MultiHeadedAttention(nn.Module):
             self.reduce_conv = nn.Conv2d(dim, dim, self.reduction, stride=self.reduction)
             self.reduce_norm = LayerNorm(dim)
 
-    def forward(self, input, height, width, prev=None):
+    def drops(self):
+        """True when F.dropout(attn, self.dropout, self.training) of the reference (pvt.py:60) is active."""
+        return self.training and self.dropout > 0
+
+    def forward(self, input, height, width, prev=None, keep=None):
         """The reference's standalone contract (models/pvt.py:31-69): input (B, L, dim) with the last height * width tokens
         on the grid (leading tokens -- a cls token -- attend but are not reduced); returns ``(out, score)`` with score =
         q k^T / sqrt(d) of shape (B, heads, L, Lk) before the softmax.  The PVT layers do not come through here (they run
@@ -65,7 +69,7 @@ class MultiHeadedAttention(nn.Module):
             kvin, Lk = x, L
         kv = VF.LinearFn.apply(kvin.reshape(B * Lk, C), self.linear_kv.weight, None)
         q2 = q.reshape(B * L, C)
-        out = VF.SrAttentionFn.apply(q2, kv, B, L, Lk, self.n_head)
+        out = VF.SrAttentionFn.apply(q2, kv, B, L, Lk, self.n_head, VF.attn_drop(self.dropout, self.training, keep))
         out = VF.LinearFn.apply(out.view(B, L, C), self.linear.weight, self.linear.bias)
         from vtx import ops
         with torch.no_grad():
@@ -75,8 +79,6 @@ class MultiHeadedAttention(nn.Module):
     def check(self):
         if self.dim_head != 64:
             raise NotImplementedError("vtx: the PVT attention kernel is built for head dim 64 (all PVT configurations)")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("vtx: attention dropout > 0 is not supported by the fused HIP path")
 
 
 class TransformerLayer(nn.Module):
@@ -94,6 +96,10 @@ class TransformerLayer(nn.Module):
     def forward(self, input, height, width):
         a, f = self.attn, self.ff
         a.check()
+        if a.drops():
+            # attention dropout: call by call (pvt.py:99-103) through the standalone module (its score output is discarded)
+            out = input + self.drop_path(a(self.norm_attn(input), height, width)[0])
+            return out + self.drop_path(f(self.norm_ff(out)))
         if not f.fused_ok():
             raise NotImplementedError("vtx: PVT runs on the fused layer only (SiLU activation, dropout 0)")
         T = VF.compute_dtype(input)

@@ -96,14 +96,17 @@ class MultiHeadedLocalAttention(nn.Module):
         if tuple(input.shape[1:3]) != self.input_size:
             raise ValueError(f"feature map {tuple(input.shape[1:3])} != input_size {self.input_size} this layer's "
                              "pos / local_mask tables were built for")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("vtx: attention dropout > 0 is not supported by the fused HIP path")
 
-    def forward(self, input):
+    def drops(self):
+        """True when F.dropout(attn, self.dropout, self.training) of the reference (swin_transformer.py:144) is active."""
+        return self.training and self.dropout > 0
+
+    def forward(self, input, keep=None):
+        """keep: an explicit uint8 keep mask [B * windows * heads, L, L] for the attention dropout (parity tests); else hashed."""
         self.check_input(input)
         T = VF.compute_dtype(input)
         qkv = VF.LinearFn.apply(input.to(T), self.weight.weight, self.weight.bias)
-        out = VF.AttentionCoreFn.apply(qkv, self.rel_pos.weight, self.meta())
+        out = VF.AttentionCoreFn.apply(qkv, self.rel_pos.weight, self.meta(), VF.attn_drop(self.dropout, self.training, keep))
         return VF.LinearFn.apply(out, self.linear.weight, self.linear.bias)
 
 
@@ -122,7 +125,8 @@ class TransformerLayer(nn.Module):
 
     def forward(self, input):
         self.attn.check_input(input)
-        if not self.ff.fused_ok():
+        if not self.ff.fused_ok() or self.attn.drops():
+            # call by call (swin_transformer.py:193-197): another activation / feed-forward dropout / attention dropout
             out = input + self.drop_path(self.attn(self.norm_attn(input)))
             return out + self.drop_path(self.ff(self.norm_ff(out)))
         T = VF.compute_dtype(input)

@@ -73,8 +73,6 @@ class MultiHeadedAttention(nn.Module):
         r = self.reduction
         if self.dim_head not in (32, 64):
             raise NotImplementedError("vtx: the sub-sampled attention kernel is built for head dim 32 or 64")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("vtx: attention dropout > 0 is not supported by the fused HIP path")
         if r <= 1:
             # reference twins.py:74-77 would chunk its 4-D (B, H, W, 2 dim) projection along dim 2 (the width) in that case;
             # TransformerLayer never builds the module that way (reduction = window_size, twins.py:182)
@@ -84,8 +82,13 @@ class MultiHeadedAttention(nn.Module):
         if (height // r) * (width // r) > 64:
             raise NotImplementedError("vtx: the sub-sampled attention kernel holds at most 64 reduced key tokens")
 
-    def forward(self, input):
-        """The reference's standalone contract (models/twins.py:56-93): input (B, H, W, dim) -> (B, H, W, dim)."""
+    def drops(self):
+        """True when F.dropout(attn, self.dropout, self.training) of the reference (twins.py:88) is active."""
+        return self.training and self.dropout > 0
+
+    def forward(self, input, keep=None):
+        """The reference's standalone contract (models/twins.py:56-93): input (B, H, W, dim) -> (B, H, W, dim).
+        keep: an explicit uint8 keep mask [B * heads, H * W, Lk] for the attention dropout (parity tests); else hashed."""
         B, H, W, C = input.shape
         self.check(H, W)
         T = VF.compute_dtype(input)
@@ -98,7 +101,8 @@ class MultiHeadedAttention(nn.Module):
         kvin = VF.LinearFn.apply(patches, w_rows, self.reduce_conv.bias)
         Lk = (H // r) * (W // r)
         kv = VF.LinearFn.apply(kvin.reshape(B * Lk, C), self.linear_kv.weight, None)
-        out = VF.SrAttentionFn.apply(q.reshape(B * H * W, C), kv, B, H * W, Lk, self.n_head)
+        out = VF.SrAttentionFn.apply(q.reshape(B * H * W, C), kv, B, H * W, Lk, self.n_head,
+                                     VF.attn_drop(self.dropout, self.training, keep))
         return VF.LinearFn.apply(out.view(B, H, W, C), self.linear.weight, self.linear.bias)
 
 
@@ -137,15 +141,18 @@ class MultiHeadedLocalAttention(nn.Module):
         return m
 
     def check(self):
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("vtx: attention dropout > 0 is not supported by the fused HIP path")
+        pass
 
-    def forward(self, input):
-        self.check()
+    def drops(self):
+        """True when F.dropout(attn, self.dropout, self.training) of the reference (twins.py:147) is active."""
+        return self.training and self.dropout > 0
+
+    def forward(self, input, keep=None):
+        """keep: an explicit uint8 keep mask [B * windows * heads, L, L] for the attention dropout (parity tests); else hashed."""
         T = VF.compute_dtype(input)
         meta, zero_bias = self.meta(input.shape[1], input.shape[2], input.device)
         qkv = VF.LinearFn.apply(input.to(T), self.weight.weight, self.weight.bias)
-        out = VF.AttentionCoreFn.apply(qkv, zero_bias, meta)
+        out = VF.AttentionCoreFn.apply(qkv, zero_bias, meta, VF.attn_drop(self.dropout, self.training, keep))
         return VF.LinearFn.apply(out, self.linear.weight, self.linear.bias)
 
 
@@ -169,7 +176,7 @@ class TransformerLayer(nn.Module):
         self.drop_path.p = p
 
     def forward(self, input):
-        if not (self.ff_local.fused_ok() and self.ff_global.fused_ok()):
+        if not (self.ff_local.fused_ok() and self.ff_global.fused_ok()) or self.attn_local.drops() or self.attn_global.drops():
             out = input + self.drop_path(self.attn_local(self.norm_attn_local(input)))
             out = out + self.drop_path(self.ff_local(self.norm_ff_local(out)))
             out = out + self.drop_path(self.attn_global(self.norm_attn_global(out)))

@@ -46,16 +46,16 @@ class MultiHeadedAttention(nn.Module):
     def meta(self, length, eps=1e-6):
         return VF.AttentionMeta(self.n_head, self.dim_head, length, eps=eps)
 
-    def check(self):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("vtx: attention-probability dropout > 0 is not supported: the probabilities never leave the "
-                                      "fused attention kernel (residual / feed-forward / positional dropout are)")
+    def drops(self):
+        """True when F.dropout(attn, p) of the reference (vit.py:39) is active: the layer then runs call by call with the
+        dropout variant of the attention kernels (keep mask regenerated in the backward from a counter-based hash)."""
+        return self.training and self.dropout.p > 0
 
-    def forward(self, input):
-        self.check()
+    def forward(self, input, keep=None):
+        """keep: an explicit uint8 keep mask [B * heads, L, L] for the attention dropout (parity tests); else hashed."""
         T = VF.compute_dtype(input)
         qkv = VF.LinearFn.apply(input.to(T), self.qkv.weight, self.qkv.bias)
-        out = VF.AttentionCoreFn.apply(qkv, None, self.meta(input.shape[1]))
+        out = VF.AttentionCoreFn.apply(qkv, None, self.meta(input.shape[1]), VF.attn_drop(self.dropout.p, self.training, keep))
         return VF.LinearFn.apply(out, self.linear.weight, self.linear.bias)
 
 
@@ -70,10 +70,9 @@ class TransformerLayer(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, input):
-        self.attn.check()
-        if self.attn.qkv.bias is None or not self.ff.fused_ok() or (self.training and self.dropout.p > 0):
-            # reference composition (vit.py:59-63) from the HIP modules: residual / feed-forward dropout > 0 (nn.Dropout on
-            # the device tensors), a bias-free qkv or another activation -- none of the BASELINE configurations
+        if self.attn.qkv.bias is None or not self.ff.fused_ok() or (self.training and self.dropout.p > 0) or self.attn.drops():
+            # reference composition (vit.py:59-63) from the HIP modules: residual / feed-forward / attention dropout > 0, a
+            # bias-free qkv or another activation -- none of the BASELINE configurations
             out = input + self.drop_path(self.dropout(self.attn(self.norm_attn(input))))
             return out + self.drop_path(self.dropout(self.ff(self.norm_ff(out))))
         T = VF.compute_dtype(input)

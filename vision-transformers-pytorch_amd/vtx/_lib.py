@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class VtxError(RuntimeError):
@@ -128,6 +128,12 @@ _SIGNATURES = {
     "vtx_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_attention_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_void_p, c_void_p]),
+    "vtx_attention_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_void_p, c_void_p]),
+    "vtx_attn_keep_mask": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_void_p]),
     "vtx_wattn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_wattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -141,6 +147,10 @@ _SIGNATURES = {
     "vtx_srattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "vtx_srattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_srattn_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    ctypes.c_uint64, c_void_p, c_void_p]),
+    "vtx_srattn_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_void_p, c_void_p]),
     "vtx_dwconv3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_dwconv3_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vtx_dwconv3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -623,45 +623,59 @@ def _wattn_ok(rel_pos, meta):
             ops.wattn_supported(meta.dim_head, meta.swin[2]) and (meta.mask is None or meta.region is not None))
 
 
-def _attn_forward(qkv, rel_pos, meta):
+_DROP_CALLS = [0]
+
+
+def attn_drop(p, training, keep=None):
+    """(p, seed, keep) of one attention-dropout call, None when the reference's F.dropout(attn, p, training) is the identity.
+    The seed advances with every call and derives from torch's seed: the same ``torch.manual_seed`` and call sequence reproduce
+    the masks.  keep: an explicit uint8 keep mask [problems, Lq, Lk] (parity tests)."""
+    if not training or not p > 0:
+        return None
+    _DROP_CALLS[0] += 1
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_CALLS[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return (float(p), seed, keep)
+
+
+def _attn_forward(qkv, rel_pos, meta, drop=None):
     """-> (o, lse, aux) where aux is what the matching backward needs (the bias tensor of the generic path)."""
     B = qkv.shape[0]
-    if _wattn_ok(rel_pos, meta):
+    if drop is None and _wattn_ok(rel_pos, meta):
         o, lse = ops.wattn_fwd(qkv, rel_pos.detach(), meta.pos, meta.region, B, meta.L, meta.n_head, meta.swin)
         return o, lse, None
     bias = ops.relpos_bias(rel_pos.detach(), meta.pos, meta.n_head) if rel_pos is not None else None
-    o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias, mask=meta.mask)
+    o, lse = ops.attention_fwd(qkv, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=bias, mask=meta.mask, drop=drop)
     return o, lse, bias
 
 
-def _attn_backward(qkv, o, do, lse, aux, meta, rel_pos=None, defer=False):
+def _attn_backward(qkv, o, do, lse, aux, meta, rel_pos=None, defer=False, drop=None):
     """-> dqkv, drel_pos (an ops.Partials with ``defer`` on the window-attention fast path: reduced later in one launch
     with the layer's LayerNorm partials)."""
     B = qkv.shape[0]
-    if _wattn_ok(rel_pos, meta):
+    if drop is None and _wattn_ok(rel_pos, meta):
         return ops.wattn_bwd(qkv, o, do, lse, rel_pos.detach(), meta.pos, meta.region, B, meta.L, meta.n_head,
                              meta.swin, meta.ntab, defer=defer)
     return ops.attention_bwd(qkv, o, do, lse, B, meta.L, meta.n_head, meta.dim_head, swin=meta.swin, bias=aux,
-                             mask=meta.mask, csr=meta.csr, ntab=meta.ntab)
+                             mask=meta.mask, csr=meta.csr, ntab=meta.ntab, drop=drop)
 
 
 class AttentionCoreFn(Function):
     """softmax(q k^T / sqrt(d) [+ rel-pos bias, -inf mask]) v on the QKV projection output."""
 
     @staticmethod
-    def forward(ctx, qkv, rel_pos, meta):
+    def forward(ctx, qkv, rel_pos, meta, drop=None):
         qkv = _c(qkv)
-        o, lse, aux = _attn_forward(qkv, rel_pos, meta)
+        o, lse, aux = _attn_forward(qkv, rel_pos, meta, drop)
         ctx.save_for_backward(qkv, o, lse, aux, rel_pos)
-        ctx.meta = meta
+        ctx.meta, ctx.drop = meta, drop
         return o
 
     @staticmethod
     def backward(ctx, do):
         side_fence(do.device)
         qkv, o, lse, aux, rel_pos = ctx.saved_tensors
-        dqkv, drel = _attn_backward(qkv, o, _c(do), lse, aux, ctx.meta, rel_pos)
-        return dqkv, drel, None
+        dqkv, drel = _attn_backward(qkv, o, _c(do), lse, aux, ctx.meta, rel_pos, drop=ctx.drop)
+        return dqkv, drel, None, None
 
 
 class TransformerLayerFn(Function):
@@ -1043,19 +1057,19 @@ class SrAttentionFn(Function):
     """softmax(q k^T / 8) v for PVT's (reduced-key) attention on the q / kv projection outputs (pvt.py:51-63)."""
 
     @staticmethod
-    def forward(ctx, q, kv, B, Lq, Lk, n_head):
+    def forward(ctx, q, kv, B, Lq, Lk, n_head, drop=None):
         q, kv = _c(q), _c(kv)
-        o, lse = ops.srattn_fwd(q, kv, B, Lq, Lk, n_head)
+        o, lse = ops.srattn_fwd(q, kv, B, Lq, Lk, n_head, drop=drop)
         ctx.save_for_backward(q, kv, o, lse)
-        ctx.geom = (B, Lq, Lk, n_head)
+        ctx.geom, ctx.drop = (B, Lq, Lk, n_head), drop
         return o
 
     @staticmethod
     def backward(ctx, do):
         side_fence(do.device)
         q, kv, o, lse = ctx.saved_tensors
-        dq, dkv = ops.srattn_bwd(q, kv, o, _c(do), lse, *ctx.geom)
-        return dq, dkv, None, None, None, None
+        dq, dkv = ops.srattn_bwd(q, kv, o, _c(do), lse, *ctx.geom, drop=ctx.drop)
+        return dq, dkv, None, None, None, None, None
 
 
 class _SrLayerPlan:

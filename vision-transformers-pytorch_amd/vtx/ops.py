@@ -583,8 +583,29 @@ def _sr_head_dim(q, kv, B, Lq, Lk, n_head):
     return D, hd
 
 
-def srattn_fwd(q, kv, B, Lq, Lk, n_head):
-    """o [B*Lq, h*D], lse from q [B*Lq, h*D] and kv [B*Lk, 2*h*D] (k | v) -- reference models/pvt.py:38-66, twins.py:56-93."""
+def _drop_args(drop, dev):
+    """(p, seed, keep) of an attention-dropout call -> (float p, int seed, keep pointer); keep: uint8 [problems][Lq][Lk] or None."""
+    p, seed, keep = drop
+    if not 0.0 < float(p) < 1.0:
+        raise VtxError(f"vtx: attention dropout probability {p} outside (0, 1)")
+    if keep is not None:
+        _dev(keep)
+        if keep.dtype != torch.uint8 or not keep.is_contiguous():
+            raise VtxError("vtx: attention keep mask must be a contiguous uint8 tensor")
+    return float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, keep
+
+
+def attn_keep_mask(nprob, Lq, Lk, p, seed, device):
+    """uint8 [nprob, Lq, Lk]: the keep decisions the dropout kernels regenerate from (p, seed) -- tests / external checkers."""
+    out = torch.empty((nprob, Lq, Lk), dtype=torch.uint8, device=device)
+    check(_lib.load().vtx_attn_keep_mask(_p(out), nprob, Lq, Lk, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+          "vtx_attn_keep_mask")
+    return out
+
+
+def srattn_fwd(q, kv, B, Lq, Lk, n_head, drop=None):
+    """o [B*Lq, h*D], lse from q [B*Lq, h*D] and kv [B*Lk, 2*h*D] (k | v) -- reference models/pvt.py:38-66, twins.py:56-93.
+    drop = (p, seed, keep): dropout of the attention probabilities (pvt.py:60)."""
     _dev(q, kv)
     D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
     o = torch.empty_like(q)
@@ -594,8 +615,15 @@ def srattn_fwd(q, kv, B, Lq, Lk, n_head):
     if ev is not None:                              # Lq x Lk products, not Lq x Lq
         _timer.records[-1] = (_timer.records[-1][0], 4.0 * B * n_head * Lq * Lk * D,
                               q.element_size() * (2.0 * B * Lq * hd + 2.0 * B * Lk * hd)) + _timer.records[-1][3:]
-    check(_lib.load().vtx_srattn_fwd(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, D, _dt(q), _stream()),
-          "vtx_srattn_fwd")
+    if drop is not None:
+        dp, seed, keep = _drop_args(drop, q.device)
+        if keep is not None and keep.numel() != B * n_head * Lq * Lk:
+            raise VtxError("vtx: srattn keep mask must be [B * heads, Lq, Lk]")
+        check(_lib.load().vtx_srattn_fwd_drop(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, D, _dt(q), dp, seed, _p(keep),
+                                              _stream()), "vtx_srattn_fwd_drop")
+    else:
+        check(_lib.load().vtx_srattn_fwd(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, D, _dt(q), _stream()),
+              "vtx_srattn_fwd")
     if ev:
         ev[1].record()
     return o, lse
@@ -610,8 +638,8 @@ def srattn_scores(q, kv, B, Lq, Lk, n_head):
     return score
 
 
-def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head):
-    """dq, dkv (deterministic)."""
+def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, drop=None):
+    """dq, dkv (deterministic); drop: the forward's (p, seed, keep)."""
     _dev(q, kv, o, dout, lse)
     lib = _lib.load()
     D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
@@ -624,8 +652,13 @@ def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head):
     if ev is not None:
         _timer.records[-1] = (_timer.records[-1][0], 10.0 * B * n_head * Lq * Lk * D,
                               q.element_size() * (4.0 * B * Lq * hd + 4.0 * B * Lk * hd)) + _timer.records[-1][3:]
-    check(lib.vtx_srattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head, D,
-                             _dt(q), _stream()), "vtx_srattn_bwd")
+    if drop is not None:
+        dp, seed, keep = _drop_args(drop, q.device)
+        check(lib.vtx_srattn_bwd_drop(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head, D,
+                                      _dt(q), dp, seed, _p(keep), _stream()), "vtx_srattn_bwd_drop")
+    else:
+        check(lib.vtx_srattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head, D,
+                                 _dt(q), _stream()), "vtx_srattn_bwd")
     if ev:
         ev[1].record()
     return dq, dkv
@@ -983,8 +1016,10 @@ def _sattn_cfg():
     return "1, 8" if options.get("SATTN_WAVES") == 8 else "2, 4"
 
 
-def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
-    """o [rows, h*D], lse.  swin = (H, W, win, shift) for window attention, None for global."""
+def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None, drop=None):
+    """o [rows, h*D], lse.  swin = (H, W, win, shift) for window attention, None for global.
+    drop = (p, seed, keep): dropout of the attention probabilities (vit.py:39, swin_transformer.py:144) on the register-resident
+    kernels; keep: uint8 [problems, L, L] replaces the hash (parity tests)."""
     _dev(qkv, bias, mask)
     H, W, win, shift = swin if swin is not None else (0, 0, 0, 0)
     rows = qkv.numel() // (3 * n_head * D)
@@ -993,21 +1028,29 @@ def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None):
         raise VtxError("vtx: attention rows mismatch")
     o = torch.empty(qkv.shape[:-1] + (n_head * D,), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
-    fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224      # mirrors sattn_ok
+    fast = drop is None and swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224      # mirrors sattn_ok
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
-    long_ = swin is None and bias is None and mask is None and L > 224
+    long_ = drop is None and swin is None and bias is None and mask is None and L > 224
     ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
                        B * nW * n_head, L, D, rows, n_head * D, qkv.element_size(), False)
-    check(_lib.load().vtx_attention_fwd(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
-                                        int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), _stream()),
-          "vtx_attention_fwd")
+    if drop is not None:
+        dp, seed, keep = _drop_args(drop, qkv.device)
+        if keep is not None and keep.numel() != B * nW * n_head * L * L:
+            raise VtxError("vtx: attention keep mask must be [B * windows * heads, L, L]")
+        check(_lib.load().vtx_attention_fwd_drop(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
+                                                 int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), dp, seed, _p(keep),
+                                                 _stream()), "vtx_attention_fwd_drop")
+    else:
+        check(_lib.load().vtx_attention_fwd(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
+                                            int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), _stream()),
+              "vtx_attention_fwd")
     if ev:
         ev[1].record()
     return o, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask=None, csr=None, ntab=0):
-    """dqkv, drel_pos (None without bias)."""
+def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask=None, csr=None, ntab=0, drop=None):
+    """dqkv, drel_pos (None without bias); drop: the forward's (p, seed, keep)."""
     _dev(qkv, o, dout, lse, bias, mask)
     lib = _lib.load()
     H, W, win, shift = swin if swin is not None else (0, 0, 0, 0)
@@ -1017,18 +1060,25 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
         order, offsets = csr
         _dev(order, offsets)
         drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
-    if bias is not None or (swin is None and L > 224):          # bias-gradient slabs / the long kernels' Dq vector
+    if bias is not None or (swin is None and L > 224 and drop is None):          # bias-gradient slabs / the long kernels' Dq vector
         wsb = lib.vtx_attention_bwd_workspace(B, L, n_head, int(swin is not None), H, W, max(win, 1))
         ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
     rows = qkv.numel() // (3 * n_head * D)
-    fast = swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224
+    fast = drop is None and swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
-    long_ = swin is None and bias is None and mask is None and L > 224
+    long_ = drop is None and swin is None and bias is None and mask is None and L > 224
     ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
                        rows // L * n_head, L, D, rows, n_head * D, qkv.element_size(), True)
-    check(lib.vtx_attention_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
-                                _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
-                                H, W, win, int(bool(shift)), _dt(qkv), _stream()), "vtx_attention_bwd")
+    if drop is not None:
+        dp, seed, keep = _drop_args(drop, qkv.device)
+        check(lib.vtx_attention_bwd_drop(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
+                                         _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
+                                         H, W, win, int(bool(shift)), _dt(qkv), dp, seed, _p(keep), _stream()),
+              "vtx_attention_bwd_drop")
+    else:
+        check(lib.vtx_attention_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
+                                    _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
+                                    H, W, win, int(bool(shift)), _dt(qkv), _stream()), "vtx_attention_bwd")
     if ev:
         ev[1].record()
     return dqkv, drel
