@@ -344,8 +344,9 @@ int vtx_timer_start(void);
 int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */
 
 /* ---- Spatial-reduction (cross) attention of PVT (csrc/attention_sr.hip; reference models/pvt.py:38-66) and the global
- * sub-sampled attention of Twins-SVT (models/twins.py:56-93): head dim D = 64 | 32, Lq queries against Lk <= 64 reduced keys
- * per (image, head).
+ * sub-sampled attention of Twins-SVT (models/twins.py:56-93): head dim D = 64 | 32, Lq queries against Lk reduced keys per
+ * (image, head): up to 64 keys on the register-resident kernels (every 224 x 224 configuration), more (PVT at 256 x 256 stage 4:
+ * 65; at 384 x 384: 144 / 145; Twins at 448 x 448: 256) on key-block / online-softmax kernels (csrc/attention_long.hip).
  *   q [B*Lq, nH*D] (= linear_q output), kv [B*Lk, 2*nH*D] (= linear_kv output: k | v halves, pvt.py:51, twins.py:74),
  *   o [B*Lq, nH*D], lse [B*nH*Lq] fp32 (saved for the backward).
  * The backward writes dq and dkv fully; key-side partials are summed in fixed order (deterministic). */

@@ -27,7 +27,11 @@ def _mk(shape, seed, dtype, scale=1.0):
                                          # head dim 32: the global sub-sampled attention of Twins-SVT (twins.py:56-93) at
                                          # its four stage geometries (7 x 7 sub-sampling of 56^2 / 28^2 / 14^2 / 7^2 tokens)
                                          (2, 3136, 64, 2, 32), (2, 784, 16, 4, 32), (3, 196, 4, 8, 32), (2, 49, 1, 16, 32),
-                                         (1, 70, 17, 3, 32)])
+                                         (1, 70, 17, 3, 32),
+                                         # more than 64 reduced keys (round 5: key-block kernels): PVT at 256 x 256 stage 4 (65), at
+                                         # 384 x 384 (144 / 145), Twins at 448 x 448 (256), a ragged odd case
+                                         (2, 65, 65, 8, 64), (2, 2304, 144, 2, 64), (1, 145, 145, 8, 64), (2, 1024, 256, 4, 32),
+                                         (1, 333, 97, 3, 32)])
 def test_sr_attention_core(dtype, B, Lq, Lk, nH, D):
     from vtx import ops
     d = dev()
@@ -129,6 +133,39 @@ def test_pvt_small_fp32_vs_reference():
         pn = k[len("pvt_small.train64.grad."):]
         e = check_summary(got[pn].grad, g.rec(k), 5e-3, k)
         report(f"pvt-small fp32: grad {pn}", e, 5e-3)
+
+
+@pytest.mark.parametrize("size", [256, 384])
+def test_pvt_at_other_resolutions_fp32_vs_oracle(size):
+    """256 x 256 (stage 4: 64 + 1 = 65 keys) and 384 x 384 (144 reduced keys in stages 1-3, 145 in stage 4): beyond the 64 keys the
+    register-resident kernel holds -- the key-block kernels behind vtx_srattn_* (reference models/pvt.py:38-66 runs at any size).
+    One layer per stage, fp32 parity mode: logits and every parameter gradient vs the CPU oracle; the standalone module's score too."""
+    from models import PyramidVisionTransformer
+    from test_gpu_models import _seeded_init
+    cfg = dict(M.PVT_SMALL, image_size=size, depths=(1, 1, 1, 1), n_class=10)
+    model = PyramidVisionTransformer(**cfg)
+    sd = _seeded_init(model, 8)
+    model.to(dev()).train()
+    x = torch.randn(2, 3, size, size, generator=torch.Generator().manual_seed(18))
+    out = model(x.to(dev()))
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = M.pvt_forward(P, x, cfg)
+    check(f"pvt {size}x{size} fp32 logits vs oracle", out, ref, 1e-4)
+    cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(19))
+    (out * cot.to(dev())).sum().backward()
+    names = [n for n, _ in model.named_parameters()]
+    rg = torch.autograd.grad((ref * cot).sum(), [P[n] for n in names])
+    got = dict(model.named_parameters())
+    for n, r in zip(names, rg):
+        check(f"pvt {size}x{size} fp32 grad {n}", got[n].grad, r, 2e-3)
+    # the standalone module (returns the pre-softmax score) at 144 keys
+    import models.pvt as PV
+    attn = PV.MultiHeadedAttention(128, 2, reduction=2).to(dev())
+    xa = torch.randn(2, 24 * 24, 128, generator=torch.Generator().manual_seed(20))
+    o, score = attn(xa.to(dev()), 24, 24)
+    assert score.shape == (2, 2, 576, 144)
+    Pa = {k: v.detach().cpu().double() for k, v in attn.state_dict().items()}
+    check("pvt attn standalone 144 keys out", o, R.pvt_attention(xa.double(), 24, 24, Pa, 2, 2), 2e-5)
 
 
 def test_pvt_small_bf16_autocast_vs_oracle():

@@ -18,8 +18,12 @@
 #define LA_KB 64                 // tokens per block (4 tiles of 16)
 #define LA_STR (LA_KB + 8)       // transposed LDS row stride
 
+// Queries and keys may come from different tensors (round 5): Lq queries of row stride ldq against Lk keys / values of row stride
+// ldkv -- the packed QKV projection (Lq = Lk, ldq = ldkv = 3 hd) or the q | kv pair of the sub-sampled attention of PVT / Twins-SVT
+// with MORE than 64 reduced keys (models/pvt.py:38-66 at 384 x 384: 144 keys, 145 in stage 4; csrc/attention_sr.hip holds <= 64).
 struct LongGeom {
-  int L, nH, hd;
+  int Lq, Lk, nH, hd;
+  int64_t ldq, ldkv;
   float scale;
 };
 
@@ -64,31 +68,31 @@ __device__ __forceinline__ void la_stage_t(T* __restrict__ xt, const T* __restri
 // ------------------------------------------------------------------------------------------------- forward
 // grid = (ceil(L / 64), B * nH); wave w of a block owns query tile 4 blockIdx.x + w
 template <typename T, int D>
-__global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
-                                                       float* __restrict__ lse, LongGeom g) {
+__global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qp, const T* __restrict__ kp_, const T* __restrict__ vp,
+                                                       T* __restrict__ o, float* __restrict__ lse, LongGeom g) {
   constexpr int DS = D / 32, DT = D / 16;
   __shared__ __attribute__((aligned(16))) T vt[D * LA_STR];
   const int bh = blockIdx.y, b = bh / g.nH, h = bh - b * g.nH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c_ = lane & 15, g_ = lane >> 4;
-  const int64_t ld = 3 * (int64_t)g.hd, row0 = (int64_t)b * g.L;
-  const T* qb = qkv + h * D;
-  const T* kb = qkv + g.hd + h * D;
-  const T* vb = qkv + 2 * g.hd + h * D;
+  const int64_t ldq = g.ldq, ld = g.ldkv, qrow0 = (int64_t)b * g.Lq, row0 = (int64_t)b * g.Lk;
+  const T* qb = qp + h * D;
+  const T* kb = kp_ + h * D;
+  const T* vb = vp + h * D;
   const int qt = blockIdx.x * 4 + wave;
   const int q = qt * 16 + c_;
-  const bool qv = q < g.L;
+  const bool qv = q < g.Lq;
   Vec8<T> qf[DS];
 #pragma unroll
-  for (int ds = 0; ds < DS; ++ds) qf[ds] = la_load<T>(qb + (row0 + (qv ? q : 0)) * ld + ds * 32 + g_ * 8, qv);
+  for (int ds = 0; ds < DS; ++ds) qf[ds] = la_load<T>(qb + (qrow0 + (qv ? q : 0)) * ldq + ds * 32 + g_ * 8, qv);
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 oacc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < g.L; k0 += LA_KB) {
+  for (int k0 = 0; k0 < g.Lk; k0 += LA_KB) {
     __syncthreads();                                           // the previous block's Vt readers are done
-    la_stage_t<T, D>(vt, vb, ld, row0, k0, g.L);
+    la_stage_t<T, D>(vt, vb, ld, row0, k0, g.Lk);
     __syncthreads();
     f32x4 st[4];
     float mb = -INFINITY;
@@ -96,14 +100,14 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qk
     for (int kt = 0; kt < 4; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int key = k0 + kt * 16 + c_;
-      const bool kv = key < g.L;
+      const bool kv = key < g.Lk;
       const T* kp = kb + (row0 + (kv ? key : 0)) * ld + g_ * 8;
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) mma16(la_load<T>(kp + ds * 32, kv), qf[ds], st[kt]);   // S^T[key][q = c_]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = k0 + kt * 16 + g_ * 4 + r;
-        st[kt][r] = kk < g.L ? st[kt][r] * g.scale : -INFINITY;
+        st[kt][r] = kk < g.Lk ? st[kt][r] * g.scale : -INFINITY;
         mb = fmaxf(mb, st[kt][r]);
       }
     }
@@ -138,14 +142,14 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qk
       for (int dt = 0; dt < DT; ++dt) mma16(pf, la_frag_t<T>(vt + (dt * 16 + c_) * LA_STR + ks * 32, g_), oacc[dt]);
     }
   }
-  if (qv && g_ == 0) lse[(int64_t)bh * g.L + q] = m_run + __logf(l_run);
+  if (qv && g_ == 0) lse[(int64_t)bh * g.Lq + q] = m_run + __logf(l_run);
   const float inv = 1.f / l_run;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float iv = shfl_f(inv, 4 * g_ + r);
     const int qo = qt * 16 + g_ * 4 + r;
-    if (qo < g.L) {
-      T* op = o + (row0 + qo) * (int64_t)g.hd + h * D + c_;
+    if (qo < g.Lq) {
+      T* op = o + (qrow0 + qo) * (int64_t)g.hd + h * D + c_;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) op[dt * 16] = from_f32<T>(oacc[dt][r] * iv);
     }
@@ -155,27 +159,28 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qk
 // ------------------------------------------------------------------------------------------------- backward: dQ
 // grid = (ceil(L / 64), B * nH); wave <-> query tile; also writes Dq[q] = rowsum(dO o O) for the dK / dV launch
 template <typename T, int D>
-__global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ oin,
+__global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__ qp, const T* __restrict__ kp_, const T* __restrict__ vp,
+                                                          const T* __restrict__ oin,
                                                           const T* __restrict__ dout, const float* __restrict__ lse,
-                                                          T* __restrict__ dqkv, float* __restrict__ dsum_out, LongGeom g) {
+                                                          T* __restrict__ dq, float* __restrict__ dsum_out, LongGeom g) {
   constexpr int DS = D / 32, DT = D / 16;
   __shared__ __attribute__((aligned(16))) T kt_s[D * LA_STR];
   const int bh = blockIdx.y, b = bh / g.nH, h = bh - b * g.nH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c_ = lane & 15, g_ = lane >> 4;
-  const int64_t ld = 3 * (int64_t)g.hd, row0 = (int64_t)b * g.L;
-  const T* qb = qkv + h * D;
-  const T* kb = qkv + g.hd + h * D;
-  const T* vb = qkv + 2 * g.hd + h * D;
+  const int64_t ldq = g.ldq, ld = g.ldkv, qrow0 = (int64_t)b * g.Lq, row0 = (int64_t)b * g.Lk;
+  const T* qb = qp + h * D;
+  const T* kb = kp_ + h * D;
+  const T* vb = vp + h * D;
   const int qt = blockIdx.x * 4 + wave;
   const int q = qt * 16 + c_;
-  const bool qv = q < g.L;
-  const int64_t qrow = row0 + (qv ? q : 0);
+  const bool qv = q < g.Lq;
+  const int64_t qrow = qrow0 + (qv ? q : 0);
   Vec8<T> qf[DS], dof[DS];
   float dsum = 0.f;
 #pragma unroll
   for (int ds = 0; ds < DS; ++ds) {
-    qf[ds] = la_load<T>(qb + qrow * ld + ds * 32 + g_ * 8, qv);
+    qf[ds] = la_load<T>(qb + qrow * ldq + ds * 32 + g_ * 8, qv);
     dof[ds] = la_load<T>(dout + qrow * g.hd + h * D + ds * 32 + g_ * 8, qv);
     Vec8<T> of = la_load<T>(oin + qrow * g.hd + h * D + ds * 32 + g_ * 8, qv);
 #pragma unroll
@@ -183,15 +188,15 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
   }
   dsum += shfl_xor_f(dsum, 16);
   dsum += shfl_xor_f(dsum, 32);
-  const float lq = qv ? lse[(int64_t)bh * g.L + q] : INFINITY;          // padded query rows: exp(. - inf) = 0
-  if (qv && g_ == 0) dsum_out[(int64_t)bh * g.L + q] = dsum;
+  const float lq = qv ? lse[(int64_t)bh * g.Lq + q] : INFINITY;          // padded query rows: exp(. - inf) = 0
+  if (qv && g_ == 0) dsum_out[(int64_t)bh * g.Lq + q] = dsum;
   f32x4 dqacc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < g.L; k0 += LA_KB) {
+  for (int k0 = 0; k0 < g.Lk; k0 += LA_KB) {
     __syncthreads();
-    la_stage_t<T, D>(kt_s, kb, ld, row0, k0, g.L);
+    la_stage_t<T, D>(kt_s, kb, ld, row0, k0, g.Lk);
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
         const int kt = 2 * ks + half;
         f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
         const int key = k0 + kt * 16 + c_;
-        const bool kv = key < g.L;
+        const bool kv = key < g.Lk;
         const int64_t krow = row0 + (kv ? key : 0);
 #pragma unroll
         for (int ds = 0; ds < DS; ++ds) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kk = k0 + kt * 16 + g_ * 4 + r;
-          const float p = kk < g.L ? __expf(pt[r] * g.scale - lq) : 0.f;
+          const float p = kk < g.Lk ? __expf(pt[r] * g.scale - lq) : 0.f;
           dsv[half][r] = p * (dpt[r] - dsum);
         }
       }
@@ -223,8 +228,8 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int qo = qt * 16 + g_ * 4 + r;
-    if (qo < g.L) {
-      T* p = dqkv + (row0 + qo) * ld + h * D + c_;
+    if (qo < g.Lq) {
+      T* p = dq + (qrow0 + qo) * ldq + h * D + c_;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) p[dt * 16] = from_f32<T>(dqacc[dt][r] * g.scale);
     }
@@ -234,9 +239,10 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
 // ------------------------------------------------------------------------------------------------- backward: dK, dV
 // grid = (ceil(L / 64), B * nH); wave <-> key tile; walks the queries in blocks of 64 (Qt, dOt staged transposed)
 template <typename T, int D>
-__global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+__global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict__ qp, const T* __restrict__ kp_, const T* __restrict__ vp,
+                                                           const T* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum_in,
-                                                           T* __restrict__ dqkv, LongGeom g) {
+                                                           T* __restrict__ dk, T* __restrict__ dv, LongGeom g) {
   constexpr int DS = D / 32, DT = D / 16;
   __shared__ __attribute__((aligned(16))) T qt_s[D * LA_STR];
   __shared__ __attribute__((aligned(16))) T dot_s[D * LA_STR];
@@ -244,14 +250,14 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
   const int bh = blockIdx.y, b = bh / g.nH, h = bh - b * g.nH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c_ = lane & 15, g_ = lane >> 4;
-  const int64_t ld = 3 * (int64_t)g.hd, row0 = (int64_t)b * g.L;
-  const T* qb = qkv + h * D;
-  const T* kb = qkv + g.hd + h * D;
-  const T* vb = qkv + 2 * g.hd + h * D;
+  const int64_t ldq = g.ldq, ld = g.ldkv, qrow0 = (int64_t)b * g.Lq, row0 = (int64_t)b * g.Lk;
+  const T* qb = qp + h * D;
+  const T* kb = kp_ + h * D;
+  const T* vb = vp + h * D;
   const T* dob = dout + h * D;
   const int kt = blockIdx.x * 4 + wave;
   const int key = kt * 16 + c_;
-  const bool kv = key < g.L;
+  const bool kv = key < g.Lk;
   const int64_t krow = row0 + (kv ? key : 0);
   Vec8<T> kf[DS], vf[DS];
 #pragma unroll
@@ -263,14 +269,14 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  for (int q0 = 0; q0 < g.L; q0 += LA_KB) {
+  for (int q0 = 0; q0 < g.Lq; q0 += LA_KB) {
     __syncthreads();
-    la_stage_t<T, D>(qt_s, qb, ld, row0, q0, g.L);
-    la_stage_t<T, D>(dot_s, dob, (int64_t)g.hd, row0, q0, g.L);
+    la_stage_t<T, D>(qt_s, qb, ldq, qrow0, q0, g.Lq);
+    la_stage_t<T, D>(dot_s, dob, (int64_t)g.hd, qrow0, q0, g.Lq);
     if (threadIdx.x < LA_KB) {
       const int qq = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = qq < g.L ? lse[(int64_t)bh * g.L + qq] : INFINITY;      // padded queries: p = 0
-      dsum_s[threadIdx.x] = qq < g.L ? dsum_in[(int64_t)bh * g.L + qq] : 0.f;
+      lse_s[threadIdx.x] = qq < g.Lq ? lse[(int64_t)bh * g.Lq + qq] : INFINITY;      // padded queries: p = 0
+      dsum_s[threadIdx.x] = qq < g.Lq ? dsum_in[(int64_t)bh * g.Lq + qq] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -281,11 +287,11 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
         const int qtl = 2 * qs + half;
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
         const int q = q0 + qtl * 16 + c_;
-        const bool qv = q < g.L;
-        const int64_t qrow = row0 + (qv ? q : 0);
+        const bool qv = q < g.Lq;
+        const int64_t qrow = qrow0 + (qv ? q : 0);
 #pragma unroll
         for (int ds = 0; ds < DS; ++ds) {
-          mma16(la_load<T>(qb + qrow * ld + ds * 32 + g_ * 8, qv), kf[ds], s);           // S [q][key = c_]
+          mma16(la_load<T>(qb + qrow * ldq + ds * 32 + g_ * 8, qv), kf[ds], s);           // S [q][key = c_]
           mma16(la_load<T>(dob + qrow * g.hd + ds * 32 + g_ * 8, qv), vf[ds], dp);       // dP
         }
 #pragma unroll
@@ -308,12 +314,12 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int ko = kt * 16 + g_ * 4 + r;
-    if (ko < g.L) {
-      T* p = dqkv + (row0 + ko) * ld + h * D + c_;
+    if (ko < g.Lk) {
+      const int64_t off = (row0 + ko) * ld + h * D + c_;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        p[g.hd + dt * 16] = from_f32<T>(dkacc[dt][r] * g.scale);
-        p[2 * g.hd + dt * 16] = from_f32<T>(dvacc[dt][r]);
+        dk[off + dt * 16] = from_f32<T>(dkacc[dt][r] * g.scale);
+        dv[off + dt * 16] = from_f32<T>(dvacc[dt][r]);
       }
     }
   }
@@ -324,32 +330,61 @@ bool lattn_ok(int dtype, int D) { return (dtype == VTX_BF16 || dtype == VTX_F32)
 size_t lattn_bwd_workspace(int B, int L, int nH) { return (size_t)B * nH * L * sizeof(float); }
 
 template <typename T, int D>
-static int lattn_fwd_t(const void* qkv, void* o, float* lse, int B, const LongGeom& g, hipStream_t st) {
-  hipLaunchKernelGGL((lattn_fwd_kernel<T, D>), dim3((g.L + 63) / 64, B * g.nH), dim3(256), 0, st, (const T*)qkv, (T*)o, lse, g);
+static int lattn_fwd_t(const void* q, const void* k, const void* v, void* o, float* lse, int B, const LongGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL((lattn_fwd_kernel<T, D>), dim3((g.Lq + 63) / 64, B * g.nH), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+                     (T*)o, lse, g);
   return vtx_check_launch();
 }
 template <typename T, int D>
-static int lattn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
-                       const LongGeom& g, hipStream_t st) {
-  dim3 grid((g.L + 63) / 64, B * g.nH);
-  hipLaunchKernelGGL((lattn_bwd_dq_kernel<T, D>), grid, dim3(256), 0, st, (const T*)qkv, (const T*)o, (const T*)dout, lse,
-                     (T*)dqkv, ws, g);
+static int lattn_bwd_t(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq, void* dk,
+                       void* dv, float* ws, int B, const LongGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL((lattn_bwd_dq_kernel<T, D>), dim3((g.Lq + 63) / 64, B * g.nH), dim3(256), 0, st, (const T*)q, (const T*)k,
+                     (const T*)v, (const T*)o, (const T*)dout, lse, (T*)dq, ws, g);
   int rc = vtx_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL((lattn_bwd_dkv_kernel<T, D>), grid, dim3(256), 0, st, (const T*)qkv, (const T*)dout, lse,
-                     (const float*)ws, (T*)dqkv, g);
+  hipLaunchKernelGGL((lattn_bwd_dkv_kernel<T, D>), dim3((g.Lk + 63) / 64, B * g.nH), dim3(256), 0, st, (const T*)q, (const T*)k,
+                     (const T*)v, (const T*)dout, lse, (const float*)ws, (T*)dk, (T*)dv, g);
   return vtx_check_launch();
 }
+template <typename T> static const void* la_off(const void* p, int64_t n) { return (const T*)p + n; }
+template <typename T> static void* la_offw(void* p, int64_t n) { return (T*)p + n; }
 
+#define LA_DISPATCH(FN, ...)                                                                                          \
+  (dtype == VTX_BF16 ? (D == 64 ? FN<bf16, 64>(__VA_ARGS__) : FN<bf16, 32>(__VA_ARGS__))                              \
+                     : (D == 64 ? FN<float, 64>(__VA_ARGS__) : FN<float, 32>(__VA_ARGS__)))
+
+// packed QKV projection [B*L, 3 hd]
 int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st) {
-  LongGeom g{L, nH, nH * D, 1.0f / sqrtf((float)D)};
-  if (dtype == VTX_BF16) return D == 64 ? lattn_fwd_t<bf16, 64>(qkv, o, lse, B, g, st) : lattn_fwd_t<bf16, 32>(qkv, o, lse, B, g, st);
-  return D == 64 ? lattn_fwd_t<float, 64>(qkv, o, lse, B, g, st) : lattn_fwd_t<float, 32>(qkv, o, lse, B, g, st);
+  const int hd = nH * D;
+  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  const size_t es = dtype == VTX_BF16 ? 2 : 4;
+  const char* base = (const char*)qkv;
+  return LA_DISPATCH(lattn_fwd_t, base, base + es * hd, base + 2 * es * hd, o, lse, B, g, st);
 }
 int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
                      int L, int nH, int D, int dtype, hipStream_t st) {
-  LongGeom g{L, nH, nH * D, 1.0f / sqrtf((float)D)};
-  if (dtype == VTX_BF16)
-    return D == 64 ? lattn_bwd_t<bf16, 64>(qkv, o, dout, lse, dqkv, ws, B, g, st) : lattn_bwd_t<bf16, 32>(qkv, o, dout, lse, dqkv, ws, B, g, st);
-  return D == 64 ? lattn_bwd_t<float, 64>(qkv, o, dout, lse, dqkv, ws, B, g, st) : lattn_bwd_t<float, 32>(qkv, o, dout, lse, dqkv, ws, B, g, st);
+  const int hd = nH * D;
+  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  const size_t es = dtype == VTX_BF16 ? 2 : 4;
+  const char* base = (const char*)qkv;
+  char* out = (char*)dqkv;
+  return LA_DISPATCH(lattn_bwd_t, base, base + es * hd, base + 2 * es * hd, o, dout, lse, out, out + es * hd, out + 2 * es * hd, ws, B, g, st);
+}
+// q [B*Lq, hd] against kv [B*Lk, 2 hd] (k | v halves): the sub-sampled attention of PVT / Twins-SVT with any number of keys
+int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
+                           hipStream_t st) {
+  const int hd = nH * D;
+  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  const size_t es = dtype == VTX_BF16 ? 2 : 4;
+  const char* kb = (const char*)kv;
+  return LA_DISPATCH(lattn_fwd_t, q, kb, kb + es * hd, o, lse, B, g, st);
+}
+int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                           float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st) {
+  const int hd = nH * D;
+  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  const size_t es = dtype == VTX_BF16 ? 2 : 4;
+  const char* kb = (const char*)kv;
+  char* out = (char*)dkv;
+  return LA_DISPATCH(lattn_bwd_t, q, kb, kb + es * hd, o, dout, lse, dq, out, out + es * hd, ws, B, g, st);
 }

@@ -379,20 +379,24 @@ __global__ __launch_bounds__(256) void srattn_score_kernel(const T* __restrict__
   __shared__ float ks[SR_LK][D + 1];
   const int bh = blockIdx.y, b = bh / nH, h = bh - b * nH;
   const int hd = nH * D;
-  for (int i = threadIdx.x; i < Lk * D; i += 256) {
-    const int j = i / D, d = i - j * D;
-    ks[j][d] = to_f32<T>(kv[((int64_t)b * Lk + j) * 2 * hd + h * D + d]);
-  }
-  __syncthreads();
   const int q0 = blockIdx.x * 64;
-  for (int idx = threadIdx.x; idx < 64 * Lk; idx += 256) {
-    const int qi = q0 + idx / Lk, j = idx % Lk;
-    if (qi >= Lq) continue;
-    const T* qp = q + ((int64_t)b * Lq + qi) * hd + h * D;
-    float s = 0.f;
+  for (int k0 = 0; k0 < Lk; k0 += SR_LK) {            // blocks of 64 keys (any Lk)
+    const int nk = min(SR_LK, Lk - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk * D; i += 256) {
+      const int j = i / D, d = i - j * D;
+      ks[j][d] = to_f32<T>(kv[((int64_t)b * Lk + k0 + j) * 2 * hd + h * D + d]);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * nk; idx += 256) {
+      const int qi = q0 + idx / nk, j = idx % nk;
+      if (qi >= Lq) continue;
+      const T* qp = q + ((int64_t)b * Lq + qi) * hd + h * D;
+      float s = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < D; ++d) s += to_f32<T>(qp[d]) * ks[j][d];
-    score[(((int64_t)b * nH + h) * Lq + qi) * Lk + j] = from_f32<T>(s * scale);
+      for (int d = 0; d < D; ++d) s += to_f32<T>(qp[d]) * ks[j][d];
+      score[(((int64_t)b * nH + h) * Lq + qi) * Lk + k0 + j] = from_f32<T>(s * scale);
+    }
   }
 }
 
@@ -438,6 +442,16 @@ static int sr_launch_bwd(const void* q, const void* kv, const void* o, const voi
    : dtype == VTX_F32 ? (D == 64 ? fn<float, 64>(__VA_ARGS__) : fn<float, 32>(__VA_ARGS__)) \
                       : VTX_ERR_DTYPE)
 
+// more than 64 reduced keys (PVT / Twins at 384 x 384 and beyond): the key-block / online-softmax kernels of attention_long.hip
+bool lattn_ok(int dtype, int D);
+int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
+                           hipStream_t st);
+int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
+                           float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st);
+static bool sr_long(int B, int Lq, int Lk, int nH, int D, int dtype) {
+  return Lk > SR_LK && B > 0 && Lq > 0 && nH > 0 && lattn_ok(dtype, D) && (int64_t)B * Lq < 0x7fffffff;
+}
+
 extern "C" {
 
 /* Pre-softmax scores q k^T / sqrt(D) [B, nH, Lq, Lk] of the same operands as vtx_srattn_fwd (reference models/pvt.py:53):
@@ -445,7 +459,7 @@ extern "C" {
 int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq, int Lk, int nH, int D, int dtype,
                       void* stream) {
   if (!q || !kv || !score) return VTX_ERR_NULL;
-  if (B <= 0 || Lq <= 0 || Lk <= 0 || Lk > SR_LK || nH <= 0 || (D != 64 && D != 32)) return VTX_ERR_SHAPE;
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || nH <= 0 || (D != 64 && D != 32)) return VTX_ERR_SHAPE;
   return SR_DISPATCH(sr_launch_scores, q, kv, score, B, Lq, Lk, nH, (hipStream_t)stream);
 }
 
@@ -455,6 +469,7 @@ int vtx_srattn_scores(const void* q, const void* kv, void* score, int B, int Lq,
 int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
                    void* stream) {
   if (!q || !kv || !o || !lse) return VTX_ERR_NULL;
+  if (sr_long(B, Lq, Lk, nH, D, dtype)) return lattn_cross_fwd_launch(q, kv, o, lse, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream);
   SrGeom g;
   int rc = sr_geom(g, Lq, Lk, nH, B, D);
   if (rc) return rc;
@@ -476,6 +491,7 @@ int vtx_srattn_fwd_drop(const void* q, const void* kv, void* o, float* lse, int 
 }
 
 size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH, int D) {
+  if (Lk > SR_LK) return (size_t)B * nH * Lq * sizeof(float);      // rowsum(dO o O) per query (attention_long.hip)
   SrGeom g;
   if (sr_geom(g, Lq, Lk, nH, B, D)) return 0;
   return (size_t)B * nH * sr_wgs(g) * SR_LK * 2 * D * sizeof(float);
@@ -485,6 +501,10 @@ size_t vtx_srattn_bwd_workspace(int B, int Lq, int Lk, int nH, int D) {
 int vtx_srattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
                    void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, void* stream) {
   if (!q || !kv || !o || !dout || !lse || !dq || !dkv || !workspace) return VTX_ERR_NULL;
+  if (sr_long(B, Lq, Lk, nH, D, dtype)) {
+    if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH, D)) return VTX_ERR_WORKSPACE;
+    return lattn_cross_bwd_launch(q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream);
+  }
   SrGeom g;
   int rc = sr_geom(g, Lq, Lk, nH, B, D);
   if (rc) return rc;

@@ -107,8 +107,7 @@ class TransformerLayer(nn.Module):
         skip = L - height * width                                     # leading cls tokens (stage 4)
         if skip < 0 or (a.reduction > 1 and (height % a.reduction or width % a.reduction)):
             raise ValueError(f"token count {L} / grid {(height, width)} / reduction {a.reduction} do not fit")
-        if a.reduction == 1 and L > 64 or a.reduction > 1 and (height // a.reduction) * (width // a.reduction) > 64:
-            raise NotImplementedError("vtx: the PVT attention kernel holds at most 64 reduced key tokens")
+        # (more than 64 reduced keys -- 256 x 256 stage 4, 384 x 384 everywhere -- run on the key-block kernels: vtx_srattn_*)
         # two independent draws per layer, attention branch first (reference pvt.py:100-101)
         s1 = drop_path_scale(self.drop_path.p, self.training, B, input.device)
         s2 = drop_path_scale(self.drop_path.p, self.training, B, input.device)

@@ -79,8 +79,7 @@ class MultiHeadedAttention(nn.Module):
             raise NotImplementedError("vtx: twins.MultiHeadedAttention needs reduction > 1 (as TransformerLayer builds it)")
         if height % r or width % r:
             raise ValueError(f"feature map {(height, width)} is not a multiple of the reduction {r}")
-        if (height // r) * (width // r) > 64:
-            raise NotImplementedError("vtx: the sub-sampled attention kernel holds at most 64 reduced key tokens")
+        # (more than 64 sub-sampled keys, e.g. 448 x 448: the key-block kernels behind vtx_srattn_*)
 
     def drops(self):
         """True when F.dropout(attn, self.dropout, self.training) of the reference (twins.py:88) is active."""
