@@ -291,6 +291,21 @@ def test_no_packed_fp32_result_feeds_the_lds_or_memory_pipe_in_the_next_issue_sl
     assert "0 packed-fp32" in r.stdout
 
 
+def test_no_mfma_result_is_read_at_the_head_of_a_branch_target_right_after_the_mfma():
+    """Round 5 (profiles/round5_mfma_branch_hazard.md): hipcc pads MFMA -> v_accvgpr_read with wait states in straight-line code but
+    not when the read is the head of a branch target -- `valid ? load8(p) : zero` for the next operand tile put an exec-mask branch
+    between a chain of fp32 MFMAs and the read of their accumulator; with every lane skipping the load (a fully padded 16-token tile)
+    the read came three instructions after the last MFMA and returned a partial sum (fp32 attention scores 5 % off).  The loads are
+    branch-free now (load8_clamped); the scanner walks every taken branch of every kernel (reuses the assembly of the scan above)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "r5", "scan_mfma_branch.py")], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "0 MFMA results read" in r.stdout
+
+
 def test_a_stationary_gemm_isa_keeps_the_invariants_its_counted_waits_rely_on():
     """Round 4: csrc/gemm_astat.hip waits for its epilogue vectors with hand-counted `s_waitcnt vmcnt(N)` and lands them in registers
     the compiler must never touch.  What hipcc may silently do against that -- spill (scratch traffic counts in vmcnt), emit a flat

@@ -37,9 +37,8 @@ __device__ __forceinline__ int64_t attn_token_row(const AttnGeom& g, int b, int 
   return ((int64_t)b * g.H + y) * g.W + x;
 }
 
-template <typename T> __device__ __forceinline__ Vec8<T> load8_or_zero(const T* p, bool valid) {
-  return valid ? load8<T>(p) : vec8_zero<T>();
-}
+// (every caller passes a clamped, readable address: see load8_clamped)
+template <typename T> __device__ __forceinline__ Vec8<T> load8_or_zero(const T* p, bool valid) { return load8_clamped<T>(p, valid); }
 
 // A-operand fragment from two accumulator tiles: k-slot (g, j) <-> rows 4g+j of tile `lo` (j<4) / tile `hi` (j>=4)
 template <typename T> __device__ __forceinline__ Vec8<T> frag_from_acc(const f32x4& lo, const f32x4& hi) {
@@ -232,11 +231,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   const T* ob = oin + h * D;
   const float* bias_h = bias ? bias + (int64_t)h * g.L * g.L : nullptr;
 
-  // rel-pos-bias gradient accumulators: wave owns key tile(s) kt = wave (+4 ...); only NKT <= 4 uses them
-  f32x4 dsacc[HAS_BIAS ? NKT : 1];
+  // rel-pos-bias gradient accumulators: wave owns key tiles kt = wave, wave + 4, ... (KPW of them); [key tile of the wave][query tile].
+  // One key tile per wave for windows of <= 64 tokens; 12 x 12 windows (NKT = 10, Swin at 384 x 384) hold 3 x 10 tiles: both phase-B
+  // loops are then fully unrolled so that every index is a compile-time one.
+  constexpr int KPW = (NKT + 3) / 4;
+  constexpr bool BIAS_WIDE = HAS_BIAS && NKT > 4;
+  f32x4 dsacc[HAS_BIAS ? KPW * NKT : 1];
   if (HAS_BIAS) {
 #pragma unroll
-    for (int i = 0; i < NKT; ++i) dsacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < KPW * NKT; ++i) dsacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   for (int bn = blockIdx.x; bn < nbn; bn += gridDim.x) {
@@ -325,7 +328,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     __syncthreads();
 
     // ---------------- phase B
-    for (int kt = wave; kt * 16 < g.L; kt += 4) {
+#pragma unroll (BIAS_WIDE ? KPW : 1)
+    for (int kti = 0; kti < KPW; ++kti) {
+      const int kt = wave + 4 * kti;
+      if (kt * 16 >= g.L) break;
       const int key = kt * 16 + c_;
       const bool kv = key < g.L;
       const int64_t krow = kv ? attn_token_row(g, b, n, key) : 0;
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
       f32x4 dkacc[DT], dvacc[DT];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll (NKT <= 4 ? KSN : 1)
+#pragma unroll ((NKT <= 4 || BIAS_WIDE) ? KSN : 1)
       for (int qs = 0; qs < KSN; ++qs) {
         f32x4 pp[2], dss[2];
 #pragma unroll
@@ -365,10 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             pp[half][r] = p * f;                       // dV = (P o F)^T dO
             dss[half][r] = p * (dp[r] * f - dq_s[qq < g.L ? qq : 0]);
           }
-          if (HAS_BIAS) {
-            // block-level accumulation requires one key tile per wave (NKT <= 4): tile index = qt
-            if constexpr (NKT <= 4) dsacc[qt] += dss[half];
-          }
+          if constexpr (HAS_BIAS) dsacc[kti * NKT + qt] += dss[half];
         }
         Vec8<T> pf = frag_from_acc<T>(pp[0], pp[1]);
         Vec8<T> dsf = frag_from_acc<T>(dss[0], dss[1]);
@@ -401,15 +404,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     // per-block slab stride padded to 4 floats (vectorised slab reduce)
     const int64_t slab = ((int64_t)g.nH * g.L * g.L + 3) & ~(int64_t)3;
     float* out = dbias_part + (int64_t)blockIdx.x * slab + (int64_t)h * g.L * g.L;
-    const int key = wave * 16 + c_;
-    if (key < g.L) {
 #pragma unroll
-      for (int qt = 0; qt < NKT; ++qt)
+    for (int kti = 0; kti < KPW; ++kti) {
+      const int key = (wave + 4 * kti) * 16 + c_;
+      if (key < g.L) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + g_ * 4 + r;
-          if (q < g.L) out[q * g.L + key] = dsacc[qt][r];
-        }
+        for (int qt = 0; qt < NKT; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + g_ * 4 + r;
+            if (q < g.L) out[q * g.L + key] = dsacc[kti * NKT + qt][r];
+          }
+      }
     }
   }
 }
@@ -478,7 +484,7 @@ static int attn_bwd_launch(const void* qkv, const void* oin, const void* dout, c
   const int nbn = B * g.nW;
   const DropArgs dv = da ? *da : DropArgs{};
   if (bias) {
-    if (NKT > 4) return VTX_ERR_SHAPE;   // register-resident bias gradient: one key tile per wave
+    if (NKT > 10) return VTX_ERR_SHAPE;   // register-resident bias gradient: up to 3 key tiles x 10 query tiles per wave
     auto kern = da ? attn_bwd_kernel<T, D, NKT, true, true> : attn_bwd_kernel<T, D, NKT, true, false>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -510,10 +516,12 @@ __global__ void attn_keep_mask_kernel(uint8_t* __restrict__ out, int64_t total, 
   do {                                                                                  \
     if (dtype == VTX_BF16) {                                                            \
       if (D == 32 && L <= 64) return FN<bf16, 32, 4>(__VA_ARGS__);                      \
+      if (D == 32 && L <= 160) return FN<bf16, 32, 10>(__VA_ARGS__);                    \
       if (D == 64 && L <= 64) return FN<bf16, 64, 4>(__VA_ARGS__);                      \
       if (D == 64 && L <= 224) return FN<bf16, 64, 14>(__VA_ARGS__);                    \
     } else if (dtype == VTX_F32) {                                                      \
       if (D == 32 && L <= 64) return FN<float, 32, 4>(__VA_ARGS__);                     \
+      if (D == 32 && L <= 160) return FN<float, 32, 10>(__VA_ARGS__);                   \
       if (D == 64 && L <= 64) return FN<float, 64, 4>(__VA_ARGS__);                     \
       if (D == 64 && L <= 224) return FN<float, 64, 14>(__VA_ARGS__);                   \
     } else {                                                                            \

@@ -27,9 +27,8 @@ struct LongGeom {
   float scale;
 };
 
-template <typename T> __device__ __forceinline__ Vec8<T> la_load(const T* p, bool valid) {
-  return valid ? load8<T>(p) : vec8_zero<T>();
-}
+// (every caller passes a clamped, readable address: see load8_clamped)
+template <typename T> __device__ __forceinline__ Vec8<T> la_load(const T* p, bool valid) { return load8_clamped<T>(p, valid); }
 template <typename T> __device__ __forceinline__ Vec8<T> la_frag_acc(const f32x4& lo, const f32x4& hi) {
   Vec8<T> f;
 #pragma unroll

@@ -53,6 +53,18 @@ template <typename T> __device__ __forceinline__ Vec8<T> vec8_zero() {
 }
 // 8 consecutive T from global / LDS memory (16 B for bf16, 32 B for float); p must be 16-B aligned
 template <typename T> __device__ __forceinline__ Vec8<T> load8(const T* p);
+// load8 from an address that is ALWAYS readable, zeros when !valid -- WITHOUT a branch around the load (the load is issued by every
+// lane, the zeros are a select).  Round 5 (tools/r5/win12_debug*.py, profiles/round5_mfma_branch_hazard.md): with `valid ?
+// load8(p) : zero` hipcc (ROCm 7.2) puts the load of the NEXT operand tile under an exec-mask branch that sits between a chain of
+// MFMAs and the v_accvgpr_read of their result; when every lane skips the load (a fully padded 16-token tile) the read follows the
+// last MFMA by three instructions and returns the accumulator BEFORE the chain has drained -- the wait states the hazard
+// recogniser inserts in straight-line code are missing on that path (fp32 attention with 10 key tiles: scores off by 5 %;
+// -O1, or reading the accumulator in the MFMA's own block, is correct).  Callers clamp the address (row 0 of the operand).
+template <typename T> __device__ __forceinline__ Vec8<T> load8_clamped(const T* p, bool valid) {
+  Vec8<T> v = load8<T>(p);
+  if (!valid) v = vec8_zero<T>();
+  return v;
+}
 template <> __device__ __forceinline__ Vec8<bf16> load8<bf16>(const bf16* p) {
   Vec8<bf16> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r;
 }
