@@ -368,6 +368,30 @@ int vtx_srattn_bwd_drop(const void* q, const void* kv, const void* o, const void
                         void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, float drop_p,
                         uint64_t seed, const uint8_t* keep, void* stream);
 
+/* ---- Halo (blocked local) attention (csrc/halo.hip, csrc/attention_long.hip; reference models/halo_transformer.py:22-115): the
+ * queries of a win x win block attend to the (win + 2 halo)^2 neighbourhood around it -- out-of-image positions are ZERO key / value
+ * rows that take part in the softmax (F.unfold's padding, halo_transformer.py:70-76) -- plus rel_pos[pos[q][k]][head].
+ *   vtx_window_gather : dst [B * nW, (win + 2 halo)^2, nc] from channels [c0, c0 + nc) of the channels-last map [B, H, W, ld]
+ *                       (halo = 0: the window partition of the queries);  vtx_window_scatter: its adjoint (sums over the
+ *                       neighbourhoods that hold a token, fixed order; halo = 0: the inverse partition); c0, nc, ld multiples of 8.
+ *   vtx_table_bias / _bwd: bias[h][cell] = table[pos[cell]][h] for any cell count, and the dense table gradient through the CSR of pos.
+ *   vtx_xattn_fwd / _bwd: softmax(q k^T / sqrt(D) + bias) v with q [B * Lq, nH * D], kv [B * Lk, 2 * nH * D] (k | v), bias [nH][Lq][Lk]
+ *                       fp32 or NULL, any Lq / Lk, D = 32 | 64 (key blocks of 64, online softmax); the backward also returns
+ *                       dbias = sum over the B problems of dS (fixed order). */
+int vtx_window_gather(const void* map, void* dst, int B, int H, int W, int64_t ld, int c0, int nc, int win, int halo, int dtype,
+                      void* stream);
+int vtx_window_scatter(const void* src, void* map, int B, int H, int W, int64_t ld, int c0, int nc, int win, int halo, int dtype,
+                       void* stream);
+int vtx_table_bias(const float* table, const int64_t* pos, float* bias, int64_t cells, int nH, void* stream);
+int vtx_table_bias_bwd(const float* full, const int* csr_order, const int* csr_offsets, float* dtable, int64_t cells, int nH, int ntab,
+                       void* stream);
+int vtx_xattn_fwd(const void* q, const void* kv, void* o, float* lse, const float* bias, int B, int Lq, int Lk, int nH, int D, int dtype,
+                  void* stream);
+size_t vtx_xattn_bwd_workspace(int B, int Lq, int nH);
+int vtx_xattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, const float* bias, void* dq,
+                  void* dkv, float* dbias, void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype,
+                  void* stream);
+
 /* ---- Positional-encoding generator of Twins-SVT (csrc/twins_misc.hip; reference models/twins.py:25-37):
  * y = x + DepthwiseConv3x3(x) on channels-last features x, y [B, H, W, C] (C % 8 == 0, C <= 1024), w = the
  * Conv2d(C, C, 3, padding=1, bias=False, groups=C) weight [C, 1, 3, 3] fp32.  The reference permutes to NCHW, convolves and

@@ -199,3 +199,36 @@ def twins_forward(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
     x = R.layer_norm(x, sd["final_linear.0.weight"], sd["final_linear.0.bias"], 1e-5)
     pooled = R._q(x.mean(dim=(1, 2)), q)
     return R.linear(pooled, sd["classifier.2.weight"], sd["classifier.2.bias"])
+
+
+# ------------------------------------------------------------------------------------------ Halo (models/halo_transformer.py)
+HALO_TINY = dict(image_size=(224, 224), n_class=10, depths=(1, 1, 2, 1), dims=(64, 128, 256, 512), dim_head=32, n_heads=(2, 4, 8, 16),
+                 dim_ffs=(128, 256, 512, 1024), window_size=7, halo_size=3)
+
+
+def halo_forward(sd, x_nchw, cfg, drop_masks=None, drop_path=0.0, q=None):
+    """HaloTransformer.forward (halo_transformer.py:272-280).  Block layout (262-270): [PatchEmbedding, layer, layer, ...] per stage,
+    patch sizes 4, 2, 2, 2 (215-218); every layer has the SAME drop_path (no schedule); head: LayerNorm(eps 1e-5) -> Linear(C, 2C) ->
+    LayerNorm -> SiLU per token, mean over the map, Linear (220-229).  ``drop_masks``: per layer (network order) two per-sample keep
+    masks."""
+    x = x_nchw.permute(0, 2, 3, 1)
+    li = 0
+    for k, patch in enumerate((4, 2, 2, 2)):
+        pre = f"block{k + 1}."
+        x = R.twins_patch_embedding(x, sd[pre + "0.linear.weight"], sd[pre + "0.linear.bias"], sd[pre + "0.norm.weight"],
+                                    sd[pre + "0.norm.bias"], patch, q)
+        for d in range(cfg["depths"][k]):
+            lp = f"{pre}{d + 1}."
+            p = {n[len(lp + "attn."):]: v for n, v in sd.items() if n.startswith(lp + "attn.")}
+            a = R.halo_attention(R.layer_norm(x, sd[lp + "norm_attn.weight"], sd[lp + "norm_attn.bias"], 1e-6), p, cfg["n_heads"][k],
+                                 cfg["dim_head"], cfg["window_size"], cfg["halo_size"], q)
+            m = drop_masks[li] if drop_masks is not None else (None, None)
+            x = x + R.drop_path_apply(a, m[0], drop_path)
+            f = R.feed_forward(R.layer_norm(x, sd[lp + "norm_ff.weight"], sd[lp + "norm_ff.bias"], 1e-6), sd[lp + "ff.0.weight"],
+                               sd[lp + "ff.0.bias"], sd[lp + "ff.3.weight"], sd[lp + "ff.3.bias"], q)
+            x = x + R.drop_path_apply(f, m[1], drop_path)
+            li += 1
+    t = R.layer_norm(x, sd["final_linear.0.weight"], sd["final_linear.0.bias"], 1e-5)
+    t = R.linear(t, sd["final_linear.1.weight"], sd["final_linear.1.bias"])
+    t = R.silu(R.layer_norm(t, sd["final_linear.2.weight"], sd["final_linear.2.bias"], 1e-5))
+    return R.linear(t.mean(dim=(1, 2)), sd["classifier.2.weight"], sd["classifier.2.bias"])

@@ -326,6 +326,45 @@ def twins_global_attention(x, p, n_head, reduction, qf=None, keep=None, drop_p=0
     return linear(out, p["linear.weight"], p["linear.bias"]).reshape(B, H, W, C)
 
 
+# ------------------------------------------------------------------------------------------ Halo (models/halo_transformer.py)
+def halo_pos(window, halo):
+    """pos[q][k] and the table size of halo attention's relative-position term (halo_transformer.py:41-57): offsets between key
+    (ky, kx) of the (window + 2 halo)^2 neighbourhood and query (qy + halo, qx + halo) in that grid, shifted by window + halo - 1."""
+    side, off = window + 2 * halo, window + halo - 1
+    pos = torch.empty(window * window, side * side, dtype=torch.int64)
+    for qy in range(window):
+        for qx in range(window):
+            for ky in range(side):
+                for kx in range(side):
+                    pos[qy * window + qx, ky * side + kx] = (ky - qy - halo + off) * side + (kx - qx - halo + off)
+    return pos, off * 2 * side + off * 2 + 1
+
+
+def halo_attention(x, p, n_head, dim_head, window, halo, qf=None):
+    """halo_transformer.MultiHeadedHaloAttention.forward (halo_transformer.py:58-115) on NHWC x: bias-free qkv Linear; the queries of
+    every window x window block against the keys / values of its (window + 2 halo)^2 neighbourhood -- positions outside the map
+    are ZERO key / value vectors that take part in the softmax (the zero padding of F.unfold, lines 70-76) -- plus the
+    relative-position term rel_pos[pos] (lines 95-98); output Linear per token.  p: weight.weight, linear.weight, linear.bias,
+    rel_pos.weight."""
+    B, H, W, _ = x.shape
+    hd, side = n_head * dim_head, window + 2 * halo
+    qkv = _q(linear(x, p["weight.weight"], None), qf)
+    q, kv = qkv[..., :hd], qkv[..., hd:]
+    kvp = torch.nn.functional.pad(kv, (0, 0, halo, halo, halo, halo))                       # zeros around the map (W then H)
+    pos, _ = halo_pos(window, halo)
+    bias = p["rel_pos.weight"][pos.reshape(-1)].reshape(window * window, side * side, n_head)
+    out = x.new_zeros(B, H, W, hd)
+    for i in range(H // window):
+        for j in range(W // window):
+            qw = q[:, i * window:(i + 1) * window, j * window:(j + 1) * window].reshape(B, window * window, n_head, dim_head)
+            nb = kvp[:, i * window:i * window + side, j * window:j * window + side].reshape(B, side * side, 2, n_head, dim_head)
+            S = torch.einsum("bqhd,bkhd->bhqk", qw, nb[:, :, 0]) / math.sqrt(dim_head) + bias.permute(2, 0, 1)
+            P = _q(torch.softmax(S, -1), qf)
+            o = torch.einsum("bhqk,bkhd->bqhd", P, nb[:, :, 1]).reshape(B, window, window, hd)
+            out[:, i * window:(i + 1) * window, j * window:(j + 1) * window] = o
+    return linear(_q(out, qf), p["linear.weight"], p["linear.bias"])
+
+
 def twins_patch_embedding(x, w, b, ln_w, ln_b, size, qf=None):
     """twins.PatchEmbedding.forward (twins.py:214-220): patchify(size) -> Linear -> LayerNorm(eps 1e-5) on NHWC x."""
     t = _q(linear(patchify(x, size), w, b), qf)

@@ -9,7 +9,8 @@ travels.  Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
 Golden ids follow SURVEY.md section 8(c): G1 pos tables, G2 local masks, G3 per-module
 fwd+bwd vectors, G4 full-model logits + grad norms, G5 ViT multi-crop, G6 one train step, G7 PVT-Small (F1), G8 DINO head + loss (F2),
 G9 mixup / cutmix / RandomErasing outputs (F4), G10 Twins-SVT (the row after F1-F4), G11 attention-probability dropout with an
-injected keep mask (vit.py:39, swin_transformer.py:144, pvt.py:60, twins.py:88,147).
+injected keep mask (vit.py:39, swin_transformer.py:144, pvt.py:60, twins.py:88,147), G12 halo attention + a small HaloTransformer
+(models/halo_transformer.py; SURVEY section 8 row F4's last sentence).
 """
 import os
 import sys
@@ -40,10 +41,11 @@ from models import vit as ref_vit                 # noqa: E402  (reference)
 from models import layer as ref_layer             # noqa: E402  (reference)
 from models import pvt as ref_pvt                 # noqa: E402  (reference)
 from models import twins as ref_twins             # noqa: E402  (reference)
+from models import halo_transformer as ref_halo   # noqa: E402  (reference)
 import loss as ref_loss                           # noqa: E402  (reference)
 
 from oracle.formula import fill, fill_state_dict, summarize, name_seed  # noqa: E402
-from oracle.ref_models import PVT_SMALL, SWIN_S, TWINS_SVT_S, VIT_S16     # noqa: E402
+from oracle.ref_models import HALO_TINY, PVT_SMALL, SWIN_S, TWINS_SVT_S, VIT_S16     # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -548,8 +550,44 @@ def gen_attn_dropout():
     save("g11_attn_dropout", rec)
 
 
+# ------------------------------------------------------------------ G12: halo attention (models/halo_transformer.py)
+def gen_halo():
+    rec = {}
+    for tag, (dim, nh, dh, w, a, hw) in {"w7a3": (64, 2, 32, 7, 3, (14, 14)), "w4a1": (64, 2, 32, 4, 1, (8, 12)),
+                                         "w8a3d64": (128, 2, 64, 8, 3, (16, 16))}.items():
+        m = load_formula(ref_halo.MultiHeadedHaloAttention(dim, nh, dh, w, a)).double()
+        rec[f"halo_{tag}.pos"] = m.pos.numpy().astype(np.int32)
+        rec[f"halo_{tag}.ntab"] = np.array(m.rel_pos.num_embeddings)
+        x = fill((2, hw[0], hw[1], dim), 91, 1.0, dtype=torch.float64).requires_grad_(True)
+        out = m(x)
+        (out * fill(out.shape, name_seed(f"halo_{tag}.cot"), 1.0).double()).sum().backward()
+        rec[f"halo_{tag}.out"] = summarize(out)
+        rec[f"halo_{tag}.dx"] = summarize(x.grad)
+        for n, p in m.named_parameters():
+            rec[f"halo_{tag}.d.{n}"] = summarize(p.grad)
+    x = fill((2, 3, 224, 224), 21, 1.0)
+    hm = load_formula(ref_halo.HaloTransformer(**HALO_TINY))
+    rec["halo_tiny.n_params"] = np.array(sum(p.numel() for p in hm.parameters()))
+    rec["halo_tiny.state_keys"] = np.array(list(hm.state_dict().keys()))
+    rec["halo_tiny.state_shapes"] = np.array([str(tuple(v.shape)) for v in hm.state_dict().values()])
+    rec["halo_tiny.param_names"] = np.array([n for n, _ in hm.named_parameters()])
+    # Forward only: the reference's TransformerLayer adds IN PLACE (halo_transformer.py:150-151: ``input += ...``), which
+    # invalidates what LayerNorm saved for its backward -- ``backward()`` of the reference model raises ("modified by an inplace
+    # operation") on this torch.  Gradients are pinned per module above (the attention module has no such add).
+    model_record(hm, x, "halo_tiny.eval", rec, False)
+    with torch.no_grad():
+        hm.train()
+        rec["halo_tiny.train_fwd.logits"] = summarize(hm(x))            # (drop_path 0: equals eval; recorded as evidence)
+    hm64 = load_formula(ref_halo.HaloTransformer(**HALO_TINY)).double().eval()
+    with torch.no_grad():
+        rec["halo_tiny.eval64.logits"] = summarize(hm64(x.double()))
+    save("g12_halo", rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input", "twins", "attn_dropout"]
+    which = sys.argv[1:] or ["tables", "modules", "models", "step", "pvt", "dino", "input", "twins", "attn_dropout", "halo"]
+    if "halo" in which:
+        gen_halo()
     if "attn_dropout" in which:
         gen_attn_dropout()
     if "tables" in which:

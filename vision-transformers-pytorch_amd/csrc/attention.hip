@@ -571,6 +571,25 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse, const float*
   ATTN_DISPATCH(attn_fwd_launch, qkv, o, lse, bias, mask, B, g, st, da);
 }
 
+/* bias[h][cell] = table[pos[cell]][h] over any number of cells (halo attention: pos is [W^2][(W + 2A)^2], reference
+ * models/halo_transformer.py:95-98) and the dense table gradient from a full [nH][cells] gradient through the CSR of pos. */
+int vtx_table_bias(const float* table, const int64_t* pos, float* bias, int64_t cells, int nH, void* stream) {
+  if (!table || !pos || !bias) return VTX_ERR_NULL;
+  if (cells <= 0 || nH <= 0 || cells * nH > 0x7fffffff) return VTX_ERR_SHAPE;
+  const int n = (int)(cells * nH);
+  hipLaunchKernelGGL(relpos_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, pos, bias, (int)cells, nH);
+  return vtx_check_launch();
+}
+int vtx_table_bias_bwd(const float* full, const int* csr_order, const int* csr_offsets, float* dtable, int64_t cells, int nH, int ntab,
+                       void* stream) {
+  if (!full || !csr_order || !csr_offsets || !dtable) return VTX_ERR_NULL;
+  if (cells <= 0 || nH <= 0 || ntab <= 0 || cells > 0x7fffffff) return VTX_ERR_SHAPE;
+  const int n = ntab * nH;
+  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, full, csr_order, csr_offsets, dtable,
+                     (int)cells, nH, ntab);
+  return vtx_check_launch();
+}
+
 int vtx_attention_fwd(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
                       int nH, int D, int swin, int H, int W, int win, int shift, int dtype, void* stream) {
   return attention_fwd_impl(qkv, o, lse, bias, mask, B, L, nH, D, swin, H, W, win, shift, dtype, (hipStream_t)stream, nullptr);

@@ -25,6 +25,7 @@ struct LongGeom {
   int Lq, Lk, nH, hd;
   int64_t ldq, ldkv;
   float scale;
+  const float* bias;      // [nH][Lq][Lk] added to the scaled scores (halo attention's relative-position term), or NULL
 };
 
 // (every caller passes a clamped, readable address: see load8_clamped)
@@ -106,8 +107,10 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qp
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = k0 + kt * 16 + g_ * 4 + r;
-        st[kt][r] = kk < g.Lk ? st[kt][r] * g.scale : -INFINITY;
-        mb = fmaxf(mb, st[kt][r]);
+        float sv = kk < g.Lk ? st[kt][r] * g.scale : -INFINITY;
+        if (g.bias != nullptr && kk < g.Lk && qv) sv += g.bias[((int64_t)h * g.Lq + q) * g.Lk + kk];
+        st[kt][r] = sv;
+        mb = fmaxf(mb, sv);
       }
     }
     mb = fmaxf(mb, shfl_xor_f(mb, 16));
@@ -215,7 +218,9 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kk = k0 + kt * 16 + g_ * 4 + r;
-          const float p = kk < g.Lk ? __expf(pt[r] * g.scale - lq) : 0.f;
+          float bb = 0.f;
+          if (g.bias != nullptr && kk < g.Lk && qv) bb = g.bias[((int64_t)h * g.Lq + q) * g.Lk + kk];
+          const float p = kk < g.Lk ? __expf(pt[r] * g.scale + bb - lq) : 0.f;
           dsv[half][r] = p * (dpt[r] - dsum);
         }
       }
@@ -296,7 +301,9 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ql = qtl * 16 + g_ * 4 + r;
-          const float p = kv ? __expf(s[r] * g.scale - lse_s[ql]) : 0.f;
+          float bb = 0.f;
+          if (g.bias != nullptr && kv && q0 + ql < g.Lq) bb = g.bias[((int64_t)h * g.Lq + q0 + ql) * g.Lk + key];
+          const float p = kv ? __expf(s[r] * g.scale + bb - lse_s[ql]) : 0.f;
           pp[half][r] = p;
           dss[half][r] = p * (dp[r] - dsum_s[ql]);
         }
@@ -320,6 +327,55 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
         dk[off + dt * 16] = from_f32<T>(dkacc[dt][r] * g.scale);
         dv[off + dt * 16] = from_f32<T>(dvacc[dt][r]);
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward: d bias
+// dbias[h][q][key] = sum over the B problems of dS[b, h, q, key] (the relative-position term of halo attention is shared by every
+// window of every image).  grid = (key tiles of 16, query blocks of 64, nH); wave <-> query tile of the block; every workgroup walks
+// ALL B problems in order and owns its output tile: deterministic, no atomics, no B x Lq x Lk intermediate.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lattn_bwd_dbias_kernel(const T* __restrict__ qp, const T* __restrict__ kp_, const T* __restrict__ vp,
+                                                             const T* __restrict__ dout, const float* __restrict__ lse,
+                                                             const float* __restrict__ dsum_in, float* __restrict__ dbias, int B,
+                                                             LongGeom g) {
+  constexpr int DS = D / 32;
+  const int h = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c_ = lane & 15, g_ = lane >> 4;
+  const int key = blockIdx.x * 16 + c_;
+  const bool kv = key < g.Lk;
+  const int qt = blockIdx.y * 4 + wave;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (qt * 16 < g.Lq) {
+    const int q = qt * 16 + c_;
+    const bool qv = q < g.Lq;
+    for (int b = 0; b < B; ++b) {
+      const int bh = b * g.nH + h;
+      const int64_t qrow = (int64_t)b * g.Lq + (qv ? q : 0), krow = (int64_t)b * g.Lk + (kv ? key : 0);
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) {
+        const Vec8<T> kf = la_load<T>(kp_ + krow * g.ldkv + h * D + ds * 32 + g_ * 8, kv);
+        const Vec8<T> vf = la_load<T>(vp + krow * g.ldkv + h * D + ds * 32 + g_ * 8, kv);
+        mma16(la_load<T>(qp + qrow * g.ldq + h * D + ds * 32 + g_ * 8, qv), kf, s);          // S [q = 16 qt + 4 g + r][key = c]
+        mma16(la_load<T>(dout + qrow * g.hd + h * D + ds * 32 + g_ * 8, qv), vf, dp);       // dP
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = qt * 16 + g_ * 4 + r;
+        if (qq < g.Lq && kv) {
+          const float bb = g.bias[((int64_t)h * g.Lq + qq) * g.Lk + key];
+          const float p = __expf(s[r] * g.scale + bb - lse[(int64_t)bh * g.Lq + qq]);
+          acc[r] += p * (dp[r] - dsum_in[(int64_t)bh * g.Lq + qq]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qt * 16 + g_ * 4 + r;
+      if (qq < g.Lq && kv) dbias[((int64_t)h * g.Lq + qq) * g.Lk + key] = acc[r];
     }
   }
 }
@@ -355,7 +411,7 @@ template <typename T> static void* la_offw(void* p, int64_t n) { return (T*)p + 
 // packed QKV projection [B*L, 3 hd]
 int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st) {
   const int hd = nH * D;
-  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D), nullptr};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* base = (const char*)qkv;
   return LA_DISPATCH(lattn_fwd_t, base, base + es * hd, base + 2 * es * hd, o, lse, B, g, st);
@@ -363,7 +419,7 @@ int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH,
 int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
                      int L, int nH, int D, int dtype, hipStream_t st) {
   const int hd = nH * D;
-  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D), nullptr};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* base = (const char*)qkv;
   char* out = (char*)dqkv;
@@ -371,19 +427,30 @@ int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const flo
 }
 // q [B*Lq, hd] against kv [B*Lk, 2 hd] (k | v halves): the sub-sampled attention of PVT / Twins-SVT with any number of keys
 int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
-                           hipStream_t st) {
+                           hipStream_t st, const float* bias) {
   const int hd = nH * D;
-  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D), bias};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* kb = (const char*)kv;
   return LA_DISPATCH(lattn_fwd_t, q, kb, kb + es * hd, o, lse, B, g, st);
 }
+template <typename T, int D>
+static int lattn_dbias_t(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* ws, float* dbias,
+                         int B, const LongGeom& g, hipStream_t st) {
+  hipLaunchKernelGGL((lattn_bwd_dbias_kernel<T, D>), dim3((g.Lk + 15) / 16, (g.Lq + 63) / 64, g.nH), dim3(256), 0, st, (const T*)q,
+                     (const T*)k, (const T*)v, (const T*)dout, lse, ws, dbias, B, g);
+  return vtx_check_launch();
+}
+// dbias [nH][Lq][Lk] fp32 (NULL without a bias): summed over the B problems in fixed order
 int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
-                           float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st) {
+                           float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st, const float* bias,
+                           float* dbias) {
   const int hd = nH * D;
-  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D)};
+  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D), bias};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* kb = (const char*)kv;
   char* out = (char*)dkv;
-  return LA_DISPATCH(lattn_bwd_t, q, kb, kb + es * hd, o, dout, lse, dq, out, out + es * hd, ws, B, g, st);
+  int rc = LA_DISPATCH(lattn_bwd_t, q, kb, kb + es * hd, o, dout, lse, dq, out, out + es * hd, ws, B, g, st);
+  if (rc || bias == nullptr || dbias == nullptr) return rc;
+  return LA_DISPATCH(lattn_dbias_t, q, kb, kb + es * hd, dout, lse, ws, dbias, B, g, st);
 }

@@ -445,9 +445,10 @@ static int sr_launch_bwd(const void* q, const void* kv, const void* o, const voi
 // more than 64 reduced keys (PVT / Twins at 384 x 384 and beyond): the key-block / online-softmax kernels of attention_long.hip
 bool lattn_ok(int dtype, int D);
 int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
-                           hipStream_t st);
+                           hipStream_t st, const float* bias = nullptr);
 int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
-                           float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st);
+                           float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st, const float* bias = nullptr,
+                           float* dbias = nullptr);
 static bool sr_long(int B, int Lq, int Lk, int nH, int D, int dtype) {
   return Lk > SR_LK && B > 0 && Lq > 0 && nH > 0 && lattn_ok(dtype, D) && (int64_t)B * Lq < 0x7fffffff;
 }

@@ -678,6 +678,53 @@ class AttentionCoreFn(Function):
         return dqkv, drel, None, None
 
 
+class HaloMeta:
+    """Static description of one halo-attention module: geometry + the integer tables on the device."""
+
+    def __init__(self, n_head, dim_head, window, halo, pos, csr, ntab):
+        self.n_head, self.dim_head, self.window, self.halo = n_head, dim_head, window, halo
+        self.pos, self.csr, self.ntab = pos, csr, ntab
+
+
+class HaloAttentionFn(Function):
+    """Attention core of halo_transformer.MultiHeadedHaloAttention (reference models/halo_transformer.py:58-104) on the bias-free QKV
+    projection output (B, H, W, 3 h D): window partition of the queries, (window + 2 halo)^2 neighbourhoods of the keys / values with
+    zero rows outside the map, softmax(q k^T / sqrt(D) + rel_pos[pos]) v, inverse partition -> (B, H, W, h D)."""
+
+    @staticmethod
+    def forward(ctx, qkv, rel_pos, meta):
+        qkv = _c(qkv)
+        B, H, W, C3 = qkv.shape
+        hd = C3 // 3
+        w, a, nH = meta.window, meta.halo, meta.n_head
+        nW, Lq, Lk = (H // w) * (W // w), w * w, (w + 2 * a) ** 2
+        q = ops.window_gather(qkv, B, H, W, 0, hd, w, 0)
+        kv = ops.window_gather(qkv, B, H, W, hd, 2 * hd, w, a)
+        bias = ops.table_bias(rel_pos.detach(), meta.pos, nH)
+        o, lse = ops.xattn_fwd(q.view(B * nW * Lq, hd), kv.view(B * nW * Lk, 2 * hd), B * nW, Lq, Lk, nH, bias)
+        out = torch.empty((B, H, W, hd), dtype=qkv.dtype, device=qkv.device)
+        ops.window_scatter(o, out, B, H, W, 0, hd, w, 0)
+        ctx.save_for_backward(q, kv, o, lse, bias)
+        ctx.meta, ctx.geom = meta, (B, H, W, hd, nW, Lq, Lk)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        side_fence(dout.device)
+        q, kv, o, lse, bias = ctx.saved_tensors
+        meta = ctx.meta
+        B, H, W, hd, nW, Lq, Lk = ctx.geom
+        w, a, nH = meta.window, meta.halo, meta.n_head
+        do = ops.window_gather(_c(dout), B, H, W, 0, hd, w, 0)
+        dq, dkv, dbias = ops.xattn_bwd(q.view(B * nW * Lq, hd), kv.view(B * nW * Lk, 2 * hd), o, do.view(B * nW * Lq, hd), lse,
+                                       B * nW, Lq, Lk, nH, bias)
+        dqkv = torch.empty((B, H, W, 3 * hd), dtype=q.dtype, device=q.device)
+        ops.window_scatter(dq, dqkv, B, H, W, 0, hd, w, 0)
+        ops.window_scatter(dkv, dqkv, B, H, W, hd, 2 * hd, w, a)          # sums over the neighbourhoods that hold a token
+        drel = ops.table_bias_bwd(dbias, meta.csr, meta.ntab, nH)
+        return dqkv, drel, None
+
+
 class TransformerLayerFn(Function):
     """One pre-LN transformer block (reference models/vit.py:59-63, models/swin_transformer.py:193-197):
          x1 = x  + s1 * proj(attn(qkv(LN1(x))))        y = x1 + s2 * fc2(silu(fc1(LN2(x1))))

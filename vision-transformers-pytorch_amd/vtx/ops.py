@@ -664,6 +664,78 @@ def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, drop=None):
     return dq, dkv
 
 
+# ------------------------------------------------------------------------------- halo attention (models/halo_transformer.py:22-115)
+def window_gather(x, B, H, W, c0, nc, win, halo):
+    """[B * nW, (win + 2 halo)^2, nc] neighbourhoods (zero rows outside the map) of channels [c0, c0 + nc) of the map x (B, H, W, ld)."""
+    _dev(x)
+    ld = x.shape[-1]
+    if x.numel() != B * H * W * ld or not x.is_contiguous():
+        raise VtxError("vtx: window_gather expects a contiguous (B, H, W, C) map")
+    nW, side = (H // win) * (W // win), win + 2 * halo
+    out = torch.empty((B * nW, side * side, nc), dtype=x.dtype, device=x.device)
+    check(_lib.load().vtx_window_gather(_p(x), _p(out), B, H, W, ld, c0, nc, win, halo, _dt(x), _stream()), "vtx_window_gather")
+    return out
+
+
+def window_scatter(src, out, B, H, W, c0, nc, win, halo):
+    """The adjoint of window_gather into channels [c0, c0 + nc) of the map ``out`` (B, H, W, ld): sums over the neighbourhoods."""
+    _dev(src, out)
+    ld = out.shape[-1]
+    check(_lib.load().vtx_window_scatter(_p(src), _p(out), B, H, W, ld, c0, nc, win, halo, _dt(out), _stream()), "vtx_window_scatter")
+    return out
+
+
+def table_bias(table, pos, n_head):
+    """bias [n_head, *pos.shape] = table[pos][..., h] for an int64 index tensor of any shape (halo_transformer.py:95-98)."""
+    _dev(table, pos)
+    _f32(table, "rel_pos")
+    if pos.dtype != torch.int64:
+        raise VtxError("vtx: pos must be int64 (the reference's buffer dtype)")
+    bias = torch.empty((n_head,) + tuple(pos.shape), dtype=torch.float32, device=table.device)
+    check(_lib.load().vtx_table_bias(_p(table), _p(pos), _p(bias), pos.numel(), n_head, _stream()), "vtx_table_bias")
+    return bias
+
+
+def table_bias_bwd(full, csr, ntab, n_head):
+    """dtable [ntab, n_head] from the full gradient [n_head, cells] through the CSR (order, offsets) of pos."""
+    order, offsets = csr
+    _dev(full, order, offsets)
+    out = torch.empty((ntab, n_head), dtype=torch.float32, device=full.device)
+    check(_lib.load().vtx_table_bias_bwd(_p(full), _p(order), _p(offsets), _p(out), full.numel() // n_head, n_head, ntab, _stream()),
+          "vtx_table_bias_bwd")
+    return out
+
+
+def xattn_fwd(q, kv, B, Lq, Lk, n_head, bias=None):
+    """o, lse = softmax(q k^T / sqrt(D) + bias) v; q [B * Lq, h D], kv [B * Lk, 2 h D], bias [h, Lq, Lk] fp32 or None."""
+    _dev(q, kv, bias)
+    D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
+    o = torch.empty_like(q)
+    lse = torch.empty(B * n_head * Lq, dtype=torch.float32, device=q.device)
+    ev = _attn_bracket("lattn_fwd_kernel (cross)", B * n_head, Lq, D, B * Lq, hd, q.element_size(), False)
+    check(_lib.load().vtx_xattn_fwd(_p(q), _p(kv), _p(o), _p(lse), _p(bias), B, Lq, Lk, n_head, D, _dt(q), _stream()), "vtx_xattn_fwd")
+    if ev:
+        ev[1].record()
+    return o, lse
+
+
+def xattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, bias=None):
+    """dq, dkv, dbias (None without a bias): deterministic."""
+    _dev(q, kv, o, dout, lse, bias)
+    lib = _lib.load()
+    D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    dbias = torch.empty_like(bias) if bias is not None else None
+    wsb = lib.vtx_xattn_bwd_workspace(B, Lq, n_head)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    ev = _attn_bracket("lattn_bwd_*_kernel (cross)", B * n_head, Lq, D, B * Lq, hd, q.element_size(), True)
+    check(lib.vtx_xattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(bias), _p(dq), _p(dkv), _p(dbias), _p(ws), wsb, B, Lq, Lk,
+                            n_head, D, _dt(q), _stream()), "vtx_xattn_bwd")
+    if ev:
+        ev[1].record()
+    return dq, dkv, dbias
+
+
 def dwconv3_fwd(x, w, adjoint=False):
     """y = x + DepthwiseConv3x3(x) on channels-last x (B, H, W, C), w (C, 1, 3, 3) fp32 -- twins.py:25-37; adjoint: the input
     gradient of the same map (x := dy)."""

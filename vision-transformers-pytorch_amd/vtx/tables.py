@@ -86,3 +86,19 @@ def mask_regions(local_mask):
     out = torch.zeros((nW, 64), dtype=torch.uint8, device=local_mask.device)
     out[:, :L] = region.to(torch.uint8)
     return out.contiguous(), ok
+
+
+def make_halo_pos(window, halo):
+    """The relative-position index table of halo attention (reference models/halo_transformer.py:41-57): pos[q][k] for query q of the
+    window x window block and key k of its (window + 2 halo)^2 neighbourhood, and the table size.  Offsets are measured in the
+    neighbourhood's own grid: dy = ky - (qy + halo) + (window + halo - 1), likewise dx; pos = dy * (window + 2 halo) + dx.
+    Returns (pos int64 [window^2, (window + 2 halo)^2], n_table)."""
+    side = window + 2 * halo
+    q = torch.arange(window)
+    k = torch.arange(side)
+    off = window + halo - 1
+    dy = k.view(1, 1, side, 1) - (q.view(window, 1, 1, 1) + halo) + off          # [qy, qx, ky, kx]
+    dx = k.view(1, 1, 1, side) - (q.view(1, window, 1, 1) + halo) + off
+    pos = (dy * side + dx).reshape(window * window, side * side).to(torch.int64)
+    n_table = off * 2 * side + off * 2 + 1
+    return pos, n_table
