@@ -24,5 +24,6 @@ case "$1" in
     timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | grep '"metric"' > gpurun_out/bench_swin_s.log
     for m in vit_s16 pvt_small; do timeout 900 python bench.py --model $m --steps 20 --warmup 5 2>&1 | grep '"metric"' > gpurun_out/bench_$m.log; done
     timeout 900 python bench.py --model dino --steps 10 --warmup 3 --cpu-batch 2 --cpu-steps 1 2>&1 | grep '"metric"' > gpurun_out/bench_dino.log
-    for m in swin_s vit_s16 pvt_small dino; do cut -c1-260 gpurun_out/bench_$m.log; done ;;
+    timeout 900 python bench.py --model twins_svt_s --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | grep '"metric"' > gpurun_out/bench_twins_svt_s.log
+    for m in swin_s vit_s16 pvt_small dino twins_svt_s; do cut -c1-260 gpurun_out/bench_$m.log; done ;;
 esac

@@ -21,5 +21,5 @@ done
 for f in gemm_bench:gemm_microbench_vs_hipblaslt attn_bench:window_attention_microbench input_bench:input_pipeline_microbench hbm_floor:hbm_streaming_floor store_pattern:store_pattern_probe; do
   [ -s gpurun_out/${f%%:*}.log ] && cp gpurun_out/${f%%:*}.log profiles/round${RN}_${f##*:}.txt
 done
-for m in swin_s vit_s16 pvt_small dino; do [ -s gpurun_out/bench_$m.log ] && cp gpurun_out/bench_$m.log profiles/round${RN}_bench_$m.json; done
+for m in swin_s vit_s16 pvt_small dino twins_svt_s; do [ -s gpurun_out/bench_$m.log ] && cp gpurun_out/bench_$m.log profiles/round${RN}_bench_$m.json; done
 ls -la profiles/ | grep round${RN}_

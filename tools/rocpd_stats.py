@@ -20,7 +20,7 @@ def demangle(names):
 
 
 def short(n):
-    n = n.replace("void ", "", 1)
+    n = n.replace("void ", "", 1).replace("(anonymous namespace)::", "")      # (kernels of csrc/gemm_pp.hip: unnamed namespace)
     depth = 0
     for i, ch in enumerate(n):              # drop the argument list (the first "(" outside template brackets)
         depth += ch == "<"

@@ -29,6 +29,7 @@ def short(name):
     """'void gemm_glds_kernel<128, 128, 64, 2>(GemmArgs)' -> 'gemm_glds_kernel<128, 128, 64, 2>' (template args kept)."""
     if name.startswith("void "):
         name = name[5:]
+    name = name.replace("(anonymous namespace)::", "")      # (kernels of csrc/gemm_pp.hip live in an unnamed namespace)
     depth = 0
     for i, ch in enumerate(name):
         depth += ch == "<"

@@ -366,7 +366,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=
         return f"gemm_skinny_kernel<{K // 32}>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K) and pp_ok(N, K, M):
         mode_ = options.get("GEMM_PP")
-        return f"gemm_pp_kernel<{mode_ % 10 if 100 <= mode_ < 1000 else pp_wmf(M, N)}, {'true' if mapped else 'false'}>"
+        return f"gemm_pp_kernel<{mode_ % 10 if 100 <= mode_ < 1000 else pp_wmf(M, N)}, {'true' if mapped else 'false'}, 0>"
     if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M, bias):
         return f"gemm_astat_kernel<{K // 64}, {'true' if mapped else 'false'}, ...>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
