@@ -38,7 +38,7 @@ def _bench_kernel(K, astat, M=0, N=0):
     round 4's A-stationary persistent kernel for 192 <= K <= 384 (option GEMM_ASTAT, default 1), the tiled LDS-DMA kernel otherwise."""
     from vtx import ops
     if ops.pp_ok(N, K, M):
-        return f"gemm_pp_kernel<{ops.pp_wmf(M, N)}, false>"
+        return f"gemm_pp_kernel<{ops.pp_wmf(M, N)}, false, 0>"
     return f"gemm_astat_kernel<{K // 64}, false, ...>" if (astat and 192 <= K <= 384) else BIG128
 
 
