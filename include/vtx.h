@@ -178,7 +178,8 @@ int vtx_attention_bwd(const void* qkv, const void* o, const void* dout, const fl
  * so -- the backward regenerates the decision from the same (drop_p, seed), no mask tensor exists in HBM -- and kept
  * probabilities are scaled by 1 / (1 - drop_p).  problem = (image * nW + window) * nH + head.  keep != NULL replaces the hash by
  * an explicit mask [problems][L][L] of bytes (1 = keep): the parity tests pass the mask the reference drew.  0 < drop_p < 1.
- * Register-resident kernels only: head dim 64 with L <= 224, head dim 32 with L <= 64 (VTX_ERR_SHAPE otherwise).
+ * Global attention of any length (key-block kernels beyond 224 tokens), window attention of <= 64 tokens (head dim 32 | 64) or <= 160
+ * tokens (head dim 32).
  * vtx_attn_keep_mask writes the hash's decisions [nprob][Lq][Lk] (what the kernels regenerate) for tests / an external checker. */
 int vtx_attention_fwd_drop(const void* qkv, void* o, float* lse, const float* bias, const uint8_t* mask, int B, int L,
                            int nH, int D, int swin, int H, int W, int win, int shift, int dtype, float drop_p, uint64_t seed,
@@ -391,6 +392,13 @@ size_t vtx_xattn_bwd_workspace(int B, int Lq, int nH);
 int vtx_xattn_bwd(const void* q, const void* kv, const void* o, const void* dout, const float* lse, const float* bias, void* dq,
                   void* dkv, float* dbias, void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype,
                   void* stream);
+
+/* vtx_xattn_* with dropout of the attention probabilities (halo_transformer.py:101); arguments as vtx_attention_fwd_drop */
+int vtx_xattn_fwd_drop(const void* q, const void* kv, void* o, float* lse, const float* bias, int B, int Lq, int Lk, int nH, int D,
+                       int dtype, float drop_p, uint64_t seed, const uint8_t* keep, void* stream);
+int vtx_xattn_bwd_drop(const void* q, const void* kv, const void* o, const void* dout, const float* lse, const float* bias, void* dq,
+                       void* dkv, float* dbias, void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype,
+                       float drop_p, uint64_t seed, const uint8_t* keep, void* stream);
 
 /* ---- Positional-encoding generator of Twins-SVT (csrc/twins_misc.hip; reference models/twins.py:25-37):
  * y = x + DepthwiseConv3x3(x) on channels-last features x, y [B, H, W, C] (C % 8 == 0, C <= 1024), w = the

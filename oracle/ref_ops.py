@@ -340,12 +340,13 @@ def halo_pos(window, halo):
     return pos, off * 2 * side + off * 2 + 1
 
 
-def halo_attention(x, p, n_head, dim_head, window, halo, qf=None):
+def halo_attention(x, p, n_head, dim_head, window, halo, qf=None, keep=None, drop_p=0.0):
     """halo_transformer.MultiHeadedHaloAttention.forward (halo_transformer.py:58-115) on NHWC x: bias-free qkv Linear; the queries of
     every window x window block against the keys / values of its (window + 2 halo)^2 neighbourhood -- positions outside the map
     are ZERO key / value vectors that take part in the softmax (the zero padding of F.unfold, lines 70-76) -- plus the
     relative-position term rel_pos[pos] (lines 95-98); output Linear per token.  p: weight.weight, linear.weight, linear.bias,
-    rel_pos.weight."""
+    rel_pos.weight.  keep (B, n_head, windows, window^2, (window + 2 halo)^2): dropout keep mask of the attention probabilities in
+    the reference's layout (line 101)."""
     B, H, W, _ = x.shape
     hd, side = n_head * dim_head, window + 2 * halo
     qkv = _q(linear(x, p["weight.weight"], None), qf)
@@ -359,7 +360,7 @@ def halo_attention(x, p, n_head, dim_head, window, halo, qf=None):
             qw = q[:, i * window:(i + 1) * window, j * window:(j + 1) * window].reshape(B, window * window, n_head, dim_head)
             nb = kvp[:, i * window:i * window + side, j * window:j * window + side].reshape(B, side * side, 2, n_head, dim_head)
             S = torch.einsum("bqhd,bkhd->bhqk", qw, nb[:, :, 0]) / math.sqrt(dim_head) + bias.permute(2, 0, 1)
-            P = _q(torch.softmax(S, -1), qf)
+            P = _q(attn_dropout(torch.softmax(S, -1), None if keep is None else keep[:, :, i * (W // window) + j], drop_p), qf)
             o = torch.einsum("bhqk,bkhd->bqhd", P, nb[:, :, 1]).reshape(B, window, window, hd)
             out[:, i * window:(i + 1) * window, j * window:(j + 1) * window] = o
     return linear(_q(out, qf), p["linear.weight"], p["linear.bias"])

@@ -35,7 +35,17 @@ CASES = {
     "twins_global": ({"linear_q.weight": (64, 64), "linear_kv.weight": (128, 64), "linear.weight": (64, 64), "linear.bias": (64,),
                       "reduce_conv.weight": (64, 64, 7, 7), "reduce_conv.bias": (64,)}, (2, 14, 14, 64), 26,
                      lambda x, p, k: R.twins_global_attention(x, p, 2, 7, keep=k, drop_p=P_DROP)),
+    "halo_w7a3": ({"weight.weight": (192, 64), "linear.weight": (64, 64), "linear.bias": (64,), "rel_pos.weight": (253, 2)}, (2, 14, 14, 64), 27,
+                  lambda x, p, k: R.halo_attention(x, p, 2, 32, 7, 3, keep=k, drop_p=P_DROP)),
 }
+
+
+def kernel_order(name, keep):
+    """The recorded mask as the kernels index it, [problems, Lq, Lk] with problem = (image, window, head): the reference's halo
+    attention tensor is (B, heads, windows, Lq, Lk), everything else already has the kernels' order."""
+    if name.startswith("halo"):
+        keep = keep.permute(0, 2, 1, 3, 4)
+    return keep.reshape(-1, keep.shape[-2], keep.shape[-1]).contiguous()
 
 
 def keep_mask(g, name):

@@ -32,6 +32,8 @@ def _module(name):
         "pvt_r1_cls": lambda: (PV.MultiHeadedAttention(128, 2, reduction=1, dropout=P), lambda m, x, k: m(x, 4, 4, keep=k)[0]),
         "twins_local": lambda: (TW.MultiHeadedLocalAttention(64, 2, 32, 7, P), lambda m, x, k: m(x, keep=k)),
         "twins_global": lambda: (TW.MultiHeadedAttention(64, 2, reduction=7, dropout=P), lambda m, x, k: m(x, keep=k)),
+        "halo_w7a3": lambda: (__import__("models.halo_transformer", fromlist=["x"]).MultiHeadedHaloAttention(64, 2, 32, 7, 3, P),
+                              lambda m, x, k: m(x, keep=k)),
     }[name]()
 
 
@@ -46,7 +48,7 @@ def test_modules_fp32_with_the_reference_keep_mask(name):
     mod, call = _module(name)
     _load(mod)
     keep = ADC.keep_mask(g, name)
-    keep_d = keep.reshape(-1, keep.shape[-2], keep.shape[-1]).contiguous().to(dev())          # [problems, Lq, Lk], the kernels' order
+    keep_d = ADC.kernel_order(name, keep).to(dev())          # [problems, Lq, Lk], the kernels' order
     x = ADC.case_input(name, torch.float32).to(dev()).requires_grad_(True)
     out = call(mod, x, keep_d)
     tol = 2e-4
@@ -61,7 +63,7 @@ def test_modules_fp32_with_the_reference_keep_mask(name):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("kind", ["global", "window", "sr"])
+@pytest.mark.parametrize("kind", ["global", "window", "sr", "sr_long", "global_long", "cross_bias"])
 def test_hashed_mask_is_the_exported_mask_and_the_backward_regenerates_it(kind, dtype):
     """The kernels' hash decisions == vtx_attn_keep_mask's; forward + backward with the hash are bit-identical to forward +
     backward with that mask passed explicitly (so the backward regenerates exactly the forward's mask)."""
@@ -69,8 +71,34 @@ def test_hashed_mask_is_the_exported_mask_and_the_backward_regenerates_it(kind, 
     d = dev()
     gen = torch.Generator().manual_seed(7)
     p, seed = 0.2, 0x1234ABCD5678
-    if kind == "sr":
-        B, Lq, Lk, nH, D = 3, 200, 49, 2, 64
+    if kind == "cross_bias":                       # halo attention's core: a score bias, its gradient, 169 keys
+        B, Lq, Lk, nH, D = 6, 49, 169, 2, 32
+        q = torch.randn(B * Lq, nH * D, generator=gen).to(dtype).to(d)
+        kv = torch.randn(B * Lk, 2 * nH * D, generator=gen).to(dtype).to(d)
+        do = torch.randn(B * Lq, nH * D, generator=gen).to(dtype).to(d)
+        bias = torch.randn(nH, Lq, Lk, generator=gen).to(d)
+        mask = ops.attn_keep_mask(B * nH, Lq, Lk, p, seed, d)
+        o1, l1 = ops.xattn_fwd(q, kv, B, Lq, Lk, nH, bias, drop=(p, seed, None))
+        o2, l2 = ops.xattn_fwd(q, kv, B, Lq, Lk, nH, bias, drop=(p, seed, mask))
+        g1 = ops.xattn_bwd(q, kv, o1, do, l1, B, Lq, Lk, nH, bias, drop=(p, seed, None))
+        g2 = ops.xattn_bwd(q, kv, o2, do, l2, B, Lq, Lk, nH, bias, drop=(p, seed, mask))
+        o0, _ = ops.xattn_fwd(q, kv, B, Lq, Lk, nH, bias)
+        # and against the oracle with the exported mask
+        from oracle import ref_ops as R
+        qr, kvr, br = q.double().cpu().requires_grad_(True), kv.double().cpu().requires_grad_(True), bias.double().cpu().requires_grad_(True)
+        Q = qr.view(B, Lq, nH, D)
+        K, V = kvr.view(B, Lk, 2, nH, D)[:, :, 0], kvr.view(B, Lk, 2, nH, D)[:, :, 1]
+        P = R.attn_dropout(torch.softmax(torch.einsum("bqhd,bkhd->bhqk", Q, K) / D ** 0.5 + br, -1), mask.cpu().view(B, nH, Lq, Lk), p)
+        oref = torch.einsum("bhqk,bkhd->bqhd", P, V).reshape(B * Lq, nH * D)
+        gq, gkv, gb = torch.autograd.grad(oref, [qr, kvr, br], do.double().cpu())
+        from gpu_util import check
+        tol = 2e-5 if dtype == torch.float32 else 1e-2
+        check(f"xattn dropout fwd vs oracle {dtype}", o1, oref, 6e-3 if dtype == torch.bfloat16 else 3e-5)
+        check(f"xattn dropout dq vs oracle {dtype}", g1[0], gq, tol)
+        check(f"xattn dropout dkv vs oracle {dtype}", g1[1], gkv, tol)
+        check(f"xattn dropout dbias vs oracle {dtype}", g1[2], gb, tol)
+    elif kind in ("sr", "sr_long"):
+        B, Lq, Lk, nH, D = (3, 200, 49, 2, 64) if kind == "sr" else (2, 300, 145, 2, 64)
         q = torch.randn(B * Lq, nH * D, generator=gen).to(dtype).to(d)
         kv = torch.randn(B * Lk, 2 * nH * D, generator=gen).to(dtype).to(d)
         do = torch.randn(B * Lq, nH * D, generator=gen).to(dtype).to(d)
@@ -81,8 +109,8 @@ def test_hashed_mask_is_the_exported_mask_and_the_backward_regenerates_it(kind, 
         g2 = ops.srattn_bwd(q, kv, o2, do, l2, B, Lq, Lk, nH, drop=(p, seed, mask))
         o0, _ = ops.srattn_fwd(q, kv, B, Lq, Lk, nH)
     else:
-        if kind == "global":
-            B, L, nH, D, swin = 3, 197, 2, 64, None
+        if kind in ("global", "global_long"):
+            B, L, nH, D, swin = 3, (197 if kind == "global" else 577), 2, 64, None
             rows, nW = B * L, 1
         else:
             B, L, nH, D, swin = 2, 49, 3, 32, (14, 14, 7, False)

@@ -547,6 +547,8 @@ def gen_attn_dropout():
         lambda m, x: m(x), 500)
     run("twins_global", ref_twins.MultiHeadedAttention(64, 2, reduction=7, dropout=P), fill((2, 14, 14, 64), 26, 1.0, dtype=torch.float64),
         lambda m, x: m(x), 501)
+    run("halo_w7a3", ref_halo.MultiHeadedHaloAttention(64, 2, 32, 7, 3, dropout=P), fill((2, 14, 14, 64), 27, 1.0, dtype=torch.float64),
+        lambda m, x: m(x), 600)
     save("g11_attn_dropout", rec)
 
 

@@ -539,9 +539,10 @@ int sattn_bwd_launch(const void* qkv, const void* o, const void* dout, const flo
 // global attention of any length (attention_long.hip): blocks of 64 keys, online softmax
 bool lattn_ok(int dtype, int D);
 size_t lattn_bwd_workspace(int B, int L, int nH);
-int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st);
+int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st,
+                     const DropArgs* da = nullptr);
 int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
-                     int L, int nH, int D, int dtype, hipStream_t st);
+                     int L, int nH, int D, int dtype, hipStream_t st, const DropArgs* da = nullptr);
 static bool attn_is_long(int L, int swin, const void* bias, const void* mask) {
   return !swin && bias == nullptr && mask == nullptr && L > 224;
 }
@@ -564,10 +565,8 @@ static int attention_fwd_impl(const void* qkv, void* o, float* lse, const float*
   int rc = attn_geom(g, L, nH, D, swin, H, W, win, shift);
   if (rc) return rc;
   if (B <= 0) return VTX_OK;
-  if (!da) {
-    if (sattn_ok(dtype, L, D, swin, bias)) return sattn_fwd_launch(qkv, o, lse, B, L, nH, st);
-    if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) return lattn_fwd_launch(qkv, o, lse, B, L, nH, D, dtype, st);
-  }
+  if (!da && sattn_ok(dtype, L, D, swin, bias)) return sattn_fwd_launch(qkv, o, lse, B, L, nH, st);
+  if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) return lattn_fwd_launch(qkv, o, lse, B, L, nH, D, dtype, st, da);
   ATTN_DISPATCH(attn_fwd_launch, qkv, o, lse, bias, mask, B, g, st, da);
 }
 
@@ -639,10 +638,10 @@ static int attention_bwd_impl(const void* qkv, const void* o, const void* dout, 
   if (rc) return rc;
   if (B <= 0) return VTX_OK;
   if (!da && sattn_ok(dtype, L, D, swin, bias)) return sattn_bwd_launch(qkv, o, dout, lse, dqkv, B, L, nH, st);
-  if (!da && attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) {
+  if (attn_is_long(L, swin, bias, mask) && lattn_ok(dtype, D)) {
     if (!workspace) return VTX_ERR_NULL;
     if (ws_bytes < lattn_bwd_workspace(B, L, nH)) return VTX_ERR_WORKSPACE;
-    return lattn_bwd_launch(qkv, o, dout, lse, dqkv, (float*)workspace, B, L, nH, D, dtype, st);
+    return lattn_bwd_launch(qkv, o, dout, lse, dqkv, (float*)workspace, B, L, nH, D, dtype, st, da);
   }
   const int nblk = attn_bwd_blocks(B * g.nW, nH);
   float* part = (float*)workspace;

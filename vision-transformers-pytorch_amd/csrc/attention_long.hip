@@ -26,7 +26,11 @@ struct LongGeom {
   int64_t ldq, ldkv;
   float scale;
   const float* bias;      // [nH][Lq][Lk] added to the scaled scores (halo attention's relative-position term), or NULL
+  DropArgs drop;          // dropout of the attention probabilities (vtx_common.h); drop.scale == 0: off.  problem = image * nH + head
 };
+__device__ __forceinline__ float la_drop(const LongGeom& g, int bh, int q, int key) {
+  return g.drop.scale == 0.f ? 1.f : drop_factor(g.drop, (unsigned)bh, q, key);
+}
 
 // (every caller passes a clamped, readable address: see load8_clamped)
 template <typename T> __device__ __forceinline__ Vec8<T> la_load(const T* p, bool valid) { return load8_clamped<T>(p, valid); }
@@ -137,6 +141,12 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qp
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) oacc[dt][r] *= a;
     }
+    if (g.drop.scale != 0.f) {                              // (wave-uniform) F.dropout on the probabilities: scaled keep factors
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] *= drop_factor(g.drop, (unsigned)bh, q, k0 + kt * 16 + g_ * 4 + r);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       Vec8<T> pf = la_frag_acc<T>(st[2 * ks], st[2 * ks + 1]);
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
           float bb = 0.f;
           if (g.bias != nullptr && kk < g.Lk && qv) bb = g.bias[((int64_t)h * g.Lq + q) * g.Lk + kk];
           const float p = kk < g.Lk ? __expf(pt[r] * g.scale + bb - lq) : 0.f;
-          dsv[half][r] = p * (dpt[r] - dsum);
+          dsv[half][r] = p * (dpt[r] * la_drop(g, bh, q, kk) - dsum);
         }
       }
       Vec8<T> dsf = la_frag_acc<T>(dsv[0], dsv[1]);
@@ -304,8 +314,9 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
           float bb = 0.f;
           if (g.bias != nullptr && kv && q0 + ql < g.Lq) bb = g.bias[((int64_t)h * g.Lq + q0 + ql) * g.Lk + key];
           const float p = kv ? __expf(s[r] * g.scale + bb - lse_s[ql]) : 0.f;
-          pp[half][r] = p;
-          dss[half][r] = p * (dp[r] - dsum_s[ql]);
+          const float f = la_drop(g, bh, q0 + ql, key);
+          pp[half][r] = p * f;
+          dss[half][r] = p * (dp[r] * f - dsum_s[ql]);
         }
       }
       Vec8<T> pf = la_frag_acc<T>(pp[0], pp[1]);
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(256) void lattn_bwd_dbias_kernel(const T* __restric
         if (qq < g.Lq && kv) {
           const float bb = g.bias[((int64_t)h * g.Lq + qq) * g.Lk + key];
           const float p = __expf(s[r] * g.scale + bb - lse[(int64_t)bh * g.Lq + qq]);
-          acc[r] += p * (dp[r] - dsum_in[(int64_t)bh * g.Lq + qq]);
+          acc[r] += p * (dp[r] * la_drop(g, bh, qq, key) - dsum_in[(int64_t)bh * g.Lq + qq]);
         }
       }
     }
@@ -409,17 +420,17 @@ template <typename T> static void* la_offw(void* p, int64_t n) { return (T*)p + 
                      : (D == 64 ? FN<float, 64>(__VA_ARGS__) : FN<float, 32>(__VA_ARGS__)))
 
 // packed QKV projection [B*L, 3 hd]
-int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st) {
+int lattn_fwd_launch(const void* qkv, void* o, float* lse, int B, int L, int nH, int D, int dtype, hipStream_t st, const DropArgs* da) {
   const int hd = nH * D;
-  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D), nullptr};
+  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D), nullptr, da ? *da : DropArgs{}};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* base = (const char*)qkv;
   return LA_DISPATCH(lattn_fwd_t, base, base + es * hd, base + 2 * es * hd, o, lse, B, g, st);
 }
 int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* ws, int B,
-                     int L, int nH, int D, int dtype, hipStream_t st) {
+                     int L, int nH, int D, int dtype, hipStream_t st, const DropArgs* da) {
   const int hd = nH * D;
-  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D), nullptr};
+  LongGeom g{L, L, nH, hd, 3 * (int64_t)hd, 3 * (int64_t)hd, 1.0f / sqrtf((float)D), nullptr, da ? *da : DropArgs{}};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* base = (const char*)qkv;
   char* out = (char*)dqkv;
@@ -427,9 +438,9 @@ int lattn_bwd_launch(const void* qkv, const void* o, const void* dout, const flo
 }
 // q [B*Lq, hd] against kv [B*Lk, 2 hd] (k | v halves): the sub-sampled attention of PVT / Twins-SVT with any number of keys
 int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
-                           hipStream_t st, const float* bias) {
+                           hipStream_t st, const float* bias, const DropArgs* da) {
   const int hd = nH * D;
-  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D), bias};
+  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D), bias, da ? *da : DropArgs{}};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* kb = (const char*)kv;
   return LA_DISPATCH(lattn_fwd_t, q, kb, kb + es * hd, o, lse, B, g, st);
@@ -444,9 +455,9 @@ static int lattn_dbias_t(const void* q, const void* k, const void* v, const void
 // dbias [nH][Lq][Lk] fp32 (NULL without a bias): summed over the B problems in fixed order
 int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
                            float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st, const float* bias,
-                           float* dbias) {
+                           float* dbias, const DropArgs* da) {
   const int hd = nH * D;
-  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D), bias};
+  LongGeom g{Lq, Lk, nH, hd, (int64_t)hd, 2 * (int64_t)hd, 1.0f / sqrtf((float)D), bias, da ? *da : DropArgs{}};
   const size_t es = dtype == VTX_BF16 ? 2 : 4;
   const char* kb = (const char*)kv;
   char* out = (char*)dkv;

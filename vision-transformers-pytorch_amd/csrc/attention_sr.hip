@@ -445,10 +445,10 @@ static int sr_launch_bwd(const void* q, const void* kv, const void* o, const voi
 // more than 64 reduced keys (PVT / Twins at 384 x 384 and beyond): the key-block / online-softmax kernels of attention_long.hip
 bool lattn_ok(int dtype, int D);
 int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
-                           hipStream_t st, const float* bias = nullptr);
+                           hipStream_t st, const float* bias = nullptr, const DropArgs* da = nullptr);
 int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
                            float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st, const float* bias = nullptr,
-                           float* dbias = nullptr);
+                           float* dbias = nullptr, const DropArgs* da = nullptr);
 static bool sr_long(int B, int Lq, int Lk, int nH, int D, int dtype) {
   return Lk > SR_LK && B > 0 && Lq > 0 && nH > 0 && lattn_ok(dtype, D) && (int64_t)B * Lq < 0x7fffffff;
 }
@@ -482,11 +482,12 @@ int vtx_srattn_fwd(const void* q, const void* kv, void* o, float* lse, int B, in
 int vtx_srattn_fwd_drop(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
                         float drop_p, uint64_t seed, const uint8_t* keep, void* stream) {
   if (!q || !kv || !o || !lse) return VTX_ERR_NULL;
-  SrGeom g;
-  int rc = sr_geom(g, Lq, Lk, nH, B, D);
-  if (rc) return rc;
   DropArgs da;
-  rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  int rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  if (rc) return rc;
+  if (sr_long(B, Lq, Lk, nH, D, dtype)) return lattn_cross_fwd_launch(q, kv, o, lse, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream, nullptr, &da);
+  SrGeom g;
+  rc = sr_geom(g, Lq, Lk, nH, B, D);
   if (rc) return rc;
   return SR_DISPATCH(sr_launch_fwd, q, kv, o, lse, B, g, (hipStream_t)stream, &da);
 }
@@ -517,12 +518,15 @@ int vtx_srattn_bwd_drop(const void* q, const void* kv, const void* o, const void
                         void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype, float drop_p,
                         uint64_t seed, const uint8_t* keep, void* stream) {
   if (!q || !kv || !o || !dout || !lse || !dq || !dkv || !workspace) return VTX_ERR_NULL;
-  SrGeom g;
-  int rc = sr_geom(g, Lq, Lk, nH, B, D);
+  DropArgs da;
+  int rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
   if (rc) return rc;
   if (ws_bytes < vtx_srattn_bwd_workspace(B, Lq, Lk, nH, D)) return VTX_ERR_WORKSPACE;
-  DropArgs da;
-  rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  if (sr_long(B, Lq, Lk, nH, D, dtype))
+    return lattn_cross_bwd_launch(q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream, nullptr,
+                                  nullptr, &da);
+  SrGeom g;
+  rc = sr_geom(g, Lq, Lk, nH, B, D);
   if (rc) return rc;
   return SR_DISPATCH(sr_launch_bwd, q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, g, (hipStream_t)stream, &da);
 }

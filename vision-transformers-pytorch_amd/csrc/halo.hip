@@ -82,10 +82,10 @@ static unsigned halo_grid(int64_t total) {
 
 bool lattn_ok(int dtype, int D);
 int lattn_cross_fwd_launch(const void* q, const void* kv, void* o, float* lse, int B, int Lq, int Lk, int nH, int D, int dtype,
-                           hipStream_t st, const float* bias = nullptr);
+                           hipStream_t st, const float* bias = nullptr, const DropArgs* da = nullptr);
 int lattn_cross_bwd_launch(const void* q, const void* kv, const void* o, const void* dout, const float* lse, void* dq, void* dkv,
                            float* ws, int B, int Lq, int Lk, int nH, int D, int dtype, hipStream_t st, const float* bias = nullptr,
-                           float* dbias = nullptr);
+                           float* dbias = nullptr, const DropArgs* da = nullptr);
 
 extern "C" {
 
@@ -149,6 +149,33 @@ int vtx_xattn_bwd(const void* q, const void* kv, const void* o, const void* dout
     return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_xattn_bwd_workspace(B, Lq, nH)) return VTX_ERR_WORKSPACE;
   return lattn_cross_bwd_launch(q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream, bias, dbias);
+}
+
+/* The same with dropout of the attention probabilities (halo_transformer.py:101: F.dropout(attn, p, training)): see
+ * vtx_attention_fwd_drop; problem = b * nH + head over the B problems, cell = query * Lk + key, keep [B * nH][Lq][Lk]. */
+int vtx_xattn_fwd_drop(const void* q, const void* kv, void* o, float* lse, const float* bias, int B, int Lq, int Lk, int nH, int D,
+                       int dtype, float drop_p, uint64_t seed, const uint8_t* keep, void* stream) {
+  if (!q || !kv || !o || !lse) return VTX_ERR_NULL;
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || nH <= 0 || !lattn_ok(dtype, D) || (int64_t)B * Lq >= 0x7fffffff || (int64_t)B * Lk >= 0x7fffffff)
+    return VTX_ERR_SHAPE;
+  DropArgs da;
+  int rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  if (rc) return rc;
+  return lattn_cross_fwd_launch(q, kv, o, lse, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream, bias, &da);
+}
+int vtx_xattn_bwd_drop(const void* q, const void* kv, const void* o, const void* dout, const float* lse, const float* bias, void* dq,
+                       void* dkv, float* dbias, void* workspace, size_t ws_bytes, int B, int Lq, int Lk, int nH, int D, int dtype,
+                       float drop_p, uint64_t seed, const uint8_t* keep, void* stream) {
+  if (!q || !kv || !o || !dout || !lse || !dq || !dkv || !workspace) return VTX_ERR_NULL;
+  if ((bias != nullptr) != (dbias != nullptr)) return VTX_ERR_NULL;
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || nH <= 0 || !lattn_ok(dtype, D) || (int64_t)B * Lq >= 0x7fffffff || (int64_t)B * Lk >= 0x7fffffff)
+    return VTX_ERR_SHAPE;
+  if (ws_bytes < vtx_xattn_bwd_workspace(B, Lq, nH)) return VTX_ERR_WORKSPACE;
+  DropArgs da;
+  int rc = drop_args(da, drop_p, seed, keep, Lq, Lk);
+  if (rc) return rc;
+  return lattn_cross_bwd_launch(q, kv, o, dout, lse, dq, dkv, (float*)workspace, B, Lq, Lk, nH, D, dtype, (hipStream_t)stream, bias, dbias,
+                                &da);
 }
 
 }  // extern "C"

@@ -51,18 +51,18 @@ class MultiHeadedHaloAttention(nn.Module):
         return VF.HaloMeta(self.n_head, self.dim_head, self.window_size, self.halo_size, self.pos, (self._csr_order, self._csr_offsets),
                            self.rel_pos.num_embeddings)
 
-    def forward(self, input):
+    def forward(self, input, keep=None):
+        """keep: an explicit uint8 keep mask [B * windows * heads, window^2, (window + 2 halo)^2] for the attention dropout (the
+        reference's attention tensor is (B, heads, windows, ...): transpose it), else the hash mask."""
         B, H, W, _ = input.shape
         w = self.window_size
         if H % w or W % w:
             raise ValueError(f"feature map {(H, W)} is not a multiple of the window size {w}")
         if self.dim_head not in (32, 64):
             raise NotImplementedError("vtx: the halo attention kernels are built for head dim 32 or 64")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("vtx: attention dropout > 0 is not built for halo attention (the other families have it)")
         T = VF.compute_dtype(input)
         qkv = VF.LinearFn.apply(input.to(T), self.weight.weight, None)
-        out = VF.HaloAttentionFn.apply(qkv, self.rel_pos.weight, self.meta())
+        out = VF.HaloAttentionFn.apply(qkv, self.rel_pos.weight, self.meta(), VF.attn_drop(self.dropout, self.training, keep))
         return VF.LinearFn.apply(out, self.linear.weight, self.linear.bias)
 
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class VtxError(RuntimeError):
@@ -159,6 +159,10 @@ _SIGNATURES = {
     "vtx_xattn_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "vtx_xattn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vtx_xattn_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   ctypes.c_uint64, c_void_p, c_void_p]),
+    "vtx_xattn_bwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_void_p, c_void_p]),
     "vtx_dwconv3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vtx_dwconv3_wgrad_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vtx_dwconv3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),

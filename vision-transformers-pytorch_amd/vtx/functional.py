@@ -692,7 +692,7 @@ class HaloAttentionFn(Function):
     zero rows outside the map, softmax(q k^T / sqrt(D) + rel_pos[pos]) v, inverse partition -> (B, H, W, h D)."""
 
     @staticmethod
-    def forward(ctx, qkv, rel_pos, meta):
+    def forward(ctx, qkv, rel_pos, meta, drop=None):
         qkv = _c(qkv)
         B, H, W, C3 = qkv.shape
         hd = C3 // 3
@@ -701,11 +701,11 @@ class HaloAttentionFn(Function):
         q = ops.window_gather(qkv, B, H, W, 0, hd, w, 0)
         kv = ops.window_gather(qkv, B, H, W, hd, 2 * hd, w, a)
         bias = ops.table_bias(rel_pos.detach(), meta.pos, nH)
-        o, lse = ops.xattn_fwd(q.view(B * nW * Lq, hd), kv.view(B * nW * Lk, 2 * hd), B * nW, Lq, Lk, nH, bias)
+        o, lse = ops.xattn_fwd(q.view(B * nW * Lq, hd), kv.view(B * nW * Lk, 2 * hd), B * nW, Lq, Lk, nH, bias, drop=drop)
         out = torch.empty((B, H, W, hd), dtype=qkv.dtype, device=qkv.device)
         ops.window_scatter(o, out, B, H, W, 0, hd, w, 0)
         ctx.save_for_backward(q, kv, o, lse, bias)
-        ctx.meta, ctx.geom = meta, (B, H, W, hd, nW, Lq, Lk)
+        ctx.meta, ctx.geom, ctx.drop = meta, (B, H, W, hd, nW, Lq, Lk), drop
         return out
 
     @staticmethod
@@ -717,12 +717,12 @@ class HaloAttentionFn(Function):
         w, a, nH = meta.window, meta.halo, meta.n_head
         do = ops.window_gather(_c(dout), B, H, W, 0, hd, w, 0)
         dq, dkv, dbias = ops.xattn_bwd(q.view(B * nW * Lq, hd), kv.view(B * nW * Lk, 2 * hd), o, do.view(B * nW * Lq, hd), lse,
-                                       B * nW, Lq, Lk, nH, bias)
+                                       B * nW, Lq, Lk, nH, bias, drop=ctx.drop)
         dqkv = torch.empty((B, H, W, 3 * hd), dtype=q.dtype, device=q.device)
         ops.window_scatter(dq, dqkv, B, H, W, 0, hd, w, 0)
         ops.window_scatter(dkv, dqkv, B, H, W, hd, 2 * hd, w, a)          # sums over the neighbourhoods that hold a token
         drel = ops.table_bias_bwd(dbias, meta.csr, meta.ntab, nH)
-        return dqkv, drel, None
+        return dqkv, drel, None, None
 
 
 class TransformerLayerFn(Function):

@@ -706,21 +706,26 @@ def table_bias_bwd(full, csr, ntab, n_head):
     return out
 
 
-def xattn_fwd(q, kv, B, Lq, Lk, n_head, bias=None):
-    """o, lse = softmax(q k^T / sqrt(D) + bias) v; q [B * Lq, h D], kv [B * Lk, 2 h D], bias [h, Lq, Lk] fp32 or None."""
+def xattn_fwd(q, kv, B, Lq, Lk, n_head, bias=None, drop=None):
+    """o, lse = softmax(q k^T / sqrt(D) + bias) v; q [B * Lq, h D], kv [B * Lk, 2 h D], bias [h, Lq, Lk] fp32 or None; drop = (p, seed, keep)."""
     _dev(q, kv, bias)
     D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
     o = torch.empty_like(q)
     lse = torch.empty(B * n_head * Lq, dtype=torch.float32, device=q.device)
     ev = _attn_bracket("lattn_fwd_kernel (cross)", B * n_head, Lq, D, B * Lq, hd, q.element_size(), False)
-    check(_lib.load().vtx_xattn_fwd(_p(q), _p(kv), _p(o), _p(lse), _p(bias), B, Lq, Lk, n_head, D, _dt(q), _stream()), "vtx_xattn_fwd")
+    if drop is not None:
+        dp, seed, keep = _drop_args(drop, q.device)
+        check(_lib.load().vtx_xattn_fwd_drop(_p(q), _p(kv), _p(o), _p(lse), _p(bias), B, Lq, Lk, n_head, D, _dt(q), dp, seed, _p(keep),
+                                             _stream()), "vtx_xattn_fwd_drop")
+    else:
+        check(_lib.load().vtx_xattn_fwd(_p(q), _p(kv), _p(o), _p(lse), _p(bias), B, Lq, Lk, n_head, D, _dt(q), _stream()), "vtx_xattn_fwd")
     if ev:
         ev[1].record()
     return o, lse
 
 
-def xattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, bias=None):
-    """dq, dkv, dbias (None without a bias): deterministic."""
+def xattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, bias=None, drop=None):
+    """dq, dkv, dbias (None without a bias): deterministic; drop: the forward's (p, seed, keep)."""
     _dev(q, kv, o, dout, lse, bias)
     lib = _lib.load()
     D, hd = _sr_head_dim(q, kv, B, Lq, Lk, n_head)
@@ -729,8 +734,13 @@ def xattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, bias=None):
     wsb = lib.vtx_xattn_bwd_workspace(B, Lq, n_head)
     ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
     ev = _attn_bracket("lattn_bwd_*_kernel (cross)", B * n_head, Lq, D, B * Lq, hd, q.element_size(), True)
-    check(lib.vtx_xattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(bias), _p(dq), _p(dkv), _p(dbias), _p(ws), wsb, B, Lq, Lk,
-                            n_head, D, _dt(q), _stream()), "vtx_xattn_bwd")
+    if drop is not None:
+        dp, seed, keep = _drop_args(drop, q.device)
+        check(lib.vtx_xattn_bwd_drop(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(bias), _p(dq), _p(dkv), _p(dbias), _p(ws), wsb, B, Lq, Lk,
+                                     n_head, D, _dt(q), dp, seed, _p(keep), _stream()), "vtx_xattn_bwd_drop")
+    else:
+        check(lib.vtx_xattn_bwd(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(bias), _p(dq), _p(dkv), _p(dbias), _p(ws), wsb, B, Lq, Lk,
+                                n_head, D, _dt(q), _stream()), "vtx_xattn_bwd")
     if ev:
         ev[1].record()
     return dq, dkv, dbias
@@ -1132,7 +1142,7 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
         order, offsets = csr
         _dev(order, offsets)
         drel = torch.empty((ntab, n_head), dtype=torch.float32, device=qkv.device)
-    if bias is not None or (swin is None and L > 224 and drop is None):          # bias-gradient slabs / the long kernels' Dq vector
+    if bias is not None or (swin is None and L > 224):          # bias-gradient slabs / the long kernels' Dq vector
         wsb = lib.vtx_attention_bwd_workspace(B, L, n_head, int(swin is not None), H, W, max(win, 1))
         ws = torch.empty(wsb, dtype=torch.uint8, device=qkv.device)
     rows = qkv.numel() // (3 * n_head * D)
