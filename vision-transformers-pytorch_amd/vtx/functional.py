@@ -628,12 +628,15 @@ _DROP_CALLS = [0]
 
 def attn_drop(p, training, keep=None):
     """(p, seed, keep) of one attention-dropout call, None when the reference's F.dropout(attn, p, training) is the identity.
-    The seed advances with every call and derives from torch's seed: the same ``torch.manual_seed`` and call sequence reproduce
-    the masks.  keep: an explicit uint8 keep mask [problems, Lq, Lk] (parity tests)."""
+    The seed advances with every call and derives from torch's seed (and the rank of a data-parallel replica): the same
+    ``torch.manual_seed`` and call sequence reproduce the masks.  keep: an explicit uint8 keep mask [problems, Lq, Lk] (parity tests)."""
     if not training or not p > 0:
         return None
     _DROP_CALLS[0] += 1
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_CALLS[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()          # (data-parallel replicas seeded alike still draw different masks)
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_CALLS[0] * 0xD1B54A32D192ED03 + rank * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
     return (float(p), seed, keep)
 
 
