@@ -333,6 +333,12 @@ def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
     # products in another slice partition
     wide = ops.wgrad_wide_tiles([(j[0].shape[1], j[1].shape[1]) for j in gpu]) > 0
     assert wide == (C == 384)
+    if wide:
+        # option 1 (lockstep multiplying waves) vs the default 2 (two wave groups half a k-step apart): the same products in the same order
+        with options.override(WGRAD_WIDE=3 - options.get("WGRAD_WIDE")):
+            other = ops.wgrad_group(gpu, T, c)
+        for (a, ab), (g, gb) in zip(other, res):
+            assert torch.equal(a, g) and torch.equal(ab, gb), "wide-tile weight gradient: lockstep and two-group loops differ"
     with options.override(WGRAD_WIDE=0):
         narrow = ops.wgrad_group(gpu, T, c)
         again = ops.wgrad_group(gpu, T, c)

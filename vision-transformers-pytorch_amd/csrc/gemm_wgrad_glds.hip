@@ -506,7 +506,12 @@ __device__ __forceinline__ Vec8<bf16> ww_frag(const unsigned char* a) {
   return wg_join(lo, hi);
 }
 
-template <bool MAPPED>
+// TG (round 5, option WGRAD_WIDE = 2): the two row halves of the multiplying waves (waves 0-3 | 4-7: one wave of each per SIMD) run HALF A
+// K-STEP APART, as in csrc/gemm_pp.hip -- while one group multiplies k-step u out of registers (24 MFMAs = 384 cycles) the other reads its
+// 20 transposed fragments of k-step u from LDS, so the matrix pipe of a SIMD always has a wave in its MFMA segment; two s_barrier per
+// k-step (phases 2u: group 0 reads, group 1 multiplies u - 1; 2u + 1: group 0 multiplies, group 1 reads).  A stage is last read in
+// phase 2u + 1 and refilled from phase 2u + 2 on; k-step u + 1 is visible before phase 2u + 2.  Same products in the same order: same bits.
+template <bool MAPPED, bool TG = false>
 __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
   unsigned char* live_tab = wg_smem + WW_RING;
@@ -660,13 +665,15 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     for (int kt = 0; kt < nkt; ++kt) {
       const bool refill = kt + WW_NS - 1 < nkt;
       if (refill) issue(kt + WW_NS - 1, buf == 0 ? WW_NS - 1 : buf - 1);
+      if constexpr (TG) __builtin_amdgcn_s_barrier();                       // end of phase 2 kt
       // k-step kt + 1 must have landed; two younger ones stay in flight (vmcnt retires in order)
       if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((WW_NS - 2) * WW_LPT) : "memory");
       else if (kt + WW_NS - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((WW_NS - 3) * WW_LPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                                         // (TG: end of phase 2 kt + 1)
       buf = buf + 1 == WW_NS ? 0 : buf + 1;
     }
+    if constexpr (TG) __builtin_amdgcn_s_barrier();                         // phase 2 nkt: group 1 multiplies its last k-step
   } else {
     // ---------------- multiplying waves: wr = row half of the dy columns (64), wc = quarter of the x columns (96)
     const int wr = wave >> 2, wc = wave & 3;
@@ -682,6 +689,43 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     const unsigned ks_off = (unsigned)(krg * 256 + ((kch ^ wg_swz(krg)) << 4));
     __builtin_amdgcn_s_barrier();
     int buf = 0;
+    if constexpr (TG) {
+      if (wr == 1) __builtin_amdgcn_s_barrier();                           // group 1 sits out phase 0
+      for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned char* st = wg_smem + buf * WW_STAGE;
+        Vec8<bf16> fp[4], fq[6];
+        // ---- read segment (the partner group multiplies meanwhile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fp[i] = ww_frag(st + fp_off[i]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fq[j] = ww_frag(st + fq_off[j]);
+        if (have_ksum) {
+          Vec8<bf16> t = load8<bf16>(reinterpret_cast<const bf16*>(st + ks_off));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ks8[e] += t.get(e);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fp[i].v));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(fq[j].v));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA segment (the partner group reads its fragments meanwhile)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mma16(fq[j], fp[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf + 1 == WW_NS ? 0 : buf + 1;
+      }
+      if (wr == 0) __builtin_amdgcn_s_barrier();                           // group 0 sits out the last phase
+    } else {
     for (int kt = 0; kt < nkt; ++kt) {
       const unsigned char* st = wg_smem + buf * WW_STAGE;
       Vec8<bf16> fp[4], fq[6];
@@ -702,6 +746,7 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
       }
       __builtin_amdgcn_s_barrier();
       buf = buf + 1 == WW_NS ? 0 : buf + 1;
+    }
     }
   }
 
@@ -826,7 +871,9 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
     for (int i = 0; i < nprob; ++i) wmapped = wmapped || hp[i].perm != nullptr;
     for (int i = 0; i < nprob; ++i)
       if (wmapped && hp[i].perm == nullptr) return VTX_ERR_SHAPE;
-    auto kern = wmapped ? wgrad_wide_kernel<true> : wgrad_wide_kernel<false>;
+    const bool tg = vtx_opt(VTX_OPT_WGRAD_WIDE) == 2;           // two wave groups half a k-step apart
+    auto kern = wmapped ? (tg ? wgrad_wide_kernel<true, true> : wgrad_wide_kernel<true, false>)
+                        : (tg ? wgrad_wide_kernel<false, true> : wgrad_wide_kernel<false, false>);
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WW_SMEM) != hipSuccess) return VTX_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nz), dim3(WW_NT), WW_SMEM, st, a);
     return vtx_check_launch();
