@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
   __syncthreads();                                    // table complete; the relh scratch (wave 0's region) is free again
   WaTok tk;
   wa_tok_init(tk, g, c_);
+  const bool w7 = g.L == 49;
 
   for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
     const int n = bn % g.nW, b = g.perm ? g.perm[bn / g.nW] : bn / g.nW;
@@ -245,6 +246,9 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
         if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          // 7 x 7 windows (49 tokens): keys 49 .. 63 are padding in every lane -- of the last key tile only register 0 (key 48 + 4 g)
+          // can be live.  Their bias is -inf, i.e. p = 0 exactly: skipping them changes no bit (round 5; ~6 % of the VALU work).
+          if (kt == 3 && r > 0 && w7) continue;
           float sv = st[kt][r] * g.scale + bb[r];
           if (MK && (rx & (0xffu << (8 * r))) != 0u) sv = -INFINITY;
           st[kt][r] = sv;
@@ -257,7 +261,11 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m); l += st[kt][r]; }
+        for (int r = 0; r < 4; ++r) {
+          if (kt == 3 && r > 0 && w7) { st[kt][r] = 0.f; continue; }
+          st[kt][r] = __expf(st[kt][r] - m);
+          l += st[kt][r];
+        }
       l += shfl_xor_f(l, 16);
       l += shfl_xor_f(l, 32);
       const float inv = 1.f / l;
@@ -594,6 +602,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, WA4_OCC) void wattn_bwd4_kernel(
   const int tcl = val ? tok : 0;
   const int ay = tcl / g.win, ax = tcl - ay * g.win;
   const bool tile_live = 16 * w < g.L;
+  const bool w7 = g.L == 49;
 
   f32x4 dsacc[4];                                     // sum over this workgroup's problems of dS[q = 16 w + c][key = 16 kt + 4 g + r]
 #pragma unroll
@@ -663,6 +672,7 @@ __global__ __launch_bounds__(64 * WA_WAVES, WA4_OCC) void wattn_bwd4_kernel(
           if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            if (kt == 3 && r > 0 && w7) { pv2[half][r] = 0.f; dsv[half][r] = 0.f; continue; }   // always-padded keys of 7 x 7 windows: p = 0
             float p = __expf(pt[r] * g.scale + bb[r] - lq);       // padded q: lse = +inf, padded key: bias = -inf
             if (MK && (rx & (0xffu << (8 * r))) != 0u) p = 0.f;
             pv2[half][r] = p;
