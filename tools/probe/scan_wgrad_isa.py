@@ -57,7 +57,7 @@ def main():
         if ntr != 20 or nmfma != 24:
             print(f"{name}: {ntr} transpose reads / {nmfma} MFMAs in the body (expected 20 / 24: one k-step, not unrolled)"); bad += 1
     print(f"{bad} violations in {n} wgrad_wide_kernel instantiations")
-    return 1 if (bad or n != 2) else 0
+    return 1 if (bad or n != 4) else 0          # lockstep and two-group loops (option WGRAD_WIDE = 1 | 2), each plain and row-mapped
 
 
 if __name__ == "__main__":
