@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         Vec8<T> kf = load8_or_zero<T>(kp + ds * 32, kv);
         mma16(kf, qf[ds], st[kt]);
       }
+      if constexpr (sizeof(T) == 4 || DROP) acc_settle(st[kt]);
     }
     // softmax over keys (fp32), row = this lane's query
     float m = -INFINITY;
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
       for (int dt = 0; dt < DT; ++dt) {
         Vec8<T> vf = frag_from_transposed<T>(vt + (dt * 16 + c_) * STR + ks * 32, g_);
         mma16(pf, vf, oacc[dt]);
+      }
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc_settle(oacc[dt]);
       }
     }
     // oacc[dt][r] = O[q = 16 qt + 4 g_ + r][d = 16 dt + c_]
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             mma16(kf, qf[ds], pt);      // pt[r]  = S [q = c_][key = 16 kt + 4 g_ + r]
             mma16(vf, dof[ds], dpt);    // dpt[r] = dP[same]
           }
+          if constexpr (sizeof(T) == 4 || DROP) { acc_settle(pt); acc_settle(dpt); }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kk = kt * 16 + g_ * 4 + r;
@@ -311,6 +317,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         for (int dt = 0; dt < DT; ++dt) {
           Vec8<T> kf = frag_from_transposed<T>(r0 + (dt * 16 + c_) * STR + ks * 32, g_);
           mma16(dsf, kf, dqacc[dt]);
+        }
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) acc_settle(dqacc[dt]);
         }
       }
 #pragma unroll
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             mma16(qf, kf[ds], s);       // s[r]  = S [q = 16 qt + 4 g_ + r][key = 16 kt + c_]
             mma16(dof, vf[ds], dp);     // dp[r] = dP[same]
           }
+          if constexpr (sizeof(T) == 4 || DROP) { acc_settle(s); acc_settle(dp); }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qq = qt * 16 + g_ * 4 + r;
@@ -381,6 +392,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
           Vec8<T> qtf = frag_from_transposed<T>(r0 + (dt * 16 + c_) * STR + qs * 32, g_);
           mma16(pf, dotf, dvacc[dt]);
           mma16(dsf, qtf, dkacc[dt]);
+        }
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) { acc_settle(dvacc[dt]); acc_settle(dkacc[dt]); }
         }
       }
 #pragma unroll

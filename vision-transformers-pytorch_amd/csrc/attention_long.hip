@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void lattn_fwd_kernel(const T* __restrict__ qp
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) mma16(pf, la_frag_t<T>(vt + (dt * 16 + c_) * LA_STR + ks * 32, g_), oacc[dt]);
     }
+    if constexpr (sizeof(T) == 4) {                  // (fp32 parity mode: see acc_settle)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc_settle(oacc[dt]);
+    }
   }
   if (qv && g_ == 0) lse[(int64_t)bh * g.Lq + q] = m_run + __logf(l_run);
   const float inv = 1.f / l_run;
@@ -237,6 +241,10 @@ __global__ __launch_bounds__(256) void lattn_bwd_dq_kernel(const T* __restrict__
       Vec8<T> dsf = la_frag_acc<T>(dsv[0], dsv[1]);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) mma16(dsf, la_frag_t<T>(kt_s + (dt * 16 + c_) * LA_STR + ks * 32, g_), dqacc[dt]);
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc_settle(dqacc[dt]);
     }
   }
 #pragma unroll
@@ -326,6 +334,10 @@ __global__ __launch_bounds__(256) void lattn_bwd_dkv_kernel(const T* __restrict_
         mma16(pf, la_frag_t<T>(dot_s + (dt * 16 + c_) * LA_STR + qs * 32, g_), dvacc[dt]);
         mma16(dsf, la_frag_t<T>(qt_s + (dt * 16 + c_) * LA_STR + qs * 32, g_), dkacc[dt]);
       }
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { acc_settle(dvacc[dt]); acc_settle(dkacc[dt]); }
     }
   }
 #pragma unroll
