@@ -621,3 +621,48 @@ def test_forward_feature_without_a_weight_scope_runs_uncompacted_and_backward_wo
     assert torch.equal(f_direct, f_model)
     for k in g_direct:
         check(f"forward_feature vs forward: d {k}", g_direct[k], g_model[k], 1e-5)
+
+
+# ------------------------------------------------------------------ option-off vs option-on of two round-4 switches
+@pytest.mark.parametrize("B,H,W,C,r", [(2, 56, 56, 64, 7), (2, 28, 28, 128, 7), (1, 14, 14, 256, 7)])
+def test_twins_subsampling_through_lds_is_bitwise_the_elementwise_kernel(B, H, W, C, r):
+    """TWINS_SUB_LDS = 1 (gather / scatter staged through LDS where the geometry gives 8- / 16-byte chunks) vs 0 (element-wise): a
+    permutation and its inverse (+ accumulate) -- identical bits."""
+    from vtx import ops, options
+    d = dev()
+    x = _mk((B, H, W, C), 701, BF).to(d)
+    g = _mk((B * (H // r) * (W // r), C * r * r), 702, BF).to(d)
+    base = _mk((B, H, W, C), 703, BF).to(d)
+    res = {}
+    for v in (1, 0):
+        with options.override(TWINS_SUB_LDS=v):
+            f = ops.twins_subsample_fwd(x, B, H, W, C, r)
+            dx = torch.empty_like(x)
+            ops.twins_subsample_bwd(g, dx, B, H, W, C, r)
+            acc = base.clone()
+            ops.twins_subsample_bwd(g, acc, B, H, W, C, r, accumulate=True)
+            torch.cuda.synchronize()
+            res[v] = (f, dx, acc)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b), "TWINS_SUB_LDS changes bits"
+
+
+def test_split_k_dgrad_of_the_dino_output_layer_vs_the_plain_gemm_and_fp64(monkeypatch):
+    """VTX_DGRAD_SPLITK (functional.dgrad: a 65 536-long contraction with 20 output tiles runs as a split-K launch): against the
+    plain GEMM path (another fixed summation partition) and against fp64."""
+    from vtx import functional as VF
+    d = dev()
+    gen = torch.Generator().manual_seed(704)
+    dy = torch.randn(640, 65536, generator=gen).to(BF)
+    w = (0.02 * torch.randn(65536, 256, generator=gen))
+    wp = (w.to(BF).to(d), None)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(VF, "_DGRAD_SPLITK", flag)
+        out[flag] = VF.dgrad(dy.to(d), wp, BF)
+        again = VF.dgrad(dy.to(d), wp, BF)
+        assert torch.equal(out[flag], again), "dgrad is not deterministic"
+    ref = dy.double() @ w.to(BF).double()
+    check("DINO output-layer dgrad, split-K vs fp64", out[True], ref, 4e-3)
+    check("DINO output-layer dgrad, plain GEMM vs fp64", out[False], ref, 4e-3)
+    check("DINO output-layer dgrad, split-K vs plain GEMM", out[True], out[False].double(), 6e-3)

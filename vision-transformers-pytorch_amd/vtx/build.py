@@ -21,8 +21,25 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version():
+    """First line of ``hipcc --version`` (cached): part of every object's stamp -- the ISA-level guards of the library (wait states hipcc
+    does not insert, profiles/round4_nondeterminism_root_cause.md, round5_mfma_branch_hazard.md) were validated against ONE compiler."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+            _HIPCC_VERSION = " | ".join(l.strip() for l in out.splitlines()[:2])
+        except OSError:
+            _HIPCC_VERSION = "unknown"
+    return _HIPCC_VERSION
+
+
 def _stamp(src):
     h = hashlib.sha1()
+    h.update(hipcc_version().encode())
     for f in [src] + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -56,7 +73,7 @@ def build(verbose=True):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"[vtx] built {LIB} from {len(objs)} objects", file=sys.stderr)
+        print(f"[vtx] built {LIB} from {len(objs)} objects ({hipcc_version()})", file=sys.stderr)
     return LIB
 
 
