@@ -10,6 +10,7 @@ LOG=gpurun_out/r5_$J.log
 case "$J" in
   pp)         # two-group GEMM: bitwise vs the other kernels, race screen, timing vs them and hipBLASLt; phase ablation
     timeout 1200 python tools/r5/pp_check.py "$@" 2>&1 | grep -v amdgpu.ids > $LOG
+    [ -f tools/r5/ablate/libvtx_pp.so ] || bash tools/r5/build_pp_ablate.sh > /dev/null 2>&1       # (the ablation build: hipcc is on the GPU box too)
     VTX_LIBVTX=$R/tools/r5/ablate/libvtx_pp.so timeout 600 python tools/r5/pp_ablate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_pp_ablate.log
     tail -50 $LOG; cat gpurun_out/r5_pp_ablate.log ;;
   skew)       # two-group GEMM: start delay per column tile (VTX_PP_SKEW, units of ~0.43 us)
