@@ -270,6 +270,51 @@ def test_wattn_backward_four_waves_per_problem_matches_the_one_wave_kernel_at_be
     check(f"wattn drel_pos, four waves vs one wave per problem (H {H})", a[1], c[1].double(), 2e-5)
 
 
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+@pytest.mark.parametrize("H,nH,shift", [(56, 3, True), (56, 3, False), (14, 12, True), (7, 24, False)])
+def test_wattn_forward_one_row_path_and_uniform_window_branch(H, nH, shift, dtype):
+    """Round 5 (option WATTN_FAST): bit 1 sends the windows of a shifted layer whose tokens share one region id down the
+    unmasked instruction stream -- same bits as the masked stream; bit 0 runs the 49th query of a 7 x 7 window as ONE row
+    (product taken as q k^T, 4 scores per lane, P through LDS) -- the other 48 queries bit for bit, the 49th within the
+    rounding of the output type of the padded-tile path and of the fp64 oracle."""
+    from oracle import tables
+    from vtx import ops, options
+    from vtx.tables import mask_regions
+    d = dev()
+    B, win, L, ntab, D = 16, 7, 49, 169, 32
+    pos_np, mask_np = tables.make_pos_mask((H, H), win, shift)
+    pos = torch.from_numpy(pos_np).to(d)
+    region = None
+    if shift:
+        region, ok = mask_regions(torch.from_numpy(mask_np).to(d))
+        assert ok
+    qkv = _mk((B, H, H, 3 * nH * D), 171, dtype)
+    rel = _mk((ntab, nH), 173, torch.float32, 0.5)
+    qd, reld = qkv.to(d), rel.to(d)
+    swin = (H, H, win, shift)
+    out = {}
+    for fast in (0, 1, 2, 3):
+        with options.override(WATTN_FAST=fast):
+            out[fast] = ops.wattn_fwd(qd, reld, pos, region, B, L, nH, swin)
+    assert torch.equal(out[2][0], out[0][0]) and torch.equal(out[2][1], out[0][1]), "uniform-window branch changed bits"
+    assert torch.equal(out[3][0], out[1][0]) and torch.equal(out[3][1], out[0 + 1][1])
+    # token 48 of every window = rows (y % 7 == 6, x % 7 == 6) after the roll; everything else must not move
+    o0, o1 = out[0][0].view(B, H, H, nH * D), out[1][0].view(B, H, H, nH * D)
+    sh = win // 2 if shift else 0
+    last = torch.zeros(H, H, dtype=torch.bool, device=d)
+    idx = torch.arange(H, device=d)
+    sel = ((idx - sh) % H) % win == win - 1          # window coordinates are those of the rolled image (roll by -shift)
+    last[sel[:, None] & sel[None, :]] = True
+    assert torch.equal(o0[:, ~last], o1[:, ~last]), "the one-row path moved a query other than the 49th"
+    ref = R.window_attention_core(qkv.double(), rel.double(), nH, D, win, shift)
+    tol = TOL[dtype]["out"] * 1.5
+    check(f"wattn fwd one-row path {H}x{H} h{nH} s{int(shift)}", out[3][0], ref, tol)
+    check(f"wattn fwd 49th query, row vs tile {H}x{H}", o1[:, last], o0[:, last].double(), tol)
+    lse0, lse1 = out[0][1].view(-1, L), out[1][1].view(-1, L)
+    assert torch.equal(lse0[:, :48], lse1[:, :48])
+    check("wattn lse of the 49th query", lse1[:, 48], lse0[:, 48].double(), 1e-5)
+
+
 # ------------------------------------------------------------------ weight gradients at the real token counts
 def _wgrad_ref(dy, x, keep, T, c):
     m = None if keep is None else (keep > 0).double().repeat_interleave(T)[:, None]

@@ -23,6 +23,8 @@
 //     round 2; the scatter survives only behind inv_cells == NULL for the tests.)
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "options.h"
 #include "vtx_common.h"
 
@@ -122,6 +124,19 @@ __device__ __forceinline__ void wa_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// true if every live lane of the wave holds the same region id
+__device__ __forceinline__ bool wa_uniform(uint8_t reg, bool live) {
+  const int first = __builtin_amdgcn_readfirstlane((int)reg);
+  return __ballot(live && (int)reg != first) == 0ull;
+}
+__device__ __forceinline__ float group_max16(float v) {      // max over the 16 lanes of a DPP row, in every lane
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+
 // the head's bias table, built once per workgroup: bias_s[q][k] (row stride WA_BSTR), -inf on padded keys.
 // Column h of rel_pos goes to LDS first (relh, WA_NBIN floats) while the 16 pos loads of every thread are in flight,
 // so the build pays ONE global round trip.
@@ -150,7 +165,7 @@ __device__ __forceinline__ void wa_build_bias(float* bias_s, float* relh, const 
 template <typename T> struct WaSmem {
   static constexpr int kImg = WA_D * WA_STR * (int)sizeof(T);          // one transposed operand image
   static constexpr int kBias = 64 * WA_BSTR * 4;
-  static constexpr int kFwdWave = kImg + 64;                           // Vt + region ids
+  static constexpr int kFwdWave = kImg + 64 + 64 * (int)sizeof(T);     // Vt + region ids + one row of P
   static constexpr int kBwdWave = 3 * kImg + 2 * WA_LP * 4 + WA_NBIN * 4 + 64;
   static constexpr int kFwd = kBias + WA_WAVES * kFwdWave;
   static constexpr int kBwd = kBias + WA_WAVES * kBwdWave;
@@ -183,13 +198,14 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
                                                                   const float* __restrict__ rel_pos,
                                                                   const int64_t* __restrict__ pos,
                                                                   const uint8_t* __restrict__ region, int nbn,
-                                                                  int nblk, int xcd_major, WinGeom g) {
+                                                                  int nblk, int xcd_major, int fast, WinGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
   float* bias_s = reinterpret_cast<float*>(wa_smem);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* wbase = wa_smem + WaSmem<T>::kBias + wave * WaSmem<T>::kFwdWave;
   T* vt = reinterpret_cast<T*>(wbase);
   uint8_t* reg_s = wbase + WaSmem<T>::kImg;
+  T* prow = reinterpret_cast<T*>(wbase + WaSmem<T>::kImg + 64);       // P[48][key] of a 7 x 7 window's last query
   int blk, h;
   wa_block_map(nblk, g.nH, xcd_major, blk, h);
   const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
@@ -200,6 +216,8 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
   WaTok tk;
   wa_tok_init(tk, g, c_);
   const bool w7 = g.L == 49;
+  const bool row48 = w7 && (fast & 1);                // VTX_WATTN_FAST bit 0: the one-row path of the 49th query
+  if (row48) tk.ay[3] = tk.ax[3] = 6;                    // every lane of the last tile reads token 48 (its padded lanes read token 0 otherwise)
 
   for (int bn = blk * WA_WAVES + wave; bn < nbn; bn += nblk * WA_WAVES) {
     const int n = bn % g.nW, b = g.perm ? g.perm[bn / g.nW] : bn / g.nW;
@@ -223,63 +241,108 @@ __global__ __launch_bounds__(64 * WA_WAVES) void wattn_fwd_kernel(const T* __res
     if (MASKED) reg_s[lane] = myreg;
     wa_wave_sync();
 
-    constexpr bool MK = MASKED;
     if (WA_ABLATE & 32) {
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
         if (val[qt]) store8<T>(o + (int64_t)row[qt] * g.hd + h * WA_D + g_ * 8, qf[qt]);
       continue;
     }
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      if (qt * 16 >= g.L) break;
-      const int q = qt * 16 + c_;
-      f32x4 st[4];
-      float m = -INFINITY;
-      const unsigned rq = MK ? reg_s[q] * 0x01010101u : 0u;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mma16(kf[kt], qf[qt], st[kt]);            // st[kt][r] = S[q = 16 qt + c][key = 16 kt + 4 g + r]
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + q * WA_BSTR + kt * 16 + g_ * 4);
-        unsigned rx = 0u;                           // byte r == 0  <=>  key r is in the query's region
-        if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // 7 x 7 windows (49 tokens): keys 49 .. 63 are padding in every lane -- of the last key tile only register 0 (key 48 + 4 g)
-          // can be live.  Their bias is -inf, i.e. p = 0 exactly: skipping them changes no bit (round 5; ~6 % of the VALU work).
-          if (kt == 3 && r > 0 && w7) continue;
-          float sv = st[kt][r] * g.scale + bb[r];
-          if (MK && (rx & (0xffu << (8 * r))) != 0u) sv = -INFINITY;
-          st[kt][r] = sv;
-          m = fmaxf(m, sv);
-        }
-      }
-      m = fmaxf(m, shfl_xor_f(m, 16));
-      m = fmaxf(m, shfl_xor_f(m, 32));
-      float l = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (kt == 3 && r > 0 && w7) { st[kt][r] = 0.f; continue; }
-          st[kt][r] = __expf(st[kt][r] - m);
-          l += st[kt][r];
-        }
-      l += shfl_xor_f(l, 16);
-      l += shfl_xor_f(l, 32);
-      const float inv = 1.f / l;
-      if (val[qt] && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
+    // P V for one query tile from the P^T fragments of its two key halves; lane (c, g) ends up with O[q = 16 qt + c][d = 8 g .. 8 g + 7]
+    auto pv_store = [&](int qt, const Vec8<T>& p0, const Vec8<T>& p1) {
       f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        Vec8<T> pf = wa_frag_acc<T>(st[2 * ks] * inv, st[2 * ks + 1] * inv);
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), pf, oacc[dt]);
-      }
+        for (int dt = 0; dt < 2; ++dt) mma16(wa_frag_t<T>(vt + (dt * 16 + c_) * WA_STR + ks * 32, g_), ks ? p1 : p0, oacc[dt]);
       // oacc[dt][r] = O[q = 16 qt + c][d = 8 g + 4 dt + r]
       if (val[qt]) store8<T>(o + (int64_t)row[qt] * g.hd + h * WA_D + g_ * 8, wa_out8<T>(oacc[0], oacc[1], 1.f));
-    }
+    };
+    auto tiles = [&](auto mk) {
+      constexpr bool MK = decltype(mk)::value;
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        if (qt * 16 >= g.L) break;
+        if (qt == 3 && row48) {
+          // 7 x 7 windows: the last query tile holds ONE live query (token 48).  All 16 rows of the q operand are that query (the
+          // token override above), the product is taken the other way round -- s[0] = S[48][key = 16 kt + c] in EVERY lane -- and the
+          // softmax of the row costs 4 values per lane instead of 16; P goes through 64 elements of LDS into the fragment layout
+          // of the P V product (round 5: ~1/7 of the forward's instructions).
+          float sv[4], m = -INFINITY;
+          const uint8_t r48 = MK ? reg_s[48] : 0;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(qf[3], kf[kt], s);
+            sv[kt] = s[0] * g.scale + bias_s[48 * WA_BSTR + kt * 16 + c_];
+            if (MK && reg_s[kt * 16 + c_] != r48) sv[kt] = -INFINITY;
+            m = fmaxf(m, sv[kt]);
+          }
+          m = group_max16(m);
+          float l = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            sv[kt] = __expf(sv[kt] - m);
+            l += sv[kt];
+          }
+          l = group_sum<16>(l);
+          const float inv = 1.f / l;
+          if (lane == 0) lse[(int64_t)prob * g.L + 48] = m + __logf(l);
+          Vec8<T> one;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            one.set(0, sv[kt] * inv);
+            prow[kt * 16 + c_] = one.v[0];
+          }
+          wa_wave_sync();
+          pv_store(3, wa_frag_t<T>(prow, g_), wa_frag_t<T>(prow + 32, g_));
+          break;
+        }
+        const int q = qt * 16 + c_;
+        f32x4 st[4];
+        float m = -INFINITY;
+        const unsigned rq = MK ? reg_s[q] * 0x01010101u : 0u;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          mma16(kf[kt], qf[qt], st[kt]);            // st[kt][r] = S[q = 16 qt + c][key = 16 kt + 4 g + r]
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + q * WA_BSTR + kt * 16 + g_ * 4);
+          unsigned rx = 0u;                           // byte r == 0  <=>  key r is in the query's region
+          if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // 7 x 7 windows (49 tokens): keys 49 .. 63 are padding in every lane -- of the last key tile only register 0 (key 48 + 4 g)
+            // can be live.  Their bias is -inf, i.e. p = 0 exactly: skipping them changes no bit (round 5; ~6 % of the VALU work).
+            if (kt == 3 && r > 0 && w7) continue;
+            float sv = st[kt][r] * g.scale + bb[r];
+            if (MK && (rx & (0xffu << (8 * r))) != 0u) sv = -INFINITY;
+            st[kt][r] = sv;
+            m = fmaxf(m, sv);
+          }
+        }
+        m = fmaxf(m, shfl_xor_f(m, 16));
+        m = fmaxf(m, shfl_xor_f(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (kt == 3 && r > 0 && w7) { st[kt][r] = 0.f; continue; }
+            st[kt][r] = __expf(st[kt][r] - m);
+            l += st[kt][r];
+          }
+        l += shfl_xor_f(l, 16);
+        l += shfl_xor_f(l, 32);
+        const float inv = 1.f / l;
+        if (val[qt] && g_ == 0) lse[(int64_t)prob * g.L + q] = m + __logf(l);
+        pv_store(qt, wa_frag_acc<T>(st[0] * inv, st[1] * inv), wa_frag_acc<T>(st[2] * inv, st[3] * inv));
+      }
+    };
+    // A window whose tokens all carry one region id (the interior windows of a shifted layer: 49 of the 64 at 56 x 56) has no masked
+    // pair: it takes the unmasked instruction stream (wave-uniform branch; same bits -- the mask arithmetic it skips selects nothing).
+    if (MASKED && !((fast & 2) && wa_uniform(myreg, lane < g.L)))
+      tiles(std::true_type{});
+    else
+      tiles(std::false_type{});
   }
 }
 
@@ -820,7 +883,7 @@ static int wattn_fwd_launch(const void* qkv, void* o, float* lse, const float* r
   if (rc) return rc;
   const int nblk = wattn_fwd_blocks(nbn, g.nH);
   hipLaunchKernelGGL(kern, dim3(nblk * g.nH), dim3(64 * WA_WAVES), WaSmem<T>::kFwd, st,
-                     (const T*)qkv, (T*)o, lse, rel_pos, pos, region, nbn, nblk, wattn_xcd_major(nblk), g);
+                     (const T*)qkv, (T*)o, lse, rel_pos, pos, region, nbn, nblk, wattn_xcd_major(nblk), vtx_opt(VTX_OPT_WATTN_FAST), g);
   return vtx_check_launch();
 }
 

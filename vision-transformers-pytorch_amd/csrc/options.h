@@ -29,7 +29,8 @@ enum VtxOptionId {
   VTX_OPT_GEMM_PP = 19,             // 1: bf16 GEMMs with N % 192 == 0, K % 64 == 0, long contractions (K >= 1152, or K >= 768 with N <= 384) and >= 3/4 of a CU-filling round of 128 x 192 tiles take the two-group kernel (gemm_pp.hip) | 2: any row count, any K | 10W: forced tile height 32 W | 0
   VTX_OPT_LN_ROWS = 20,             // LayerNorm rows in flight per lane group: bit 0 forward, two rows of the three-vector groups (C = 384 / 768 exact fit) | bit 1 backward, two rows of the one- / two-vector groups
   VTX_OPT_SKINNY_WAVES = 21,        // waves per persistent workgroup of the weight-resident streaming GEMMs (gemm_skinny.hip): 4 | 8 | 16
-  VTX_OPT_COUNT = 22
+  VTX_OPT_WATTN_FAST = 22,          // window-attention forward: bit 0, 7 x 7 windows run their 49th query as one row (4 scores per lane) instead of a padded 16-query tile | bit 1, windows of a masked layer whose tokens share one region id take the unmasked instruction stream
+  VTX_OPT_COUNT = 23
 };
 
 int vtx_opt(int id);   // current value (relaxed atomic load); capi.hip
