@@ -270,9 +270,48 @@ def test_wattn_backward_four_waves_per_problem_matches_the_one_wave_kernel_at_be
     check(f"wattn drel_pos, four waves vs one wave per problem (H {H})", a[1], c[1].double(), 2e-5)
 
 
+@pytest.mark.parametrize("B,H,nH,win,shift", [(128, 56, 3, 7, True), (128, 56, 3, 7, False), (128, 14, 12, 7, True), (128, 7, 24, 7, False),
+                                              (3, 28, 6, 7, True), (5, 16, 2, 4, True), (2, 20, 3, 5, False), (1, 12, 2, 6, True)])
+def test_wattn_forward_four_waves_per_problem_is_bitwise_the_one_wave_kernel(B, H, nH, win, shift):
+    """Round 5: the bf16 window-attention forward shares a problem between the four waves of its workgroup (wattn_fwd4_kernel; option
+    WATTN_FWD4): one 16-token tile per wave, rotating from problem to problem, K / V through plain LDS images, next-problem prefetch.
+    Same products in the same order: o and lse must equal the one-wave kernel's bit for bit, at the Swin-S B = 128 geometries (several
+    problems per workgroup: every rotation), at odd problem counts and at windows with padding-only tiles (16, 25, 36 tokens), under
+    every WATTN_FAST setting."""
+    from oracle import tables
+    from vtx import ops, options
+    from vtx.tables import mask_regions
+    d = dev()
+    L, ntab, D = win * win, (2 * win - 1) ** 2, 32
+    pos_np, mask_np = tables.make_pos_mask((H, H), win, shift)
+    pos = torch.from_numpy(pos_np).to(d)
+    region = None
+    if shift:
+        region, ok = mask_regions(torch.from_numpy(mask_np).to(d))
+        assert ok
+    qkv = _mk((B * H * H, 3 * nH * D), 181, BF, device=d)
+    rel = _mk((ntab, nH), 183, torch.float32, 0.5, device=d)
+    swin = (H, H, win, shift)
+    nbn = B * (H // win) ** 2
+    assert ops.wattn_fwd_kernel_name(BF, shift, nbn).startswith("wattn_fwd4_kernel" if nbn >= 4096 else "wattn_fwd_kernel<__bf16")
+    for fast in (3, 0, 1, 2):
+        with options.override(WATTN_FAST=fast, WATTN_FWD4=2):
+            assert ops.wattn_fwd_kernel_name(BF, shift, nbn) == f"wattn_fwd4_kernel<{'true' if shift else 'false'}>"
+            a = ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin)
+            with options.override(WATTN_FWD4=0):
+                assert ops.wattn_fwd_kernel_name(BF, shift, nbn).startswith("wattn_fwd_kernel<__bf16")
+                b = ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin)
+        assert torch.equal(a[0], b[0]), f"o of the four-wave forward differs from the one-wave kernel (WATTN_FAST={fast})"
+        assert torch.equal(a[1], b[1]), f"lse of the four-wave forward differs from the one-wave kernel (WATTN_FAST={fast})"
+    if B <= 8:
+        ref = R.window_attention_core(qkv.view(B, H, H, -1).cpu().double(), rel.cpu().double(), nH, D, win, shift)
+        check(f"wattn fwd4 {H}x{H} win {win} h{nH} s{int(shift)}", a[0].view(B, H, H, -1), ref, TOL[BF]["out"] * 1.5)
+
+
 @pytest.mark.parametrize("dtype", [BF, torch.float32])
 @pytest.mark.parametrize("H,nH,shift", [(56, 3, True), (56, 3, False), (14, 12, True), (7, 24, False)])
-def test_wattn_forward_one_row_path_and_uniform_window_branch(H, nH, shift, dtype):
+@pytest.mark.parametrize("fwd4", [2, 0])
+def test_wattn_forward_one_row_path_and_uniform_window_branch(H, nH, shift, dtype, fwd4):
     """Round 5 (option WATTN_FAST): bit 1 sends the windows of a shifted layer whose tokens share one region id down the
     unmasked instruction stream -- same bits as the masked stream; bit 0 runs the 49th query of a 7 x 7 window as ONE row
     (product taken as q k^T, 4 scores per lane, P through LDS) -- the other 48 queries bit for bit, the 49th within the
@@ -294,7 +333,7 @@ def test_wattn_forward_one_row_path_and_uniform_window_branch(H, nH, shift, dtyp
     swin = (H, H, win, shift)
     out = {}
     for fast in (0, 1, 2, 3):
-        with options.override(WATTN_FAST=fast):
+        with options.override(WATTN_FAST=fast, WATTN_FWD4=fwd4):
             out[fast] = ops.wattn_fwd(qd, reld, pos, region, B, L, nH, swin)
     assert torch.equal(out[2][0], out[0][0]) and torch.equal(out[2][1], out[0][1]), "uniform-window branch changed bits"
     assert torch.equal(out[3][0], out[1][0]) and torch.equal(out[3][1], out[0 + 1][1])

@@ -41,7 +41,7 @@ case "$J" in
   wfast)      # window-attention forward under WATTN_FAST: the option test, the micro-benchmark, the train step
     timeout 900 python -m pytest tests/test_gpu_dispatch.py -m gpu -x -q -k "wattn or window" 2>&1 | tail -15 > $LOG
     timeout 600 python tools/r5/wattn_fast_check.py 2>&1 | grep -v amdgpu.ids >> $LOG
-    for rep in 1 2; do for v in 0 3; do
+    for rep in 1 2; do for v in "0 VTX_WATTN_FWD4=0" "3 VTX_WATTN_FWD4=0" "3 VTX_WATTN_FWD4=1"; do
       echo "== WATTN_FAST=$v" >> $LOG
       env VTX_WATTN_FAST=$v timeout 600 python bench.py --model swin_s --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | grep '"metric"' | cut -c1-200 >> $LOG
     done; done

@@ -34,6 +34,10 @@ def timeit(fn, nset, iters=20):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--all", action="store_true", help="every WATTN_FAST value (default: 0 and 3)")
+    a = ap.parse_args()
     B, win, L, D = 128, 7, 49, 32
     g = torch.Generator(device=dev).manual_seed(3)
     for H, nH in ((56, 3), (28, 6), (14, 12), (7, 24)):
@@ -49,15 +53,14 @@ def main():
             nbytes = 4 * B * H * H * nH * D * 2
             row = [f"{H:2d}x{H:<2d} heads {nH:2d} {'shifted' if shift else 'plain  '} {nbytes / 1e6:6.1f} MB"]
             best = {}
-            for order in ((0, 1, 2, 3), (3, 2, 1, 0), (0, 1, 2, 3)):          # (clocks drift over a process: best of three passes in both orders)
-                for fast in order:
-                    if (fast & 2) and not shift:
-                        continue
-                    with options.override(WATTN_FAST=fast):
+            cfgs = [(f4, fast) for f4 in (0, 2) for fast in ((0, 1, 2, 3) if a.all else (0, 3)) if shift or not (fast & 2) or fast == 3]
+            for order in (cfgs, cfgs[::-1], cfgs):          # (clocks drift over a process: best of three passes in both orders)
+                for f4, fast in order:
+                    with options.override(WATTN_FAST=fast, WATTN_FWD4=f4):
                         t = timeit(lambda i: ops.wattn_fwd(qkv[i], rel, pos, region, B, L, nH, (H, H, win, shift)), nset)
-                    best[fast] = min(t, best.get(fast, 1e9))
-            for fast, t in sorted(best.items()):
-                row.append(f"FAST={fast} {t:6.1f} us {nbytes / t / 1e6:5.2f} TB/s")
+                    best[(f4, fast)] = min(t, best.get((f4, fast), 1e9))
+            for (f4, fast), t in sorted(best.items()):
+                row.append(f"{'4w' if f4 else '1w'} FAST={fast} {t:6.1f} us {nbytes / t / 1e6:5.2f} TB/s")
             print(" | ".join(row), flush=True)
             del qkv
 

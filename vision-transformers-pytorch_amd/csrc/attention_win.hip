@@ -820,6 +820,229 @@ __global__ __launch_bounds__(64 * WA_WAVES, WA4_OCC) void wattn_bwd4_kernel(
   }
 }
 
+// --------------------------------------------------------------------------------------------- forward, 4 waves per problem
+// Round 5 (bf16).  The one-wave forward above pays each problem's 12 global loads, ~1 300 instructions and the stores one after the
+// other per wave (116 registers: 4 waves per SIMD, no room for a prefetch -- measured slower with one in round 4): its stage-1 launch
+// sits at 78 us, 22 us above what its loads and stores alone take (profiles/round5_wattn_fwd_row_path.txt).  Here, as in the backward
+// above, the four waves of the persistent workgroup share ONE problem: a wave owns one 16-token tile -- it loads only those rows
+// (3 x 16 B per lane; the NEXT problem's rows are requested right after the staging barrier, 12 registers), puts its K and V rows
+// into plain [token][d] LDS images, and runs scores / softmax / P V for its 16 queries against all keys (K fragments: ds_read_b128,
+// V contracted over tokens: ds_read_b64_tr_b16).  The tile a wave owns ROTATES from problem to problem ((wave + iteration) % 4): the
+// last tile of a 7 x 7 window holds one live query (the one-row path of the one-wave kernel), and the wave index decides the SIMD --
+// without the rotation one SIMD of every CU would idle.  Arithmetic per element is that of the one-wave kernel (bit for bit).
+#ifndef WF4_OCC
+#define WF4_OCC 5        // workgroups per CU the four-wave forward is compiled for
+#endif
+#ifndef WF4_PF
+#define WF4_PF 1         // problems a wave has requested ahead of the one it works on (1 | 2; measured: 2 is 3-10 % slower, the loads-only floor does not move)
+#endif
+#ifndef WF4_COAL
+#define WF4_COAL 0       // 1: global loads / stores with lane -> (token lane / 4, 16-byte piece lane % 4): a quarter wave touches 4 lines of
+#endif                   //    64 contiguous bytes instead of 16 lines of 16 bytes; Q and O pass through LDS for the MFMA layout | 0: lane -> (c, g)
+                         //    (measured: no gain -- the loads-only floor is the same 63 us at stage 1; profiles/round5_wattn_fwd4.txt)
+#ifndef WF4_DB
+#define WF4_DB 0         // 1: two sets of K / V images and region ids, ONE workgroup barrier per problem instead of two
+#endif
+struct Wf4Smem {
+  static constexpr int kBias = WA4_BROWS * WA_BSTR * 4;
+  static constexpr int kPlain = WA_LP * WA4_PSTR * 2;          // one plain image (bf16)
+  static constexpr int kRow = 64 * 2;                          // P[48][key] of the one-row path
+  static constexpr int kSmall = 64;                            // region ids
+  static constexpr int kSet = (2 + WF4_COAL) * kPlain + kSmall; // K, V [, Q / O], region ids of one problem
+  static constexpr int kTotal = kBias + kRow + (1 + WF4_DB) * kSet;
+};
+static_assert(WF4_OCC * Wf4Smem::kTotal <= 160 * 1024, "WF4_OCC workgroups per CU");
+static_assert(WA_NBIN * 4 <= Wf4Smem::kPlain, "the rel_pos column scratch of the table build must fit the K image");
+
+template <bool MASKED>
+__global__ __launch_bounds__(64 * WA_WAVES, WF4_OCC) void wattn_fwd4_kernel(
+    const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse, const float* __restrict__ rel_pos,
+    const int64_t* __restrict__ pos, const uint8_t* __restrict__ region, int nbn, int nblk, int xcd_major, int fast, WinGeom g) {
+  using T = bf16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wa_smem[];
+  float* bias_s = reinterpret_cast<float*>(wa_smem);
+  unsigned char* base = wa_smem + Wf4Smem::kBias;
+  T* prow = reinterpret_cast<T*>(base);
+  base += Wf4Smem::kRow;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, c_ = lane & 15, g_ = lane >> 4;
+  const int lt = WF4_COAL ? lane >> 2 : c_, lp = WF4_COAL ? lane & 3 : g_;      // global-memory side: token of the tile, 16-byte piece
+  int blk, h;
+  wa_block_map(nblk, g.nH, xcd_major, blk, h);
+  const int64_t ld = 3 * (int64_t)g.hd;
+  wa_build_bias(bias_s, reinterpret_cast<float*>(base), rel_pos, pos, g.L, g.nH, h, (2 * g.win - 1) * (2 * g.win - 1), WA4_BROWS);
+  __syncthreads();                                    // table complete; the relh scratch (the K image) is free again
+  const bool w7 = g.L == 49;
+  const bool row48 = w7 && (fast & 1);
+  // this lane's token of each tile, (ay | ax << 8 | live << 16) inside its window, once per kernel (see WaTok); four scalars, not an
+  // array: the tile index is a run-time value and an indexed array would live in scratch.  With the one-row path every lane of
+  // the last tile reads token 48 (see the one-wave kernel).
+  auto tok_pack = [&](int t4) {
+    const int tok = 16 * t4 + lt;
+    const bool live = tok < g.L;
+    const int tc = (t4 == 3 && row48) ? 48 : (live ? tok : 0);
+    const int ay = tc / g.win;
+    return ay | ((tc - ay * g.win) << 8) | ((int)live << 16);
+  };
+  const int tp0 = tok_pack(0), tp1 = tok_pack(1), tp2 = tok_pack(2), tp3 = tok_pack(3);
+
+  // this wave's rows of the problems to come (WF4_PF of them in flight), + wave 0: the region ids
+  struct Rows { Vec8<T> q, k, v; int row; uint8_t reg; };
+  auto request = [&](int bn, int t, Rows& s) __attribute__((always_inline)) {
+    const int n = bn % g.nW, b = g.perm ? g.perm[bn / g.nW] : bn / g.nW;
+    const int wi = n / g.nWx, wj = n - wi * g.nWx;
+    const int tp = t == 0 ? tp0 : t == 1 ? tp1 : t == 2 ? tp2 : tp3;
+    const int ay = tp & 0xff, ax = (tp >> 8) & 0xff;
+    int y = wi * g.win + ay + g.shift;
+    y -= y >= g.H ? g.H : 0;
+    int x = wj * g.win + ax + g.shift;
+    x -= x >= g.W ? g.W : 0;
+    s.row = (b * g.H + y) * g.W + x;
+    const T* p = qkv + (int64_t)s.row * ld + h * WA_D + lp * 8;
+    s.q = load8<T>(p);
+    s.k = load8<T>(p + g.hd);
+    s.v = load8<T>(p + 2 * g.hd);
+    if (MASKED && w == 0) s.reg = region[(int64_t)n * 64 + lane];
+  };
+  // (WF4_PF named sets, loop unrolled by as many: a register copy between sets would wait for the loads in flight)
+  Rows rs[WF4_PF];
+#pragma unroll
+  for (int u = 0; u < WF4_PF; ++u) {
+    rs[u].reg = 0;
+    if (blk + u * nblk < nbn) request(blk + u * nblk, (w + u) & 3, rs[u]);
+  }
+  for (int bn = blk, it = 0; bn < nbn;) {
+#pragma unroll
+  for (int u = 0; u < WF4_PF; ++u, bn += nblk, ++it) {
+    if (bn >= nbn) break;
+    Rows& nx = rs[u];
+    const int t = (w + it) & 3;                       // this wave's token tile of this problem
+    const Vec8<T> qg = nx.q, kf = nx.k, vf = nx.v;    // rows of token 16 t + lt, piece lp
+    const int row = nx.row;
+    const uint8_t myreg = nx.reg;
+    const int tok = 16 * t + c_, ltok = 16 * t + lt;
+    const bool val = tok < g.L;                       // the query of the MFMA layout is live
+    const bool gval = ((t == 0 ? tp0 : t == 1 ? tp1 : t == 2 ? tp2 : tp3) >> 16) != 0;   // the token of the global-memory layout is
+    const int prob = bn * g.nH + h;
+    unsigned char* set = base + (WF4_DB ? (it & 1) * Wf4Smem::kSet : 0);
+    T* pk = reinterpret_cast<T*>(set);                // K [token][d]
+    T* pv = reinterpret_cast<T*>(set + Wf4Smem::kPlain);
+    T* pq = reinterpret_cast<T*>(set + 2 * Wf4Smem::kPlain);        // (WF4_COAL) Q, later O: a wave touches the rows of its own tile only
+    uint8_t* reg_s = set + (2 + WF4_COAL) * Wf4Smem::kPlain;
+    if (!WF4_DB && bn != blk) wa_wg_sync();           // every wave is done reading the previous problem's images
+    *reinterpret_cast<Vec8<T>*>(pk + ltok * WA4_PSTR + lp * 8) = kf;
+    *reinterpret_cast<Vec8<T>*>(pv + ltok * WA4_PSTR + lp * 8) = vf;
+    if (WF4_COAL) *reinterpret_cast<Vec8<T>*>(pq + ltok * WA4_PSTR + lp * 8) = qg;
+    if (MASKED && w == 0) reg_s[lane] = myreg;
+    wa_wg_sync();                                     // (two image sets: a wave is at most one problem ahead of the slowest)
+    // global latency of the problems to come runs under this one's arithmetic
+    if (bn + WF4_PF * nblk < nbn) request(bn + WF4_PF * nblk, (w + it + WF4_PF) & 3, nx);
+    if (WA_ABLATE & 32) {
+      if (gval) store8<T>(o + (int64_t)row * g.hd + h * WA_D + lp * 8, qg);
+      continue;
+    }
+    if (16 * t >= g.L) continue;                      // a tile of padding only
+    Vec8<T> qf = qg;                                  // MFMA layout: token 16 t + c, channels 8 g .. 8 g + 7
+    if (WF4_COAL) qf = *reinterpret_cast<const Vec8<T>*>(pq + tok * WA4_PSTR + g_ * 8);
+
+    // P V for this tile from the P^T fragments of the two key halves; lane (c, g) ends up with O[q = 16 t + c][d = 8 g .. 8 g + 7]
+    auto pv_store = [&](const Vec8<T>& p0, const Vec8<T>& p1) {
+      f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) mma16(wa4_frag_trp(pv, ks * 32, dt, lane), ks ? p1 : p0, oacc[dt]);
+      Vec8<T> ov = wa_out8<T>(oacc[0], oacc[1], 1.f);
+      if (WF4_COAL) {                                 // back to the global-memory layout through this tile's rows of the Q image
+        wa_wave_sync();
+        *reinterpret_cast<Vec8<T>*>(pq + tok * WA4_PSTR + g_ * 8) = ov;
+        wa_wave_sync();
+        ov = *reinterpret_cast<const Vec8<T>*>(pq + ltok * WA4_PSTR + lp * 8);
+      }
+      if (gval) store8<T>(o + (int64_t)row * g.hd + h * WA_D + lp * 8, ov);
+    };
+    auto tile = [&](auto mk) {
+      constexpr bool MK = decltype(mk)::value;
+      if (t == 3 && row48) {                          // the 49th query as one row (see the one-wave kernel)
+        float sv[4], m = -INFINITY;
+        const uint8_t r48 = MK ? reg_s[48] : 0;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const Vec8<T> kk = *reinterpret_cast<const Vec8<T>*>(pk + (16 * kt + c_) * WA4_PSTR + g_ * 8);
+          f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+          mma16(qf, kk, s);
+          sv[kt] = s[0] * g.scale + bias_s[48 * WA_BSTR + kt * 16 + c_];
+          if (MK && reg_s[kt * 16 + c_] != r48) sv[kt] = -INFINITY;
+          m = fmaxf(m, sv[kt]);
+        }
+        m = group_max16(m);
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          sv[kt] = __expf(sv[kt] - m);
+          l += sv[kt];
+        }
+        l = group_sum<16>(l);
+        const float inv = 1.f / l;
+        if (lane == 0) lse[(int64_t)prob * g.L + 48] = m + __logf(l);
+        Vec8<T> one;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          one.set(0, sv[kt] * inv);
+          prow[kt * 16 + c_] = one.v[0];
+        }
+        wa_wave_sync();
+        pv_store(wa_frag_t<T>(prow, g_), wa_frag_t<T>(prow + 32, g_));
+        return;
+      }
+      const int q = val ? tok : 0;                    // (padded queries: any table row, nothing of theirs is stored)
+      f32x4 st[4];
+      float m = -INFINITY;
+      const unsigned rq = MK ? reg_s[tok] * 0x01010101u : 0u;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const Vec8<T> kk = *reinterpret_cast<const Vec8<T>*>(pk + (16 * kt + c_) * WA4_PSTR + g_ * 8);
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma16(kk, qf, st[kt]);                        // st[kt][r] = S[q = 16 t + c][key = 16 kt + 4 g + r]
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + q * WA_BSTR + kt * 16 + g_ * 4);
+        unsigned rx = 0u;                             // byte r == 0  <=>  key r is in the query's region
+        if (MK) rx = *reinterpret_cast<const unsigned*>(reg_s + kt * 16 + g_ * 4) ^ rq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt == 3 && r > 0 && w7) continue;       // always-padded keys of 7 x 7 windows: p = 0
+          float sv = st[kt][r] * g.scale + bb[r];
+          if (MK && (rx & (0xffu << (8 * r))) != 0u) sv = -INFINITY;
+          st[kt][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      }
+      m = fmaxf(m, shfl_xor_f(m, 16));
+      m = fmaxf(m, shfl_xor_f(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt == 3 && r > 0 && w7) { st[kt][r] = 0.f; continue; }
+          st[kt][r] = __expf(st[kt][r] - m);
+          l += st[kt][r];
+        }
+      l += shfl_xor_f(l, 16);
+      l += shfl_xor_f(l, 32);
+      const float inv = 1.f / l;
+      if (val && g_ == 0) lse[(int64_t)prob * g.L + tok] = m + __logf(l);
+      pv_store(wa_frag_acc<T>(st[0] * inv, st[1] * inv), wa_frag_acc<T>(st[2] * inv, st[3] * inv));
+    };
+    bool masked = MASKED;
+    if (MASKED && (fast & 2)) masked = !wa_uniform(reg_s[lane], lane < g.L);
+    if (masked)
+      tile(std::true_type{});
+    else
+      tile(std::false_type{});
+  }
+  }
+}
+
 static int win_geom(WinGeom& g, int L, int nH, int H, int W, int win, int shift) {
   if (win <= 0 || H % win || W % win || L != win * win || L > WA_LP) return VTX_ERR_SHAPE;
   if ((2 * win - 1) * (2 * win - 1) > WA_NBIN) return VTX_ERR_SHAPE;
@@ -862,6 +1085,14 @@ static int wattn_bwd4_blocks(int nbn, int nH) {
   if (blocks >= 8 && vtx_opt(VTX_OPT_WATTN_XCD_MAJOR)) blocks = (blocks + 7) / 8 * 8;
   return blocks;
 }
+static int wattn_fwd4_blocks(int nbn, int nH) {
+  int per_head = 256 * WF4_OCC / nH;
+  if (per_head < 1) per_head = 1;
+  const int ppw = (nbn + per_head - 1) / per_head;            // problems per workgroup
+  int blocks = (nbn + ppw - 1) / ppw;
+  if (blocks >= 8 && vtx_opt(VTX_OPT_WATTN_XCD_MAJOR)) blocks = (blocks + 7) / 8 * 8;
+  return blocks;
+}
 // rows of rel_pos-gradient partials a backward launch leaves ([rows][172 * nH]): whichever kernel runs fills them all
 static int wattn_bwd_rows(int nbn, int nH) {
   const int a = wattn_bwd_blocks(nbn, nH) * WA_WAVES, b = wattn_bwd4_blocks(nbn, nH);
@@ -878,6 +1109,18 @@ template <typename K> static int wa_smem_attr(K kern, int bytes) {
 template <typename T, bool MASKED>
 static int wattn_fwd_launch(const void* qkv, void* o, float* lse, const float* rel_pos, const int64_t* pos,
                             const uint8_t* region, int nbn, const WinGeom& g, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    // four waves per problem: measured faster only with many problems per head (Swin-S stage 1, 8 192: 70 vs 75-76 us; stage 3, 512: 23.0-23.8
+    // vs 22.5-23.0 us; profiles/round5_wattn_fwd4.txt)
+    const int f4 = vtx_opt(VTX_OPT_WATTN_FWD4);
+    if (f4 >= 2 || (f4 == 1 && nbn >= 4096)) {
+      const int nb4 = wattn_fwd4_blocks(nbn, g.nH);
+      hipLaunchKernelGGL(wattn_fwd4_kernel<MASKED>, dim3(nb4 * g.nH), dim3(64 * WA_WAVES), Wf4Smem::kTotal, st,
+                         (const bf16*)qkv, (bf16*)o, lse, rel_pos, pos, region, nbn, nb4, wattn_xcd_major(nb4),
+                         vtx_opt(VTX_OPT_WATTN_FAST), g);
+      return vtx_check_launch();
+    }
+  }
   auto kern = wattn_fwd_kernel<T, MASKED>;
   int rc = wa_smem_attr(kern, WaSmem<T>::kFwd);
   if (rc) return rc;

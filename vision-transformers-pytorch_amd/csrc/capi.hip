@@ -14,7 +14,7 @@ const OptDef kOptDefs[VTX_OPT_COUNT] = {
     {"VTX_LN_FIT", 1},      {"VTX_GLDS_EPI", 1},    {"VTX_SATTN_WAVES", 8},
     {"VTX_WATTN_BWD4", 1},  {"VTX_GEMM_SKINNY", 1}, {"VTX_GEMM_ASTAT", 1},
     {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1}, {"VTX_GEMM_PP", 1},
-    {"VTX_LN_ROWS", 0},     {"VTX_SKINNY_WAVES", 4}, {"VTX_WATTN_FAST", 3},
+    {"VTX_LN_ROWS", 0},     {"VTX_SKINNY_WAVES", 4}, {"VTX_WATTN_FAST", 3}, {"VTX_WATTN_FWD4", 1},
 };
 struct OptTable {
   std::atomic<int> v[VTX_OPT_COUNT];

@@ -258,8 +258,7 @@ def _describe_timer_rec(r):
     if r.tag in (3, 6):                                                 # window attention: n heads of 32, k tokens per window
         bwd = r.tag == 6
         nprob = rows // k * n
-        name = (wattn_bwd_kernel_name(dt, bool(fl & 16)) if bwd else
-                f"wattn_fwd_kernel<{tn}, {'true' if fl & 16 else 'false'}>")
+        name = wattn_bwd_kernel_name(dt, bool(fl & 16)) if bwd else wattn_fwd_kernel_name(dt, bool(fl & 16), rows // k)
         return name, (10.0 if bwd else 4.0) * nprob * k * k * 32, (8.0 if bwd else 4.0) * rows * n * 32 * es, r.ms
     if r.tag in (4, 7):                                                 # global attention: n heads of D, k tokens per image
         bwd = r.tag == 7
@@ -295,6 +294,16 @@ def _describe_timer_rec(r):
         kern = "patchify_kernel" if not fl & 64 else "twins_subsample_kernel"
         return kern, 0.0, (3.0 if fl & 1 else 2.0) * rows * n * es, r.ms
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
+
+
+def wattn_fwd_kernel_name(dtype, masked, nbn):
+    """Mirrors wattn_fwd_launch (attention_win.hip): bf16 with >= 4 096 (image, window) problems per head takes the four-wave kernel
+    (option WATTN_FWD4: 1 | 2 always | 0 never)."""
+    m = "true" if masked else "false"
+    f4 = options.get("WATTN_FWD4")
+    if dtype == torch.bfloat16 and (f4 >= 2 or (f4 == 1 and nbn >= 4096)):
+        return f"wattn_fwd4_kernel<{m}>"
+    return f"wattn_fwd_kernel<{'__bf16' if dtype == torch.bfloat16 else 'float'}, {m}>"
 
 
 def wattn_bwd_kernel_name(dtype, masked, inverse_map=True):
@@ -1181,8 +1190,7 @@ def wattn_fwd(qkv, rel_pos, pos, region, B, L, n_head, swin):
     o = torch.empty(qkv.shape[:-1] + (n_head * 32,), dtype=qkv.dtype, device=qkv.device)
     nW = (H // win) * (W // win)
     lse = torch.empty(B * nW * n_head * L, dtype=torch.float32, device=qkv.device)
-    tn = "__bf16" if qkv.dtype == torch.bfloat16 else "float"
-    ev = _attn_bracket(f"wattn_fwd_kernel<{tn}, {'true' if region is not None else 'false'}>", B * nW * n_head, L, 32,
+    ev = _attn_bracket(wattn_fwd_kernel_name(qkv.dtype, region is not None, B * nW), B * nW * n_head, L, 32,
                        B * nW * L, n_head * 32, qkv.element_size(), False)
     check(_lib.load().vtx_wattn_fwd(_p(qkv), _p(o), _p(lse), _p(rel_pos), _p(pos), _p(region), B, L, n_head, H, W, win,
                                     int(bool(shift)), _dt(qkv), _stream()), "vtx_wattn_fwd")
