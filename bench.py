@@ -394,6 +394,17 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
     if rank == 0:
         if timer is not None:
             allk = timer.summary()
+            if args.shape_table:
+                rows_ = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+                with open(args.shape_table, "w") as f:
+                    f.write(f"{model_name} B = {batch}: launches timed inside libvtx over {nsampled} sampled step(s), HIP events on the launch stream; "
+                            "shape = rows x n x k of the timer record (GEMM: C[rows, n] over k; LayerNorm: rows x C; attention: tokens x heads x "
+                            "tokens per problem; grouped weight gradient: tokens x C x ff); bytes / flops algorithmic\n\n")
+                    f.write("| kernel | shape | launches / step | avg us | ms / step | GB/s | TFLOP/s |\n|---|---|---|---|---|---|---|\n")
+                    for (kn, shp), v in rows_:
+                        us = v["ms"] / v["launches"] * 1e3
+                        f.write(f"| `{kn}` | {shp} | {v['launches'] / nsampled:.1f} | {us:.1f} | {v['ms'] / nsampled:.3f} | "
+                                f"{v['bytes'] / v['ms'] / 1e6:.0f} | {v['flops'] / v['ms'] / 1e9:.0f} |\n")
             peak = PEAK_BF16_TFLOPS if ac else PEAK_F32_TFLOPS
             sampled_ms = sum(a.elapsed_time(b) for a, b in step_events) / nsampled
 
@@ -461,6 +472,7 @@ def main():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--shape-table", default="", help="write the per-(kernel, shape) table of the sampled steps' in-library launches to this file")
     ap.add_argument("--event-every", type=int, default=0,
                     help="HIP-event brackets around every kernel launch in every N-th timed step; 0 (default): only in the "
                          "first timed step.  A sampled step runs single-stream and each bracket costs ~2 us of stream "

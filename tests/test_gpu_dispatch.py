@@ -192,6 +192,34 @@ def test_a_stationary_gemm_with_a_partial_last_strip_is_bitwise_the_tiled_kernel
         assert torch.equal(a, g), f"{name} differs"
 
 
+@pytest.mark.parametrize("M,N,K", [(100352, 576, 192), (128 * 49 * 4 + 77, 576, 192), (25088 + 5, 320, 384), (12800, 448, 256), (3000, 832, 320)])
+def test_a_stationary_gemm_with_a_ragged_last_column_tile_is_bitwise_the_tiled_kernel(M, N, K):
+    """Round 5: N % 128 == 64 (Swin-S stage-2 qkv forward, N = 576).  In the last column tile of a strip the second wave column works on
+    the first one's 64 columns again (same weight rows, same bits to the same addresses), so every wave still stores every vector;
+    plain and bias-only launches only -- the other kinds stay on the tiled kernel."""
+    from vtx import ops, options
+    d = dev()
+    assert N % 128 == 64
+    x, w, b = _mk((M, K), 191, BF, device=d), _mk((N, K), 192, BF, 0.05, device=d), _mk((N,), 193, torch.float32, 0.1, device=d)
+    res = _mk((M, N), 195, BF, device=d)
+
+    def run():
+        return ops.gemm(x, w, 0, bias=b), ops.gemm(x, w, 0), ops.gemm(x, w, 0, bias=b, resid=res)
+
+    with options.override(GEMM_ASTAT=0, GEMM_PP=0):
+        assert not ops.gemm_kernel_name(BF, N, 0, K=K, M=M).startswith("gemm_astat_kernel")
+        base = run()
+    with options.override(GEMM_ASTAT=2, GEMM_PP=0):
+        assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M).startswith("gemm_astat_kernel")
+        assert not ops.gemm_kernel_name(BF, N, 0, K=K, M=M, vec=True).startswith("gemm_astat_kernel")
+        got = run()
+    for a, g, name in zip(base, got, ("bias", "plain", "bias + residual (tiled kernel in both runs)")):
+        assert torch.equal(a, g), f"{name} differs"
+    if M == 100352:
+        assert ops.gemm_kernel_name(BF, N, 0, K=K, M=M).startswith("gemm_astat_kernel<3"), "the stage-2 qkv forward must take this kernel by default"
+    check(f"astat ragged N {M}x{N}x{K}", got[0], _mm64(x.cpu(), w.cpu()) + b.cpu().double(), TOL[BF]["out"])
+
+
 @pytest.mark.parametrize("M,N,K,T", [(66395, 288, 96, 49), (66395, 96, 96, 49), (66395, 384, 96, 49),
                                      (40100, 128, 64, 100), (33100, 256, 128, 100), (36100, 512, 64, 100),
                                      (33100, 1024, 128, 100), (33100, 2048, 64, 100)])   # (column chunks: 2, 4)

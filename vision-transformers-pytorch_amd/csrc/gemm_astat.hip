@@ -83,6 +83,9 @@ struct AstatSched {
   int ntiles;         // tiles of the COMPUTED strips (rows [0, Mk) of a mapped launch)
   int nwg;            // persistent workgroups (== gridDim.x)
   int copy_row0;      // mapped launch with a residual: rows [copy_row0, M) are copy-only (C = resid); == M otherwise
+  int ragged;         // N % 128 == 64 (round 5: Swin-S stage-2 qkv, N = 576): in the LAST column tile of a strip the second wave column works
+                      // on the FIRST one's 64 columns again -- same weight rows, same bits stored to the same addresses (as the rows past M of
+                      // a partial last strip): every wave still stores every vector, the counted waits do not change
 };
 
 // logical row -> row of the operands (GemmArgs::perm through its LDS copy; identity without a map); *smp: the sample whose
@@ -234,11 +237,12 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
         const int n = 64 * (r >> 6) + 4 * (r & 15) + ((r >> 4) & 3);
         wsrc[j] = (const bf16*)p.B + (int64_t)n * p.ldb + ((slot ^ (r & 7)) << 3);
       }
+      const int64_t wrag = sc.ragged ? -64 * (int64_t)p.ldb : 0;     // ragged last column tile: LDS rows 64 .. 127 <- the weight rows of rows 0 .. 63
       const int64_t wtile = (int64_t)AS_BN * p.ldb;       // elements between column tiles of W
       auto issue_w = [&](int tnw, int kt, int stage) {
 #pragma unroll
         for (int j = 0; j < AS_LW; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[j] + tnw * wtile + kt * AS_BK),
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[j] + tnw * wtile + kt * AS_BK + ((tnw == ntn - 1 && ((lw * AS_RPW + j * 8) >> 6)) ? wrag : 0)),
                                            (lds_void_t*)(sw + stage * AS_KT_BYTES + (lw * AS_RPW + j * 8) * ROWB), 16, 0, 0);
       };
       // A refill: LDS row r <- row r of the NEXT strip (row map applied; rows past the computed ones read the last one)
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 
   if constexpr (VEC) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) request_vec(v, row_entry(strip, v).x + colq, tn * AS_BN);
+    for (int v = 0; v < NV; ++v) request_vec(v, row_entry(strip, v).x + colq, tn * AS_BN - ((sc.ragged && tn == ntn - 1 && wn == 1) ? 64 : 0));
   }
   int stage = 0;
 #if ASTAT_TRACE
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
   // one tile period: NKT k-steps of tile (strip, tn); EPI: with the previous tile's epilogue behind the MFMAs (a compile-time flag:
   // as a run-time branch it splits every k-step into basic blocks and the MFMAs cannot be scheduled among the epilogue's VALU work)
   auto tile_period = [&](auto EPI, bool last_of_strip) {
-    const int n0 = tn * AS_BN;
+    const int n0 = tn * AS_BN - ((sc.ragged && tn == ntn - 1 && wn == 1) ? 64 : 0);     // (ragged last tile: see AstatSched)
     if (last_of_strip) {                                    // the next strip's row tables (see srow / srowa), one row per lane
       if (lane < AS_BM / AS_NCW) fill_row(strip + 1, wave * (AS_BM / AS_NCW) + lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (written before this wave reaches the barrier below)
@@ -563,7 +567,9 @@ static int astat_cus() { return vtx_cu_count_cached(); }
 bool gemm_astat_ok(const GemmArgs& a) {
   const int mode = vtx_opt(VTX_OPT_GEMM_ASTAT);
   if (mode == 0) return false;
-  if (a.K % 64 != 0 || a.K < 192 || a.K > 384 || a.N % 128 != 0 || a.N < 256 || (a.N > AS_MAXN && a.bias != nullptr)) return false;
+  if (a.K % 64 != 0 || a.K < 192 || a.K > 384 || a.N % 64 != 0 || a.N < 256 || (a.N > AS_MAXN && a.bias != nullptr)) return false;
+  // N % 128 == 64 (a ragged last column tile, see AstatSched): plain / bias-only launches (the stage-2 qkv forward of Swin-S, N = 576)
+  if (a.N % 128 != 0 && (a.resid != nullptr || a.aux_in != nullptr || a.aux_out != nullptr || a.act != 0 || a.perm != nullptr)) return false;
   if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
   if ((int64_t)a.M * a.ldc >= (1ll << 30) || (int64_t)a.M * a.lda >= (1ll << 30)) return false;    // 32-bit byte offsets
   if (a.kscale != nullptr || a.ksum_out != nullptr) return false;
@@ -574,7 +580,7 @@ bool gemm_astat_ok(const GemmArgs& a) {
   if ((a.resid == a.C || a.aux_in == a.C || a.aux_out == a.C || a.A == a.C) && a.M % AS_BM != 0) return false;
   const long rows = a.perm != nullptr ? a.Mk : a.M;
   if (rows <= 0) return false;
-  const long tiles = (rows + AS_BM - 1) / AS_BM * (a.N / AS_BN);
+  const long tiles = (rows + AS_BM - 1) / AS_BM * ((a.N + AS_BN - 1) / AS_BN);
   if (mode != 2 && 4 * tiles < (mode == 3 ? 5L : 8L) * astat_cus()) return false;      // under two tiles per CU (mode 3: 1.25): the tiled kernels' job
   if (a.rowscale != nullptr && (a.rows_per_scale <= 0 || (a.M + a.rows_per_scale - 1) / a.rows_per_scale > AS_MAXS)) return false;
   if (a.perm != nullptr) {
@@ -592,7 +598,8 @@ template <int NKT, bool MAPPED, int ACT, bool RESID, bool AUX> static int astat_
   const int rows = MAPPED ? a.Mk : a.M;
   const int nstrips = (rows + AS_BM - 1) / AS_BM;
   AstatSched sc;
-  sc.ntn = a.N / AS_BN;
+  sc.ntn = (a.N + AS_BN - 1) / AS_BN;
+  sc.ragged = a.N % AS_BN != 0;
   sc.ntiles = nstrips * sc.ntn;
   sc.nwg = sc.ntiles < astat_cus() ? sc.ntiles : astat_cus();
   sc.copy_row0 = (MAPPED && a.resid != nullptr && nstrips * AS_BM < a.M) ? nstrips * AS_BM : a.M;

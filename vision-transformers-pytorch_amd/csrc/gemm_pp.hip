@@ -365,8 +365,10 @@ bool gemm_pp_ok(const GemmArgs& a) {
   if (mode == 0) return false;
   if (a.N % PP_BN != 0 || a.K % 64 != 0) return false;
   // where it wins (profiles/round5_gemm_pp_microbench.txt): long contractions -- K >= 1152, or K >= 768 under narrow outputs (N <= 384);
-  // the K <= 384 layers stay on the A-stationary kernel, K = 768 with N >= 768 (Swin stage 4 qkv / fc1 / fc2-dgrad) on the tiled one
-  if (mode < 2 && !(a.K >= 1152 || (a.K >= 768 && a.N <= 384))) return false;
+  // the K <= 384 layers stay on the A-stationary kernel, K = 768 with N >= 768 (Swin stage 4 qkv / fc1 / fc2-dgrad) on the tiled one;
+  // one column tile (N = 192: Swin stage-2 qkv dgrad K = 576, patch merging 1 -> 2 K = 384) from K = 384 up (tools/r5/tail_shapes.py:
+  // 45.9 vs 55.2 us, 36.8 vs 42.3 us; K = 192 loses, 26.4 vs 22.4 us)
+  if (mode < 2 && !(a.K >= 1152 || (a.K >= 768 && a.N <= 384) || (a.K >= 384 && a.N == PP_BN))) return false;
   if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
   if (a.kscale != nullptr || a.ksum_out != nullptr) return false;
   if ((a.act == 2 || a.act == 4) && a.aux_in == nullptr) return false;

@@ -146,6 +146,7 @@ class KernelTimer:
     def __init__(self):
         self.records = []
         self.extra = []            # (name, flops, bytes, ms): launches timed inside libvtx (vtx_timer_*: the one-call layers)
+        self.shapes = []           # per `extra` record: "rows x n x k flags f" of the launch (tools: per-shape tables)
 
     def bracket(self, name, flops, nbytes=0.0):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -165,6 +166,17 @@ class KernelTimer:
             d["ms"] += e0.elapsed_time(e1)
         for name, flops, nbytes, ms in self.extra:
             d = out.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            d["ms"] += ms
+        return out
+
+    def by_shape(self):
+        """{(kernel, shape string): dict(launches, flops, bytes, ms)} of the launches timed inside libvtx."""
+        out = {}
+        for (name, flops, nbytes, ms), shape in zip(self.extra, self.shapes):
+            d = out.setdefault((name, shape), dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += flops
             d["bytes"] += nbytes
@@ -232,7 +244,10 @@ def set_kernel_timer(timer):
         cap = 16384
         buf = (_lib.TimerRec * cap)()
         n = lib.vtx_timer_stop(buf, cap)
-        _timer.extra.extend(_describe_timer_rec(buf[i]) for i in range(n))
+        for i in range(n):
+            r = buf[i]
+            _timer.extra.append(_describe_timer_rec(r))
+            _timer.shapes.append(f"{r.rows} x {r.n} x {r.k} flags {r.flags & 255}")
     if timer is not None and timer is not _timer:
         lib.vtx_timer_start()
     _timer = timer
@@ -333,13 +348,14 @@ def cu_count():
 
 
 
-def astat_ok(N, K, M, bias=True):
+def astat_ok(N, K, M, bias=True, plain=True):
     """Mirrors gemm_astat_ok (gemm_astat.hip) for contiguous bf16 operands: the A-stationary persistent kernel takes C[M, N] over
-    192 <= K <= 384 once a launch has two 128 x 128 tiles per CU (M: the rows a mapped launch computes)."""
+    192 <= K <= 384 once a launch has two 128 x 128 tiles per CU (M: the rows a mapped launch computes); N % 128 == 64 (a ragged last
+    column tile) only for ``plain`` launches: no residual / activation / saved z / row map."""
     mode = options.get("GEMM_ASTAT")
-    if not mode or K % 64 or K < 192 or K > 384 or N % 128 or N < 256 or (N > 1536 and bias) or M <= 0:
+    if not mode or K % 64 or K < 192 or K > 384 or N % 64 or N < 256 or (N > 1536 and bias) or M <= 0 or (N % 128 and not plain):
         return False
-    return mode == 2 or 4 * ((M + 127) // 128) * (N // 128) >= (5 if mode == 3 else 8) * cu_count()
+    return mode == 2 or 4 * ((M + 127) // 128) * ((N + 127) // 128) >= (5 if mode == 3 else 8) * cu_count()
 
 
 def pp_wmf(M, N):
@@ -356,13 +372,13 @@ def pp_wmf(M, N):
 
 def pp_ok(N, K, M):
     """Mirrors gemm_pp_ok (csrc/gemm_pp.hip) for contiguous bf16 operands: the two-group kernel takes the long contractions
-    (K >= 1152, or K >= 768 with N <= 384) of N % 192 == 0 layers once a launch nearly fills a round (M: the rows it computes)."""
+    (K >= 1152, or K >= 768 with N <= 384, or K >= 384 with N = 192) of N % 192 == 0 layers once a launch nearly fills a round (M: the rows it computes)."""
     mode = options.get("GEMM_PP")
     if not mode or N % 192 or K % 64 or M <= 0:
         return False
     if mode >= 2:
         return True
-    return (K >= 1152 or (K >= 768 and N <= 384)) and 4 * ((M + 127) // 128) * (N // 192) >= 3 * cu_count()
+    return (K >= 1152 or (K >= 768 and N <= 384) or (K >= 384 and N == 192)) and 4 * ((M + 127) // 128) * (N // 192) >= 3 * cu_count()
 
 
 def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=False, bias=True):
@@ -376,7 +392,7 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K) and pp_ok(N, K, M):
         mode_ = options.get("GEMM_PP")
         return f"gemm_pp_kernel<{mode_ % 10 if 100 <= mode_ < 1000 else pp_wmf(M, N)}, {'true' if mapped else 'false'}, 0>"
-    if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M, bias):
+    if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M, bias, plain=not vec and not mapped):
         return f"gemm_astat_kernel<{K // 64}, {'true' if mapped else 'false'}, ...>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
         force = options.get("GLDS_BM")                                     # mirrors glds_pick_bm in gemm_glds.hip
