@@ -639,7 +639,7 @@ def test_one_call_layer_under_no_grad_and_shared_param_backward():
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3), ("swin_astat", 0.45)])
+@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3), ("swin_astat", 0.45), ("swin_fwd4", 0.45)])
 def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, p, monkeypatch, request):
     """Round 3: with host-drawn DropPath masks every branch of a Swin layer runs over its KEPT samples only (row-mapped
     LayerNorm / LDS-DMA GEMMs / window attention, copy-only tiles for the dropped samples, weight gradients skipping their
@@ -663,6 +663,15 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
         request.addfinalizer(lambda: options.set("GEMM_ASTAT", prev))
         options.set("GEMM_ASTAT", 2)
         family, nb = "swin", 32
+    fwd4 = family == "swin_fwd4"
+    if fwd4:
+        # (round 5) the four-wave window-attention forward at any problem count (the benchmark reaches it at stage 1 only): row-mapped
+        # in the compacted run; afterwards the one-wave kernel must give the same bits
+        from vtx import options
+        prev4 = options.get("WATTN_FWD4")
+        request.addfinalizer(lambda: options.set("WATTN_FWD4", prev4))
+        options.set("WATTN_FWD4", 2)
+        family = "swin"
     if family == "swin":
         model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=(64, 128, 384, 768), dim_head=32,
                                 n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=p).to(d).train()
@@ -703,6 +712,11 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
         options.set("GEMM_ASTAT", 0)                                     # ... and the tiled kernels give the same bits
         out_c, _ = _layer_io(model, x, True, 91, side)
         assert torch.equal(out_a, out_c)
+    if fwd4:
+        from vtx import options
+        options.set("WATTN_FWD4", 0)
+        out_c, g_c = _layer_io(model, x, True, 91, side)
+        assert torch.equal(out_b, out_c) and all(torch.equal(g_b[k], g_c[k]) for k in g_b), "four-wave forward != one-wave forward in the model"
 
 
 def test_forward_feature_without_a_weight_scope_runs_uncompacted_and_backward_works(monkeypatch):
