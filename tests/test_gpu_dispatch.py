@@ -133,7 +133,11 @@ def test_glds_tile_and_wave_variants_are_bitwise_identical():
                                      (111 * 196, 384, 1536, 196),  # a compacted stage-3 row count (192-row tiles, ragged last tile)
                                      (6272, 768, 3072, 49),        # Swin-S stage-4 fc2 forward (128-row tiles, four column tiles per panel)
                                      (100352, 192, 768, 784),      # Swin-S stage-2 fc2 forward (one column tile)
-                                     (1000, 576, 128, 50)])        # two k-tiles: the ring never wraps
+                                     (1000, 576, 128, 50),         # two k-tiles: the ring never wraps
+                                     (25088, 256, 1024, 196),      # (round 5) 256-column tiles: Twins-SVT-S stage-3 fc2 forward / fc1 dgrad
+                                     (6272 + 49, 512, 2048, 49),   # two 256-column tiles per panel, ragged last row tile
+                                     (100352, 128, 1024, 784),     # 128-column tiles: PVT-Small stage-2 fc2 forward
+                                     (3000, 640, 192, 60)])        # N = 640 = 5 x 128, three k-tiles
 def test_two_group_gemm_is_bitwise_the_tiled_kernel_and_matches_the_oracle(M, N, K, T):
     """Round 5: gemm_pp_kernel (BM x 192 tiles, one workgroup per CU, two wave groups half a k-step apart, ring of three 64-deep
     k-tiles) accumulates the same products in the same k order and applies the same epilogue expression as the tiled kernels:
@@ -155,7 +159,8 @@ def test_two_group_gemm_is_bitwise_the_tiled_kernel_and_matches_the_oracle(M, N,
         base = run()
     for wmf in (0, 4, 5, 6, 7):
         with options.override(GEMM_PP=100 + wmf if wmf else 2):
-            assert "gemm_pp_kernel" in ops.gemm_kernel_name(BF, N, 0, K=K, M=M)
+            kn = ops.gemm_kernel_name(BF, N, 0, K=K, M=M)
+            assert ("gemm_pp_kernel" if N % 192 == 0 else f"gemm_ppn_kernel<{min(wmf, 5 if N % 256 == 0 else 7) or ops.pp_wmf(M, N)}") in kn, kn
             got = run()
         for a, g, name in zip(base, got, ("y", "h", "z", "dz", "plain")):
             assert torch.equal(a, g), f"{name} differs between the tiled and the two-group kernel (tile height {32 * wmf or 'auto'})"

@@ -30,11 +30,19 @@ def timeit(fn, nset, iters=16):
 
 
 def main():
-    T = 784
+    T = 49
     shapes = [("s2 qkv fwd", 100352, 576, 192, "bias"), ("s2 qkv dgrad", 100352, 192, 576, "plain"), ("s2 proj fwd", 100352, 192, 192, "bias+resid"),
               ("s2 proj dgrad", 100352, 192, 192, "plain"), ("s2 fc2 fwd", 100352, 192, 768, "bias+resid"), ("s2 fc1 dgrad", 100352, 192, 768, "plain"),
               ("s1 fc2 fwd", 401408, 96, 384, "bias+resid"), ("s1 fc1 dgrad", 401408, 96, 384, "plain"), ("s1 qkv dgrad", 401408, 96, 288, "plain"),
-              ("s1 proj dgrad", 401408, 96, 96, "plain"), ("merge 2->3", 25088, 384, 768, "plain"), ("merge 1->2", 100352, 192, 384, "plain")]
+              ("s1 proj dgrad", 401408, 96, 96, "plain"), ("merge 2->3", 25088, 384, 768, "plain"), ("merge 1->2", 100352, 192, 384, "plain"),
+              # Twins-SVT-S / PVT-Small shapes whose N is not a multiple of 192 (128- / 256-column tiles of the two-group kernel)
+              ("tw3 fc2 fwd", 25088, 256, 1024, "bias+resid"), ("tw3 fc1 dgrad", 25088, 256, 1024, "plain"), ("tw3 proj", 25088, 256, 256, "bias+resid"),
+              ("tw2 fc2 fwd", 100352, 128, 512, "bias+resid"), ("tw2 fc1 dgrad", 100352, 128, 512, "plain"),
+              ("tw4 fc2 fwd", 6272, 512, 2048, "bias+resid"), ("tw4 fc1 dgrad", 6272, 512, 2048, "plain"), ("tw4 fc1 fwd", 6272, 2048, 512, "bias"),
+              ("pvt2 fc2 fwd", 100352, 128, 1024, "bias+resid"), ("pvt2 fc1 dgrad", 100352, 128, 1024, "plain"),
+              ("pvt4 fc2 fwd", 6400, 512, 2048, "bias+resid"), ("tw3 fc1 fwd", 25088, 1024, 256, "bias")]
+    if len(sys.argv) > 1:
+        shapes = [s for s in shapes if any(k in s[0] for k in sys.argv[1:])]
     variants = [("default", {}), ("PP=2", dict(GEMM_PP=2)), ("ASTAT=0 PP=0 SKINNY=0", dict(GEMM_ASTAT=0, GEMM_PP=0, GEMM_SKINNY=0))]
     g = torch.Generator(device=dev).manual_seed(1)
     for name, M, N, K, ename in shapes:

@@ -51,8 +51,8 @@ template <int N_, int... I> __device__ __forceinline__ void pp_pin(bf16x8 (&f)[N
   (pp_pin1(f[I]), ...);
 }
 
-template <int WMF> constexpr int pp_slot_bytes() { return (32 * WMF + PP_BN) * 128; }
-template <int WMF> constexpr int pp_smem_bytes() { return PP_NS * pp_slot_bytes<WMF>(); }
+template <int WMF, int NF = PP_NF> constexpr int pp_slot_bytes() { return (32 * WMF + 64 * NF) * 128; }
+template <int WMF, int NF = PP_NF> constexpr int pp_smem_bytes() { return PP_NS * pp_slot_bytes<WMF, NF>(); }
 
 // logical row -> row of the row-indexed operands (stochastic-depth compaction: GemmArgs::perm)
 template <bool MAPPED> __device__ __forceinline__ int pp_orow(const GemmArgs& p, int row, int* smp) {
@@ -70,10 +70,13 @@ struct PpGrid { int ntm, ntn, skew; };   // skew: start delay per column tile, i
 
 // ABL: phase ablation for timing probes (tools/r5/pp_ablate.py; results are garbage, durations are what is measured):
 // 1 no MFMAs | 2 no DMA requests inside the loop | 4 no fragment reads | 8 no A requests | 16 no B requests | 32 no barriers.  0 in the product.
-template <int WMF, bool MAPPED, int ABL = 0>
-__global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr) {
-  constexpr int BM = 32 * WMF, BN = PP_BN, NF = PP_NF, NS = PP_NS;
-  constexpr int A_BYTES = BM * 128, SLOT = pp_slot_bytes<WMF>();
+// NF: 16-column accumulator tiles per wave = tile width / 64 (3: the 192-column tile everything above describes; round 5 also 2 and 4 --
+// N = 128 / 256 / 512 layers of Twins-SVT and PVT that are not multiples of 192 -- as gemm_ppn_kernel<WMF, MAPPED, NF>; 128 registers per
+// wave bound WMF x NF: NF = 4 runs with WMF <= 5, and its ring of three (32 WMF + 256)-row k-tiles fills the LDS at WMF = 5)
+template <int WMF, bool MAPPED, int ABL, int NF>
+__device__ __forceinline__ void pp_body(const GemmArgs& p, const PpGrid& gr) {
+  constexpr int BM = 32 * WMF, BN = 64 * NF, WC = 16 * NF, NS = PP_NS;
+  constexpr int A_BYTES = BM * 128, SLOT = pp_slot_bytes<WMF, NF>();
   constexpr int NIA = WMF, NIB = BN / 32;                              // DMA instructions per wave and k-tile: A waves | B waves
   constexpr int LPT = NIA > NIB ? NIA : NIB;                           // both kinds issue this many (the shorter list repeats its last piece)
   constexpr int H0 = (LPT + 1) / 2;                                    // requested in the first MFMA segment of a k-tile, the rest in the second
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
       const int jj = j < NIB ? j : NIB - 1;
-      src[j] = (const bf16*)p.B + (int64_t)(n0 + wn * 48 + jj * 8 + lr) * p.ldb + sw;
+      src[j] = (const bf16*)p.B + (int64_t)(n0 + wn * WC + jj * 8 + lr) * p.ldb + sw;
     }
-    dst0 = A_BYTES + wn * 48 * 128;
+    dst0 = A_BYTES + wn * WC * 128;
   }
   constexpr int NIMIN = NIA < NIB ? NIA : NIB;
   const int ni = grp == 0 ? NIA : NIB;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr
   const unsigned lds0 = (unsigned)(size_t)pp_smem;
   const unsigned fro = c_ * 128 + ((g_ ^ (c_ & 7)) << 4);                // k-step 0 of a k-tile; k-step 1: chunk ^ 4, i.e. byte offset ^ 64
   const unsigned fragA[2] = {lds0 + grp * (16 * WMF) * 128 + fro, lds0 + grp * (16 * WMF) * 128 + (fro ^ 64)};
-  const unsigned fragB[2] = {lds0 + A_BYTES + wn * 48 * 128 + fro, lds0 + A_BYTES + wn * 48 * 128 + (fro ^ 64)};
+  const unsigned fragB[2] = {lds0 + A_BYTES + wn * WC * 128 + fro, lds0 + A_BYTES + wn * WC * 128 + (fro ^ 64)};
 
   f32x4 acc[WMF][NF];
 #pragma unroll
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr
   const bool act_fwd = p.act == 1 || p.act == 3, act_bwd = p.act == 2 || p.act == 4;
   float bcol[NF];
 #pragma unroll
-  for (int j = 0; j < NF; ++j) bcol[j] = p.bias ? p.bias[n0 + wn * 48 + j * 16 + c_] : 0.f;
+  for (int j = 0; j < NF; ++j) bcol[j] = p.bias ? p.bias[n0 + wn * WC + j * 16 + c_] : 0.f;
 
 #pragma unroll
   for (int i0 = 0; i0 < WMF; i0 += PP_IP) {
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr
         for (int j = 0; j < NF; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            cbuf[((grp * PP_IP + ii) * 16 + g_ * 4 + r) * CSTR + wn * 48 + j * 16 + c_] = acc[i0 + ii < WMF ? i0 + ii : 0][j][r] + bcol[j];
+            cbuf[((grp * PP_IP + ii) * 16 + g_ * 4 + r) * CSTR + wn * WC + j * 16 + c_] = acc[i0 + ii < WMF ? i0 + ii : 0][j][r] + bcol[j];
       }
     }
     __syncthreads();
@@ -320,36 +323,43 @@ __global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr
   }
 }
 
+template <int WMF, bool MAPPED, int ABL = 0>
+__global__ __launch_bounds__(PP_NT, 2) void gemm_pp_kernel(GemmArgs p, PpGrid gr) { pp_body<WMF, MAPPED, ABL, PP_NF>(p, gr); }
+template <int WMF, bool MAPPED, int NF>
+__global__ __launch_bounds__(PP_NT, 2) void gemm_ppn_kernel(GemmArgs p, PpGrid gr) { pp_body<WMF, MAPPED, 0, NF>(p, gr); }
+
 int pp_skew() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("VTX_PP_SKEW"); v = e ? atoi(e) : 0; }
   return v;
 }
 
-template <int WMF, bool MAPPED, int ABL = 0> int pp_launch_k(const GemmArgs& a, hipStream_t st) {
-  constexpr int smem = pp_smem_bytes<WMF>();
-  auto kern = gemm_pp_kernel<WMF, MAPPED, ABL>;
+template <int WMF, bool MAPPED, int ABL = 0, int NF = PP_NF> int pp_launch_k(const GemmArgs& a, hipStream_t st) {
+  constexpr int smem = pp_smem_bytes<WMF, NF>();
+  void (*kern)(GemmArgs, PpGrid);
+  if constexpr (NF == PP_NF) kern = gemm_pp_kernel<WMF, MAPPED, ABL>;
+  else kern = gemm_ppn_kernel<WMF, MAPPED, NF>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return VTX_ERR_LAUNCH;
   // (a mapped launch with dropped samples and a residual: copy-only tiles behind the computed ones)
   const int rows = (MAPPED && (a.Mk == a.M || a.resid == nullptr)) ? a.Mk : a.M;
   PpGrid gr;
   gr.ntm = (rows + 32 * WMF - 1) / (32 * WMF);
-  gr.ntn = a.N / PP_BN;
+  gr.ntn = a.N / (64 * NF);
   gr.skew = pp_skew();
   const int blocks = 8 * ((gr.ntm + 7) / 8) * gr.ntn;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(PP_NT), smem, st, a, gr);
   return vtx_check_launch();
 }
-template <int WMF> int pp_launch_m(const GemmArgs& a, hipStream_t st) {
-  return a.perm != nullptr ? pp_launch_k<WMF, true>(a, st) : pp_launch_k<WMF, false>(a, st);
+template <int WMF, int NF = PP_NF> int pp_launch_m(const GemmArgs& a, hipStream_t st) {
+  return a.perm != nullptr ? pp_launch_k<WMF, true, 0, NF>(a, st) : pp_launch_k<WMF, false, 0, NF>(a, st);
 }
 
 // Tile height: the fewest rounds of one-workgroup-per-CU tiles, then the smallest tiles that still fit that many rounds.
-int pp_pick_wmf(long rows, int ntn) {
+int pp_pick_wmf(long rows, int ntn, int wmax = 7) {
   const int cus = vtx_cu_count_cached();
-  int best = 7;
+  int best = wmax;
   long best_cost = 1L << 60;
-  for (int w = 7; w >= 4; --w) {
+  for (int w = wmax; w >= 4; --w) {
     const long tiles = (rows + 32 * w - 1) / (32 * w) * ntn;
     const long rounds = (tiles + cus - 1) / cus;
     const long cost = rounds * (w + 2);                                // (+2: prologue / epilogue of a tile in 32-row units)
@@ -360,10 +370,33 @@ int pp_pick_wmf(long rows, int ntn) {
 
 }  // namespace
 
+// accumulator tiles per wave for N columns: 3 (192-column tiles) where N allows, else 4 (256) or 2 (128); 0: not this kernel's shape
+static int pp_nf(int N) { return N % 192 == 0 ? 3 : (N % 256 == 0 ? 4 : (N % 128 == 0 ? 2 : 0)); }
+static int pp_wmax(int nf) { return nf == 4 ? 5 : 7; }
+
 bool gemm_pp_ok(const GemmArgs& a) {
   const int mode = vtx_opt(VTX_OPT_GEMM_PP);
   if (mode == 0) return false;
-  if (a.N % PP_BN != 0 || a.K % 64 != 0) return false;
+  const int nf = pp_nf(a.N);
+  if (nf == 0 || a.K % 64 != 0) return false;
+  if (nf != PP_NF) {
+    // 128- / 256-column tiles (round 5; tools/r5/tail_shapes.py, profiles/round5_tail_gemm_shapes.txt): only the N = 128, K = 1024 layers
+    // of PVT-Small stage 2 gain (fc2 forward 64 -> 59 us, fc1 dgrad 63 -> 55 us); 256-column tiles lose everywhere they were tried
+    // (25 088 x 256 x 1024: 157 tiles of 160 x 256 on 256 CUs, 26.6 vs 21.6 us) and stay behind GEMM_PP = 2
+    if (mode < 2 && !(nf == 2 && a.K >= 1024)) return false;
+    if ((a.lda % 8) || (a.ldb % 8) || (a.ldc % 8)) return false;
+    if (a.kscale != nullptr || a.ksum_out != nullptr) return false;
+    if ((a.act == 2 || a.act == 4) && a.aux_in == nullptr) return false;
+    const long rows_ = a.perm != nullptr ? a.Mk : a.M;
+    if (rows_ <= 0) return false;
+    if (mode < 2 && (rows_ + 127) / 128 * (a.N / (64 * nf)) < (3L * vtx_cu_count_cached()) / 4) return false;
+    if (a.perm != nullptr) {
+      if (a.map_T <= 0 || a.M % a.map_T != 0) return false;
+      if (a.rowscale != nullptr && a.rows_per_scale != a.map_T) return false;
+      if (a.Mk < a.M && a.resid == nullptr) return false;
+    }
+    return true;
+  }
   // where it wins (profiles/round5_gemm_pp_microbench.txt): long contractions -- K >= 1152, or K >= 768 under narrow outputs (N <= 384);
   // the K <= 384 layers stay on the A-stationary kernel, K = 768 with N >= 768 (Swin stage 4 qkv / fc1 / fc2-dgrad) on the tiled one;
   // one column tile (N = 192: Swin stage-2 qkv dgrad K = 576, patch merging 1 -> 2 K = 384) from K = 384 up (tools/r5/tail_shapes.py:
@@ -386,6 +419,19 @@ bool gemm_pp_ok(const GemmArgs& a) {
 
 int gemm_pp_launch(const GemmArgs& a, hipStream_t st) {
   const int mode = vtx_opt(VTX_OPT_GEMM_PP);
+  const int nf = pp_nf(a.N);
+  if (nf != PP_NF) {
+    int w = pp_pick_wmf(a.perm != nullptr ? a.Mk : a.M, a.N / (64 * nf), pp_wmax(nf));
+    if (mode >= 100 && mode < 1000) w = mode % 10 > pp_wmax(nf) ? pp_wmax(nf) : mode % 10;
+    if (nf == 4) return w == 4 ? pp_launch_m<4, 4>(a, st) : pp_launch_m<5, 4>(a, st);
+    switch (w) {
+      case 4: return pp_launch_m<4, 2>(a, st);
+      case 5: return pp_launch_m<5, 2>(a, st);
+      case 6: return pp_launch_m<6, 2>(a, st);
+      case 7: return pp_launch_m<7, 2>(a, st);
+      default: return VTX_ERR_SHAPE;
+    }
+  }
   int wmf = pp_pick_wmf(a.perm != nullptr ? a.Mk : a.M, a.N / PP_BN);
 #ifdef VTX_PP_ABLATE
   if (mode >= 1000 && a.perm == nullptr) {                             // timing probes: mode = 1000 * ablation bits (WMF 7)

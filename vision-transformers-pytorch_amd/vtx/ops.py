@@ -358,11 +358,18 @@ def astat_ok(N, K, M, bias=True, plain=True):
     return mode == 2 or 4 * ((M + 127) // 128) * ((N + 127) // 128) >= (5 if mode == 3 else 8) * cu_count()
 
 
+def pp_nf(N):
+    """16-column accumulator tiles per wave of the two-group GEMM = tile width / 64 (mirrors pp_nf, csrc/gemm_pp.hip); 0: not its shape."""
+    return 3 if N % 192 == 0 else (4 if N % 256 == 0 else (2 if N % 128 == 0 else 0))
+
+
 def pp_wmf(M, N):
     """Tile height (in 32-row units) the two-group GEMM picks (mirrors pp_pick_wmf, csrc/gemm_pp.hip)."""
-    cus, ntn = cu_count(), N // 192
-    best, cost = 7, None
-    for w in (7, 6, 5, 4):
+    nf = pp_nf(N)
+    cus, ntn = cu_count(), N // (64 * nf)
+    wmax = 5 if nf == 4 else 7
+    best, cost = wmax, None
+    for w in range(wmax, 3, -1):
         tiles = (M + 32 * w - 1) // (32 * w) * ntn
         c = ((tiles + cus - 1) // cus) * (w + 2)
         if cost is None or c < cost:
@@ -374,10 +381,13 @@ def pp_ok(N, K, M):
     """Mirrors gemm_pp_ok (csrc/gemm_pp.hip) for contiguous bf16 operands: the two-group kernel takes the long contractions
     (K >= 1152, or K >= 768 with N <= 384, or K >= 384 with N = 192) of N % 192 == 0 layers once a launch nearly fills a round (M: the rows it computes)."""
     mode = options.get("GEMM_PP")
-    if not mode or N % 192 or K % 64 or M <= 0:
+    nf = pp_nf(N)
+    if not mode or not nf or K % 64 or M <= 0:
         return False
     if mode >= 2:
         return True
+    if nf != 3:                      # 128-column tiles from K = 1024 up (PVT-Small stage 2); 256-column tiles only under GEMM_PP = 2
+        return nf == 2 and K >= 1024 and 4 * ((M + 127) // 128) * (N // 128) >= 3 * cu_count()
     return (K >= 1152 or (K >= 768 and N <= 384) or (K >= 384 and N == 192)) and 4 * ((M + 127) // 128) * (N // 192) >= 3 * cu_count()
 
 
@@ -391,7 +401,11 @@ def gemm_kernel_name(dtype, N, mode, out_f32=False, K=0, M=0, mapped=False, vec=
         return f"gemm_skinny_kernel<{K // 32}>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K) and pp_ok(N, K, M):
         mode_ = options.get("GEMM_PP")
-        return f"gemm_pp_kernel<{mode_ % 10 if 100 <= mode_ < 1000 else pp_wmf(M, N)}, {'true' if mapped else 'false'}, 0>"
+        nf = pp_nf(N)
+        w = min(mode_ % 10, 5 if nf == 4 else 7) if 100 <= mode_ < 1000 else pp_wmf(M, N)
+        if nf != 3:
+            return f"gemm_ppn_kernel<{w}, {'true' if mapped else 'false'}, {nf}>"
+        return f"gemm_pp_kernel<{w}, {'true' if mapped else 'false'}, 0>"
     if dtype == torch.bfloat16 and mode == 0 and astat_ok(N, K, M, bias, plain=not vec and not mapped):
         return f"gemm_astat_kernel<{K // 64}, {'true' if mapped else 'false'}, ...>"
     if dtype == torch.bfloat16 and mode == 0 and K > 0 and glds_ok(N, K):
