@@ -48,6 +48,9 @@ int vtx_abi_version(void);
 /* Compute units of the current device (256 on MI355X): what the one-workgroup-per-CU kernels size their grids and the
  * dispatch heuristics their thresholds with; the Python mirrors of those heuristics (vtx/ops.py) ask here. */
 int vtx_cu_count(void);
+/* Test helper: fill the LDS of every CU with `pattern` (160-KB workgroups, `rounds` per CU): LDS is not cleared between workgroups, and a
+ * kernel that reads LDS it never wrote sees what the previous workgroup left there (tests/test_gpu_lds_poison.py). */
+int vtx_debug_lds_poison(unsigned pattern, int rounds, void* stream);
 
 /* ---- Dispatch switches (csrc/options.h).  Which kernel variant an entry point launches -- LDS-DMA vs register-staged
  * GEMM, tile height, waves per workgroup, split-K target, fused vs separate split-K reduction, persistent-grid sizes --

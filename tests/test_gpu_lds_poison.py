@@ -1,0 +1,152 @@
+"""-m gpu: kernels must not depend on what a previous workgroup left in the LDS.
+
+LDS is not cleared between workgroups.  Round 5 found (on one box, in the very first launch of a process) non-finite dK from the ViT
+attention backward at L = 197: phase A never writes D[q] of the query tile that holds no query (rows 208 .. 223), phase B multiplies
+(dP - D) of those rows by p = 0, and 0 x (whatever the LDS held) is NaN when that happens to be a NaN or an infinity.  Here every
+LDS-using kernel family runs twice -- after `vtx_debug_lds_poison` filled the LDS of every CU with zeros, and after it filled it with
+NaN / -inf bit patterns -- and must give the same bits, all finite."""
+import pytest
+import torch
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+PATTERNS = (0x7FC07FC0, 0xFF80FF80, 0x7F807F80)      # bf16 NaN pairs = fp32 NaN; bf16 -inf pairs (fp32 NaN); bf16 +inf pairs (fp32 NaN)
+
+
+def _mk(shape, seed, dtype, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(dtype)
+
+
+def _poison(pattern):
+    from vtx import _lib, ops
+    ops.check(_lib.load().vtx_debug_lds_poison(pattern, 3, ops._stream()), "vtx_debug_lds_poison")
+
+
+def _flat(out):
+    if isinstance(out, torch.Tensor):
+        return [out]
+    res = []
+    for o in out:
+        if o is not None:
+            res.extend(_flat(o))
+    return res
+
+
+def _check(name, fn):
+    dev()
+    _poison(0)
+    ref = [t.clone() for t in _flat(fn())]
+    assert ref, name
+    for t in ref:
+        assert torch.isfinite(t.float()).all(), f"{name}: non-finite output after a ZERO fill"
+    for pat in PATTERNS:
+        _poison(pat)
+        got = _flat(fn())
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.isfinite(b.float()).all(), f"{name}: output {i} has non-finite values after LDS pattern {pat:#x}"
+            assert torch.equal(a, b), f"{name}: output {i} depends on the LDS contents (pattern {pat:#x})"
+
+
+@pytest.mark.parametrize("L,nH,D,dtype", [(197, 6, 64, BF), (37, 6, 64, BF), (50, 3, 64, BF), (130, 2, 64, BF), (193, 2, 64, BF), (224, 2, 64, BF),
+                                          (209, 2, 64, BF), (65, 2, 64, BF), (197, 3, 64, torch.float32), (100, 4, 32, BF), (257, 2, 64, BF),
+                                          (40, 2, 32, torch.float32)])
+def test_global_attention_forward_and_backward(L, nH, D, dtype):
+    from vtx import ops
+    B = 24
+    qkv, do = _mk((B, L, 3 * nH * D), 1, dtype), _mk((B, L, nH * D), 2, dtype)
+
+    def run():
+        o, lse = ops.attention_fwd(qkv, B, L, nH, D)
+        return o, lse, ops.attention_bwd(qkv, o, do, lse, B, L, nH, D)
+
+    _check(f"attention L {L} D {D} {dtype}", run)
+
+
+@pytest.mark.parametrize("H,win,nH,shift,dtype,B", [(14, 7, 4, True, BF, 16), (28, 7, 2, False, BF, 8), (56, 7, 3, True, BF, 128), (16, 4, 2, True, BF, 8),
+                                                    (20, 5, 3, False, BF, 4), (12, 6, 2, True, BF, 4), (14, 7, 2, True, torch.float32, 8),
+                                                    (24, 12, 2, True, BF, 2), (16, 8, 2, False, BF, 4)])
+def test_window_attention_forward_and_backward(H, win, nH, shift, dtype, B):
+    from oracle import tables
+    from vtx import ops, options
+    from vtx.tables import mask_regions
+    d = dev()
+    L, ntab = win * win, (2 * win - 1) ** 2
+    pos_np, mask_np = tables.make_pos_mask((H, H), win, shift)
+    pos = torch.from_numpy(pos_np).to(d)
+    qkv, do = _mk((B, H, H, 3 * nH * 32), 3, dtype), _mk((B, H, H, nH * 32), 4, dtype)
+    rel = _mk((ntab, nH), 5, torch.float32, 0.5)
+    if ops.wattn_supported(32, win):
+        region = mask_regions(torch.from_numpy(mask_np).to(d))[0] if shift else None
+        swin = (H, H, win, shift)
+
+        def run():
+            o, lse = ops.wattn_fwd(qkv, rel, pos, region, B, L, nH, swin)
+            return o, lse, ops.wattn_bwd(qkv, o, do, lse, rel, pos, region, B, L, nH, swin, ntab)
+
+        for f4 in (0, 2):
+            with options.override(WATTN_FWD4=f4, WATTN_BWD4=1 if f4 else 0):
+                _check(f"wattn {H}x{H} win {win} {dtype} four-wave kernels {bool(f4)}", run)
+    else:
+        bias = ops.relpos_bias(rel, pos, nH)
+        mask = torch.from_numpy(mask_np).to(d) if shift else None
+        csr = tuple(t.to(d) for t in ops.pos_csr(torch.from_numpy(pos_np), ntab))
+
+        def run():
+            o, lse = ops.attention_fwd(qkv, B, L, nH, 32, swin=(H, H, win, shift), bias=bias, mask=mask)
+            return o, lse, ops.attention_bwd(qkv, o, do, lse, B, L, nH, 32, swin=(H, H, win, shift), bias=bias, mask=mask, csr=csr, ntab=ntab)
+
+        _check(f"window attention {H}x{H} win {win} (generic kernels)", run)
+
+
+@pytest.mark.parametrize("Lq,Lk,nH,D", [(3136, 49, 1, 64), (784, 49, 2, 64), (196, 49, 5, 64), (49, 49, 8, 64), (196, 4, 8, 32), (784, 100, 2, 64),
+                                        (100, 196, 2, 32), (64, 144, 2, 32)])
+def test_subsampled_and_cross_attention(Lq, Lk, nH, D):
+    from vtx import ops
+    B = 6
+    q, kv, do = _mk((B * Lq, nH * D), 6, BF), _mk((B * Lk, 2 * nH * D), 7, BF), _mk((B * Lq, nH * D), 8, BF)
+
+    def run():
+        o, lse = ops.srattn_fwd(q, kv, B, Lq, Lk, nH)
+        return o, lse, ops.srattn_bwd(q, kv, o, do, lse, B, Lq, Lk, nH)
+
+    _check(f"srattn Lq {Lq} Lk {Lk} D {D}", run)
+    if D == 32:
+        bias = _mk((nH, Lq, Lk), 9, torch.float32, 0.3)
+
+        def runx():
+            o, lse = ops.xattn_fwd(q, kv, B, Lq, Lk, nH, bias=bias)
+            return o, lse, ops.xattn_bwd(q, kv, o, do, lse, B, Lq, Lk, nH, bias=bias)
+
+        _check(f"xattn Lq {Lq} Lk {Lk}", runx)
+
+
+@pytest.mark.parametrize("rows,C", [(25088, 384), (6272, 768), (12345, 96), (4000, 192), (3000, 320), (777, 64), (1000, 1024)])
+def test_layernorm(rows, C):
+    from vtx import ops
+    x, dy, dres = _mk((rows, C), 10, BF), _mk((rows, C), 11, BF), _mk((rows, C), 12, BF)
+    gamma, beta = _mk((C,), 13, torch.float32, 0.2) + 1, _mk((C,), 14, torch.float32, 0.1)
+
+    def run():
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+        return y, mean, rstd, ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres)
+
+    _check(f"layernorm {rows} x {C}", run)
+
+
+@pytest.mark.parametrize("M,N,K", [(25088, 384, 1536), (25088 + 77, 1536, 384), (100352, 576, 192), (66395, 96, 96), (5000, 256, 1024), (3000, 320, 1280),
+                                   (401408 // 8, 96, 384), (12800, 128, 1024), (1000, 200, 104)])
+def test_gemm_and_weight_gradient(M, N, K):
+    from vtx import ops
+    x, w, b = _mk((M, K), 15, BF), _mk((N, K), 16, BF, 0.05), _mk((N,), 17, torch.float32, 0.1)
+    dy, res = _mk((M, N), 18, BF), _mk((M, N), 19, BF)
+
+    def run():
+        outs = [ops.gemm(x, w, 0, bias=b), ops.gemm(x, w, 0, bias=b, resid=res), ops.gemm(x, w, 0, bias=b, act=ops.ACT_SILU, want_aux=True)]
+        if N % 8 == 0 and K % 8 == 0:
+            outs.append(ops.wgrad(dy, x))
+        return outs
+
+    _check(f"gemm / wgrad {M} x {N} x {K}", run)

@@ -16,6 +16,8 @@
 // fp32 (parity mode) and other head dims use the generic kernels in attention.hip.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "options.h"
 #include "vtx_common.h"
 
@@ -108,6 +110,12 @@ __device__ __forceinline__ Vec8<bf16> sa_gload(const bf16* p, bool valid) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // TP = query tiles a wave works on at a time (2: every K / V fragment read feeds two MFMAs | 1), NW = waves per workgroup
+#ifndef SA_DQ_INIT
+#define SA_DQ_INIT 1     // 0: the backward as it was before the fix (tests/test_gpu_lds_poison.py must then fail at L = 197)
+#endif
+#ifndef SA_SKIP_DEAD
+#define SA_SKIP_DEAD 1   // 0: the round-4 forward, which computes the all-padding last tile too (tools/r5/sattn_dead_tile_check.py compares)
+#endif
 template <int NKT, int TP, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void sattn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, SeqGeom g) {
@@ -129,6 +137,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_fwd_kernel(const bf16* __res
   __syncthreads();
 
   const int nqt = (g.L + 15) >> 4;
+  // the LAST key tile of the instantiation holds no key at all for L <= 16 (NKT - 1) (ViT-S/16: L = 197 -> 13 live tiles of 14; the 96 x 96
+  // DINO crops: L = 37 -> 3 of 4): its scores are exact zeros after the softmax -- skipped (round 5; same bits, 1 / NKT of the score work)
+  const bool last_dead = SA_SKIP_DEAD && nqt < NKT;
   for (int qp = wave; qp * TP < nqt; qp += NW) {
     Vec8<bf16> qf[TP][2];
     bool qv[TP];
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_fwd_kernel(const bf16* __res
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int t = 0; t < TP; ++t) st[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt == NKT - 1 && last_dead) continue;
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) {
         Vec8<bf16> kf = sa_frag_row(ks, kt * 16 + c_, ds, g_);
@@ -157,20 +169,24 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_fwd_kernel(const bf16* __res
     for (int t = 0; t < TP; ++t) {
       float m = -INFINITY;
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt == NKT - 1 && last_dead) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s = (kt * 16 + g_ * 4 + r) < g.L ? st[t][kt][r] * g.scale : -INFINITY;
           st[t][kt][r] = s;
           m = fmaxf(m, s);
         }
+      }
       m = fmaxf(m, shfl_xor_f(m, 16));
       m = fmaxf(m, shfl_xor_f(m, 32));
       float l = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt == NKT - 1 && last_dead) continue;       // (st[t][NKT - 1] is still the zero it was initialised with)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { st[t][kt][r] = __expf(st[t][kt][r] - m); l += st[t][kt][r]; }
+      }
       l += shfl_xor_f(l, 16);
       l += shfl_xor_f(l, 32);
       inv[t] = 1.f / l;
@@ -233,7 +249,13 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_bwd_kernel(const bf16* __res
   sa_stage<LP, NW>(im0, qb + g.hd, ld, g.L, wave, lane);
   sa_stage<LP, NW>(im1, qb + 2 * g.hd, ld, g.L, wave, lane);
   // lse * log2 e, +inf for padded query rows: exp2(. - inf) = 0 masks them in both phases without a select
-  for (int i = threadIdx.x; i < LP; i += 64 * NW) lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] * 1.4426950408889634f : INFINITY;
+  for (int i = threadIdx.x; i < LP; i += 64 * NW) {
+    lse_s[i] = i < g.L ? lse[(int64_t)prob * g.L + i] * 1.4426950408889634f : INFINITY;
+    // D[q] of a query tile WITHOUT queries (L = 197: rows 208 .. 223) is never written by phase A, and phase B multiplies (dP - D) of those
+    // rows by p = 0: whatever the previous workgroup left in this LDS would reach dK as 0 x NaN (round 5: seen once, on one box, as
+    // non-finite dqkv of the very first launch of a process; tests/test_gpu_lds_poison.py)
+    if (SA_DQ_INIT && i >= nt * 16) dq_s[i] = 0.f;
+  }
   const float sl = g.scale * 1.4426950408889634f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -268,6 +290,9 @@ __global__ __launch_bounds__(64 * NW, 2) void sattn_bwd_kernel(const bf16* __res
     for (int t = 0; t < TP; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dqacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the key tile without keys that the forward skips is computed here: skipping it behind a run-time branch costs the ViT-S/16 backward
+    //  more than the tile saves -- 128 vs 124 us -- and peeling the last step into a second instantiation of the loop body costs registers:
+    //  148 vs 119 us; tools/r5/sattn_dead_tile_check.py)
 #pragma unroll 1
     for (int k2 = 0; k2 < KSN; ++k2) {
       f32x4 dsv[TP][2];

@@ -41,6 +41,14 @@ int vtx_cu_count_cached() {
 
 int vtx_opt(int id) { return opt_table().v[id].load(std::memory_order_relaxed); }
 
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned pattern, int nwords) {
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < nwords; i += 256) lds_words[i] = pattern;
+  __syncthreads();
+  for (int d = 0; d < 64; ++d) __builtin_amdgcn_s_sleep(64);        // hold the CU while the other workgroups of the round start elsewhere
+  if (lds_words[(threadIdx.x * 97) % nwords] != pattern) __builtin_trap();
+}
+
 extern "C" {
 
 int vtx_option_count(void) { return VTX_OPT_COUNT; }
@@ -68,5 +76,16 @@ const char* vtx_strerror(int code) {
 int vtx_abi_version(void) { return 19; }
 
 int vtx_cu_count(void) { return vtx_cu_count_cached(); }
+
+/* Test helper: fills the LDS of every CU with `pattern` (e.g. 0x7fc07fc0: bf16 / fp32 NaNs).  LDS is not cleared between
+ * workgroups: a kernel that reads LDS it never wrote sees what the previous workgroup on that CU left there.  Workgroups of 160 KB,
+ * one per CU at a time, `rounds` per CU, each holding its CU for a few microseconds so that every CU gets one. */
+int vtx_debug_lds_poison(unsigned pattern, int rounds, void* stream) {
+  const int bytes = 160 * 1024;
+  if (hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return VTX_ERR_LAUNCH;
+  if (rounds < 1) rounds = 1;
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(vtx_cu_count_cached() * rounds), dim3(256), bytes, (hipStream_t)stream, pattern, bytes / 4);
+  return vtx_check_launch();
+}
 
 }  // extern "C"

@@ -5,7 +5,7 @@ non-zero code this module raises -- it never routes to PyTorch ops or to the CPU
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
@@ -97,6 +97,7 @@ _SIGNATURES = {
     "vtx_strerror": (c_char_p, [c_int]),
     "vtx_abi_version": (c_int, []),
     "vtx_cu_count": (c_int, []),
+    "vtx_debug_lds_poison": (c_int, [c_uint, c_int, c_void_p]),
     "vtx_option_count": (c_int, []),
     "vtx_option_name": (c_char_p, [c_int]),
     "vtx_get_option": (c_int, [c_int]),
