@@ -150,3 +150,79 @@ def test_gemm_and_weight_gradient(M, N, K):
         return outs
 
     _check(f"gemm / wgrad {M} x {N} x {K}", run)
+
+
+@pytest.mark.parametrize("family", ["swin", "vit", "vit_crops", "pvt", "twins", "halo"])
+@pytest.mark.parametrize("layer_call", [False, True], ids=["call_by_call", "one_call_layers"])
+def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, layer_call, monkeypatch):
+    """Forward + backward of a small model of every family with the LDS of every CU refilled (NaN / +-inf patterns in turn) behind EVERY
+    call into libvtx: logits and all gradients must equal, bit for bit, the run with zero fills.  Call by call every kernel of the
+    model starts on poisoned LDS; with the one-call layers (vtx_layer_fwd / _bwd: several launches per call) every layer does."""
+    from models import HaloTransformer, SwinTransformer, VisionTransformer
+    from models.pvt import PyramidVisionTransformer
+    from models.twins import TwinsSVT
+    from oracle import ref_models as M
+    from vtx import _lib, ops
+    from vtx import functional as VF
+    from vtx.nn import Linear
+    d = dev()
+    torch.manual_seed(51)
+    if family == "swin":
+        model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 2, 1), dims=(64, 128, 384, 768), dim_head=32,
+                                n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=0.0)
+        x = torch.randn(4, 3, 224, 224, device=d)
+    elif family.startswith("vit"):
+        model = VisionTransformer(Linear(384, 16), 224, 16, 2, 384, 6, 1536, 0.0, 0.0, 0.0, 0.0)
+        x = torch.randn(6, 3, 224, 224, device=d)                # L = 197: 13 live tiles of 14
+        if family == "vit_crops":
+            x = [x, torch.randn(12, 3, 96, 96, device=d)]        # L = 37: 3 live tiles of 4
+    elif family == "pvt":
+        cfg = dict(M.PVT_SMALL); cfg["depths"] = (1, 1, 1, 1); cfg["n_class"] = 16
+        model = PyramidVisionTransformer(**cfg, drop_path=0.0)
+        x = torch.randn(3, 3, 224, 224, device=d)
+    elif family == "twins":
+        cfg = dict(M.TWINS_SVT_S); cfg["depths"] = (1, 1, 1, 1); cfg["n_class"] = 16
+        model = TwinsSVT(**cfg)
+        x = torch.randn(3, 3, 224, 224, device=d)
+    else:
+        model = HaloTransformer(**M.HALO_TINY)
+        x = torch.randn(2, 3, 224, 224, device=d)
+    model.to(d).train()
+    monkeypatch.setattr(VF, "_LAYER_CALL", layer_call)
+    lib = _lib.load()
+    real = _lib.check
+    state = dict(pattern=0, n=0, busy=False)
+
+    def check_then_poison(code, what):
+        real(code, what)
+        if state["busy"] or "option" in what:
+            return
+        state["busy"] = True
+        try:
+            pat = state["pattern"] if state["pattern"] == 0 else PATTERNS[state["n"] % len(PATTERNS)]
+            state["n"] += 1
+            real(lib.vtx_debug_lds_poison(pat, 1, ops._stream()), "vtx_debug_lds_poison")
+        finally:
+            state["busy"] = False
+
+    monkeypatch.setattr(_lib, "check", check_then_poison)
+    monkeypatch.setattr(ops, "check", check_then_poison)
+
+    def run(pattern):
+        state["pattern"], state["n"] = pattern, 0
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=BF):
+            out = model(x)
+        out.float().square().mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, state["n"]
+
+    out0, g0, n0 = run(0)
+    out1, g1, n1 = run(1)
+    assert n0 == n1 and n0 > 8, f"only {n0} library calls were intercepted"
+    assert torch.isfinite(out1).all(), f"{family}: non-finite logits with poisoned LDS"
+    assert torch.equal(out0, out1), f"{family}: logits depend on the LDS contents"
+    assert g0.keys() == g1.keys() and len(g0) > 10
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), f"{family}: gradient of {k} is not finite with poisoned LDS"
+        assert torch.equal(g0[k], g1[k]), f"{family}: gradient of {k} depends on the LDS contents"
