@@ -48,6 +48,17 @@ def _check(name, fn):
         for i, (a, b) in enumerate(zip(ref, got)):
             assert torch.isfinite(b.float()).all(), f"{name}: output {i} has non-finite values after LDS pattern {pat:#x}"
             assert torch.equal(a, b), f"{name}: output {i} depends on the LDS contents (pattern {pat:#x})"
+    # ... and with every torch.empty() buffer (outputs, workspaces) NaN-filled by torch's deterministic-mode debug fill: every element of
+    # every output is written, nothing is read before it is written
+    prev = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        _poison(PATTERNS[0])
+        got = _flat(fn())
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), f"{name}: output {i} differs when torch.empty() buffers start as NaN"
 
 
 @pytest.mark.parametrize("L,nH,D,dtype", [(197, 6, 64, BF), (37, 6, 64, BF), (50, 3, 64, BF), (130, 2, 64, BF), (193, 2, 64, BF), (224, 2, 64, BF),
@@ -156,8 +167,9 @@ def test_gemm_and_weight_gradient(M, N, K):
 @pytest.mark.parametrize("layer_call", [False, True], ids=["call_by_call", "one_call_layers"])
 def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, layer_call, monkeypatch):
     """Forward + backward of a small model of every family with the LDS of every CU refilled (NaN / +-inf patterns in turn) behind EVERY
-    call into libvtx: logits and all gradients must equal, bit for bit, the run with zero fills.  Call by call every kernel of the
-    model starts on poisoned LDS; with the one-call layers (vtx_layer_fwd / _bwd: several launches per call) every layer does."""
+    call into libvtx -- and every torch.empty() buffer NaN-filled -- logits and all gradients must equal, bit for bit, the run with zero
+    fills.  Call by call every kernel of the model starts on poisoned LDS; with the one-call layers (vtx_layer_fwd / _bwd: several launches
+    per call) every layer does."""
     from models import HaloTransformer, SwinTransformer, VisionTransformer
     from models.pvt import PyramidVisionTransformer
     from models.twins import TwinsSVT
@@ -218,7 +230,16 @@ def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, la
         return out.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, state["n"]
 
     out0, g0, n0 = run(0)
-    out1, g1, n1 = run(1)
+    # second run: poisoned LDS AND every torch.empty() buffer filled with NaN (torch's deterministic-mode debug fill): nothing the
+    # library allocates as an output or a workspace may be read before it is written
+    prev = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    assert torch.utils.deterministic.fill_uninitialized_memory
+    try:
+        assert torch.isnan(torch.empty(1024, device=d)).all(), "the debug fill of torch.empty is not active"
+        out1, g1, n1 = run(1)
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
     assert n0 == n1 and n0 > 8, f"only {n0} library calls were intercepted"
     assert torch.isfinite(out1).all(), f"{family}: non-finite logits with poisoned LDS"
     assert torch.equal(out0, out1), f"{family}: logits depend on the LDS contents"
