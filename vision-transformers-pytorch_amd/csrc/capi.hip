@@ -73,7 +73,7 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 19; }
+int vtx_abi_version(void) { return 20; }
 
 int vtx_cu_count(void) { return vtx_cu_count_cached(); }
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class VtxError(RuntimeError):
