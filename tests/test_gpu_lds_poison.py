@@ -247,3 +247,91 @@ def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, la
     for k in g0:
         assert torch.isfinite(g1[k]).all(), f"{family}: gradient of {k} is not finite with poisoned LDS"
         assert torch.equal(g0[k], g1[k]), f"{family}: gradient of {k} depends on the LDS contents"
+
+
+@pytest.mark.parametrize("family", ["swin", "dino"])
+def test_train_steps_with_the_lds_poisoned_behind_every_library_call(family, monkeypatch):
+    """Two full bf16 train steps (forward, backward, MixLoss / DINOLoss, clip, fused AdamW, weight casts, EMA teacher) of two identical
+    copies of a model -- one with zero fills, one with NaN / inf patterns behind every library call and NaN-filled torch.empty()
+    buffers: every parameter must end up with the same bits."""
+    import copy
+
+    from vtx import _lib, ops
+    from vtx.optim import FusedAdamW
+    from vtx.train_step import MixLoss, make_param_groups, train_step
+    d = dev()
+    torch.manual_seed(61)
+    g = torch.Generator(device="cuda").manual_seed(62)
+    if family == "swin":
+        from models import SwinTransformer
+        base = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 2, 1), dims=(32, 64, 128, 256), dim_head=32,
+                               n_heads=(1, 2, 4, 8), dim_ffs=(128, 256, 512, 1024), window_size=7, drop_path=0.0).to(d).train()
+        x = torch.randn(8, 3, 224, 224, device=d, generator=g)
+        l1 = torch.arange(8, device=d)
+        data = (x, l1, l1.roll(1), torch.rand(8, device=d, generator=g))
+    else:
+        from models.vit import dino
+        from vtx.dino import DINOLoss, dino_train_step
+        mk = lambda: dino(224, 16, 2, 128, 2, 512, 0.0, 0.0, 0.0, 0.0, 1024, depth_head=3, dim_head_ff=256, dim_head_bottleneck=64).to(d).train()
+        base = mk()
+        crops = [torch.randn(4, 3, 224, 224, device=d, generator=g) for _ in range(2)] + [torch.randn(4, 3, 96, 96, device=d, generator=g) for _ in range(3)]
+    lib = _lib.load()
+    real = _lib.check
+    state = dict(pattern=0, n=0, busy=False)
+
+    def check_then_poison(code, what):
+        real(code, what)
+        if state["busy"] or "option" in what:
+            return
+        state["busy"] = True
+        try:
+            pat = state["pattern"] if state["pattern"] == 0 else PATTERNS[state["n"] % len(PATTERNS)]
+            state["n"] += 1
+            real(lib.vtx_debug_lds_poison(pat, 1, ops._stream()), "vtx_debug_lds_poison")
+        finally:
+            state["busy"] = False
+
+    monkeypatch.setattr(_lib, "check", check_then_poison)
+    monkeypatch.setattr(ops, "check", check_then_poison)
+
+    def run(pattern):
+        state["pattern"], state["n"] = pattern, 0
+        torch.manual_seed(63)
+        if family == "swin":
+            model = copy.deepcopy(base)
+        else:                                   # (weight_norm parametrisation: no deepcopy)
+            model, teacher = mk(), mk()
+            model.load_state_dict(base.state_dict())
+            teacher.load_state_dict(base.state_dict())
+        if family == "swin":
+            opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.05, "vit"), lr=1e-3)
+            crit = MixLoss(0.1)
+            losses = [train_step(model, crit, opt, data, clip_grad_norm=5.0, autocast_dtype=BF) for _ in range(2)]
+            extra = {}
+        else:
+            for p in teacher.parameters():
+                p.requires_grad = False
+            crit = DINOLoss(1024, 5, 0.04, 0.07, 30, 300).to(d)
+            opt = FusedAdamW(make_param_groups(model.named_parameters(), 0.04, "dino"), lr=5e-4)
+            losses = [dino_train_step(model, teacher, crit, opt, crops, epoch=1, momentum=0.99, clip_grad_norm=3.0, freeze_last_layer=1,
+                                      autocast_dtype=BF) for _ in range(2)]
+            extra = {"teacher." + n: p.detach().clone() for n, p in teacher.named_parameters()}
+            extra["center"] = crit.center.detach().clone()
+        torch.cuda.synchronize()
+        res = {n: p.detach().clone() for n, p in model.named_parameters()}
+        res.update(extra)
+        res["losses"] = torch.stack([l.detach().float().reshape(()) for l in losses])
+        return res, state["n"]
+
+    a, na = run(0)
+    prev = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        b, nb = run(1)
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
+    assert na == nb and na > 20
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.isfinite(b[k].float()).all(), f"{family}: {k} is not finite after two poisoned train steps"
+        assert torch.equal(a[k], b[k]), f"{family}: {k} depends on LDS / uninitialised-buffer contents"
