@@ -335,3 +335,60 @@ def test_train_steps_with_the_lds_poisoned_behind_every_library_call(family, mon
     for k in a:
         assert torch.isfinite(b[k].float()).all(), f"{family}: {k} is not finite after two poisoned train steps"
         assert torch.equal(a[k], b[k]), f"{family}: {k} depends on LDS / uninitialised-buffer contents"
+
+
+@pytest.mark.parametrize("name,batch,drop_path", [("swin_s", 128, 0.3), ("vit_s16", 256, 0.1), ("pvt_small", 128, 0.1), ("twins_svt_s", 128, 0.1)])
+def test_benchmark_configurations_with_the_lds_poisoned_behind_every_library_call(name, batch, drop_path, monkeypatch):
+    """The benchmark's own models at its batch sizes (the dispatch of bench.py: two-group / A-stationary / streaming GEMMs, wide weight
+    gradients, four-wave window attention, stochastic-depth compaction with host-drawn masks): forward + backward with poisoned LDS and
+    NaN-filled buffers against the run with zero fills, same DropPath masks -- logits and gradients bit for bit."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from vtx import _lib, ops
+    d = dev()
+    torch.manual_seed(71)
+    model = bench.build_model(name, drop_path).to(d).train()
+    x = torch.randn(batch, 3, 224, 224, device=d, generator=torch.Generator(device="cuda").manual_seed(72))
+    lib = _lib.load()
+    real = _lib.check
+    state = dict(pattern=0, n=0, busy=False)
+
+    def check_then_poison(code, what):
+        real(code, what)
+        if state["busy"] or "option" in what:
+            return
+        state["busy"] = True
+        try:
+            pat = state["pattern"] if state["pattern"] == 0 else PATTERNS[state["n"] % len(PATTERNS)]
+            state["n"] += 1
+            real(lib.vtx_debug_lds_poison(pat, 1, ops._stream()), "vtx_debug_lds_poison")
+        finally:
+            state["busy"] = False
+
+    monkeypatch.setattr(_lib, "check", check_then_poison)
+    monkeypatch.setattr(ops, "check", check_then_poison)
+
+    def run(pattern):
+        state["pattern"], state["n"] = pattern, 0
+        torch.manual_seed(73)                                    # the same DropPath masks in both runs
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=BF):
+            out = model(x)
+        out.float().square().mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, state["n"]
+
+    out0, g0, n0 = run(0)
+    prev = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        out1, g1, n1 = run(1)
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
+    assert n0 == n1 and n0 > 20
+    assert torch.isfinite(out1).all() and torch.equal(out0, out1), f"{name}: logits depend on LDS / uninitialised-buffer contents"
+    assert g0.keys() == g1.keys() and len(g0) > 50
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), f"{name}: gradient of {k} is not finite with poisoned LDS"
+        assert torch.equal(g0[k], g1[k]), f"{name}: gradient of {k} depends on LDS / uninitialised-buffer contents"
