@@ -164,8 +164,8 @@ def test_gemm_and_weight_gradient(M, N, K):
 
 
 @pytest.mark.parametrize("family", ["swin", "vit", "vit_crops", "pvt", "twins", "halo"])
-@pytest.mark.parametrize("layer_call", [False, True], ids=["call_by_call", "one_call_layers"])
-def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, layer_call, monkeypatch):
+@pytest.mark.parametrize("layer_call,bf16", [(False, True), (True, True), (False, False)], ids=["call_by_call", "one_call_layers", "fp32"])
+def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, layer_call, bf16, monkeypatch):
     """Forward + backward of a small model of every family with the LDS of every CU refilled (NaN / +-inf patterns in turn) behind EVERY
     call into libvtx -- and every torch.empty() buffer NaN-filled -- logits and all gradients must equal, bit for bit, the run with zero
     fills.  Call by call every kernel of the model starts on poisoned LDS; with the one-call layers (vtx_layer_fwd / _bwd: several launches
@@ -223,7 +223,7 @@ def test_whole_models_with_the_lds_poisoned_behind_every_library_call(family, la
     def run(pattern):
         state["pattern"], state["n"] = pattern, 0
         model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=BF):
+        with torch.autocast("cuda", dtype=BF, enabled=bf16):
             out = model(x)
         out.float().square().mean().backward()
         torch.cuda.synchronize()
