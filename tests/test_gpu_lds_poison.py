@@ -74,6 +74,13 @@ def test_global_attention_forward_and_backward(L, nH, D, dtype):
         return o, lse, ops.attention_bwd(qkv, o, do, lse, B, L, nH, D)
 
     _check(f"attention L {L} D {D} {dtype}", run)
+    drop = (0.1, 1234, None)                               # attention-probability dropout (hash mask): the *_drop entry points
+
+    def run_drop():
+        o, lse = ops.attention_fwd(qkv, B, L, nH, D, drop=drop)
+        return o, lse, ops.attention_bwd(qkv, o, do, lse, B, L, nH, D, drop=drop)
+
+    _check(f"attention with dropout L {L} D {D} {dtype}", run_drop)
 
 
 @pytest.mark.parametrize("H,win,nH,shift,dtype,B", [(14, 7, 4, True, BF, 16), (28, 7, 2, False, BF, 8), (56, 7, 3, True, BF, 128), (16, 4, 2, True, BF, 8),
@@ -124,6 +131,13 @@ def test_subsampled_and_cross_attention(Lq, Lk, nH, D):
         return o, lse, ops.srattn_bwd(q, kv, o, do, lse, B, Lq, Lk, nH)
 
     _check(f"srattn Lq {Lq} Lk {Lk} D {D}", run)
+    drop = (0.1, 4321, None)
+
+    def run_drop():
+        o, lse = ops.srattn_fwd(q, kv, B, Lq, Lk, nH, drop=drop)
+        return o, lse, ops.srattn_bwd(q, kv, o, do, lse, B, Lq, Lk, nH, drop=drop)
+
+    _check(f"srattn with dropout Lq {Lq} Lk {Lk} D {D}", run_drop)
     if D == 32:
         bias = _mk((nH, Lq, Lk), 9, torch.float32, 0.3)
 
