@@ -11,7 +11,7 @@ from vtx.train_step import MixLoss, make_param_groups, train_step
 
 name = sys.argv[1] if len(sys.argv) > 1 else "swin_s"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-B = {"swin_s": 128, "vit_s16": 256, "pvt_small": 128}[name]
+B = {"swin_s": 128, "vit_s16": 256, "pvt_small": 128, "twins_svt_s": 128}[name]
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = bench.build_model(name, 0.3 if name == "swin_s" else 0.1).to(dev).train()
