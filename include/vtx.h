@@ -102,6 +102,19 @@ int vtx_layernorm_bwd(const void* dy, const void* x, const float* mean, const fl
 int vtx_gemm(int mode, int dtype, const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
              int64_t ldb, int64_t ldc, const float* bias, const void* resid, const float* rowscale,
              int rows_per_scale, void* aux_out, const void* aux_in, int act, void* stream);
+/* ---- Fused MLP of the narrow stages (csrc/mlp_fused.hip; reference models/layer.py:186-196 inside models/swin_transformer.py:193-197):
+ * bf16, C = 64 / 96, ff % 32 == 0, both weights resident in LDS, >= 32 768 rows (vtx_mlp_fused_ok tells; option MLP_FUSED).
+ *   vtx_mlp_fwd: y = resid + rowscale[row / rows_per_scale] * (silu(ln2 . w1^T + b1) . w2^T + b2); z (the bf16 pre-activation) and
+ *                h = silu(z) are written only when their pointers are given (the one-call layers pass NULL: nothing ff-wide is stored);
+ *   vtx_mlp_bwd: z and h recomputed from ln2; dz = rowscale * (dy . w2) * silu'(z) and h written for the weight gradients
+ *                (dW2 = dy^T h, dW1 = dz^T ln2: vtx_wgrad_group), dln2 = dz . w1.
+ * w1 [ff][C], w2 [C][ff] bf16 (the forward-layout copies); b1 / b2 / resid / rowscale may be NULL.  Element values: those of the
+ * four vtx_gemm launches they replace, bit for bit. */
+int vtx_mlp_fused_ok(int dtype, int64_t M, int C, int ff);
+int vtx_mlp_fwd(int dtype, const void* ln2, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid,
+                const float* rowscale, int rows_per_scale, void* y, void* z, void* h, int64_t M, int C, int ff, void* stream);
+int vtx_mlp_bwd(int dtype, const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
+                int rows_per_scale, void* h, void* dz, void* dln2, int64_t M, int C, int ff, void* stream);
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
 /* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
  * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that
@@ -286,6 +299,7 @@ typedef struct VtxLayerBwd {
   float *dWq, *dbq, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2, *drel;
   const int *perm1, *perm2;                    /* the forward's (see VtxLayerFwd) */
   int Bk1, Bk2;
+  const float* b1;                             /* fc1 bias: a forward that ran the fused MLP (vtx_mlp_fwd) kept no z -- the backward recomputes it */
 } VtxLayerBwd;
 int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream);
 int vtx_layer_desc_bytes(int which);
@@ -342,7 +356,9 @@ enum { VTX_T_LN_FWD = 1, VTX_T_GEMM = 2, VTX_T_WATTN_FWD = 3, VTX_T_ATTN_FWD = 4
         * k = r*r*C; _SPLITK = ONE problem dW[n, k] over rows tokens (the reduction conv's forward on the split-K launch);
         * _GATHER = operand gather / scatter of rows x n elements */
        VTX_T_SRATTN_FWD = 9, VTX_T_SRATTN_BWD = 10, VTX_T_WGRAD_SR_A = 11, VTX_T_WGRAD_SR_B = 12, VTX_T_WGRAD_SPLITK = 13,
-       VTX_T_GATHER = 14 };
+       VTX_T_GATHER = 14,
+       /* the fused MLP of the narrow stages (vtx_mlp_fwd / vtx_mlp_bwd inside vtx_layer_*): rows, n = C, k = ff */
+       VTX_T_MLP_FWD = 15, VTX_T_MLP_BWD = 16 };
 typedef struct VtxTimerRec { int tag, n, k, flags; int64_t rows; float ms; } VtxTimerRec;
 int vtx_timer_start(void);
 int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */

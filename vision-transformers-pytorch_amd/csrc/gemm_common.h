@@ -181,6 +181,12 @@ int gemm_astat_launch(const GemmArgs& a, hipStream_t st);
 // gemm_pp.hip: BM x 192 tiles, one workgroup per CU, two wave groups half a k-step apart (N % 192 == 0, K % 64 == 0)
 bool gemm_pp_ok(const GemmArgs& a);
 int gemm_pp_launch(const GemmArgs& a, hipStream_t st);
+// mlp_fused.hip: the whole MLP of a C = 64 / 96 layer in one launch each way (both weights resident in LDS)
+bool mlp_fused_ok(int dtype, int64_t M, int C, int ff);
+int mlp_fused_fwd(const void* ln2, const void* w1, const float* b1, const void* w2, const float* b2, const void* resid,
+                  const float* rowscale, int rows_per_scale, void* y, void* z, void* h, int64_t M, int C, int ff, hipStream_t st);
+int mlp_fused_bwd(const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
+                  int rows_per_scale, void* h, void* dz, void* dln2, int64_t M, int C, int ff, hipStream_t st);
 // mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE
 int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st);
 

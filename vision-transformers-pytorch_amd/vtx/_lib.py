@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class VtxError(RuntimeError):
@@ -41,7 +41,7 @@ class LayerBwd(ctypes.Structure):
                                    "ln1_ws", "ln2_ws", "attn_ws", "wgrad_ws")] +
                 [(n, _Z) for n in ("ln_ws_bytes", "attn_ws_bytes", "wgrad_ws_bytes")] +
                 [(n, _P) for n in ("dWq", "dbq", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2", "dbe2", "drel",
-                                   "perm1", "perm2")] + [("Bk1", _I), ("Bk2", _I)])
+                                   "perm1", "perm2")] + [("Bk1", _I), ("Bk2", _I), ("b1", _P)])
 
 
 class SrLayerFwd(ctypes.Structure):
@@ -112,6 +112,11 @@ _SIGNATURES = {
                                   c_void_p]),
     "vtx_gemm": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                          c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vtx_mlp_fused_ok": (c_int, [c_int, c_int64, c_int, c_int]),
+    "vtx_mlp_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                            c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vtx_mlp_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                            c_int64, c_int, c_int, c_void_p]),
     "vtx_wgrad_workspace": (c_size_t, [c_int64, c_int, c_int]),
     "vtx_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64,
                           c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p]),

@@ -807,13 +807,13 @@ class TransformerLayerFn(Function):
         d.mean1, d.rstd1, d.mean2, d.rstd2, d.lse = (base + fo["mean1"], base + fo["rstd1"], base + fo["mean2"],
                                                      base + fo["rstd2"], base + fo["lse"])
         _lib.check(_lib.load().vtx_layer_fwd(ctypes.byref(d), ops._stream()), "vtx_layer_fwd")
-        ctx.save_for_backward(x, buf, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, s1, s2, rel_pos)
+        ctx.save_for_backward(x, buf, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, s1, s2, rel_pos, fc1_b)
         ctx.plan = pl
         return y
 
     @staticmethod
     def _backward_one_call(ctx, dy):
-        x, buf, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, s1, s2, rel_pos = ctx.saved_tensors
+        x, buf, ln1_w, qkv_w, proj_w, ln2_w, fc1_w, fc2_w, s1, s2, rel_pos, fc1_b = ctx.saved_tensors
         pl, m, kind = ctx.plan, ctx.meta, ctx.kind
         if pl.f_off["z"] is None:
             raise VtxError("vtx: this layer's forward ran without a graph (no pre-activation was kept)")
@@ -854,6 +854,7 @@ class TransformerLayerFn(Function):
         d.mean1, d.rstd1, d.mean2, d.rstd2, d.lse = (base + fo["mean1"], base + fo["rstd1"], base + fo["mean2"],
                                                      base + fo["rstd2"], base + fo["lse"])
         d.ln1_w, d.ln2_w = ln1_w.data_ptr(), ln2_w.data_ptr()
+        d.b1 = fc1_b.data_ptr()                     # (the fused MLP's backward recomputes z)
         d.wq, d.wo, d.w1, d.w2 = (wq[0].data_ptr(), wo[0].data_ptr(), w1[0].data_ptr(), w2[0].data_ptr())
         d.wqt, d.wot, d.w1t, d.w2t = _dp(wq[1]), _dp(wo[1]), _dp(w1[1]), _dp(w2[1])
         if kind == _lib.ATTN_WINDOW:

@@ -308,6 +308,12 @@ def _describe_timer_rec(r):
     if r.tag == 14:                                                     # operand gather / scatter: rows x n elements in and out
         kern = "patchify_kernel" if not fl & 64 else "twins_subsample_kernel"
         return kern, 0.0, (3.0 if fl & 1 else 2.0) * rows * n * es, r.ms
+    if r.tag in (15, 16):                                               # fused MLP of the narrow stages: rows x C (n), ff = k
+        bwd = r.tag == 16
+        waves = 8 if options.get("MLP_FUSED") == 8 else 4
+        # forward: ln2, x1 in, y out (2 products); backward: ln2, dy in, dln2, h, dz out (z and dh recomputed: 3 products)
+        return (f"mlp_{'bwd' if bwd else 'fwd'}_kernel<{n // 32}, {waves}>", (6.0 if bwd else 4.0) * rows * n * k,
+                float(es * rows * ((3 * n + 2 * k) if bwd else 3 * n) + 2 * es * n * k), r.ms)
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
 
 
