@@ -341,6 +341,7 @@ typedef struct VtxSrLayerBwd {
   void *ln1_ws, *ln2_ws, *lns_ws, *attn_ws, *wgrad_ws, *wgrad2_ws;
   size_t ln_ws_bytes, lns_ws_bytes, attn_ws_bytes, wgrad_ws_bytes, wgrad2_ws_bytes;
   float *dWq, *dWkv, *dWsr, *dbsr, *dWo, *dbo, *dW1, *db1, *dW2, *db2, *dg1, *dbe1, *dg2, *dbe2, *dgs, *dbs;
+  const float* b1;                             /* fc1 bias (the fused MLP's backward recomputes z: see VtxLayerBwd) */
 } VtxSrLayerBwd;
 int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream);
 /* sizeof the descriptors: 0 / 1 VtxLayerFwd / Bwd, 2 / 3 VtxSrLayerFwd / Bwd */

@@ -54,7 +54,7 @@ def _unfused(ln2, x1, dy, w1, b1, w2, b2, s, rps):
     return y, z, h, dz, dln2
 
 
-@pytest.mark.parametrize("waves", [1, 8])
+@pytest.mark.parametrize("waves", [1, 404, 809, 812, 816])      # option MLP_FUSED: default | 100 b + f variant codes
 @pytest.mark.parametrize("M,C,ff,drop", [(34496, 96, 384, 0.0), (34496, 96, 384, 0.25), (32777, 96, 384, 0.25), (401, 96, 384, 0.0),
                                          (37632, 64, 256, 0.25), (33001, 64, 512, 0.1)])
 def test_fused_mlp_is_bitwise_the_four_gemm_launches(M, C, ff, drop, waves):
@@ -121,19 +121,25 @@ def test_swin_layers_with_the_fused_mlp_are_bitwise_the_unfused_ones(dim, ff, mo
             out_a, g_a = _layer_io(model, x, True, 78, True)
     finally:
         torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
-    with options.override(MLP_FUSED=8):
+    with options.override(MLP_FUSED=812):
         out_c, g_c = _layer_io(model, x, True, 78, True)
     with options.override(MLP_FUSED=0):
         out_b, g_b = _layer_io(model, x, True, 78, True)
-    monkeypatch.setattr(VF, "_LAYER_CALL", False)
-    out_d, g_d = _layer_io(model, x, True, 78, True)
     assert torch.isfinite(out_a).all()
-    for tag, out_o, g_o in (("MLP_FUSED = 0", out_b, g_b), ("MLP_FUSED = 8", out_c, g_c), ("call by call", out_d, g_d)):
+    for tag, out_o, g_o in (("MLP_FUSED = 0", out_b, g_b), ("MLP_FUSED = 812", out_c, g_c)):
         assert torch.equal(out_a, out_o), f"logits differ from {tag}"
         assert g_a.keys() == g_o.keys() and len(g_a) > 20
         for k in g_a:
             assert torch.isfinite(g_a[k]).all(), k
             assert torch.equal(g_a[k], g_o[k]), f"gradient of {k} differs from {tag}: {(g_a[k] - g_o[k]).abs().max().item():.3e}"
+    # the call-by-call path (no fused MLP there): same logits bit for bit; its weight-gradient launches split the tokens into another
+    # number of slices at this batch size (stage 2 as well, where nothing is fused): gradients to fp32 summation order
+    monkeypatch.setattr(VF, "_LAYER_CALL", False)
+    out_d, g_d = _layer_io(model, x, True, 78, True)
+    assert torch.equal(out_a, out_d), "logits differ from the call-by-call path"
+    for k in g_a:
+        err = ((g_a[k] - g_d[k]).norm() / g_d[k].norm().clamp_min(1e-30)).item()
+        assert err < 1e-5, f"gradient of {k} differs from the call-by-call path: rel-L2 {err:.3e}"
 
 
 def test_fused_mlp_timer_records():
@@ -145,7 +151,7 @@ def test_fused_mlp_timer_records():
     r = Rec()
     r.tag, r.rows, r.n, r.k, r.flags, r.ms = 15, 401408, 96, 384, 32, 0.1
     name, fl, nb, ms = ops._describe_timer_rec(r)
-    assert name.startswith("mlp_fwd_kernel<3") and fl == 4.0 * 401408 * 96 * 384 and nb == 2 * 401408 * 3 * 96 + 4 * 96 * 384
+    assert name == "mlp_fwd_kernel<3, 12, false>" and fl == 4.0 * 401408 * 96 * 384 and nb == 2 * 401408 * 3 * 96 + 4 * 96 * 384
     r.tag = 16
     name, fl, nb, ms = ops._describe_timer_rec(r)
-    assert name.startswith("mlp_bwd_kernel<3") and nb == 2 * 401408 * (3 * 96 + 2 * 384) + 4 * 96 * 384
+    assert name == "mlp_bwd_kernel<3, 4, true>" and nb == 2 * 401408 * (3 * 96 + 2 * 384) + 4 * 96 * 384

@@ -49,9 +49,9 @@ case "$J" in
   mlp)        # fused MLP of the narrow stages: parity tests, micro-benchmark vs the four GEMM launches, same-box A/B in Swin-S
     timeout 1200 python -m pytest tests/test_gpu_mlp_fused.py -m gpu -q 2>&1 | tail -40 > $LOG
     timeout 600 python tools/r5/mlp_fused_bench.py 2>&1 | grep -v amdgpu.ids >> $LOG
-    for rep in 1 2; do for v in 0 1 8; do
+    for rep in 1 2; do for v in ${MLPV:-0 1}; do
       echo "== MLP_FUSED=$v" >> $LOG
-      env VTX_MLP_FUSED=$v timeout 600 python bench.py --model swin_s --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | grep '"metric"' | cut -c1-200 >> $LOG
+      env VTX_MLP_FUSED=$v timeout 600 python bench.py --model ${MLPM:-swin_s} --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | grep '"metric"' | cut -c1-200 >> $LOG
     done; done
     cat $LOG ;;
   *) echo "unknown job $J"; exit 2 ;;

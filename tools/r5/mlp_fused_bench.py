@@ -65,12 +65,15 @@ def main():
             print(f"  unfused {n:28s} {v:8.1f} us")
         vals = list(t.values())
         print(f"  unfused forward {vals[0] + vals[1]:8.1f} us   backward (two dgrads) {vals[2] + vals[3]:8.1f} us")
-        for w in (1, 8):
-            with options.override(MLP_FUSED=w):
-                tf, tb = timed(f_fwd, sets), timed(f_bwd, sets)
-            r = ff / C
-            print(f"  fused ({4 if w == 1 else 8} waves)  forward {tf:8.1f} us ({3 * unit / tf / 1e3:.2f} TB/s of 3 units)   "
-                  f"backward {tb:8.1f} us ({(3 + 2 * r) * unit / tb / 1e3:.2f} TB/s of {3 + 2 * r:.0f} units)")
+        r = ff / C
+        for f in (4, 8, 9, 12, 16):
+            with options.override(MLP_FUSED=400 + f):
+                tf = timed(f_fwd, sets)
+            print(f"  fused forward  variant {f:2d}: {tf:8.1f} us ({3 * unit / tf:.2f} TB/s of 3 units)")
+        for b in (4, 8):
+            with options.override(MLP_FUSED=100 * b + 8):
+                tb = timed(f_bwd, sets)
+            print(f"  fused backward variant {b:2d}: {tb:8.1f} us ({(3 + 2 * r) * unit / tb:.2f} TB/s of {3 + 2 * r:.0f} units)")
 
 
 if __name__ == "__main__":

@@ -340,6 +340,9 @@ int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream) {
   if (rc) return rc;
   rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream));
   if (rc) return rc;
+  if (mlp_fused_ok(dt, M, C, ff))                 // (as in vtx_layer_fwd: PVT-Small / Twins-SVT-S stage 1, C = 64)
+    return TCALL(VTX_T_MLP_FWD, M, C, ff, F_RESID, stream,
+                 mlp_fused_fwd(a->ln2, a->w1, a->b1, a->w2, a->b2, a->x1, a->s2, a->rows_per_scale, a->y, nullptr, nullptr, M, C, ff, (hipStream_t)stream));
   rc = TCALL(VTX_T_GEMM, M, ff, C, a->z ? F_AUXOUT : 0, stream, vtx_gemm(0, dt, a->ln2, a->w1, a->h, M, ff, C, C, C, ff, a->b1, nullptr, nullptr, 1, a->z, nullptr, 1, stream));
   if (rc) return rc;
   return TCALL(VTX_T_GEMM, M, C, ff, F_RESID, stream,
@@ -355,10 +358,18 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
   const int rows = a->B * a->Lk;
   g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
   // ---- MLP branch
-  int rc = TCALL(VTX_T_GEMM, M, ff, C, F_AUXIN, stream, layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream));
-  if (rc) return rc;
-  rc = TCALL(VTX_T_GEMM, M, C, ff, 0, stream, layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream));
-  if (rc) return rc;
+  int rc;
+  if (mlp_fused_ok(dt, M, C, ff)) {
+    if (!a->h || !a->b1) return VTX_ERR_NULL;
+    rc = TCALL(VTX_T_MLP_BWD, M, C, ff, 0, stream,
+               mlp_fused_bwd(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->dln2, M, C, ff, (hipStream_t)stream));
+    if (rc) return rc;
+  } else {
+    rc = TCALL(VTX_T_GEMM, M, ff, C, F_AUXIN, stream, layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream));
+    if (rc) return rc;
+    rc = TCALL(VTX_T_GEMM, M, C, ff, 0, stream, layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream));
+    if (rc) return rc;
+  }
   rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
              vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes, M, C, dt, 0, 0, 0, stream));
   if (rc) return rc;

@@ -62,9 +62,12 @@ template <int KS> __device__ __forceinline__ void mf_load_rows(bf16x8 (&f)[2][KS
 }
 
 // ------------------------------------------------------------------------------------------------------------------ forward
-template <int KS, int WAVES>
+// PF: the next block's row operands are requested before the current block is multiplied and the residual vectors before the hidden loop
+// (one or two waves per SIMD: nobody else hides the latency); !PF (three or four waves per SIMD): loads where they are used, 24 + 24
+// registers less per lane
+template <int KS, int WAVES, bool PF>
 __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
-  constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES;
+  constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = PF ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
   const int ff = p.ff, S2 = ff + 8, M = p.M;
   bf16* w1s = reinterpret_cast<bf16*>(mf_smem);                       // [ff][C + 8]
@@ -91,26 +94,32 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
 
   bf16x8 an[2][KS];
   int rb = blockIdx.x * WAVES + wave;
-  if (rb < nrb) mf_load_rows<KS>(an, p.a, rb, M, c, g);
+  if (PF && rb < nrb) mf_load_rows<KS>(an, p.a, rb, M, c, g);
   for (; rb < nrb; rb += stride) {
     bf16x8 a[2][KS];
+    if constexpr (PF) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a[mt][ks] = an[mt][ks];
-    if (rb + stride < nrb) mf_load_rows<KS>(an, p.a, rb + stride, M, c, g);
+        for (int ks = 0; ks < KS; ++ks) a[mt][ks] = an[mt][ks];
+      if (rb + stride < nrb) mf_load_rows<KS>(an, p.a, rb + stride, M, c, g);
+    } else {
+      mf_load_rows<KS>(a, p.a, rb, M, c, g);
+    }
     int row[2];
     float rsc[2];
     bool ok[2];
-    Vec8<bf16> rv[2][KS];                                  // residual vectors of the output pairs: requested now, used behind the loop
+    Vec8<bf16> rv[2][KS];                                  // residual vectors of the output pairs (PF: requested now, used behind the loop)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       row[mt] = rb * MF_ROWS + mt * 16 + c;
       ok[mt] = row[mt] < M;
       rsc[mt] = (ok[mt] && p.rowscale) ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+      if constexpr (PF) {
 #pragma unroll
-      for (int tp = 0; tp < KS; ++tp)
-        rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)min(row[mt], M - 1) * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
+        for (int tp = 0; tp < KS; ++tp)
+          rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)min(row[mt], M - 1) * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
+      }
     }
     f32x4 oacc[2][2 * KS];
 #pragma unroll
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
 #pragma unroll
       for (int t = 0; t < 2 * KS; ++t) oacc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
+#pragma unroll MF_UNR
     for (int np = 0; np < npairs; ++np) {
       // ---- z = ln2 . W1^T for hidden columns 32 np + 8 g .. + 7 of rows (mt, c)
       f32x4 zacc[2][2];
@@ -170,6 +179,13 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
         }
     }
     // oacc[mt][2 tp + j][r] = (h . W2^T)[row (mt, c)][32 tp + 8 g + 4 j + r]
+    if constexpr (!PF) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int tp = 0; tp < KS; ++tp)
+          rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)min(row[mt], M - 1) * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
+    }
 #pragma unroll
     for (int tp = 0; tp < KS; ++tp) {
       const int col = tp * 32 + 8 * g;
@@ -190,9 +206,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ backward
-template <int KS, int WAVES>
+template <int KS, int WAVES, bool PF>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
-  constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES;
+  constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = PF ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
   const int ff = p.ff, M = p.M;
   bf16* w1s = reinterpret_cast<bf16*>(mf_smem);                       // [ff][C + 8]: W1
@@ -222,14 +238,19 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
 
   bf16x8 an[2][KS], dn[2][KS];
   int rb = blockIdx.x * WAVES + wave;
-  if (rb < nrb) { mf_load_rows<KS>(an, p.a, rb, M, c, g); mf_load_rows<KS>(dn, p.dy, rb, M, c, g); }
+  if (PF && rb < nrb) { mf_load_rows<KS>(an, p.a, rb, M, c, g); mf_load_rows<KS>(dn, p.dy, rb, M, c, g); }
   for (; rb < nrb; rb += stride) {
     bf16x8 a[2][KS], d[2][KS];
+    if constexpr (PF) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) { a[mt][ks] = an[mt][ks]; d[mt][ks] = dn[mt][ks]; }
-    if (rb + stride < nrb) { mf_load_rows<KS>(an, p.a, rb + stride, M, c, g); mf_load_rows<KS>(dn, p.dy, rb + stride, M, c, g); }
+        for (int ks = 0; ks < KS; ++ks) { a[mt][ks] = an[mt][ks]; d[mt][ks] = dn[mt][ks]; }
+      if (rb + stride < nrb) { mf_load_rows<KS>(an, p.a, rb + stride, M, c, g); mf_load_rows<KS>(dn, p.dy, rb + stride, M, c, g); }
+    } else {
+      mf_load_rows<KS>(a, p.a, rb, M, c, g);
+      mf_load_rows<KS>(d, p.dy, rb, M, c, g);
+    }
     int row[2];
     float rsc[2];
     bool ok[2];
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
 #pragma unroll
       for (int t = 0; t < 2 * KS; ++t) xacc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
+#pragma unroll MF_UNR
     for (int np = 0; np < npairs; ++np) {
       // ---- z = ln2 . W1^T (recomputed) and dh = dy . W2 for hidden columns 32 np + 8 g .. + 7 of rows (mt, c)
       f32x4 zacc[2][2], hacc[2][2];
@@ -330,19 +351,41 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
 size_t mlp_fwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 2 + (size_t)C * (ff + 8) * 2 + (size_t)(ff + C) * 4; }
 size_t mlp_bwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 4 + (size_t)ff * 4; }
 
-template <int KS, int WAVES> int mlp_fwd_launch_k(const MlpArgs& a, hipStream_t st) {
+template <int KS, int WAVES, bool PF> int mlp_fwd_launch_k(const MlpArgs& a, hipStream_t st) {
   const size_t smem = mlp_fwd_smem(32 * KS, a.ff);
-  auto kern = mlp_fwd_kernel<KS, WAVES>;
+  auto kern = mlp_fwd_kernel<KS, WAVES, PF>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
 }
-template <int KS, int WAVES> int mlp_bwd_launch_k(const MlpArgs& a, hipStream_t st) {
+template <int KS, int WAVES, bool PF> int mlp_bwd_launch_k(const MlpArgs& a, hipStream_t st) {
   const size_t smem = mlp_bwd_smem(32 * KS, a.ff);
-  auto kern = mlp_bwd_kernel<KS, WAVES>;
+  auto kern = mlp_bwd_kernel<KS, WAVES, PF>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
+}
+// option MLP_FUSED: 1 = the defaults below; 100 b + f = variant codes (tools / tests): forward f in {4, 8 (prefetching), 9 (8 waves, loads in
+// place), 12, 16}, backward b in {4 (prefetching), 8 (loads in place)}
+constexpr int MF_FWD_DEFAULT = 12, MF_BWD_DEFAULT = 4;      // (profiles/round5_mlp_fused.txt)
+int mf_fwd_code() { const int o = vtx_opt(VTX_OPT_MLP_FUSED); return o >= 100 ? o % 100 : MF_FWD_DEFAULT; }
+int mf_bwd_code() { const int o = vtx_opt(VTX_OPT_MLP_FUSED); return o >= 100 ? o / 100 : MF_BWD_DEFAULT; }
+template <int KS> int mlp_fwd_launch(const MlpArgs& a, hipStream_t st) {
+  switch (mf_fwd_code()) {
+    case 4: return mlp_fwd_launch_k<KS, 4, true>(a, st);
+    case 8: return mlp_fwd_launch_k<KS, 8, true>(a, st);
+    case 9: return mlp_fwd_launch_k<KS, 8, false>(a, st);
+    case 12: return mlp_fwd_launch_k<KS, 12, false>(a, st);
+    case 16: return mlp_fwd_launch_k<KS, 16, false>(a, st);
+    default: return VTX_ERR_SHAPE;
+  }
+}
+template <int KS> int mlp_bwd_launch(const MlpArgs& a, hipStream_t st) {
+  switch (mf_bwd_code()) {
+    case 4: return mlp_bwd_launch_k<KS, 4, true>(a, st);
+    case 8: return mlp_bwd_launch_k<KS, 8, false>(a, st);
+    default: return VTX_ERR_SHAPE;
+  }
 }
 
 }  // namespace
@@ -364,9 +407,8 @@ int mlp_fused_fwd(const void* ln2, const void* w1, const float* b1, const void* 
   a.a = (const bf16*)ln2; a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.b1 = b1; a.b2 = b2; a.resid = (const bf16*)resid;
   a.y = (bf16*)y; a.z = (bf16*)z; a.h = (bf16*)h; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   a.M = (int)M; a.ff = ff;
-  const bool w8 = vtx_opt(VTX_OPT_MLP_FUSED) == 8;
-  if (C == 96) return w8 ? mlp_fwd_launch_k<3, 8>(a, st) : mlp_fwd_launch_k<3, 4>(a, st);
-  if (C == 64) return w8 ? mlp_fwd_launch_k<2, 8>(a, st) : mlp_fwd_launch_k<2, 4>(a, st);
+  if (C == 96) return mlp_fwd_launch<3>(a, st);
+  if (C == 64) return mlp_fwd_launch<2>(a, st);
   return VTX_ERR_SHAPE;
 }
 
@@ -377,9 +419,8 @@ int mlp_fused_bwd(const void* ln2, const void* dy, const void* w1, const float* 
   a.a = (const bf16*)ln2; a.dy = (const bf16*)dy; a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.b1 = b1;
   a.h = (bf16*)h; a.dz = (bf16*)dz; a.dx = (bf16*)dln2; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   a.M = (int)M; a.ff = ff;
-  const bool w8 = vtx_opt(VTX_OPT_MLP_FUSED) == 8;
-  if (C == 96) return w8 ? mlp_bwd_launch_k<3, 8>(a, st) : mlp_bwd_launch_k<3, 4>(a, st);
-  if (C == 64) return w8 ? mlp_bwd_launch_k<2, 8>(a, st) : mlp_bwd_launch_k<2, 4>(a, st);
+  if (C == 96) return mlp_bwd_launch<3>(a, st);
+  if (C == 64) return mlp_bwd_launch<2>(a, st);
   return VTX_ERR_SHAPE;
 }
 

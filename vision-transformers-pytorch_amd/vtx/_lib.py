@@ -67,7 +67,7 @@ class SrLayerBwd(ctypes.Structure):
                                    "lns_ws", "attn_ws", "wgrad_ws", "wgrad2_ws")] +
                 [(n, _Z) for n in ("ln_ws_bytes", "lns_ws_bytes", "attn_ws_bytes", "wgrad_ws_bytes", "wgrad2_ws_bytes")] +
                 [(n, _P) for n in ("dWq", "dWkv", "dWsr", "dbsr", "dWo", "dbo", "dW1", "db1", "dW2", "db2", "dg1", "dbe1", "dg2",
-                                   "dbe2", "dgs", "dbs")])
+                                   "dbe2", "dgs", "dbs", "b1")])
 
 
 ATTN_WINDOW, ATTN_GLOBAL = 1, 2

@@ -1312,7 +1312,7 @@ class PvtLayerFn(Function):
                   "mean2", "rstd2", "means", "rstds", "lse", "splitk_ws"):
             setattr(d, k, at(k))
         _lib.check(_lib.load().vtx_srlayer_fwd(ctypes.byref(d), ops._stream()), "vtx_srlayer_fwd")
-        ctx.save_for_backward(x, buf, ln1_w, ln2_w, srn_w, s1, s2)
+        ctx.save_for_backward(x, buf, ln1_w, ln2_w, srn_w, s1, s2, fc1_b)
         ctx.wp = (wq, wkv, wo, w1, w2, wsr)
         ctx.plan, ctx.one_call = pl, True
         ctx.meta, ctx.rps, ctx.dp_c, ctx.Lk, ctx.sr_shape = m, L, float(dp_c), Lk, (None if sr_w is None else sr_w.shape)
@@ -1321,7 +1321,7 @@ class PvtLayerFn(Function):
 
     @staticmethod
     def _backward_one_call(ctx, dy):
-        x, buf, ln1_w, ln2_w, srn_w, s1, s2 = ctx.saved_tensors
+        x, buf, ln1_w, ln2_w, srn_w, s1, s2, fc1_b = ctx.saved_tensors
         pl, m = ctx.plan, ctx.meta
         if pl.f_off["z"] is None:
             raise VtxError("vtx: this layer's forward ran without a graph (no pre-activation was kept)")
@@ -1362,6 +1362,7 @@ class PvtLayerFn(Function):
             setattr(d, k, fa(k))
         d.kvin = fa("kvin") if (r > 1 and has_srn) else (fa("red") if r > 1 else fa("ln1"))
         d.ln1_w, d.ln2_w, d.srn_w = ln1_w.data_ptr(), ln2_w.data_ptr(), _dp(srn_w)
+        d.b1 = fc1_b.data_ptr()                     # (the fused MLP's backward recomputes z)
         d.wq, d.wkv, d.wo, d.w1, d.w2 = wq[0].data_ptr(), wkv[0].data_ptr(), wo[0].data_ptr(), w1[0].data_ptr(), w2[0].data_ptr()
         d.wqt, d.wkvt, d.wot, d.w1t, d.w2t = _dp(wqt), _dp(wkvt), _dp(wot), _dp(w1t), _dp(w2t)
         if r > 1:

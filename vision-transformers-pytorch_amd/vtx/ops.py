@@ -310,7 +310,9 @@ def _describe_timer_rec(r):
         return kern, 0.0, (3.0 if fl & 1 else 2.0) * rows * n * es, r.ms
     if r.tag in (15, 16):                                               # fused MLP of the narrow stages: rows x C (n), ff = k
         bwd = r.tag == 16
-        waves = 8 if options.get("MLP_FUSED") == 8 else 4
+        code = options.get("MLP_FUSED")
+        code = (code // 100 if bwd else code % 100) if code >= 100 else (4 if bwd else 12)         # mlp_fused.hip: mf_fwd_code / mf_bwd_code
+        waves = {9: "8, false"}.get(code, f"{code}, {'true' if code <= 8 and not (bwd and code == 8) else 'false'}")
         # forward: ln2, x1 in, y out (2 products); backward: ln2, dy in, dln2, h, dz out (z and dh recomputed: 3 products)
         return (f"mlp_{'bwd' if bwd else 'fwd'}_kernel<{n // 32}, {waves}>", (6.0 if bwd else 4.0) * rows * n * k,
                 float(es * rows * ((3 * n + 2 * k) if bwd else 3 * n) + 2 * es * n * k), r.ms)
