@@ -65,7 +65,9 @@ template <int KS> __device__ __forceinline__ void mf_load_rows(bf16x8 (&f)[2][KS
 // PF: the next block's row operands are requested before the current block is multiplied and the residual vectors before the hidden loop
 // (one or two waves per SIMD: nobody else hides the latency); !PF (three or four waves per SIMD): loads where they are used, 24 + 24
 // registers less per lane
-template <int KS, int WAVES, bool PF>
+// ZH: z and h are also written (tests; the layer calls never ask).  Rows past M (the last block only) are row M - 1 again -- operands and
+// addresses: the same bits stored to the same place, no exec-mask branch anywhere in the hidden loop.
+template <int KS, int WAVES, bool PF, bool ZH>
 __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
   constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = PF ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
@@ -108,17 +110,15 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
     }
     int row[2];
     float rsc[2];
-    bool ok[2];
     Vec8<bf16> rv[2][KS];                                  // residual vectors of the output pairs (PF: requested now, used behind the loop)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      row[mt] = rb * MF_ROWS + mt * 16 + c;
-      ok[mt] = row[mt] < M;
-      rsc[mt] = (ok[mt] && p.rowscale) ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+      row[mt] = min(rb * MF_ROWS + mt * 16 + c, M - 1);
+      rsc[mt] = p.rowscale ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
       if constexpr (PF) {
 #pragma unroll
         for (int tp = 0; tp < KS; ++tp)
-          rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)min(row[mt], M - 1) * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
+          rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)row[mt] * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
       }
     }
     f32x4 oacc[2][2 * KS];
@@ -163,8 +163,10 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
         for (int e = 0; e < 8; ++e) zv.set(e, val[e]);         // activation of the ROUNDED pre-activation (what the backward recomputes)
 #pragma unroll
         for (int e = 0; e < 8; ++e) hv[mt].set(e, silu_f(zv.get(e)) + 0.f);      // (+ 0: the unfused epilogue's `v * scale + residual` turns -0 into +0)
-        if (p.z != nullptr && ok[mt]) store8<bf16>(p.z + (int64_t)row[mt] * ff + col, zv);
-        if (p.h != nullptr && ok[mt]) store8<bf16>(p.h + (int64_t)row[mt] * ff + col, hv[mt]);
+        if constexpr (ZH) {
+          store8<bf16>(p.z + (int64_t)row[mt] * ff + col, zv);
+          store8<bf16>(p.h + (int64_t)row[mt] * ff + col, hv[mt]);
+        }
       }
       // ---- y^T += W2[:, 32 np ..] . h^T: k-slots (g, e) <-> hidden column 32 np + 8 g + e, which is what hv holds
 #pragma unroll
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int tp = 0; tp < KS; ++tp)
-          rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)min(row[mt], M - 1) * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
+          rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)row[mt] * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
     }
 #pragma unroll
     for (int tp = 0; tp < KS; ++tp) {
@@ -192,7 +194,6 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
       const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2s + col), c1 = *reinterpret_cast<const f32x4*>(b2s + col + 4);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        if (!ok[mt]) continue;
         float val[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { val[r] = oacc[mt][2 * tp][r] + c0[r]; val[4 + r] = oacc[mt][2 * tp + 1][r] + c1[r]; }
@@ -254,6 +255,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
     int row[2];
     float rsc[2];
     bool ok[2];
+    // (the stores stay under `ok`: with unconditional stores of clamped rows -- as in the forward -- this kernel measured 252 instead of
+    //  229-232 us at 401 408 x 96 x 384, profiles/round5_mlp_fused.txt)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       row[mt] = rb * MF_ROWS + mt * 16 + c;
@@ -353,7 +356,8 @@ size_t mlp_bwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 4 + (size_t)f
 
 template <int KS, int WAVES, bool PF> int mlp_fwd_launch_k(const MlpArgs& a, hipStream_t st) {
   const size_t smem = mlp_fwd_smem(32 * KS, a.ff);
-  auto kern = mlp_fwd_kernel<KS, WAVES, PF>;
+  if ((a.z == nullptr) != (a.h == nullptr)) return VTX_ERR_NULL;             // (both or neither)
+  auto kern = a.z != nullptr ? mlp_fwd_kernel<KS, WAVES, PF, true> : mlp_fwd_kernel<KS, WAVES, PF, false>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
