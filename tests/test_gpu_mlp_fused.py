@@ -54,7 +54,7 @@ def _unfused(ln2, x1, dy, w1, b1, w2, b2, s, rps):
     return y, z, h, dz, dln2
 
 
-@pytest.mark.parametrize("waves", [1, 404, 809, 812, 816])      # option MLP_FUSED: default | 100 b + f variant codes
+@pytest.mark.parametrize("waves", [1, 404, 809, 812, 816, 708, 512, 612])      # option MLP_FUSED: default | 100 b + f variant codes
 @pytest.mark.parametrize("M,C,ff,drop", [(34496, 96, 384, 0.0), (34496, 96, 384, 0.25), (32777, 96, 384, 0.25), (401, 96, 384, 0.0),
                                          (37632, 64, 256, 0.25), (33001, 64, 512, 0.1)])
 def test_fused_mlp_is_bitwise_the_four_gemm_launches(M, C, ff, drop, waves):
@@ -151,7 +151,7 @@ def test_fused_mlp_timer_records():
     r = Rec()
     r.tag, r.rows, r.n, r.k, r.flags, r.ms = 15, 401408, 96, 384, 32, 0.1
     name, fl, nb, ms = ops._describe_timer_rec(r)
-    assert name == "mlp_fwd_kernel<3, 12, false>" and fl == 4.0 * 401408 * 96 * 384 and nb == 2 * 401408 * 3 * 96 + 4 * 96 * 384
+    assert name == "mlp_fwd_kernel<3, 12, false, false>" and fl == 4.0 * 401408 * 96 * 384 and nb == 2 * 401408 * 3 * 96 + 4 * 96 * 384
     r.tag = 16
     name, fl, nb, ms = ops._describe_timer_rec(r)
-    assert name == "mlp_bwd_kernel<3, 4, true>" and nb == 2 * 401408 * (3 * 96 + 2 * 384) + 4 * 96 * 384
+    assert name == "mlp_bwd_kernel<3, 4, true, false, 0, true>" and nb == 2 * 401408 * (3 * 96 + 2 * 384) + 4 * 96 * 384

@@ -70,7 +70,7 @@ def main():
             with options.override(MLP_FUSED=400 + f):
                 tf = timed(f_fwd, sets)
             print(f"  fused forward  variant {f:2d}: {tf:8.1f} us ({3 * unit / tf:.2f} TB/s of 3 units)")
-        for b in (4, 8):
+        for b in [int(v) for v in os.environ.get("MLP_BWD_CODES", "4,5,8,9").split(",")]:
             with options.override(MLP_FUSED=100 * b + 8):
                 tb = timed(f_bwd, sets)
             print(f"  fused backward variant {b:2d}: {tb:8.1f} us ({(3 + 2 * r) * unit / tb:.2f} TB/s of {3 + 2 * r:.0f} units)")

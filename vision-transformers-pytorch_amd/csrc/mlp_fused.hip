@@ -23,6 +23,8 @@
 // Element values: the same products in the same k order and the same epilogue expressions as the launches they replace (z rounded to
 // bf16 before the activation, h and dz rounded to bf16 before the next product): bit-identical to the unfused path
 // (tests/test_gpu_mlp_fused.py).
+#include <type_traits>
+
 #include "gemm_common.h"
 #include "options.h"
 
@@ -207,9 +209,13 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ backward
-template <int KS, int WAVES, bool PF>
+// NTS: h and dz (616 MB per Swin-S stage-1 launch, read next by the weight-gradient launch only) are stored non-temporally.
+// ABL: timing probes (results garbage): 1 no h / dz stores | 2 no silu / silu' arithmetic | 3 no dln2 product
+// PAIR: the h / dz vectors of an even 32-column step are stored together with the following odd step's: every row's 128-byte line is
+// written by two instructions issued back to back (ff % 64 == 0).
+template <int KS, int WAVES, bool PF, bool NTS = false, int ABL = 0, bool PAIR = false>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
-  constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = PF ? 2 : 1;
+  constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = (PF && WAVES <= 4) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
   const int ff = p.ff, M = p.M;
   bf16* w1s = reinterpret_cast<bf16*>(mf_smem);                       // [ff][C + 8]: W1
@@ -269,8 +275,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
 #pragma unroll
       for (int t = 0; t < 2 * KS; ++t) xacc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll MF_UNR
-    for (int np = 0; np < npairs; ++np) {
+    Vec8<bf16> hheld[2], dzheld[2];                       // PAIR: an even pair's h / dz, stored with the odd pair's (whole 128-byte lines back to back)
+    auto step = [&](int np, auto PH_) __attribute__((always_inline)) {
+      constexpr int PH = decltype(PH_)::value;             // 0 store now | 1 hold | 2 store the held vectors and these
       // ---- z = ln2 . W1^T (recomputed) and dh = dy . W2 for hidden columns 32 np + 8 g .. + 7 of rows (mt, c)
       f32x4 zacc[2][2], hacc[2][2];
 #pragma unroll
@@ -309,17 +316,37 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
         Vec8<bf16> zv, hv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) zv.set(e, zval[e]);
+        if constexpr (ABL == 2) {
+          hv = zv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hv.set(e, silu_f(zv.get(e)) + 0.f);
+          for (int e = 0; e < 8; ++e) dzv[mt].set(e, dval[e] * rsc[mt]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { float v = dval[e]; v *= dsilu_f(zv.get(e)); dzv[mt].set(e, v * rsc[mt] + 0.f); }
-        if (ok[mt]) {
-          store8<bf16>(p.h + (int64_t)row[mt] * ff + col, hv);
-          store8<bf16>(p.dz + (int64_t)row[mt] * ff + col, dzv[mt]);
+          for (int e = 0; e < 8; ++e) hv.set(e, silu_f(zv.get(e)) + 0.f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { float v = dval[e]; v *= dsilu_f(zv.get(e)); dzv[mt].set(e, v * rsc[mt] + 0.f); }
+        }
+        if constexpr (PH == 1) {
+          hheld[mt] = hv; dzheld[mt] = dzv[mt];
+        } else if (ok[mt] && (ABL != 1 || hv.get(0) == 12345.678f)) {
+          bf16* hp = p.h + (int64_t)row[mt] * ff + col;
+          bf16* zp = p.dz + (int64_t)row[mt] * ff + col;
+          if constexpr (NTS) {
+            __builtin_nontemporal_store(hv.v, reinterpret_cast<bf16x8*>(hp));
+            __builtin_nontemporal_store(dzv[mt].v, reinterpret_cast<bf16x8*>(zp));
+          } else {
+            if constexpr (PH == 2) { store8<bf16>(hp - 32, hheld[mt]); store8<bf16>(hp, hv); store8<bf16>(zp - 32, dzheld[mt]); store8<bf16>(zp, dzv[mt]); }
+            else { store8<bf16>(hp, hv); store8<bf16>(zp, dzv[mt]); }
+          }
         }
       }
       // ---- dln2^T += W1[32 np .., :]^T . dz^T: the A fragments are COLUMNS of the W1 image (transpose reads)
       const bf16* blk = w1s + np * 32 * S1 + tr_off;
+      if constexpr (ABL == 3) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) xacc[mt][0][0] += dzv[mt].get(0);
+        return;
+      }
 #pragma unroll
       for (int tp = 0; tp < KS; ++tp)
 #pragma unroll
@@ -334,6 +361,12 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) mma16(wf, dzv[mt], xacc[mt][2 * tp + j]);
         }
+    };
+    if constexpr (PAIR) {
+      for (int np = 0; np < npairs; np += 2) { step(np, std::integral_constant<int, 1>{}); step(np + 1, std::integral_constant<int, 2>{}); }
+    } else {
+#pragma unroll MF_UNR
+      for (int np = 0; np < npairs; ++np) step(np, std::integral_constant<int, 0>{});
     }
     // xacc[mt][2 tp + j][r] = (dz . W1)[row (mt, c)][32 tp + 8 g + 4 j + r]
 #pragma unroll
@@ -362,16 +395,17 @@ template <int KS, int WAVES, bool PF> int mlp_fwd_launch_k(const MlpArgs& a, hip
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
 }
-template <int KS, int WAVES, bool PF> int mlp_bwd_launch_k(const MlpArgs& a, hipStream_t st) {
+template <int KS, int WAVES, bool PF, bool NTS = false, int ABL = 0, bool PAIR = false> int mlp_bwd_launch_k(const MlpArgs& a, hipStream_t st) {
   const size_t smem = mlp_bwd_smem(32 * KS, a.ff);
-  auto kern = mlp_bwd_kernel<KS, WAVES, PF>;
+  if (PAIR && a.ff % 64 != 0) return VTX_ERR_SHAPE;
+  auto kern = mlp_bwd_kernel<KS, WAVES, PF, NTS, ABL, PAIR>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
 }
 // option MLP_FUSED: 1 = the defaults below; 100 b + f = variant codes (tools / tests): forward f in {4, 8 (prefetching), 9 (8 waves, loads in
-// place), 12, 16}, backward b in {4 (prefetching), 8 (loads in place)}
-constexpr int MF_FWD_DEFAULT = 12, MF_BWD_DEFAULT = 4;      // (profiles/round5_mlp_fused.txt)
+// place), 12, 16}, backward b in {4 (4 waves, prefetching), 6 (the same with paired stores: the default), 7 (8 waves, prefetching), 8 (loads in place), 5 / 9 (the same with non-temporal h / dz stores)}
+constexpr int MF_FWD_DEFAULT = 12, MF_BWD_DEFAULT = 6;      // (profiles/round5_mlp_fused.txt)
 int mf_fwd_code() { const int o = vtx_opt(VTX_OPT_MLP_FUSED); return o >= 100 ? o % 100 : MF_FWD_DEFAULT; }
 int mf_bwd_code() { const int o = vtx_opt(VTX_OPT_MLP_FUSED); return o >= 100 ? o / 100 : MF_BWD_DEFAULT; }
 template <int KS> int mlp_fwd_launch(const MlpArgs& a, hipStream_t st) {
@@ -387,7 +421,18 @@ template <int KS> int mlp_fwd_launch(const MlpArgs& a, hipStream_t st) {
 template <int KS> int mlp_bwd_launch(const MlpArgs& a, hipStream_t st) {
   switch (mf_bwd_code()) {
     case 4: return mlp_bwd_launch_k<KS, 4, true>(a, st);
+    case 5: return mlp_bwd_launch_k<KS, 4, true, true>(a, st);
+    case 6: return mlp_bwd_launch_k<KS, 4, true, false, 0, true>(a, st);
+    case 7: return mlp_bwd_launch_k<KS, 8, true>(a, st);
     case 8: return mlp_bwd_launch_k<KS, 8, false>(a, st);
+    case 9: return mlp_bwd_launch_k<KS, 8, false, true>(a, st);
+#ifdef VTX_MLP_ABLATE
+    case 41: return mlp_bwd_launch_k<KS, 4, true, false, 1>(a, st);
+    case 42: return mlp_bwd_launch_k<KS, 4, true, false, 2>(a, st);
+    case 43: return mlp_bwd_launch_k<KS, 4, true, false, 3>(a, st);
+    case 81: return mlp_bwd_launch_k<KS, 8, false, false, 1>(a, st);
+    case 82: return mlp_bwd_launch_k<KS, 8, false, false, 2>(a, st);
+#endif
     default: return VTX_ERR_SHAPE;
   }
 }

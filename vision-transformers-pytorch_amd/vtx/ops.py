@@ -311,8 +311,11 @@ def _describe_timer_rec(r):
     if r.tag in (15, 16):                                               # fused MLP of the narrow stages: rows x C (n), ff = k
         bwd = r.tag == 16
         code = options.get("MLP_FUSED")
-        code = (code // 100 if bwd else code % 100) if code >= 100 else (4 if bwd else 12)         # mlp_fused.hip: mf_fwd_code / mf_bwd_code
-        waves = {9: "8, false"}.get(code, f"{code}, {'true' if code <= 8 and not (bwd and code == 8) else 'false'}")
+        code = (code // 100 if bwd else code % 100) if code >= 100 else (6 if bwd else 12)         # mlp_fused.hip: mf_fwd_code / mf_bwd_code
+        targs = ({4: "4, true, false", 8: "8, true, false", 9: "8, false, false", 12: "12, false, false", 16: "16, false, false"} if not bwd else
+                 {4: "4, true, false, 0, false", 5: "4, true, true, 0, false", 6: "4, true, false, 0, true", 7: "8, true, false, 0, false",
+                  8: "8, false, false, 0, false", 9: "8, false, true, 0, false"}).get(code, str(code))
+        waves = targs
         # forward: ln2, x1 in, y out (2 products); backward: ln2, dy in, dln2, h, dz out (z and dh recomputed: 3 products)
         return (f"mlp_{'bwd' if bwd else 'fwd'}_kernel<{n // 32}, {waves}>", (6.0 if bwd else 4.0) * rows * n * k,
                 float(es * rows * ((3 * n + 2 * k) if bwd else 3 * n) + 2 * es * n * k), r.ms)
