@@ -155,3 +155,12 @@ def test_fused_mlp_timer_records():
     r.tag = 16
     name, fl, nb, ms = ops._describe_timer_rec(r)
     assert name == "mlp_bwd_kernel<3, 4, true, false, 0, true>" and nb == 2 * 401408 * (3 * 96 + 2 * 384) + 4 * 96 * 384
+
+
+@pytest.mark.parametrize("C,ff", [(96, 384), (64, 512)])
+def test_fused_mlp_does_not_depend_on_the_lds_contents(C, ff):
+    """both kernels fill their weight images before any wave reads them: zero / NaN / inf LDS fills behind them, same bits
+    (the check of tests/test_gpu_lds_poison.py, which also runs them with every torch.empty() buffer NaN-filled)"""
+    from test_gpu_lds_poison import _check
+    ops_ = _operands(33001, C, ff, 21, 0.2, 49)
+    _check(f"fused MLP C = {C}, ff = {ff}", lambda: _fused(*ops_, 49, want_zh=True))
