@@ -14,7 +14,10 @@ from vtx import ops, options
 
 dev = torch.device("cuda")
 SHAPES = [("swin s1", 128, 3136, 96, 384, 2), ("swin s2", 128, 784, 192, 768, 2), ("swin s3", 128, 196, 384, 1536, 18),
-          ("swin s4", 128, 49, 768, 3072, 2), ("vit-s", 256, 197, 384, 1536, 12)]
+          ("swin s4", 128, 49, 768, 3072, 2), ("vit-s", 256, 197, 384, 1536, 12),
+          # widths of the other families (round 5: 128 x 64 J tiles): PVT-Small stage 2 / 3 / 4, Twins-SVT-S stage 3
+          ("pvt s2", 128, 784, 128, 1024, 4), ("pvt s3", 128, 196, 320, 1280, 6), ("pvt s4", 128, 49, 512, 2048, 3),
+          ("twins s3", 128, 196, 256, 1024, 10)]
 
 
 def jobs(B, T, C, ff):
@@ -54,7 +57,7 @@ def main():
             line += f"  {us:8.1f} us {flops / us / 1e6:6.0f} TF"
         print(line)
     print("variants:", variants)
-    print("per-step ms (swin = first four rows):", [round(t, 3) for t in tot])
+    print("per-step ms (all rows x their layer counts):", [round(t, 3) for t in tot])
 
 
 if __name__ == "__main__":

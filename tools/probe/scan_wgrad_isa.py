@@ -31,6 +31,10 @@ def main():
         name, body = m.group(1), m.group(2).split("\n")
         n += 1
         barriers = [i for i, l in enumerate(body) if l.strip().startswith("s_barrier")]
+        mfmas = [i for i, l in enumerate(body) if l.strip().startswith("v_mfma_f32_16x16x32")]
+        loop_end = mfmas[-1] if mfmas else 0        # the multiplying waves' k-loop is the last loop of the kernel (the epilogue's own
+        #                                             __syncthreads, behind it, may drain whatever it likes)
+        J = int(re.search(r"Li(\d)EE", name).group(1))    # 16-column accumulator tiles per wave: 128 x 64 J output tiles
         in_asm = False
         ntr = nmfma = 0
         for i, l in enumerate(body):
@@ -50,14 +54,15 @@ def main():
                 print(f"{name}: flat access: {code}"); bad += 1
             ntr += code.startswith("ds_read_b64_tr_b16")
             nmfma += code.startswith("v_mfma_f32_16x16x32")
-            if not in_asm and barriers and barriers[0] < i < barriers[-1] and re.match(r"s_waitcnt\b.*vmcnt\(0\)", code):
+            if not in_asm and barriers and barriers[0] < i < loop_end and re.match(r"s_waitcnt\b.*vmcnt\(0\)", code):
                 print(f"{name}: compiler-inserted vmcnt(0) inside the loops (line {i}): {code}"); bad += 1
         if len(barriers) < 4:
             print(f"{name}: only {len(barriers)} s_barrier found -- the scanner no longer recognises the kernel"); bad += 1
-        if ntr != 20 or nmfma != 24:
-            print(f"{name}: {ntr} transpose reads / {nmfma} MFMAs in the body (expected 20 / 24: one k-step, not unrolled)"); bad += 1
+        if ntr != 2 * (4 + J) or nmfma != 4 * J:
+            print(f"{name}: {ntr} transpose reads / {nmfma} MFMAs in the body (expected {2 * (4 + J)} / {4 * J}: one k-step, not unrolled)"); bad += 1
     print(f"{bad} violations in {n} wgrad_wide_kernel instantiations")
-    return 1 if (bad or n != 4) else 0          # lockstep and two-group loops (option WGRAD_WIDE = 1 | 2), each plain and row-mapped
+    # J = 6: lockstep and two-group loops (option WGRAD_WIDE = 1 | 2), each plain and row-mapped; J = 5, 4, 3: lockstep, plain and row-mapped
+    return 1 if (bad or n != 10) else 0
 
 
 if __name__ == "__main__":

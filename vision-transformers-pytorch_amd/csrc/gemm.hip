@@ -399,9 +399,10 @@ static int group_tiles(int nprob, const int* N, const int* Kin) {
 }
 
 // slices of a group under the current options: 128 x 384 tiles (wgrad_wide_tiles) or 128 x 128
-static int group_slices(int nprob, const int* N, const int* Kin, int64_t mtok, bool* wide) {
-  const int wt = wgrad_wide_tiles(nprob, N, Kin);
-  if (wide) *wide = wt > 0;
+static int group_slices(int nprob, const int* N, const int* Kin, int64_t mtok, int* wide) {
+  int J = 0;
+  const int wt = wgrad_wide_tiles(nprob, N, Kin, &J);
+  if (wide) *wide = wt > 0 ? J : 0;
   return wt ? wgrad_glds_slices(mtok, wt, true) : wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
 }
 
@@ -413,10 +414,8 @@ int vtx_wgrad_group_slices(int nprob, const int* N, const int* Kin, int64_t mtok
 size_t vtx_wgrad_group_workspace(int nprob, const int* N, const int* Kin, int64_t mtok) {
   // (the larger of the two tilings' slice counts: a size taken under one setting of WGRAD_WIDE serves the other)
   int nz = wgrad_glds_slices(mtok, group_tiles(nprob, N, Kin));
-  bool w128 = true;
-  int wt = 0;
-  for (int i = 0; i < nprob; ++i) { w128 = w128 && N[i] % 128 == 0 && Kin[i] % 384 == 0; wt += (N[i] / 128) * (Kin[i] / 384); }
-  if (w128 && wt >= 1 && wt <= 256) { const int nzw = wgrad_glds_slices(mtok, wt, true); nz = nzw > nz ? nzw : nz; }
+  const int wt = wgrad_wide_tiles_any(nprob, N, Kin);
+  if (wt >= 1) { const int nzw = wgrad_glds_slices(mtok, wt, true); nz = nzw > nz ? nzw : nz; }
   size_t fl = 0;
   for (int i = 0; i < nprob; ++i) fl += (size_t)nz * ((size_t)N[i] * Kin[i] + (size_t)N[i]);
   return (fl + 4) * sizeof(float);
@@ -457,7 +456,7 @@ int vtx_wgrad_group_mapped(int dtype, int nprob, const void* const* dy, const vo
   if (!vtx_wgrad_group_ok(dtype, nprob, N, Kin, mtok, any_scale, rows_per_scale, scale_const)) return VTX_ERR_SHAPE;
   if (ws_bytes < vtx_wgrad_group_workspace(nprob, N, Kin, mtok)) return VTX_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  bool wide = false;
+  int wide = 0;
   const int nz = group_slices(nprob, N, Kin, mtok, &wide);
   if (accumulate && nz < 2) return VTX_ERR_SHAPE;          // accumulation lives in the slab reduce (vtx_wgrad_group_slices tells)
   WgradProbHost hp[8];

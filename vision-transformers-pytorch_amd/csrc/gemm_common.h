@@ -208,7 +208,8 @@ bool wgrad_glds_ok(int dtype, int N, int Kin, const float* rowscale, float scale
 int wgrad_glds_resident();
 int wgrad_glds_max_problems();
 int wgrad_glds_tiles(int N, int Kin);
-int wgrad_wide_tiles(int nprob, const int* N, const int* Kin);   // 128 x 384 tiles of the group, or 0: the group stays on 128 x 128 tiles
+int wgrad_wide_tiles(int nprob, const int* N, const int* Kin, int* J = nullptr);   // 128 x 64 J tiles of the group (J = 3 .. 6), or 0: the group stays on 128 x 128 tiles
+int wgrad_wide_tiles_any(int nprob, const int* N, const int* Kin, int* J = nullptr);   // the same whatever option WGRAD_WIDE says (workspace sizing)
 int wgrad_glds_slices(int64_t mtok, int ntiles, bool wide = false);
 int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
-                            int nz, int kchunk, hipStream_t st, bool wide = false);
+                            int nz, int kchunk, hipStream_t st, int wide = 0);

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_gl
 #endif
 constexpr int WW_BK = 32, WW_NS = 4, WW_PANEL = WW_BK * 256, WW_STAGE = 4 * WW_PANEL, WW_RING = WW_NS * WW_STAGE;
 constexpr int WW_NCW = 8, WW_NLW = 4, WW_NT = 64 * (WW_NCW + WW_NLW);
-constexpr int WW_LPT = 8;                                  // DMA instructions per request wave and k-step (2 row groups x 4 panels)
+// (DMA instructions per request wave and k-step: 2 row groups x (1 + NXP) panels -- 8 for the 384-column tiles)
 constexpr int WW_SMEM = WW_RING + WG_MAXSAMPLES + WG_MAXSAMPLES * 4;
 
 __device__ __forceinline__ Vec8<bf16> ww_frag(const unsigned char* a) {
@@ -511,8 +511,13 @@ __device__ __forceinline__ Vec8<bf16> ww_frag(const unsigned char* a) {
 // 20 transposed fragments of k-step u from LDS, so the matrix pipe of a SIMD always has a wave in its MFMA segment; two s_barrier per
 // k-step (phases 2u: group 0 reads, group 1 multiplies u - 1; 2u + 1: group 0 multiplies, group 1 reads).  A stage is last read in
 // phase 2u + 1 and refilled from phase 2u + 2 on; k-step u + 1 is visible before phase 2u + 2.  Same products in the same order: same bits.
-template <bool MAPPED, bool TG = false>
+// J (round 5, last session): 16-column accumulator tiles per multiplying wave -- a workgroup's tile is 128 x 64 J columns of dW
+// (J = 6: 384 | 5: 320, PVT stage 3 | 4: 256, Twins stage 3 / 512-wide stages | 3: 192, Swin stage 2) held in ceil(J / 2) x panels of
+// 128 columns; a ring stage keeps its four 8-KB panel slots whatever J is.  N need not be a multiple of 128 any more: dy chunks at or
+// past column N and x chunks past the tile's last column come from the zero row, rows >= N are not stored.
+template <bool MAPPED, bool TG = false, int J = 6>
 __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
+  constexpr int NXP = (J + 1) / 2, KW = 64 * J, WW_LPT = 2 * (1 + NXP);
   extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
   unsigned char* live_tab = wg_smem + WW_RING;
   int* perm_tab = reinterpret_cast<int*>(wg_smem + WW_RING + WG_MAXSAMPLES);
@@ -530,8 +535,8 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     if (i < p.nprob && tile >= p.pr[i].tile0) pi = i;
   const WgradProb& q = p.pr[pi];
   const int lt = tile - q.tile0;
-  const int tq = lt % q.ntk, tp = lt / q.ntk;               // (ntk = Kin / 384 here)
-  const int n0 = tp * 128, k0 = tq * 384;
+  const int tq = lt % q.ntk, tp = lt / q.ntk;               // (ntk = Kin / KW here)
+  const int n0 = tp * 128, k0 = tq * KW;
   const int N = q.N, Kin = q.Kin;
   const bf16* __restrict__ gdy = q.dy;
   const bf16* __restrict__ gx = q.x;
@@ -556,11 +561,11 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
 
   const bool have_ksum = q.ksum_out != nullptr && tq == 0;
   float ks8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[4][6];
+  f32x4 acc[4][J];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < J; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (wave >= WW_NCW) {
     // ---------------- request waves: wave lw owns token rows 8 lw .. 8 lw + 7 of the four panels (dy | x0 | x1 | x2) of a k-step
@@ -569,6 +574,10 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     const int qq = pslot ^ (((prow & 3) | ((lw & 1) << 2)) << 1);      // wg_swz(r): r & 3 = prow, (r >> 3) & 1 = lw & 1 for both row groups
     const bf16* zero = reinterpret_cast<const bf16*>(vtx_zero_row);
     const bf16* pz = zero + (qq << 3);
+    const bool a_ok = n0 + (qq << 3) < N;                                // this lane's 8 dy columns exist (N % 8 == 0)
+    bool b_ok[NXP];
+#pragma unroll
+    for (int pn = 0; pn < NXP; ++pn) b_ok[pn] = pn * 128 + (qq << 3) < KW && k0 + pn * 128 + (qq << 3) < Kin;
     const int nfull = (mend - mbeg) / WW_BK;
     const bf16* pa[2];
     const bf16* pb[2];
@@ -614,15 +623,16 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
             srca = reinterpret_cast<const char*>(pa[j]) + ro * inca;
             srcb = reinterpret_cast<const char*>(pb[j]) + ro * incb;
           } else {
-            srca = reinterpret_cast<const char*>(nlive[j] ? pa[j] : pz);
-            srcb = reinterpret_cast<const char*>(nlive[j] ? pb[j] : pz);
+            srca = reinterpret_cast<const char*>(pa[j]);
+            srcb = reinterpret_cast<const char*>(pb[j]);
           }
-          const unsigned step = (MAPPED || nlive[j]) ? 256u : 0u;        // (a dropped sample's rows: four times the zero row)
+          const bool lv = MAPPED || nlive[j];                            // (a dropped sample's rows: the zero row in every panel)
           unsigned char* d = sa + j * 4 * 256;
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)d, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(d + WW_PANEL), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + step), (lds_void_t*)(d + 2 * WW_PANEL), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + 2 * step), (lds_void_t*)(d + 3 * WW_PANEL), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)((lv && a_ok) ? srca : reinterpret_cast<const char*>(pz)), (lds_void_t*)d, 16, 0, 0);
+#pragma unroll
+          for (int pn = 0; pn < NXP; ++pn)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((lv && b_ok[pn]) ? srcb + pn * 256 : reinterpret_cast<const char*>(pz)),
+                                             (lds_void_t*)(d + (1 + pn) * WW_PANEL), 16, 0, 0);
           if (!MAPPED) {
             pa[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pa[j]) + inca);
             pb[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pb[j]) + incb);
@@ -644,14 +654,13 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
           if (live && has_rs) live = live_tab[tok / rps - s0] != 0;
           int64_t ro = tok;
           if (MAPPED && live) { const int sq = tok / rps; ro = (int64_t)perm_tab[sq - s0] + (tok - sq * rps); }
-          const bf16* srca = live ? gdy + ro * ld_dy + n0 + (qq << 3) : pz;
-          const bf16* srcb = live ? gx + ro * ld_x + k0 + (qq << 3) : pz;
-          const int step = live ? 128 : 0;
+          const bf16* srca = (live && a_ok) ? gdy + ro * ld_dy + n0 + (qq << 3) : pz;
+          const bf16* srcb = gx + ro * ld_x + k0 + (qq << 3);
           unsigned char* d = sa + j * 4 * 256;
           __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)d, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(d + WW_PANEL), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + step), (lds_void_t*)(d + 2 * WW_PANEL), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcb + 2 * step), (lds_void_t*)(d + 3 * WW_PANEL), 16, 0, 0);
+#pragma unroll
+          for (int pn = 0; pn < NXP; ++pn)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((live && b_ok[pn]) ? srcb + pn * 128 : pz), (lds_void_t*)(d + (1 + pn) * WW_PANEL), 16, 0, 0);
         }
       }
     };
@@ -675,14 +684,14 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     }
     if constexpr (TG) __builtin_amdgcn_s_barrier();                         // phase 2 nkt: group 1 multiplies its last k-step
   } else {
-    // ---------------- multiplying waves: wr = row half of the dy columns (64), wc = quarter of the x columns (96)
+    // ---------------- multiplying waves: wr = row half of the dy columns (64), wc = quarter of the x columns (16 J: 96 of 384)
     const int wr = wave >> 2, wc = wave & 3;
-    unsigned fp_off[4], fq_off[6];
+    unsigned fp_off[4], fq_off[J];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fp_off[i] = wg_lane_off(wr * 64 + i * 16, lane);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int qc = wc * 96 + j * 16;
+    for (int j = 0; j < J; ++j) {
+      const int qc = wc * (16 * J) + j * 16;
       fq_off[j] = (unsigned)((1 + (qc >> 7)) * WW_PANEL) + wg_lane_off(qc & 127, lane);
     }
     const int kch = threadIdx.x & 15, krg = threadIdx.x >> 4;             // bias-gradient sums: 16-byte chunk, token row (0..31)
@@ -693,12 +702,12 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
       if (wr == 1) __builtin_amdgcn_s_barrier();                           // group 1 sits out phase 0
       for (int kt = 0; kt < nkt; ++kt) {
         const unsigned char* st = wg_smem + buf * WW_STAGE;
-        Vec8<bf16> fp[4], fq[6];
+        Vec8<bf16> fp[4], fq[J];
         // ---- read segment (the partner group multiplies meanwhile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) fp[i] = ww_frag(st + fp_off[i]);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) fq[j] = ww_frag(st + fq_off[j]);
+        for (int j = 0; j < J; ++j) fq[j] = ww_frag(st + fq_off[j]);
         if (have_ksum) {
           Vec8<bf16> t = load8<bf16>(reinterpret_cast<const bf16*>(st + ks_off));
 #pragma unroll
@@ -708,14 +717,14 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fp[i].v));
 #pragma unroll
-        for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(fq[j].v));
+        for (int j = 0; j < J; ++j) asm volatile("" : "+v"(fq[j].v));
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA segment (the partner group reads its fragments meanwhile)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i) mma16(fq[j], fp[i], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
@@ -728,14 +737,14 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     } else {
     for (int kt = 0; kt < nkt; ++kt) {
       const unsigned char* st = wg_smem + buf * WW_STAGE;
-      Vec8<bf16> fp[4], fq[6];
+      Vec8<bf16> fp[4], fq[J];
       if (!(WW_ABLATE & 2)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) fp[i] = ww_frag(st + fp_off[i]);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) fq[j] = ww_frag(st + fq_off[j]);
+      for (int j = 0; j < J; ++j) fq[j] = ww_frag(st + fq_off[j]);
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
+      for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) mma16(fq[j], fp[i], acc[i][j]);
       }
@@ -764,22 +773,25 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
       float s = 0.f;
 #pragma unroll
       for (int qd = 0; qd < 32; ++qd) s += red[qd * 128 + threadIdx.x];
-      if (split) q.ksum_part[(int64_t)tz * N + n0 + threadIdx.x] = s * sc;
-      else q.ksum_out[n0 + threadIdx.x] = s * sc;
+      if (n0 + (int)threadIdx.x < N) {
+        if (split) q.ksum_part[(int64_t)tz * N + n0 + threadIdx.x] = s * sc;
+        else q.ksum_out[n0 + threadIdx.x] = s * sc;
+      }
     }
   }
   if (wave >= WW_NCW) return;
   if ((WW_ABLATE & 4) && acc[0][0][0] != 12345.678f) return;
-  // acc[i][j][r] = dW[n0 + 64 wr + 16 i + c][k0 + 96 wc + 16 j + 4 g + r]
+  // acc[i][j][r] = dW[n0 + 64 wr + 16 i + c][k0 + 16 J wc + 16 j + 4 g + r]
   const int wr = wave >> 2, wc = wave & 3, c_ = lane & 15, g_ = lane >> 4;
-  float* Cout = (split ? q.slab + (int64_t)tz * N * Kin : q.out) + (int64_t)(n0 + wr * 64 + c_) * Kin + k0 + wc * 96 + g_ * 4;
+  const int row0 = n0 + wr * 64 + c_;
+  float* Cout = (split ? q.slab + (int64_t)tz * N * Kin : q.out) + (int64_t)row0 * Kin + k0 + wc * (16 * J) + g_ * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < J; ++j) {
       f32x4 v = acc[i][j] * sc;
       vmem_guard(v);
-      *reinterpret_cast<f32x4*>(Cout + (int64_t)(i * 16) * Kin + j * 16) = v;
+      if (row0 + i * 16 < N) *reinterpret_cast<f32x4*>(Cout + (int64_t)(i * 16) * Kin + j * 16) = v;
     }
 }
 
@@ -826,37 +838,59 @@ int wgrad_glds_slices(int64_t mtok, int ntiles, bool wide) {
 
 int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) / 128); }
 
-// A group takes the 128 x 384 tiles when every problem is made of whole ones and whole slices of them fill >= 85 % of the CUs
-// (C = 384 layers: 36 tiles x 7 slices = 252; a C = 768 layer's 144 tiles would leave 112 CUs idle: 128 x 128 tiles there).
-int wgrad_wide_tiles(int nprob, const int* N, const int* Kin) {
-  if (!vtx_opt(VTX_OPT_WGRAD_WIDE)) return 0;
-  int tiles = 0;
-  for (int i = 0; i < nprob; ++i) {
-    if (N[i] % 128 || Kin[i] % 384) return 0;
-    tiles += (N[i] / 128) * (Kin[i] / 384);
-  }
+// A group takes 128 x 64 J tiles (J = 6, 5, 4, 3: the widest whose width divides every Kin of the group) when whole slices of them fill
+// >= 85 % of the CUs (C = 384 layers: 36 tiles x 7 slices = 252; a C = 768 layer's 144 tiles of 384 columns would leave 112 CUs idle and
+// its 216 tiles of 256 columns 40: 128 x 128 tiles there).  N is any multiple of 8 of at least 64 (wgrad_glds_ok): the last row tile may
+// be ragged.  Option WGRAD_WIDE bit 2 (value 4 | 5 | 6) keeps the round-4 rule: 384-column tiles of whole-tile problems only.
+static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, bool r4) {
   const int cus = vtx_cu_count_cached();
-  if (tiles < 1 || tiles > cus) return 0;
-  return 100 * ((cus / tiles) * tiles) >= 85 * cus ? tiles : 0;
+  for (int J = 6; J >= (r4 ? 6 : 3); --J) {
+    const int kw = 64 * J;
+    int tiles = 0;
+    bool ok = true;
+    for (int i = 0; i < nprob && ok; ++i) {
+      ok = Kin[i] % kw == 0 && N[i] % 8 == 0 && N[i] >= 64 && !(r4 && N[i] % 128);
+      tiles += ((N[i] + 127) / 128) * (Kin[i] / kw);
+    }
+    if (!ok || tiles < 1 || tiles > cus) continue;
+    if (100 * ((cus / tiles) * tiles) >= 85 * cus) {
+      if (Jout) *Jout = J;
+      return tiles;
+    }
+  }
+  return 0;
+}
+int wgrad_wide_tiles_any(int nprob, const int* N, const int* Kin, int* Jout) { return wgrad_wide_rule(nprob, N, Kin, Jout, false); }
+int wgrad_wide_tiles(int nprob, const int* N, const int* Kin, int* Jout) {
+  const int on = vtx_opt(VTX_OPT_WGRAD_WIDE);
+  return on ? wgrad_wide_rule(nprob, N, Kin, Jout, (on & 4) != 0) : 0;
 }
 
 // slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)
+template <bool MAPPED, bool TG, int J> static int wgrad_wide_launch_cfg(const WgradArgs& a, hipStream_t st) {
+  auto kern = wgrad_wide_kernel<MAPPED, TG, J>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WW_SMEM) != hipSuccess) return VTX_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nz), dim3(WW_NT), WW_SMEM, st, a);
+  return vtx_check_launch();
+}
+
+// wide: 0 = 128 x 128 tiles | J = 3 .. 6: 128 x 64 J tiles (wgrad_wide_tiles)
 int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, int rows_per_scale, float scale_const,
-                            int nz, int kchunk, hipStream_t st, bool wide) {
+                            int nz, int kchunk, hipStream_t st, int wide) {
   if (nprob < 1 || nprob > WG_MAXPROB) return VTX_ERR_SHAPE;
   WgradArgs a;
   int t0 = 0;
   bool any_scale = false;
   for (int i = 0; i < nprob; ++i) {
-    if (wide && (hp[i].N % 128 || hp[i].Kin % 384)) return VTX_ERR_SHAPE;
+    if (wide && (wide < 3 || wide > 6 || hp[i].Kin % (64 * wide) || hp[i].N % 8)) return VTX_ERR_SHAPE;
     WgradProb& q = a.pr[i];
     q.dy = (const bf16*)hp[i].dy; q.x = (const bf16*)hp[i].x; q.slab = hp[i].slab; q.out = hp[i].out;
     q.ksum_part = hp[i].ksum_part; q.ksum_out = hp[i].ksum_out; q.rowscale = hp[i].rowscale;
     q.ld_dy = hp[i].ld_dy; q.ld_x = hp[i].ld_x; q.N = hp[i].N; q.Kin = hp[i].Kin;
-    q.ntk = wide ? hp[i].Kin / 384 : (hp[i].Kin + 127) / 128; q.tile0 = t0; q.live_only = hp[i].live_only;
+    q.ntk = wide ? hp[i].Kin / (64 * wide) : (hp[i].Kin + 127) / 128; q.tile0 = t0; q.live_only = hp[i].live_only;
     q.perm = hp[i].perm; q.Mtok = hp[i].perm ? hp[i].Mtok : (int)mtok; q.scale = hp[i].scale;
     any_scale = any_scale || hp[i].perm != nullptr;          // (the sample table of a mapped problem has the same bound)
-    t0 += wide ? (hp[i].N / 128) * (hp[i].Kin / 384) : wgrad_glds_tiles(hp[i].N, hp[i].Kin);
+    t0 += wide ? ((hp[i].N + 127) / 128) * (hp[i].Kin / (64 * wide)) : wgrad_glds_tiles(hp[i].N, hp[i].Kin);
     any_scale = any_scale || hp[i].rowscale != nullptr;
   }
   for (int i = nprob; i < WG_MAXPROB; ++i) a.pr[i] = a.pr[0];
@@ -871,12 +905,14 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
     for (int i = 0; i < nprob; ++i) wmapped = wmapped || hp[i].perm != nullptr;
     for (int i = 0; i < nprob; ++i)
       if (wmapped && hp[i].perm == nullptr) return VTX_ERR_SHAPE;
-    const bool tg = vtx_opt(VTX_OPT_WGRAD_WIDE) == 2;           // two wave groups half a k-step apart
-    auto kern = wmapped ? (tg ? wgrad_wide_kernel<true, true> : wgrad_wide_kernel<true, false>)
-                        : (tg ? wgrad_wide_kernel<false, true> : wgrad_wide_kernel<false, false>);
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WW_SMEM) != hipSuccess) return VTX_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nz), dim3(WW_NT), WW_SMEM, st, a);
-    return vtx_check_launch();
+    const bool tg = (vtx_opt(VTX_OPT_WGRAD_WIDE) & 3) == 2;     // two wave groups half a k-step apart (384-column tiles only)
+    if (wide == 6) {
+      if (tg) return wmapped ? wgrad_wide_launch_cfg<true, true, 6>(a, st) : wgrad_wide_launch_cfg<false, true, 6>(a, st);
+      return wmapped ? wgrad_wide_launch_cfg<true, false, 6>(a, st) : wgrad_wide_launch_cfg<false, false, 6>(a, st);
+    }
+    if (wide == 5) return wmapped ? wgrad_wide_launch_cfg<true, false, 5>(a, st) : wgrad_wide_launch_cfg<false, false, 5>(a, st);
+    if (wide == 4) return wmapped ? wgrad_wide_launch_cfg<true, false, 4>(a, st) : wgrad_wide_launch_cfg<false, false, 4>(a, st);
+    return wmapped ? wgrad_wide_launch_cfg<true, false, 3>(a, st) : wgrad_wide_launch_cfg<false, false, 3>(a, st);
   }
   if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
   // (ring geometries measured in round 2 and removed: 64 tokens x 3 stages, 32 x 3 / 4 / 5 -- all slower than 64 x 2,

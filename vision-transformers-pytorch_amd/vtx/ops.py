@@ -476,14 +476,20 @@ def gemm(a, w, mode=0, bias=None, resid=None, rowscale=None, rows_per_scale=1, a
     return (c, aux) if want_aux else c
 
 
-def wgrad_wide_tiles(pairs):
-    """128 x 384 tiles of a grouped weight gradient [(N, Kin), ...], or 0 when the group stays on 128 x 128 tiles (mirrors
-    wgrad_wide_tiles, csrc/gemm_wgrad_glds.hip)."""
-    if not options.get("WGRAD_WIDE") or any(n % 128 or k % 384 for n, k in pairs):
-        return 0
-    tiles = sum((n // 128) * (k // 384) for n, k in pairs)
+def wgrad_wide_tiles(pairs, want_j=False):
+    """128 x 64 J tiles (J = 6 .. 3, the widest whose width divides every Kin) of a grouped weight gradient [(N, Kin), ...], or 0 when
+    the group stays on 128 x 128 tiles (mirrors wgrad_wide_tiles, csrc/gemm_wgrad_glds.hip).  ``want_j``: (tiles, J)."""
+    on = options.get("WGRAD_WIDE")
+    r4 = bool(on & 4)                  # the round-4 rule: whole 128 x 384 tiles only
     cus = cu_count()
-    return tiles if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= 85 * cus else 0
+    for J in ((6,) if r4 else (6, 5, 4, 3)) if on else ():
+        kw = 64 * J
+        if any(k % kw or n % 8 or n < 64 or (r4 and n % 128) for n, k in pairs):
+            continue
+        tiles = sum(((n + 127) // 128) * (k // kw) for n, k in pairs)
+        if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= 85 * cus:
+            return (tiles, J) if want_j else tiles
+    return (0, 0) if want_j else 0
 
 
 def wgrad_group_kernel_name(pairs, mapped="false"):
