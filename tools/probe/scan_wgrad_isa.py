@@ -4,10 +4,11 @@ assembly hipcc generates (no GPU needed):
   1. no register spills / private-segment traffic (one workgroup of 12 waves per CU: 168 registers per wave, and a spill goes
      through vmcnt, which the request waves count by hand);
   2. no flat_* instruction;
-  3. no compiler-inserted `s_waitcnt vmcnt(0)` between the first and the last s_barrier (the hand-written waits sit in inline-asm
+  3. no compiler-inserted `s_waitcnt vmcnt(0)` between the first s_barrier and the last MFMA, i.e. in the loops (the hand-written waits sit in inline-asm
      blocks and are not counted): hipcc inserts one in front of an LDS read of a wave that issued LDS-DMA when it cannot prove the
      two disjoint -- the request waves read the liveness / row tables of the same LDS allocation;
-  4. every transpose read and every MFMA of the k-loop is there (20 ds_read_b64_tr_b16 and 24 v_mfma per k-step).
+  4. every transpose read and every MFMA of the k-loop is there (2 (4 + J) ds_read_b64_tr_b16 and 4 J v_mfma per k-step of a
+     128 x 64 J tile: 20 / 24 for the 384-column tiles).
 
     python tools/probe/scan_wgrad_isa.py        exit status 1 on a violation
 """
