@@ -442,6 +442,15 @@ def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
     d = dev()
     cpu, gpu, c = _layer_jobs(B, T, C, ff, d)
     assert ops.wgrad_group_ok(gpu, T, c)
+    # (128 x 256 tiles are opt-in, WGRAD_WIDE bit 3: no gain inside the Twins-SVT-S step; the C = 256 case runs them here)
+    import contextlib
+    j4 = options.override(WGRAD_WIDE=9) if C == 256 else contextlib.nullcontext()
+    with j4:
+        _grouped_wgrad_case(B, T, C, ff, d, cpu, gpu, c)
+
+
+def _grouped_wgrad_case(B, T, C, ff, d, cpu, gpu, c):
+    from vtx import ops, options
     res = ops.wgrad_group(gpu, T, c)
     for (dy, x, _, s), (dW, db), name in zip(cpu, res, ("fc2", "fc1", "proj", "qkv")):
         rW, rb = _wgrad_ref(dy, x, s, T, c)
@@ -460,6 +469,8 @@ def test_grouped_layer_wgrads_vs_oracle_and_switches(B, T, C, ff):
         # the round-4 rule (whole 128 x 384 tiles only) leaves these widths on 128 x 128 tiles
         with options.override(WGRAD_WIDE=5):
             assert ops.wgrad_wide_tiles([(j[0].shape[1], j[1].shape[1]) for j in gpu]) == 0
+        with options.override(WGRAD_WIDE=1):
+            assert (ops.wgrad_wide_tiles([(j[0].shape[1], j[1].shape[1]) for j in gpu]) > 0) == (wj != 4)
     if wide and wj == 6:
         # option 1 (lockstep multiplying waves) vs the default 2 (two wave groups half a k-step apart): the same products in the same order
         with options.override(WGRAD_WIDE=3 - options.get("WGRAD_WIDE")):

@@ -842,9 +842,13 @@ int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) /
 // >= 85 % of the CUs (C = 384 layers: 36 tiles x 7 slices = 252; a C = 768 layer's 144 tiles of 384 columns would leave 112 CUs idle and
 // its 216 tiles of 256 columns 40: 128 x 128 tiles there).  N is any multiple of 8 of at least 64 (wgrad_glds_ok): the last row tile may
 // be ragged.  Option WGRAD_WIDE bit 2 (value 4 | 5 | 6) keeps the round-4 rule: 384-column tiles of whole-tile problems only.
-static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, bool r4) {
+// J = 4 (256 columns: the C = 256 layers of Twins-SVT stage 3) is opt-in (bit 3, value 9): 67 -> 60 us per layer stand-alone, but the
+// Twins-SVT-S step does not move with it -- +0.03, +0.08, -0.05 ms on three boxes, inside the run-to-run spread of that (host-bound)
+// step, whose occasional 10.8-ms runs show up under every setting (profiles/round5_wgrad_wide_all_widths.txt).
+static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, bool r4, bool j4) {
   const int cus = vtx_cu_count_cached();
   for (int J = 6; J >= (r4 ? 6 : 3); --J) {
+    if (J == 4 && !j4) continue;
     const int kw = 64 * J;
     int tiles = 0;
     bool ok = true;
@@ -860,10 +864,10 @@ static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, b
   }
   return 0;
 }
-int wgrad_wide_tiles_any(int nprob, const int* N, const int* Kin, int* Jout) { return wgrad_wide_rule(nprob, N, Kin, Jout, false); }
+int wgrad_wide_tiles_any(int nprob, const int* N, const int* Kin, int* Jout) { return wgrad_wide_rule(nprob, N, Kin, Jout, false, true); }
 int wgrad_wide_tiles(int nprob, const int* N, const int* Kin, int* Jout) {
   const int on = vtx_opt(VTX_OPT_WGRAD_WIDE);
-  return on ? wgrad_wide_rule(nprob, N, Kin, Jout, (on & 4) != 0) : 0;
+  return on ? wgrad_wide_rule(nprob, N, Kin, Jout, (on & 4) != 0, (on & 8) != 0) : 0;
 }
 
 // slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)

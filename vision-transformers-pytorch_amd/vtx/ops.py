@@ -482,7 +482,7 @@ def wgrad_wide_tiles(pairs, want_j=False):
     on = options.get("WGRAD_WIDE")
     r4 = bool(on & 4)                  # the round-4 rule: whole 128 x 384 tiles only
     cus = cu_count()
-    for J in ((6,) if r4 else (6, 5, 4, 3)) if on else ():
+    for J in ((6,) if r4 else ((6, 5, 4, 3) if on & 8 else (6, 5, 3))) if on else ():
         kw = 64 * J
         if any(k % kw or n % 8 or n < 64 or (r4 and n % 128) for n, k in pairs):
             continue
