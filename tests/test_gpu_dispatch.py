@@ -665,7 +665,8 @@ def test_one_call_layer_under_no_grad_and_shared_param_backward():
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3), ("swin_astat", 0.45), ("swin_fwd4", 0.45)])
+@pytest.mark.parametrize("family,p", [("swin", 0.45), ("swin", 0.1), ("vit", 0.4), ("vit_multicrop", 0.3), ("swin_astat", 0.45), ("swin_fwd4", 0.45),
+                                      ("swin_wide", 0.45)])
 def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, p, monkeypatch, request):
     """Round 3: with host-drawn DropPath masks every branch of a Swin layer runs over its KEPT samples only (row-mapped
     LayerNorm / LDS-DMA GEMMs / window attention, copy-only tiles for the dropped samples, weight gradients skipping their
@@ -698,9 +699,21 @@ def test_stochastic_depth_compaction_matches_the_compute_and_scale_path(family, 
         request.addfinalizer(lambda: options.set("WATTN_FWD4", prev4))
         options.set("WATTN_FWD4", 2)
         family = "swin"
+    dims, heads, ffs = (64, 128, 384, 768), (2, 4, 12, 24), (256, 512, 1536, 3072)
+    if family == "swin_wide":
+        # (round 5) widths 256 / 640: the compacted layers' grouped weight gradients run the ROW-MAPPED wide-tile kernel on 128 x 256
+        # (opt-in: WGRAD_WIDE=9) / 128 x 320 tiles, the call-by-call run the plain one through the DropPath masks
+        from vtx import ops, options
+        prevw = options.get("WGRAD_WIDE")
+        request.addfinalizer(lambda: options.set("WGRAD_WIDE", prevw))
+        options.set("WGRAD_WIDE", 9)
+        assert ops.wgrad_wide_tiles([(256, 1024), (1024, 256), (256, 256), (768, 256)], want_j=True)[1] == 4
+        assert ops.wgrad_wide_tiles([(640, 2560), (2560, 640), (640, 640), (1920, 640)], want_j=True)[1] == 5
+        dims, heads, ffs = (64, 128, 256, 640), (2, 4, 8, 20), (256, 512, 1024, 2560)
+        family = "swin"
     if family == "swin":
-        model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=(64, 128, 384, 768), dim_head=32,
-                                n_heads=(2, 4, 12, 24), dim_ffs=(256, 512, 1536, 3072), window_size=7, drop_path=p).to(d).train()
+        model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(1, 1, 3, 2), dims=dims, dim_head=32,
+                                n_heads=heads, dim_ffs=ffs, window_size=7, drop_path=p).to(d).train()
         for m in model.modules():
             if hasattr(m, "rel_pos"):
                 torch.nn.init.normal_(m.rel_pos.weight, std=0.3)

@@ -330,4 +330,4 @@ def test_wide_tile_weight_gradient_isa_has_no_spills_and_no_compiler_drain_in_it
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "probe", "scan_wgrad_isa.py")], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "0 violations in 10" in r.stdout          # (128 x 384: lockstep and two-group loops; 128 x 320 / 256 / 192: lockstep; each plain and row-mapped)
+    assert "0 violations in 9" in r.stdout           # (128 x 384: lockstep and two-group loops; 128 x 320 / 256: lockstep; each plain and row-mapped; 128 x 192: plain)

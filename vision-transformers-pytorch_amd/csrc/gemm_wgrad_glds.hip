@@ -916,7 +916,9 @@ int wgrad_glds_group_launch(int nprob, const WgradProbHost* hp, int64_t mtok, in
     }
     if (wide == 5) return wmapped ? wgrad_wide_launch_cfg<true, false, 5>(a, st) : wgrad_wide_launch_cfg<false, false, 5>(a, st);
     if (wide == 4) return wmapped ? wgrad_wide_launch_cfg<true, false, 4>(a, st) : wgrad_wide_launch_cfg<false, false, 4>(a, st);
-    return wmapped ? wgrad_wide_launch_cfg<true, false, 3>(a, st) : wgrad_wide_launch_cfg<false, false, 3>(a, st);
+    // (row-mapped problems come from compacted layers, whose C and ff are multiples of 128: a group whose widths also divide by 192
+    //  divides by 384 and has taken J = 6 -- no row-mapped 192-column instantiation)
+    return wmapped ? VTX_ERR_SHAPE : wgrad_wide_launch_cfg<false, false, 3>(a, st);
   }
   if (vtx_opt(VTX_OPT_WG_WAVES) == 4) return wgrad_glds_launch_cfg<64, 2, 4>(a, st);
   // (ring geometries measured in round 2 and removed: 64 tokens x 3 stages, 32 x 3 / 4 / 5 -- all slower than 64 x 2,
