@@ -46,7 +46,10 @@ def timeit(fn, iters=20):
 def main():
     variants = [{}] + [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[1:]]
     tot = [0.0] * len(variants)
+    only = os.environ.get("WGRAD_ONLY")            # e.g. WGRAD_ONLY="swin s3": that row alone (profiling)
     for name, B, T, C, ff, layers in SHAPES:
+        if only and name != only:
+            continue
         J, c = jobs(B, T, C, ff)
         flops = sum(2.0 * B * T * a[0].shape[1] * a[1].shape[1] for a in J)
         line = f"{name:8s}"
