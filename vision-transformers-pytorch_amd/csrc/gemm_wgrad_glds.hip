@@ -495,6 +495,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_gl
 #ifndef WW_ABLATE
 #define WW_ABLATE 0
 #endif
+#ifndef WW_NT_STORE
+#define WW_NT_STORE 0          // 1: split-K slab stores non-temporal (A/B builds: tools/r5/build_ww_ablate.sh 0 -DWW_NT_STORE=1)
+#endif
 constexpr int WW_BK = 32, WW_NS = 4, WW_PANEL = WW_BK * 256, WW_STAGE = 4 * WW_PANEL, WW_RING = WW_NS * WW_STAGE;
 constexpr int WW_NCW = 8, WW_NLW = 4, WW_NT = 64 * (WW_NCW + WW_NLW);
 // (DMA instructions per request wave and k-step: 2 row groups x (1 + NXP) panels -- 8 for the 384-column tiles)
@@ -791,7 +794,13 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
     for (int j = 0; j < J; ++j) {
       f32x4 v = acc[i][j] * sc;
       vmem_guard(v);
-      if (row0 + i * 16 < N) *reinterpret_cast<f32x4*>(Cout + (int64_t)(i * 16) * Kin + j * 16) = v;
+      if (row0 + i * 16 < N) {
+#if WW_NT_STORE
+        if (split) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cout + (int64_t)(i * 16) * Kin + j * 16));
+        else
+#endif
+        *reinterpret_cast<f32x4*>(Cout + (int64_t)(i * 16) * Kin + j * 16) = v;
+      }
     }
 }
 
