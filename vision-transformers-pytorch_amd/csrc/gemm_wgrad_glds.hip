@@ -854,7 +854,7 @@ int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) /
 // J = 4 (256 columns: the C = 256 layers of Twins-SVT stage 3) is opt-in (bit 3, value 9): 67 -> 60 us per layer stand-alone, but the
 // Twins-SVT-S step does not move with it -- +0.03, +0.08, -0.05 ms on three boxes, inside the run-to-run spread of that (host-bound)
 // step, whose occasional 10.8-ms runs show up under every setting (profiles/round5_wgrad_wide_all_widths.txt).
-static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, bool r4, bool j4) {
+static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, bool r4, bool j4, int fill = 85) {
   const int cus = vtx_cu_count_cached();
   for (int J = 6; J >= (r4 ? 6 : 3); --J) {
     if (J == 4 && !j4) continue;
@@ -866,17 +866,18 @@ static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, b
       tiles += ((N[i] + 127) / 128) * (Kin[i] / kw);
     }
     if (!ok || tiles < 1 || tiles > cus) continue;
-    if (100 * ((cus / tiles) * tiles) >= 85 * cus) {
+    if (100 * ((cus / tiles) * tiles) >= fill * cus) {
       if (Jout) *Jout = J;
       return tiles;
     }
   }
   return 0;
 }
-int wgrad_wide_tiles_any(int nprob, const int* N, const int* Kin, int* Jout) { return wgrad_wide_rule(nprob, N, Kin, Jout, false, true); }
+int wgrad_wide_tiles_any(int nprob, const int* N, const int* Kin, int* Jout) { return wgrad_wide_rule(nprob, N, Kin, Jout, false, true, 50); }
 int wgrad_wide_tiles(int nprob, const int* N, const int* Kin, int* Jout) {
   const int on = vtx_opt(VTX_OPT_WGRAD_WIDE);
-  return on ? wgrad_wide_rule(nprob, N, Kin, Jout, (on & 4) != 0, (on & 8) != 0) : 0;
+  // (bits 4 .. 11: fill threshold in percent when not 0 -- probe switch, e.g. 9 + (70 << 4) = 1129)
+  return on ? wgrad_wide_rule(nprob, N, Kin, Jout, (on & 4) != 0, (on & 8) != 0, ((on >> 4) & 255) ? ((on >> 4) & 255) : 85) : 0;
 }
 
 // slabs / ksum_part: nz > 1 only ([nz][N][Kin] / [nz][N] per problem, carved from the caller's workspace by the host)

@@ -487,7 +487,7 @@ def wgrad_wide_tiles(pairs, want_j=False):
         if any(k % kw or n % 8 or n < 64 or (r4 and n % 128) for n, k in pairs):
             continue
         tiles = sum(((n + 127) // 128) * (k // kw) for n, k in pairs)
-        if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= 85 * cus:
+        if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= (((on >> 4) & 255) or 85) * cus:
             return (tiles, J) if want_j else tiles
     return (0, 0) if want_j else 0
 
