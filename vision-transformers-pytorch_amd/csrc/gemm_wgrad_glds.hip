@@ -856,8 +856,14 @@ int wgrad_glds_tiles(int N, int Kin) { return ((N + 127) / 128) * ((Kin + 127) /
 // step, whose occasional 10.8-ms runs show up under every setting (profiles/round5_wgrad_wide_all_widths.txt).
 static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, bool r4, bool j4, int fill = 85) {
   const int cus = vtx_cu_count_cached();
+  // 256-column tiles WITHOUT the opt-in: the fallback of a group whose widths divide by 384 but whose 384-column tiles miss the fill rule
+  // (C = 768: 144 tiles = 56 %; 216 tiles of 256 columns = 84 %), from 75 % on -- Swin-S stage 4 131 -> 118 us per layer stand-alone,
+  // the Swin-S step 14.392 -> 14.352 ms (4 x 100-step runs each, every pair ordered the same way: profiles/round5_wgrad_wide_all_widths.txt)
+  bool all384 = !r4;
+  for (int i = 0; i < nprob; ++i) all384 = all384 && Kin[i] % 384 == 0;
   for (int J = 6; J >= (r4 ? 6 : 3); --J) {
-    if (J == 4 && !j4) continue;
+    if (J == 4 && !j4 && !all384) continue;
+    const int need = (J == 4 && !j4 && fill > 75) ? 75 : fill;
     const int kw = 64 * J;
     int tiles = 0;
     bool ok = true;
@@ -866,7 +872,7 @@ static int wgrad_wide_rule(int nprob, const int* N, const int* Kin, int* Jout, b
       tiles += ((N[i] + 127) / 128) * (Kin[i] / kw);
     }
     if (!ok || tiles < 1 || tiles > cus) continue;
-    if (100 * ((cus / tiles) * tiles) >= fill * cus) {
+    if (100 * ((cus / tiles) * tiles) >= need * cus) {
       if (Jout) *Jout = J;
       return tiles;
     }

@@ -25,7 +25,7 @@ enum VtxOptionId {
   VTX_OPT_GEMM_SKINNY = 15,         // 1: bf16 GEMMs with K = 64 / 96 / 128 over >= 32 768 rows take the weight-resident streaming kernel (gemm_skinny.hip) | 0
   VTX_OPT_GEMM_ASTAT = 16,          // 1: bf16 GEMMs with 192 <= K <= 384 (K % 64 == 0, N % 128 == 0, N >= 256) and >= 2 tiles per CU take the A-stationary kernel (gemm_astat.hip) | 2: any row count | 3: >= 1.25 tiles per CU | 0
   VTX_OPT_TWINS_SUB_LDS = 17,       // 1: the Twins sub-sampling gather / scatter staged through LDS (one workgroup per row of patches) where the geometry allows | 0: element-wise
-  VTX_OPT_WGRAD_WIDE = 18,          // 1: grouped weight gradients made of whole 128 x 384 tiles (C = 384 layers) take the wide-tile kernel, one workgroup per CU | 2: the same with its multiplying waves in two groups half a k-step apart | +4 (5 | 6): only those (the round-4 rule); without it 128 x 64 J tiles, J = 6, 5, 3 (+8: 4 too), for every group whose Kin are multiples of one of them (C = 192 / 320 layers too; C = 256 / 512 with +8), ragged N | bits 4-11: fill threshold in percent instead of 85 (probe: 1209 = 256-column tiles + 75 %) | 0: 128 x 128 tiles
+  VTX_OPT_WGRAD_WIDE = 18,          // 1: grouped weight gradients made of whole 128 x 384 tiles (C = 384 layers) take the wide-tile kernel, one workgroup per CU | 2: the same with its multiplying waves in two groups half a k-step apart | +4 (5 | 6): only those (the round-4 rule); without it 128 x 64 J tiles, J = 6, 5, 3 (+8: 4 too; without it J = 4 only as the >= 75 % fallback of groups whose widths divide by 384, C = 768), for every group whose Kin are multiples of one of them (C = 192 / 320 layers too; C = 256 / 512 with +8), ragged N | bits 4-11: fill threshold in percent instead of 85 (probe: 1209 = 256-column tiles + 75 %) | 0: 128 x 128 tiles
   VTX_OPT_GEMM_PP = 19,             // 1: bf16 GEMMs with N % 192 == 0, K % 64 == 0, long contractions (K >= 1152, or K >= 768 with N <= 384) and >= 3/4 of a CU-filling round of 128 x 192 tiles take the two-group kernel (gemm_pp.hip) | 2: any row count, any K | 10W: forced tile height 32 W | 0
   VTX_OPT_LN_ROWS = 20,             // LayerNorm rows in flight per lane group: bit 0 forward, two rows of the three-vector groups (C = 384 / 768 exact fit) | bit 1 backward, two rows of the one- / two-vector groups
   VTX_OPT_SKINNY_WAVES = 21,        // waves per persistent workgroup of the weight-resident streaming GEMMs (gemm_skinny.hip): 4 | 8 | 16

@@ -482,12 +482,17 @@ def wgrad_wide_tiles(pairs, want_j=False):
     on = options.get("WGRAD_WIDE")
     r4 = bool(on & 4)                  # the round-4 rule: whole 128 x 384 tiles only
     cus = cu_count()
-    for J in ((6,) if r4 else ((6, 5, 4, 3) if on & 8 else (6, 5, 3))) if on else ():
+    fill = ((on >> 4) & 255) or 85
+    all384 = not r4 and all(k % 384 == 0 for _, k in pairs)      # 256-column tiles as the fallback of under-filled 384-column groups (C = 768)
+    for J in ((6,) if r4 else (6, 5, 4, 3)) if on else ():
+        if J == 4 and not (on & 8) and not all384:
+            continue
+        need = 75 if (J == 4 and not (on & 8) and fill > 75) else fill
         kw = 64 * J
         if any(k % kw or n % 8 or n < 64 or (r4 and n % 128) for n, k in pairs):
             continue
         tiles = sum(((n + 127) // 128) * (k // kw) for n, k in pairs)
-        if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= (((on >> 4) & 255) or 85) * cus:
+        if 1 <= tiles <= cus and 100 * ((cus // tiles) * tiles) >= need * cus:
             return (tiles, J) if want_j else tiles
     return (0, 0) if want_j else 0
 
