@@ -10,8 +10,9 @@ One process per GPU; RCCL gradient all-reduce (vtx.ddp) overlapped with backward
 fixed).  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself
 (re-exec through torch.distributed.run on 127.0.0.1, like the reference's ``dist.launch(main, conf.n_gpu, ...)``,
 train.py:389-396).  Rank 0 prints ONE JSON line.  `roofline` = the HIP kernel with the largest share of the step
-(every launch class is bracketed with HIP events on its launch stream, in every --event-every-th step of the timed
-region; those sampled steps run single-stream so that durations are attributable) + the per-kernel table;
+(every launch class is bracketed with HIP events on its launch stream in --event-steps steps that run right BEHIND the
+timed region -- same process, same data; they run single-stream so that durations are attributable; the K timed steps
+carry no brackets) + the per-kernel table;
 `cpu_baseline` = the CPU oracle (a port of the reference's path, parity-checked against the reference's own outputs)
 timed on this box's host cores as BASELINE.md section 3 prescribes.
 """
@@ -296,6 +297,62 @@ def describe_buckets(ddp):
              "last": b.names[-1]} for b in ddp.buckets]
 
 
+def padded_tile_ratio(kernel, shape):
+    """MFMA work issued / algorithmic work of an attention launch: scores are computed in whole 16 x 16 tiles.  `shape` is the timer
+    record's "rows x n x k flags f" (vtx/ops.py _describe_timer_rec): window / global attention: k tokens per problem on both sides
+    (Swin 49 -> 64; ViT 197 -> 208 query rows x 224 keys: the fast path pairs key tiles); sub-sampled attention: the `rows` queries
+    are whole tiles per image up to the last one, k reduced keys (49 / 50 -> 64)."""
+    try:
+        rows, n, k = (int(t) for t in shape.split(" flags")[0].split(" x "))
+    except ValueError:
+        return 1.0
+    if k <= 0:
+        return 1.0
+    up = lambda v, m: (v + m - 1) // m * m
+    if kernel.startswith("srattn"):
+        return up(k, 16) / k
+    if kernel.startswith("sattn"):
+        return up(k, 16) * up(k, 32) / (k * k)
+    return up(k, 16) ** 2 / (k * k)
+
+
+def measured_peaks(dev):
+    """What THIS box does on the two rooflines ("record the exact peak figure used, ideally a measured ...
+    micro-benchmark on the box"): dense bf16 MFMA rate of a register-only v_mfma_f32_32x32x16_bf16 loop (libvtx vtx_debug_mfma_peak, 16
+    waves per CU) and the HBM rate of a 1-GiB device-to-device copy (read + write bytes).  ~50 ms of GPU time, outside every timed region.
+    The `frac` figures of the line stay on the NOMINAL peaks (2.5 PFLOP/s, 8 TB/s); these are reported beside them."""
+    import ctypes
+    from vtx import _lib, ops
+    lib = _lib.load()
+    sink = torch.zeros(16, device=dev)
+    fl = ctypes.c_double(0.0)
+    best = 0.0
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.vtx_debug_mfma_peak(20000, 16, sink.data_ptr(), ctypes.byref(fl), ops._stream()), "vtx_debug_mfma_peak")
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    bw = 0.0
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        if it:
+            bw = max(bw, 2.0 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return {"mfma_bf16_tflops": round(best, 1), "hbm_copy_gbps": round(bw, 1),
+            "how": "register-only v_mfma_f32_32x32x16_bf16 loop, 16 waves per CU; torch device-to-device copy of 1 GiB fp32 (read + write)"}
+
+
 def default_batch(name):
     """Per-GPU batch of BASELINE.json's configurations: 256 ViT-S/16 (cfg-2), 128 Swin-S / PVT-Small (cfg-3 / 4), 64 DINO (cfg-5)."""
     return 256 if name == "vit_s16" else (64 if name == "dino" else 128)
@@ -311,7 +368,9 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
     drop_path = 0.3 if model_name == "swin_s" else 0.1
     torch.manual_seed(0)                       # identical init on every rank (+ rank-0 broadcast in GradAllReduce)
     model = build_model(model_name, drop_path).to(dev).train()
-    ddp = GradAllReduce(model)
+    # --force-ddp (N = 1): a one-rank RCCL group with every hook / bucket / pack / collective launch / finish() of the N > 1 run live --
+    # the code path the 8-GPU run takes, on the one GPU there is (profiles/round6_ddp_overhead_one_gpu.txt, tests/test_gpu_bench_line.py)
+    ddp = GradAllReduce(model, force=bool(getattr(args, "force_ddp", False)))
     if world > 1 and rank == 0:
         print(f"[bench] gradient buckets ({model_name}): {json.dumps(describe_buckets(ddp))}", file=sys.stderr)
     ac = torch.bfloat16 if args.dtype == "bf16" else None
@@ -358,36 +417,60 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
 
     for _ in range(warmup):
         step()
-    timer = None if args.no_kernel_events else ops.KernelTimer()
-    nsampled = 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    step_events = []
     for i in range(steps):
-        sampled = timer is not None and (i % args.event_every == 0 if args.event_every > 0 else i == 0)
-        if sampled:                                   # inside the timed region, on the launch stream
-            ops.set_kernel_timer(timer)
-            nsampled += 1
-            step_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-            step_events[-1][0].record()
         loss = step()
-        if sampled:
-            step_events[-1][1].record()
-            ops.set_kernel_timer(None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.set_kernel_timer(None)
     if world > 1:
         t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss).item(), "non-finite loss"
+
+    # The event-sampled step(s) run BEHIND the timed region (round 6): the same step of the same process on the same
+    # data, every launch class bracketed with HIP events on its launch stream -- a sampled step records ~1 200 events and runs
+    # single-stream (~20 % slower than a timed step), which used to sit inside the K timed steps and cost the headline ~1.2 %.  Every rank
+    # runs them (the data-parallel collectives stay matched); rank 0 reads them.
+    timer = None if args.no_kernel_events else ops.KernelTimer()
+    nsampled = 0
+    step_events = []
+    for i in range(max(1, args.event_steps) if timer is not None else 0):
+        ops.set_kernel_timer(timer)
+        nsampled += 1
+        step_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        step_events[-1][0].record()
+        step()
+        step_events[-1][1].record()
+        ops.set_kernel_timer(None)
+    # ... and two single-stream steps WITHOUT brackets: the denominator of `kernels_coverage` -- what share of a single-stream step's GPU
+    # time the table's kernels account for; the remainder is launch boundaries (~1.5-1.9 us x ~600 dependent launches) and torch glue,
+    # not the ~1 200 event records of the sampled step (those are what `sampled_step_ms` additionally carries)
+    single_ms = None
+    if timer is not None:
+        from vtx import functional as VF_
+        prev_side, VF_._SIDE_ENABLED = VF_._SIDE_ENABLED, False
+        try:
+            step()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            step()
+            step()
+            eb.record()
+            torch.cuda.synchronize()
+            single_ms = ea.elapsed_time(eb) / 2
+        finally:
+            VF_._SIDE_ENABLED = prev_side
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
 
     value = batch * world * steps / dt
     roof = None
@@ -420,7 +503,23 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
                              hbm_bound_tflops=round(v["flops"] / v["bytes"] * PEAK_HBM_TBPS, 1))
                 return r
 
-            table = {k: row(k, v) for k, v in sorted(allk.items(), key=lambda kv: -kv[1]["ms"])}
+            # "report both algorithmic and padded-tile FLOPs" for the attention cores -- what the MFMA pipe is
+            # asked to do: every 16-token query / key tile whole (49 -> 64 tokens per window, 197 -> 208 x 224 per ViT image, 49 / 50
+            # reduced keys -> 64); from the shapes of the in-library timer records of the sampled steps
+            padded = {}
+            for (kn, shp), v in timer.by_shape().items():
+                if "attn" in kn and v["flops"] > 0:
+                    padded[kn] = padded.get(kn, 0.0) + v["flops"] * padded_tile_ratio(kn, shp)
+
+            def row_p(k, v):
+                r = row(k, v)
+                if k in padded:
+                    sec = v["ms"] * 1e-3
+                    r["padded_tile_tflops"] = round(padded[k] / sec / 1e12, 1)
+                    r["padded_tile_frac_mfma"] = round(padded[k] / sec / 1e12 / peak, 4)
+                return r
+
+            table = {k: row_p(k, v) for k, v in sorted(allk.items(), key=lambda kv: -kv[1]["ms"])}
             name, d = max(allk.items(), key=lambda kv: kv[1]["ms"])
             traffic, tsrc, tcommit = pmc_traffic(model_name, name)
             # the roofline that bounds the kernel: MFMA when its algorithmic intensity (FLOP per algorithmic HBM byte)
@@ -450,15 +549,19 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
                         executed_gflop_per_step=round(sum(v["flops"] for v in allk.values()) / nsampled / 1e9, 1),
                         # every launch class of the step (HIP events on the launch stream, sampled steps are
                         # single-stream): coverage = sum of the table / GPU time of the sampled steps
-                        sampled_step_ms=round(sampled_ms, 3),
-                        kernels_coverage=round(sum(v["ms"] for v in allk.values()) / nsampled / sampled_ms, 4),
-                        # (the sampled steps record two HIP events per launch and run single-stream: they are ~20 % slower than
-                        #  the timed steps, which is most of what the coverage above is missing; against the TIMED step the table
-                        #  sums to >= 1 because the timed steps overlap the weight gradients on a second stream)
+                        sampled_step_ms=round(sampled_ms, 3), single_stream_step_ms=round(single_ms, 3),
+                        kernels_coverage=round(sum(v["ms"] for v in allk.values()) / nsampled / single_ms, 4),
+                        kernels_coverage_of_sampled_step=round(sum(v["ms"] for v in allk.values()) / nsampled / sampled_ms, 4),
+                        # (kernels_coverage: against a single-stream step without brackets -- the remainder is launch boundaries and
+                        #  torch glue; _of_sampled_step: against the bracketed step itself, whose ~1 200 event records are most of what it
+                        #  is missing; against the TIMED step the table sums to >= 1 because the timed steps overlap the weight gradients
+                        #  on a second stream)
                         kernels_sum_ms=round(sum(v["ms"] for v in allk.values()) / nsampled, 3),
                         kernels_sum_over_timed_step=round(sum(v["ms"] for v in allk.values()) / nsampled / (1e3 * dt / steps), 4),
                         kernels=table)
-    return dict(value=value, ms_per_step=1e3 * dt / steps, workload=workload, roofline=roof)
+    return dict(value=value, ms_per_step=1e3 * dt / steps, workload=workload, roofline=roof,
+                ddp=dict(active=bool(ddp.active), buckets=len(ddp.buckets), world=ddp.world,
+                         reduced_MB=round(sum(b.flat_numel for b in ddp.buckets) * 4 / 2**20, 1)))
 
 
 def main():
@@ -473,11 +576,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--shape-table", default="", help="write the per-(kernel, shape) table of the sampled steps' in-library launches to this file")
-    ap.add_argument("--event-every", type=int, default=0,
-                    help="HIP-event brackets around every kernel launch in every N-th timed step; 0 (default): only in the "
-                         "first timed step.  A sampled step runs single-stream and each bracket costs ~2 us of stream "
-                         "time (~600 launches: the sampled step is ~15 %% slower than the others; it is inside the timed "
-                         "region and counted in `value`)")
+    ap.add_argument("--event-steps", type=int, default=1,
+                    help="event-sampled steps run BEHIND the timed region (HIP-event brackets around every kernel launch of the step, "
+                         "single-stream: the per-kernel table and the `roofline` object come from them; the K timed steps carry no "
+                         "brackets)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--selftest-launch", action="store_true", help="launcher plumbing only (gloo on CPU, no model)")
@@ -490,6 +592,10 @@ def main():
     ap.add_argument("--preflight-only", action="store_true",
                     help="N > 1: run only the pre-flight of the data-parallel branch (ranks, devices, RCCL version, ReduceOp.AVG, "
                          "side-stream collective) and print what it saw")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="--gpus 1 only: run the data-parallel machinery of the N > 1 run (RCCL process group of ONE rank, gradient buckets, "
+                         "autograd hooks, packing copies, one all_reduce launch per bucket on the side stream, finish()) instead of bypassing "
+                         "it -- what that machinery costs with nothing to exchange; the line carries `ddp`")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: every rank uses cuda:(LOCAL_RANK mod device count) -- two ranks on the one GPU of a test box")
     args = ap.parse_args()
@@ -531,6 +637,13 @@ def main():
     elif args.preflight_only:
         print(json.dumps({"preflight": {"world": 1, "note": "single process: nothing to check"}}))
         return
+    elif args.force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     batch = args.batch or default_batch(args.model)
     cpu = None
@@ -562,6 +675,16 @@ def main():
                               "roofline": {k: rf.get(k) for k in ("kernel", "bound", "frac", "frac_hbm", "frac_mfma",
                                                                   "avg_launch_us", "launches_per_step", "end_to_end_frac",
                                                                   "executed_flop_frac")}})
+    peaks = None
+    if rank == 0 and not args.no_kernel_events:
+        try:
+            peaks = measured_peaks(dev)
+            rf = res["roofline"]
+            if rf and peaks["mfma_bf16_tflops"] > 0 and peaks["hbm_copy_gbps"] > 0 and (rf["bound"] == "hbm" or args.dtype == "bf16"):
+                # the dominant kernel's fraction against what this box measurably does (beside `frac`, which stays on the nominal peak)
+                rf["frac_of_measured_peak"] = round(rf["achieved"] / (peaks["mfma_bf16_tflops"] if rf["bound"] == "mfma" else peaks["hbm_copy_gbps"]), 4)
+        except Exception as exc:           # noqa: BLE001  (a measurement helper never takes the headline line down)
+            peaks = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     if rank == 0:
         line = {
             "metric": "images/sec training (fwd+bwd+step)", "value": round(res["value"], 2), "unit": "images/sec",
@@ -573,11 +696,11 @@ def main():
             "world_size_observed": dist.get_world_size() if world > 1 else 1,
             "backend": (args.backend if world > 1 else None),
             "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and args.backend == "nccl" else None,
-            "side_stream_wgrad": bool(VF._SIDE_ENABLED),
-            "roofline": res["roofline"], "cpu_baseline": cpu, "secondary": secondary,
+            "side_stream_wgrad": bool(VF._SIDE_ENABLED), "ddp": res["ddp"],
+            "roofline": res["roofline"], "measured_peaks": peaks, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or (args.force_ddp and dist.is_initialized()):
         dist.destroy_process_group()
 
 

@@ -51,6 +51,11 @@ int vtx_cu_count(void);
 /* Test helper: fill the LDS of every CU with `pattern` (160-KB workgroups, `rounds` per CU): LDS is not cleared between workgroups, and a
  * kernel that reads LDS it never wrote sees what the previous workgroup left there (tests/test_gpu_lds_poison.py). */
 int vtx_debug_lds_poison(unsigned pattern, int rounds, void* stream);
+/* Measurement helper (bench.py `measured_peaks`, SURVEY.md section 8(d): "ideally a measured MFMA micro-benchmark on the box"): one launch of
+ * waves_per_cu / 4 256-thread workgroups per CU (waves_per_cu in 4, 8, .. 32), every wave issuing 4 * iters dense bf16 MFMAs
+ * (v_mfma_f32_32x32x16_bf16, 32 768 FLOP each) on register operands, no memory traffic.  *flops receives the FLOPs of the launch; the caller
+ * brackets the call with events on `stream`.  `sink`: any device buffer of >= 4 bytes. */
+int vtx_debug_mfma_peak(int iters, int waves_per_cu, void* sink, double* flops, void* stream);
 
 /* ---- Dispatch switches (csrc/options.h).  Which kernel variant an entry point launches -- LDS-DMA vs register-staged
  * GEMM, tile height, waves per workgroup, split-K target, fused vs separate split-K reduction, persistent-grid sizes --

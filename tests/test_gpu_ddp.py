@@ -168,3 +168,35 @@ def test_bench_world2_branch_runs_on_one_gpu_over_gloo():
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
     assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 0.02 * d["value"]      # whole-job images / (max-over-ranks step time)
+
+
+def test_bench_one_gpu_with_the_forced_rccl_group_takes_the_path_of_the_8_gpu_run():
+    """`bench.py --gpus 1 --force-ddp` -- a ONE-rank RCCL process group with every piece of the N > 1 step live
+    (gradient buckets, autograd hooks, packing copies, one all_reduce launch per bucket behind the side stream, finish() before the
+    clip): the code path the driver's 2 / 4 / 8-GPU runs take, executed on the one GPU a test box has, through bench.py's own main().
+    The line must say the machinery was active, carry every key of the contract, and a measured roofline."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--force-ddp", "--batch", "16", "--steps", "3",
+                        "--warmup", "2", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["ddp"]["active"] is True and d["ddp"]["world"] == 1 and d["ddp"]["buckets"] >= 4
+    assert 185 < d["ddp"]["reduced_MB"] < 200                      # Swin-S: 49.6 M fp32 gradients (+ slot padding) through the collective
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "measured_peaks"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["roofline"]["kernels_coverage"] > 0.5 and d["roofline"]["event_sampled_steps"] == 1
+    assert d["measured_peaks"]["mfma_bf16_tflops"] > 1500 and d["measured_peaks"]["hbm_copy_gbps"] > 3000
+    # the attention rows carry the padded-tile MFMA fraction beside the algorithmic one (SURVEY.md section 8(d))
+    att = [v for k, v in d["roofline"]["kernels"].items() if k.startswith("wattn_")]
+    assert att and all("padded_tile_frac_mfma" in v and v["padded_tile_frac_mfma"] > v["frac_mfma"] for v in att)

@@ -70,6 +70,43 @@ def test_fused_mlp_is_bitwise_the_four_gemm_launches(M, C, ff, drop, waves):
         assert torch.equal(a, b), f"fused MLP {name} differs from the unfused launches ({(a.float() - b.float()).abs().max().item():.3e} max)"
 
 
+@pytest.mark.parametrize("M,C,ff", [(33001, 96, 288), (32801, 96, 160), (33001, 64, 96), (33001, 64, 480)])
+def test_fused_mlp_with_an_odd_number_of_32_column_pairs(M, C, ff):
+    """ff = 32 x odd: mlp_fused_ok admits it, the default backward (paired stores: two 32-column pairs per step) must not refuse
+    it -- the dispatcher hands it to the unpaired variant of the same kernel; bit-identical to the four launches either way."""
+    from vtx import _lib
+    rps = 49
+    ops_ = _operands(M, C, ff, 3 + ff % 11, 0.25, rps)
+    assert _lib.load().vtx_mlp_fused_ok(1, 1 << 20, C, ff) == 1
+    y, z, h, hb, dz, dln2 = _fused(*ops_, rps, want_zh=True)
+    ry, rz, rh, rdz, rdln2 = _unfused(*ops_, rps)
+    for name, a, b in (("y", y, ry), ("z", z, rz), ("h", h, rh), ("h (backward)", hb, rh), ("dz", dz, rdz), ("dln2", dln2, rdln2)):
+        assert torch.isfinite(a.float()).all(), f"{name}: non-finite or unwritten elements"
+        assert torch.equal(a, b), f"fused MLP {name} differs from the unfused launches ({(a.float() - b.float()).abs().max().item():.3e} max)"
+
+
+def test_fused_mlp_is_bitwise_the_four_launches_at_the_bench_size():
+    """the Swin-S stage-1 row count of the benchmark (128 x 3 136 = 401 408 rows, C = 96, ff = 384, per-sample DropPath
+    scales), fused against unfused, bit for bit -- and against the fp64 oracle on a strided sample of the rows."""
+    from oracle import ref_ops as R
+    M, C, ff, rps = 401408, 96, 384, 3136
+    ops_ = _operands(M, C, ff, 17, 0.3, rps)
+    y, z, h, hb, dz, dln2 = _fused(*ops_, rps, want_zh=True)
+    ry, rz, rh, rdz, rdln2 = _unfused(*ops_, rps)
+    for name, a, b in (("y", y, ry), ("z", z, rz), ("h", h, rh), ("h (backward)", hb, rh), ("dz", dz, rdz), ("dln2", dln2, rdln2)):
+        assert torch.isfinite(a.float()).all(), f"{name}: non-finite or unwritten elements"
+        assert torch.equal(a, b), f"fused MLP {name} differs from the unfused launches at M = {M}"
+    ln2, x1, dy, w1, b1, w2, b2, s = ops_
+    idx = torch.arange(0, M, 97, device=ln2.device)
+    f = lambda t: t.detach().double().cpu()
+    sr = f(s).repeat_interleave(rps)[:M][idx.cpu(), None]
+    a = f(ln2[idx]).requires_grad_(True)
+    ref_y = f(x1[idx]) + sr * R.feed_forward(a, f(w1), f(b1), f(w2), f(b2))
+    check("fused MLP forward at M = 401 408 vs fp64 oracle (every 97th row)", y[idx], ref_y, 4e-3)
+    (ref_dln2,) = torch.autograd.grad(ref_y, a, f(dy[idx]))
+    check("fused MLP dln2 at M = 401 408 vs fp64 oracle (every 97th row)", dln2[idx], ref_dln2, 8e-3)
+
+
 def test_fused_mlp_vs_fp64_oracle():
     from oracle import ref_ops as R
     M, C, ff, rps = 2 * 3136 + 5, 96, 384, 3136

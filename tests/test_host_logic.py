@@ -331,3 +331,17 @@ def test_wide_tile_weight_gradient_isa_has_no_spills_and_no_compiler_drain_in_it
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "0 violations in 9" in r.stdout           # (128 x 384: lockstep and two-group loops; 128 x 320 / 256: lockstep; each plain and row-mapped; 128 x 192: plain)
+
+
+def test_fused_mlp_default_kernels_have_no_scratch_and_fit_their_wave_budget():
+    """Round 6: the default fused-MLP forward `mlp_fwd_kernel<3, 12, false, false>` spilled one register (8 bytes of
+    scratch at the 168-register budget of 12 waves per CU) and no scanner covered csrc/mlp_fused.hip.  The row index and the DropPath
+    scale are computed behind the hidden loop now (158 registers); the scanner checks every instantiation the dispatcher reaches by
+    default (forward 12 waves, backward paired stores and its ff = 32 x odd fallback; C = 64 and C = 96)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "probe", "scan_mlp_isa.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "0 violations in 6 default" in r.stdout

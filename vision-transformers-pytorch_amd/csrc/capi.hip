@@ -50,6 +50,25 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(unsigned pattern, int n
   if (lds_words[(threadIdx.x * 97) % nwords] != pattern) __builtin_trap();
 }
 
+// MFMA rate probe (bench.py `measured_peaks`): every wave issues `iters` x 4 independent v_mfma_f32_32x32x16_bf16 on register operands --
+// no memory traffic, four accumulator tiles so that no MFMA waits for the one before it.  The caller times the launch.
+typedef __attribute__((ext_vector_type(8))) __bf16 peak_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float peak_f32x16;
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) {
+  peak_bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)((threadIdx.x + i) & 7)); b[i] = (__bf16)(0.002f * (float)((threadIdx.x * 3 + i) & 7)); }
+  peak_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (s == 12345.678f) sink[0] = s;          // (keeps the chain alive; never true for these operands)
+}
+
 extern "C" {
 
 int vtx_option_count(void) { return VTX_OPT_COUNT; }
@@ -74,7 +93,7 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 21; }
+int vtx_abi_version(void) { return 22; }
 
 int vtx_cu_count(void) { return vtx_cu_count_cached(); }
 
@@ -86,6 +105,17 @@ int vtx_debug_lds_poison(unsigned pattern, int rounds, void* stream) {
   if (hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return VTX_ERR_LAUNCH;
   if (rounds < 1) rounds = 1;
   hipLaunchKernelGGL(lds_poison_kernel, dim3(vtx_cu_count_cached() * rounds), dim3(256), bytes, (hipStream_t)stream, pattern, bytes / 4);
+  return vtx_check_launch();
+}
+
+/* Measurement helper (bench.py `measured_peaks`): one launch of `waves_per_cu` / 4 256-thread workgroups per CU, every wave issuing
+ * 4 * iters dense bf16 MFMAs (32 x 32 x 16: 32 768 FLOP each) on register operands.  *flops receives the FLOPs of the launch; the caller
+ * brackets the call with events on `stream`.  `sink` = any device buffer of >= 4 bytes (never written in practice). */
+int vtx_debug_mfma_peak(int iters, int waves_per_cu, void* sink, double* flops, void* stream) {
+  if (!sink || iters <= 0 || waves_per_cu < 4 || waves_per_cu > 32 || waves_per_cu % 4) return VTX_ERR_SHAPE;
+  const int grid = vtx_cu_count_cached() * (waves_per_cu / 4);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, iters, (float*)sink);
+  if (flops) *flops = (double)grid * 4.0 * (double)iters * 4.0 * 32768.0;
   return vtx_check_launch();
 }
 

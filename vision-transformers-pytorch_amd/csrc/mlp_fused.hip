@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       row[mt] = min(rb * MF_ROWS + mt * 16 + c, M - 1);
-      rsc[mt] = p.rowscale ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+      if constexpr (PF || ZH) rsc[mt] = p.rowscale ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
       if constexpr (PF) {
 #pragma unroll
         for (int tp = 0; tp < KS; ++tp)
@@ -185,10 +185,15 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
     // oacc[mt][2 tp + j][r] = (h . W2^T)[row (mt, c)][32 tp + 8 g + 4 j + r]
     if constexpr (!PF) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        if constexpr (!ZH) {       // (three waves per SIMD, 168 registers: nothing of the output side is alive across the hidden loop -- no spill)
+          row[mt] = min(rb * MF_ROWS + mt * 16 + c, M - 1);
+          rsc[mt] = p.rowscale ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+        }
 #pragma unroll
         for (int tp = 0; tp < KS; ++tp)
           rv[mt][tp] = p.resid ? load8<bf16>(p.resid + (int64_t)row[mt] * C + tp * 32 + 8 * g) : vec8_zero<bf16>();
+      }
     }
 #pragma unroll
     for (int tp = 0; tp < KS; ++tp) {
@@ -422,7 +427,9 @@ template <int KS> int mlp_bwd_launch(const MlpArgs& a, hipStream_t st) {
   switch (mf_bwd_code()) {
     case 4: return mlp_bwd_launch_k<KS, 4, true>(a, st);
     case 5: return mlp_bwd_launch_k<KS, 4, true, true>(a, st);
-    case 6: return mlp_bwd_launch_k<KS, 4, true, false, 0, true>(a, st);
+    case 6:                                                  // (paired stores take two 32-column pairs per step: ff = 32 x odd runs the
+      if (a.ff % 64 != 0) return mlp_bwd_launch_k<KS, 4, true>(a, st);   //  unpaired variant of the same kernel, bit-identical -- mlp_fused_ok admits ff % 32 == 0)
+      return mlp_bwd_launch_k<KS, 4, true, false, 0, true>(a, st);
     case 7: return mlp_bwd_launch_k<KS, 8, true>(a, st);
     case 8: return mlp_bwd_launch_k<KS, 8, false>(a, st);
     case 9: return mlp_bwd_launch_k<KS, 8, false, true>(a, st);

@@ -180,12 +180,24 @@ class GradAllReduce:
         if self._counting_only:
             return
         self._counting_only = True
+        self._log_counting_once()
         for b in self.buckets:
             if len(b.handles) != len(b.params):
                 pend = b.pending
                 self._count_hooks(b)
                 if b.work is not None:          # already reduced in this cycle: stays reduced until finish()
                     b.pending = pend
+
+    def _log_counting_once(self):
+        """ the fallback is silent otherwise: correct, but every backward then runs one Python hook per parameter (329 for
+        Swin-S) instead of one per bucket"""
+        if not getattr(self, "_logged_counting", False):
+            self._logged_counting = True
+            import warnings
+            warnings.warn("vtx.ddp.GradAllReduce: gradients existed at the entry of a backward (no_sync() accumulation, finish() per "
+                          "micro-batch or zero_grad(set_to_none=False)): bucket-level trigger hooks cannot verify arrival there, the object "
+                          "stays on per-parameter counting hooks from now on (exact; ~one Python hook call per parameter and backward)",
+                          RuntimeWarning, stacklevel=3)
 
     def _count_hooks(self, b):
         for h in b.handles.values():
@@ -299,6 +311,7 @@ class GradAllReduce:
         if self._pending_counting:
             self._pending_counting = False
             self._counting_only = True
+            self._log_counting_once()
         for b in late:
             # a bucket on its bucket-level hook that was not reduced during backward: the trigger's parameter was not the
             # last one this time (or received no gradient).  Backward is over: reduce now if every gradient is there, and

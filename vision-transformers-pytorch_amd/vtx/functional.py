@@ -623,20 +623,21 @@ def _wattn_ok(rel_pos, meta):
             ops.wattn_supported(meta.dim_head, meta.swin[2]) and (meta.mask is None or meta.region is not None))
 
 
-_DROP_CALLS = [0]
-
-
 def attn_drop(p, training, keep=None):
     """(p, seed, keep) of one attention-dropout call, None when the reference's F.dropout(attn, p, training) is the identity.
-    The seed advances with every call and derives from torch's seed (and the rank of a data-parallel replica): the same
-    ``torch.manual_seed`` and call sequence reproduce the masks.  keep: an explicit uint8 keep mask [problems, Lq, Lk] (parity tests)."""
+    The 64-bit seed of the counter-based mask hash is DRAWN FROM TORCH'S GENERATOR (one CPU `randint` per active call, ~5 us of host
+    time; no device sync): ``torch.manual_seed``, ``torch.set_rng_state`` and a checkpointed RNG state govern the masks exactly as
+    they govern the reference's ``F.dropout`` (the former process-global call counter survived a re-seed and was in no
+    RNG state).  Data-parallel replicas seeded alike still draw different masks: the rank is mixed in.
+    keep: an explicit uint8 keep mask [problems, Lq, Lk] (parity tests).  p >= 1 is refused by the kernels' wrappers (the reference
+    yields zeros there; no configuration uses it)."""
     if not training or not p > 0:
         return None
-    _DROP_CALLS[0] += 1
     rank = 0
     if torch.distributed.is_available() and torch.distributed.is_initialized():
-        rank = torch.distributed.get_rank()          # (data-parallel replicas seeded alike still draw different masks)
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_CALLS[0] * 0xD1B54A32D192ED03 + rank * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
+        rank = torch.distributed.get_rank()
+    draw = int(torch.randint(0, 1 << 62, (1,)).item())            # (CPU generator: torch.manual_seed seeds it together with the device's)
+    seed = (draw * 0x9E3779B97F4A7C15 + rank * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
     return (float(p), seed, keep)
 
 

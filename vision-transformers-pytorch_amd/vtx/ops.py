@@ -644,8 +644,10 @@ def _sr_head_dim(q, kv, B, Lq, Lk, n_head):
     return D, hd
 
 
-def _drop_args(drop, dev):
-    """(p, seed, keep) of an attention-dropout call -> (float p, int seed, keep pointer); keep: uint8 [problems][Lq][Lk] or None."""
+def _drop_args(drop, dev, cells=None):
+    """(p, seed, keep) of an attention-dropout call -> (float p, int seed, keep pointer); keep: uint8 [problems][Lq][Lk] or None.
+    ``cells`` = problems * Lq * Lk of THIS call: a keep mask of any other size (a transposed or per-image layout) would be read out of
+    bounds by the kernels' drop_factor -- refused here, forward and backward alike."""
     p, seed, keep = drop
     if not 0.0 < float(p) < 1.0:
         raise VtxError(f"vtx: attention dropout probability {p} outside (0, 1)")
@@ -653,6 +655,8 @@ def _drop_args(drop, dev):
         _dev(keep)
         if keep.dtype != torch.uint8 or not keep.is_contiguous():
             raise VtxError("vtx: attention keep mask must be a contiguous uint8 tensor")
+        if cells is not None and keep.numel() != cells:
+            raise VtxError(f"vtx: attention keep mask has {keep.numel()} cells, this call needs [problems, Lq, Lk] = {cells}")
     return float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, keep
 
 
@@ -677,9 +681,7 @@ def srattn_fwd(q, kv, B, Lq, Lk, n_head, drop=None):
         _timer.records[-1] = (_timer.records[-1][0], 4.0 * B * n_head * Lq * Lk * D,
                               q.element_size() * (2.0 * B * Lq * hd + 2.0 * B * Lk * hd)) + _timer.records[-1][3:]
     if drop is not None:
-        dp, seed, keep = _drop_args(drop, q.device)
-        if keep is not None and keep.numel() != B * n_head * Lq * Lk:
-            raise VtxError("vtx: srattn keep mask must be [B * heads, Lq, Lk]")
+        dp, seed, keep = _drop_args(drop, q.device, B * n_head * Lq * Lk)
         check(_lib.load().vtx_srattn_fwd_drop(_p(q), _p(kv), _p(o), _p(lse), B, Lq, Lk, n_head, D, _dt(q), dp, seed, _p(keep),
                                               _stream()), "vtx_srattn_fwd_drop")
     else:
@@ -714,7 +716,7 @@ def srattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, drop=None):
         _timer.records[-1] = (_timer.records[-1][0], 10.0 * B * n_head * Lq * Lk * D,
                               q.element_size() * (4.0 * B * Lq * hd + 4.0 * B * Lk * hd)) + _timer.records[-1][3:]
     if drop is not None:
-        dp, seed, keep = _drop_args(drop, q.device)
+        dp, seed, keep = _drop_args(drop, q.device, B * n_head * Lq * Lk)
         check(lib.vtx_srattn_bwd_drop(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(dq), _p(dkv), _p(ws), wsb, B, Lq, Lk, n_head, D,
                                       _dt(q), dp, seed, _p(keep), _stream()), "vtx_srattn_bwd_drop")
     else:
@@ -742,6 +744,13 @@ def window_scatter(src, out, B, H, W, c0, nc, win, halo):
     """The adjoint of window_gather into channels [c0, c0 + nc) of the map ``out`` (B, H, W, ld): sums over the neighbourhoods."""
     _dev(src, out)
     ld = out.shape[-1]
+    nW, side = (H // win) * (W // win), win + 2 * halo
+    if out.numel() != B * H * W * ld or not out.is_contiguous():
+        raise VtxError("vtx: window_scatter expects a contiguous (B, H, W, C) destination map")
+    if src.dtype != out.dtype or not src.is_contiguous() or src.numel() != B * nW * side * side * nc:
+        raise VtxError(f"vtx: window_scatter source must be a contiguous [{B * nW}, {side * side}, {nc}] tensor of the map's dtype")
+    if c0 < 0 or nc <= 0 or c0 + nc > ld:
+        raise VtxError(f"vtx: window_scatter channels [{c0}, {c0 + nc}) outside the map's {ld}")
     check(_lib.load().vtx_window_scatter(_p(src), _p(out), B, H, W, ld, c0, nc, win, halo, _dt(out), _stream()), "vtx_window_scatter")
     return out
 
@@ -775,7 +784,7 @@ def xattn_fwd(q, kv, B, Lq, Lk, n_head, bias=None, drop=None):
     lse = torch.empty(B * n_head * Lq, dtype=torch.float32, device=q.device)
     ev = _attn_bracket("lattn_fwd_kernel (cross)", B * n_head, Lq, D, B * Lq, hd, q.element_size(), False)
     if drop is not None:
-        dp, seed, keep = _drop_args(drop, q.device)
+        dp, seed, keep = _drop_args(drop, q.device, B * n_head * Lq * Lk)
         check(_lib.load().vtx_xattn_fwd_drop(_p(q), _p(kv), _p(o), _p(lse), _p(bias), B, Lq, Lk, n_head, D, _dt(q), dp, seed, _p(keep),
                                              _stream()), "vtx_xattn_fwd_drop")
     else:
@@ -796,7 +805,7 @@ def xattn_bwd(q, kv, o, dout, lse, B, Lq, Lk, n_head, bias=None, drop=None):
     ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
     ev = _attn_bracket("lattn_bwd_*_kernel (cross)", B * n_head, Lq, D, B * Lq, hd, q.element_size(), True)
     if drop is not None:
-        dp, seed, keep = _drop_args(drop, q.device)
+        dp, seed, keep = _drop_args(drop, q.device, B * n_head * Lq * Lk)
         check(lib.vtx_xattn_bwd_drop(_p(q), _p(kv), _p(o), _p(dout), _p(lse), _p(bias), _p(dq), _p(dkv), _p(dbias), _p(ws), wsb, B, Lq, Lk,
                                      n_head, D, _dt(q), dp, seed, _p(keep), _stream()), "vtx_xattn_bwd_drop")
     else:
@@ -1177,9 +1186,7 @@ def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None, drop=No
     ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
                        B * nW * n_head, L, D, rows, n_head * D, qkv.element_size(), False)
     if drop is not None:
-        dp, seed, keep = _drop_args(drop, qkv.device)
-        if keep is not None and keep.numel() != B * nW * n_head * L * L:
-            raise VtxError("vtx: attention keep mask must be [B * windows * heads, L, L]")
+        dp, seed, keep = _drop_args(drop, qkv.device, B * nW * n_head * L * L)
         check(_lib.load().vtx_attention_fwd_drop(_p(qkv), _p(o), _p(lse), _p(bias), _p(mask), B, L, n_head, D,
                                                  int(swin is not None), H, W, win, int(bool(shift)), _dt(qkv), dp, seed, _p(keep),
                                                  _stream()), "vtx_attention_fwd_drop")
@@ -1213,7 +1220,7 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
     ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
                        rows // L * n_head, L, D, rows, n_head * D, qkv.element_size(), True)
     if drop is not None:
-        dp, seed, keep = _drop_args(drop, qkv.device)
+        dp, seed, keep = _drop_args(drop, qkv.device, rows * n_head * L)
         check(lib.vtx_attention_bwd_drop(_p(qkv), _p(o), _p(dout), _p(lse), _p(bias), _p(mask), _p(order), _p(offsets),
                                          _p(dqkv), _p(drel), ntab, _p(ws), wsb, B, L, n_head, D, int(swin is not None),
                                          H, W, win, int(bool(shift)), _dt(qkv), dp, seed, _p(keep), _stream()),
