@@ -120,6 +120,14 @@ int vtx_mlp_fwd(int dtype, const void* ln2, const void* w1, const float* b1, con
                 const float* rowscale, int rows_per_scale, void* y, void* z, void* h, int64_t M, int C, int ff, void* stream);
 int vtx_mlp_bwd(int dtype, const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
                 int rows_per_scale, void* h, void* dz, void* dln2, int64_t M, int C, int ff, void* stream);
+/*   vtx_mlp_bwd_ln (round 6, option LN_FOLD): vtx_mlp_bwd with the LayerNorm backward of the block's norm_ff (models/swin_transformer.py:196:
+ *                out + drop_path(ff(norm_ff(out)))) in its epilogue -- dx1 = dy + LN'(dln2) with LN' over x1 / mean / rstd / gamma, the bits of
+ *                vtx_mlp_bwd followed by vtx_layernorm_bwd(dln2, x1, mean, rstd, gamma, dres = dy); dln2 is never stored.  part: the
+ *                [part_rows][2 C] fp32 dgamma | dbeta partial rows of vtx_layernorm_bwd's deferred reduce (vtx_colreduce_multi); part_rows >=
+ *                vtx_cu_count(): the launch writes one row per workgroup and zeroes the others. */
+int vtx_mlp_bwd_ln(int dtype, const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
+                   int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
+                   void* dx1, float* part, int part_rows, int64_t M, int C, int ff, void* stream);
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
 /* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
  * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that

@@ -154,11 +154,11 @@ def test_swin_layers_with_the_fused_mlp_are_bitwise_the_unfused_ones(dim, ff, mo
     monkeypatch.setattr(torch.utils.deterministic, "fill_uninitialized_memory", True)
     try:
         assert torch.isnan(torch.empty(1024, device=d)).all(), "the debug fill of torch.empty is not active"
-        with options.override(MLP_FUSED=1):
+        with options.override(MLP_FUSED=1, LN_FOLD=0):       # (the LayerNorm fold regroups the rows of dgamma / dbeta: its own test below)
             out_a, g_a = _layer_io(model, x, True, 78, True)
     finally:
         torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
-    with options.override(MLP_FUSED=812):
+    with options.override(MLP_FUSED=812, LN_FOLD=0):
         out_c, g_c = _layer_io(model, x, True, 78, True)
     with options.override(MLP_FUSED=0):
         out_b, g_b = _layer_io(model, x, True, 78, True)
@@ -201,3 +201,93 @@ def test_fused_mlp_does_not_depend_on_the_lds_contents(C, ff):
     from test_gpu_lds_poison import _check
     ops_ = _operands(33001, C, ff, 21, 0.2, 49)
     _check(f"fused MLP C = {C}, ff = {ff}", lambda: _fused(*ops_, 49, want_zh=True))
+
+
+# ------------------------------------------------------------------------------------------------------------ round 6: LayerNorm fold
+@pytest.mark.parametrize("M,C,ff,drop", [(34496, 96, 384, 0.0), (32777, 96, 384, 0.25), (401, 96, 384, 0.0), (33001, 96, 288, 0.25),
+                                         (37632, 64, 256, 0.25), (33001, 64, 512, 0.1), (33001, 64, 96, 0.0)])
+def test_layernorm_backward_folded_into_the_fused_mlp_backward(M, C, ff, drop):
+    """vtx_mlp_bwd_ln (option LN_FOLD, round 6) = vtx_mlp_bwd + vtx_layernorm_bwd(dln2, x1, mean, rstd, gamma, dres = dy) in ONE launch:
+    h, dz and dx1 bit for bit (the row sums are formed in the stand-alone kernel's association), dgamma / dbeta to fp32 summation order
+    (another grouping of the rows) and against fp64.  Buffers NaN-filled: every row and every partial row must be written."""
+    from vtx import _lib, ops
+    lib = _lib.load()
+    rps = 49
+    ln2_in, x1, dy, w1, b1, w2, b2, s = _operands(M, C, ff, 7 + M % 5, drop, rps)
+    d = x1.device
+    g = torch.Generator().manual_seed(3)
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.1 * torch.randn(C, generator=g)).to(d)
+    ln2, mean, rstd = ops.layernorm_fwd(x1, gamma, beta, 1e-6)
+    p = lambda t: None if t is None else t.data_ptr()
+    nan = lambda *sh: torch.full(sh, float("nan"), dtype=torch.bfloat16, device=d)
+    # stand-alone: fused-MLP backward, then the LayerNorm backward with dy as the residual-stream gradient
+    h0, dz0, dln2 = nan(M, ff), nan(M, ff), nan(M, C)
+    _lib.check(lib.vtx_mlp_bwd(1, p(ln2), p(dy), p(w1), p(b1), p(w2), p(s), rps, p(h0), p(dz0), p(dln2), M, C, ff, ops._stream()), "vtx_mlp_bwd")
+    dx_ref, dg_ref, db_ref = ops.layernorm_bwd(dln2, x1, mean, rstd, gamma, dres=dy)
+    # folded
+    nb = lib.vtx_layernorm_bwd_blocks(M, C)
+    nb = max(nb, lib.vtx_cu_count())
+    part = torch.full((nb, 2 * C), float("nan"), dtype=torch.float32, device=d)
+    h1, dz1, dx1 = nan(M, ff), nan(M, ff), nan(M, C)
+    _lib.check(lib.vtx_mlp_bwd_ln(1, p(ln2), p(dy), p(w1), p(b1), p(w2), p(s), rps, p(h1), p(dz1), p(x1), p(mean), p(rstd), p(gamma),
+                                  p(dx1), p(part), nb, M, C, ff, ops._stream()), "vtx_mlp_bwd_ln")
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all(), "a dgamma / dbeta partial row was left unwritten"
+    for name, a, b in (("h", h1, h0), ("dz", dz1, dz0), ("dx1", dx1, dx_ref)):
+        assert torch.isfinite(a.float()).all(), f"{name}: non-finite or unwritten elements"
+        assert torch.equal(a, b), f"LayerNorm fold: {name} differs from the two launches ({(a.float() - b.float()).abs().max().item():.3e} max)"
+    dg, db = part[:, :C].sum(0), part[:, C:].sum(0)
+    check("LayerNorm fold: dgamma vs the stand-alone launch", dg, dg_ref.double().cpu(), 2e-5)
+    check("LayerNorm fold: dbeta vs the stand-alone launch", db, db_ref.double().cpu(), 2e-5)
+    f = lambda t: t.detach().double().cpu()
+    xh = (f(x1) - f(mean)[:, None]) * f(rstd)[:, None]
+    check("LayerNorm fold: dgamma vs fp64", dg, (f(dln2) * xh).sum(0), 2e-5)
+    check("LayerNorm fold: dbeta vs fp64", db, f(dln2).sum(0), 2e-5)
+
+
+def test_layernorm_fold_at_the_bench_size_and_in_the_model(monkeypatch):
+    """M = 401 408 (Swin-S stage 1 of the benchmark) bit for bit; and a whole model with LN_FOLD on / off: logits, every gradient except
+    the folded norms' weight / bias bit for bit, those two to fp32 summation order."""
+    from models import SwinTransformer
+    from vtx import _lib, ops, options
+    from vtx import functional as VF
+    from test_gpu_dispatch import _layer_io
+    lib = _lib.load()
+    M, C, ff, rps = 401408, 96, 384, 3136
+    ln2_in, x1, dy, w1, b1, w2, b2, s = _operands(M, C, ff, 19, 0.3, rps)
+    d = x1.device
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=torch.Generator().manual_seed(5))).to(d)
+    ln2, mean, rstd = ops.layernorm_fwd(x1, gamma, torch.zeros_like(gamma), 1e-6)
+    p = lambda t: None if t is None else t.data_ptr()
+    nan = lambda *sh: torch.full(sh, float("nan"), dtype=torch.bfloat16, device=d)
+    h0, dz0, dln2 = nan(M, ff), nan(M, ff), nan(M, C)
+    _lib.check(lib.vtx_mlp_bwd(1, p(ln2), p(dy), p(w1), p(b1), p(w2), p(s), rps, p(h0), p(dz0), p(dln2), M, C, ff, ops._stream()), "vtx_mlp_bwd")
+    dx_ref, dg_ref, db_ref = ops.layernorm_bwd(dln2, x1, mean, rstd, gamma, dres=dy)
+    nb = lib.vtx_layernorm_bwd_blocks(M, C)
+    part = torch.full((nb, 2 * C), float("nan"), dtype=torch.float32, device=d)
+    h1, dz1, dx1 = nan(M, ff), nan(M, ff), nan(M, C)
+    _lib.check(lib.vtx_mlp_bwd_ln(1, p(ln2), p(dy), p(w1), p(b1), p(w2), p(s), rps, p(h1), p(dz1), p(x1), p(mean), p(rstd), p(gamma),
+                                  p(dx1), p(part), nb, M, C, ff, ops._stream()), "vtx_mlp_bwd_ln")
+    assert torch.equal(dx1, dx_ref) and torch.equal(h1, h0) and torch.equal(dz1, dz0)
+    check("LayerNorm fold at M = 401 408: dgamma", part[:, :C].sum(0), dg_ref.double().cpu(), 2e-5)
+    del h0, dz0, h1, dz1, dln2
+    torch.manual_seed(43)
+    model = SwinTransformer(image_size=(224, 224), n_class=16, depths=(2, 2, 2, 2), dims=(96, 192, 384, 768), dim_head=32,
+                            n_heads=(3, 6, 12, 24), dim_ffs=(384, 768, 1536, 3072), window_size=7, drop_path=0.2)
+    x = torch.randn(11, 3, 224, 224, device=d)
+    model.to(d).train()
+    monkeypatch.setattr(VF, "_LAYER_CALL", True)
+    with options.override(LN_FOLD=1):
+        out_a, g_a = _layer_io(model, x, True, 78, True)
+    with options.override(LN_FOLD=0):
+        out_b, g_b = _layer_io(model, x, True, 78, True)
+    assert torch.equal(out_a, out_b)
+    folded = [k for k in g_a if k.startswith("block1.") and ".norm_ff." in k]
+    assert len(folded) == 4
+    for k in g_a:
+        if k in folded:
+            err = ((g_a[k] - g_b[k]).norm() / g_b[k].norm().clamp_min(1e-30)).item()
+            assert err < 1e-5, f"{k}: rel-L2 {err:.3e}"
+        else:
+            assert torch.equal(g_a[k], g_b[k]), f"gradient of {k} differs with LN_FOLD: {(g_a[k] - g_b[k]).abs().max().item():.3e}"

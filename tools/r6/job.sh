@@ -32,13 +32,14 @@ case "$J" in
   ddp)        # what the data-parallel machinery costs on one GPU (one-rank RCCL group, forced) vs the bypass
     timeout 1500 python tools/r6/ddp_overhead_one_gpu.py "$@" 2>&1 | grep -v amdgpu.ids > $LOG; cat $LOG ;;
   prof)       # rocprofv3 kernel stats of a short run of one model (single-stream so that durations are attributable): prof swin_s
-    M=${1:-swin_s}
+    M=${1:-swin_s}; shift; TAG=${PTAG:-$M}      # extra arguments go to bench.py; PTAG names the output; SIDE=1 keeps the second stream
     cd /tmp
-    mkdir -p $R/gpurun_out/r6_prof_$M
-    VTX_SIDE_WGRAD=0 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r6_prof_$M -o trace -- python $R/bench.py --model $M --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-kernel-events > $R/$LOG 2>&1
+    mkdir -p $R/gpurun_out/r6_prof_$TAG
+    VTX_SIDE_WGRAD=${SIDE:-0} timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r6_prof_$TAG -o trace -- python $R/bench.py --model $M --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-kernel-events "$@" > $R/gpurun_out/r6_prof_$TAG.log 2>&1
     cd $R
-    python tools/rocpd_stats.py gpurun_out/r6_prof_$M/trace_results.db --steps 7 --top 70 > gpurun_out/r6_kernel_stats_$M.md 2>> $LOG || true
-    rm -f gpurun_out/r6_prof_$M/trace_results.db
+    python tools/rocpd_stats.py gpurun_out/r6_prof_$TAG/trace_results.db --steps 7 --top 70 > gpurun_out/r6_kernel_stats_$TAG.md 2>> gpurun_out/r6_prof_$TAG.log || true
+    rm -f gpurun_out/r6_prof_$TAG/trace_results.db
+    M=$TAG
     head -40 gpurun_out/r6_kernel_stats_$M.md ;;
   py)         # any python tool: tools/r6/job.sh py name script.py args...
     N=$1; shift

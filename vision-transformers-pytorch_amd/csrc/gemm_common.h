@@ -187,6 +187,14 @@ int mlp_fused_fwd(const void* ln2, const void* w1, const float* b1, const void* 
                   const float* rowscale, int rows_per_scale, void* y, void* z, void* h, int64_t M, int C, int ff, hipStream_t st);
 int mlp_fused_bwd(const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
                   int rows_per_scale, void* h, void* dz, void* dln2, int64_t M, int C, int ff, hipStream_t st);
+// the same with the LayerNorm backward of the layer's norm_ff in its epilogue (option LN_FOLD bit 0): dx1 = dy + LN'(dln2) out, dln2 never stored;
+// part: the [part_rows][2 C] workspace of vtx_layernorm_bwd's deferred dgamma / dbeta partial rows (part_rows = vtx_layernorm_bwd_blocks)
+bool mlp_fused_ln_ok(int dtype, int64_t M, int C, int ff);
+int mlp_fused_bwd_ln(const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
+                     int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
+                     void* dx1, float* part, int part_rows, int64_t M, int C, int ff, hipStream_t st);
+extern "C" int vtx_layernorm_bwd_blocks(int64_t rows, int C);
+extern "C" size_t vtx_layernorm_bwd_workspace(int64_t rows, int C);
 // mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE
 int gemm_glds_launch_mapped(const GemmArgs& a, hipStream_t st);
 

@@ -218,22 +218,35 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
   if (!mapped) {
     // ---- MLP branch
     int rc;
+    bool ln2_folded = false;
     if (mlp_fused_ok(dt, M, C, ff)) {
       // (the forward kept neither z nor h: both are recomputed; h lands in the layer's own h buffer for the weight gradient below)
       if (!a->h || !a->b1) return VTX_ERR_NULL;
-      rc = TCALL(VTX_T_MLP_BWD, M, C, ff, 0, stream,
-                 mlp_fused_bwd(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->dln2, M, C, ff, (hipStream_t)stream));
-      if (rc) return rc;
+      if (mlp_fused_ln_ok(dt, M, C, ff)) {
+        // (option LN_FOLD bit 0) ... and the LayerNorm backward of norm_ff in its epilogue: dx1 out, dln2 never stored, one launch less
+        if (a->ln_ws_bytes < vtx_layernorm_bwd_workspace(M, C)) return VTX_ERR_WORKSPACE;
+        rc = TCALL(VTX_T_MLP_BWD, M, C, ff, F_RESID, stream,
+                   mlp_fused_bwd_ln(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->x1, a->mean2, a->rstd2,
+                                    a->ln2_w, a->dx1, (float*)a->ln2_ws, vtx_layernorm_bwd_blocks(M, C), M, C, ff, (hipStream_t)stream));
+        if (rc) return rc;
+        ln2_folded = true;
+      } else {
+        rc = TCALL(VTX_T_MLP_BWD, M, C, ff, 0, stream,
+                   mlp_fused_bwd(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->dln2, M, C, ff, (hipStream_t)stream));
+        if (rc) return rc;
+      }
     } else {
       rc = TCALL(VTX_T_GEMM, M, ff, C, F_AUXIN, stream, layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream));
       if (rc) return rc;
       rc = TCALL(VTX_T_GEMM, M, C, ff, 0, stream, layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream));
       if (rc) return rc;
     }
-    rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
-               vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
-                                 M, C, dt, 0, 0, 0, stream));
-    if (rc) return rc;
+    if (!ln2_folded) {
+      rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+                 vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes,
+                                   M, C, dt, 0, 0, 0, stream));
+      if (rc) return rc;
+    }
     // ---- attention branch
     rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream));
     if (rc) return rc;
@@ -359,20 +372,32 @@ int vtx_srlayer_bwd(const VtxSrLayerBwd* a, void* stream, void* side_stream) {
   g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
   // ---- MLP branch
   int rc;
+  bool ln2_folded = false;
   if (mlp_fused_ok(dt, M, C, ff)) {
     if (!a->h || !a->b1) return VTX_ERR_NULL;
-    rc = TCALL(VTX_T_MLP_BWD, M, C, ff, 0, stream,
-               mlp_fused_bwd(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->dln2, M, C, ff, (hipStream_t)stream));
-    if (rc) return rc;
+    if (mlp_fused_ln_ok(dt, M, C, ff)) {               // (as in vtx_layer_bwd: the norm_ff backward in the epilogue of the fused-MLP backward)
+      if (a->ln_ws_bytes < vtx_layernorm_bwd_workspace(M, C)) return VTX_ERR_WORKSPACE;
+      rc = TCALL(VTX_T_MLP_BWD, M, C, ff, F_RESID, stream,
+                 mlp_fused_bwd_ln(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->x1, a->mean2, a->rstd2,
+                                  a->ln2_w, a->dx1, (float*)a->ln2_ws, vtx_layernorm_bwd_blocks(M, C), M, C, ff, (hipStream_t)stream));
+      if (rc) return rc;
+      ln2_folded = true;
+    } else {
+      rc = TCALL(VTX_T_MLP_BWD, M, C, ff, 0, stream,
+                 mlp_fused_bwd(a->ln2, a->dy, a->w1, a->b1, a->w2, a->s2, rps, const_cast<void*>(a->h), a->dz, a->dln2, M, C, ff, (hipStream_t)stream));
+      if (rc) return rc;
+    }
   } else {
     rc = TCALL(VTX_T_GEMM, M, ff, C, F_AUXIN, stream, layer_dgrad(dt, a->dy, a->w2, a->w2t, a->dz, M, ff, C, nullptr, a->s2, rps, a->z, 2, stream));
     if (rc) return rc;
     rc = TCALL(VTX_T_GEMM, M, C, ff, 0, stream, layer_dgrad(dt, a->dz, a->w1, a->w1t, a->dln2, M, C, ff, nullptr, nullptr, 1, nullptr, 0, stream));
     if (rc) return rc;
   }
-  rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
-             vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes, M, C, dt, 0, 0, 0, stream));
-  if (rc) return rc;
+  if (!ln2_folded) {
+    rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+               vtx_layernorm_bwd(a->dln2, a->x1, a->mean2, a->rstd2, a->ln2_w, a->dy, a->dx1, nullptr, nullptr, a->ln2_ws, a->ln_ws_bytes, M, C, dt, 0, 0, 0, stream));
+    if (rc) return rc;
+  }
   // ---- attention branch
   rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, layer_dgrad(dt, a->dx1, a->wo, a->wot, a->dout, M, C, C, nullptr, a->s1, rps, nullptr, 0, stream));
   if (rc) return rc;

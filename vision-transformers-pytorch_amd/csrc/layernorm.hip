@@ -197,10 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float d = td[rr][k].get(e);
-            xh[k][e] = (tx[rr][k].get(e) - mu[rr]) * rs[rr];
-            gv[k][e] = d * gm[k][e];
-            s1 += gv[k][e];
-            s2 += gv[k][e] * xh[k][e];
+            ln_bwd_elem_accum(d, tx[rr][k].get(e), mu[rr], rs[rr], gm[k][e], s1, s2, xh[k][e], gv[k][e]);   // (vtx_common.h: shared with mlp_fused.hip)
             dg[k][e] += d * xh[k][e];
             db[k][e] += d;
           }
@@ -218,10 +215,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           Vec8<T> o;
           if (dres != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.set(e, tr[rr][k].get(e) + rs[rr] * (gv[k][e] - c1 - xh[k][e] * c2));
+            for (int e = 0; e < 8; ++e) o.set(e, ln_bwd_elem_out(tr[rr][k].get(e), rs[rr], gv[k][e], c1, xh[k][e], c2));
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.set(e, rs[rr] * (gv[k][e] - c1 - xh[k][e] * c2));
+            for (int e = 0; e < 8; ++e) o.set(e, ln_bwd_elem_out(rs[rr], gv[k][e], c1, xh[k][e], c2));
           }
           store8<T>(dx + off, o);
         }

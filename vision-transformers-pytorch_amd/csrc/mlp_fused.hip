@@ -49,6 +49,13 @@ struct MlpArgs {
   const float* rowscale;
   int rows_per_scale;
   int M, ff;
+  // LayerNorm-backward fold (backward, LNB): dx receives dx1 = dy + LN2'(dln2) instead of dln2
+  const bf16* x1;       // [M][C]: the LayerNorm's input
+  const float* mean;    // [M]
+  const float* rstd;    // [M]
+  const float* gamma;   // [C]
+  float* part;          // [part_rows][2 C] fp32: dgamma | dbeta partial rows (the stand-alone launch's workspace layout)
+  int part_rows;        // rows the deferred column reduce will sum: this launch writes gridDim.x of them and zeroes the rest
 };
 
 constexpr int MF_ROWS = 32;
@@ -218,7 +225,18 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
 // ABL: timing probes (results garbage): 1 no h / dz stores | 2 no silu / silu' arithmetic | 3 no dln2 product
 // PAIR: the h / dz vectors of an even 32-column step are stored together with the following odd step's: every row's 128-byte line is
 // written by two instructions issued back to back (ff % 64 == 0).
-template <int KS, int WAVES, bool PF, bool NTS = false, int ABL = 0, bool PAIR = false>
+// LNB (round 6, option LN_FOLD bit 0): the LayerNorm backward that follows this launch in the layer (models/swin_transformer.py:196,
+// layer.py: x1 + ff(norm_ff(x1))) runs in its epilogue.  The block's dln2 sits in the accumulators in the layout of the dy operand -- lane
+// (c, g) holds columns 32 tp + 8 g .. + 7 of rows (mt, c), i.e. whole 8-element vectors v = 4 tp + g of the stand-alone kernel's lane
+// groups <16 lanes, 1 vector> -- so dx1 = dy + rstd (g - mean(g) - xhat mean(g xhat)), g = bf16(dln2) gamma, needs x1 (one more row
+// operand, requested in front of the hidden loop) and two row sums over the four lanes c, c + 16, c + 32, c + 48.  dln2 is neither
+// written nor read back (2 of the stand-alone launch's 4 units), and that launch is gone (Swin-S stage 1: 76 us of 401 408 x 96).
+// Bit-identical dx1: the element expressions are the stand-alone kernel's (vtx_common.h ln_bwd_elem_*), dln2 goes through its bf16
+// rounding, and the row sums are formed in group_sum<16>'s association -- per-vector partials in element order, then
+// ((v0 + v1) + (v2 + v3)) per quad, (q0 + q1) + (q2 + q3) with the quads past C / 32 zero.  dgamma / dbeta: per-lane register sums over
+// the rows a lane visits, DPP sums over c, one partial row per workgroup in the stand-alone workspace layout (the rows beyond
+// gridDim.x zeroed): another row grouping than the stand-alone launch, i.e. fp32 summation order, not bits.
+template <int KS, int WAVES, bool PF, bool NTS = false, int ABL = 0, bool PAIR = false, bool LNB = false>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
   constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = (PF && WAVES <= 4) ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
@@ -248,6 +266,18 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
   // second half of the k-slots), 4-column piece at column 8 (c & 3) (+ 4 j)
   const int tr_off = (8 * g + (c >> 2)) * S1 + 8 * (c & 3);
 
+  float gmv[LNB ? KS : 1][8], dgacc[LNB ? KS : 1][8], dbacc[LNB ? KS : 1][8];
+  if constexpr (LNB) {
+#pragma unroll
+    for (int tp = 0; tp < KS; ++tp) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + tp * 32 + 8 * g), g1 = *reinterpret_cast<const f32x4*>(p.gamma + tp * 32 + 8 * g + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gmv[tp][e] = g0[e]; gmv[tp][4 + e] = g1[e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dgacc[tp][e] = 0.f; dbacc[tp][e] = 0.f; }
+    }
+  }
+
   bf16x8 an[2][KS], dn[2][KS];
   int rb = blockIdx.x * WAVES + wave;
   if (PF && rb < nrb) { mf_load_rows<KS>(an, p.a, rb, M, c, g); mf_load_rows<KS>(dn, p.dy, rb, M, c, g); }
@@ -273,6 +303,13 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
       row[mt] = rb * MF_ROWS + mt * 16 + c;
       ok[mt] = row[mt] < M;
       rsc[mt] = (ok[mt] && p.rowscale) ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+    }
+    bf16x8 xr[LNB ? 2 : 1][LNB ? KS : 1];                   // LNB: the LayerNorm's input rows and statistics, used behind the hidden loop
+    float lmu[2], lrs[2];
+    if constexpr (LNB) {
+      mf_load_rows<KS>(xr, p.x1, rb, M, c, g);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) { const int rc = min(row[mt], M - 1); lmu[mt] = p.mean[rc]; lrs[mt] = p.rstd[rc]; }
     }
     f32x4 xacc[2][2 * KS];
 #pragma unroll
@@ -374,17 +411,79 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
       for (int np = 0; np < npairs; ++np) step(np, std::integral_constant<int, 0>{});
     }
     // xacc[mt][2 tp + j][r] = (dz . W1)[row (mt, c)][32 tp + 8 g + 4 j + r]
+    if constexpr (!LNB) {
 #pragma unroll
-    for (int tp = 0; tp < KS; ++tp) {
-      const int col = tp * 32 + 8 * g;
+      for (int tp = 0; tp < KS; ++tp) {
+        const int col = tp * 32 + 8 * g;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (!ok[mt]) continue;
+          Vec8<bf16> o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { o.set(r, xacc[mt][2 * tp][r]); o.set(4 + r, xacc[mt][2 * tp + 1][r]); }
+          store8<bf16>(p.dx + (int64_t)row[mt] * C + col, o);
+        }
+      }
+    } else {
+      constexpr float invC = 1.f / (float)C;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        if (!ok[mt]) continue;
-        Vec8<bf16> o;
+        float xh[KS][8], gv[KS][8], q1[KS], q2[KS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { o.set(r, xacc[mt][2 * tp][r]); o.set(4 + r, xacc[mt][2 * tp + 1][r]); }
-        store8<bf16>(p.dx + (int64_t)row[mt] * C + col, o);
+        for (int tp = 0; tp < KS; ++tp) {
+          Vec8<bf16> dl, xv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { dl.set(r, xacc[mt][2 * tp][r]); dl.set(4 + r, xacc[mt][2 * tp + 1][r]); }      // (the bf16 the stand-alone path stores)
+          xv.v = xr[mt][tp];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = dl.get(e);
+            ln_bwd_elem_accum(d, xv.get(e), lmu[mt], lrs[mt], gmv[tp][e], s1, s2, xh[tp][e], gv[tp][e]);
+            if (ok[mt]) { dgacc[tp][e] += d * xh[tp][e]; dbacc[tp][e] += d; }
+          }
+          // vector v = 4 tp + g of the row: pairs (g, g ^ 1), then the quad -- the first two steps of group_sum<16>
+          s1 += shfl_xor_f(s1, 16);
+          s2 += shfl_xor_f(s2, 16);
+          q1[tp] = s1 + shfl_xor_f(s1, 32);
+          q2[tp] = s2 + shfl_xor_f(s2, 32);
+        }
+        // 8-lane halves (q0 + q1), (q2 + q3), then their sum; quads past C / 32 hold zeros in the stand-alone kernel
+        float c1, c2;
+        if constexpr (KS == 2) { c1 = ((q1[0] + q1[1]) + 0.f) * invC; c2 = ((q2[0] + q2[1]) + 0.f) * invC; }
+        else if constexpr (KS == 3) { c1 = ((q1[0] + q1[1]) + (q1[2] + 0.f)) * invC; c2 = ((q2[0] + q2[1]) + (q2[2] + 0.f)) * invC; }
+        else { c1 = ((q1[0] + q1[1]) + (q1[2] + q1[KS - 1])) * invC; c2 = ((q2[0] + q2[1]) + (q2[2] + q2[KS - 1])) * invC; }
+        if (!ok[mt]) continue;
+#pragma unroll
+        for (int tp = 0; tp < KS; ++tp) {
+          Vec8<bf16> dv, o;
+          dv.v = d[mt][tp];                                    // the residual-stream gradient that bypasses the norm: dy itself
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.set(e, ln_bwd_elem_out(dv.get(e), lrs[mt], gv[tp][e], c1, xh[tp][e], c2));
+          store8<bf16>(p.dx + (int64_t)row[mt] * C + tp * 32 + 8 * g, o);
+        }
       }
+    }
+  }
+  if constexpr (LNB) {
+    // dgamma / dbeta: sum over the 16 lanes c of a DPP row (they hold the same columns), then over the waves through the (now dead) W1
+    // image, in wave order; one partial row per workgroup, the workspace rows nobody owns zeroed for the deferred column reduce
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(mf_smem);            // [WAVES][2 C]
+#pragma unroll
+    for (int tp = 0; tp < KS; ++tp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = group_sum<16>(dgacc[tp][e]), b = group_sum<16>(dbacc[tp][e]);
+        if (c == 0) { red[wave * 2 * C + tp * 32 + 8 * g + e] = a; red[wave * 2 * C + C + tp * 32 + 8 * g + e] = b; }
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += NT) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) a += red[w * 2 * C + i];
+      p.part[(int64_t)blockIdx.x * 2 * C + i] = a;
+      for (int r = blockIdx.x + gridDim.x; r < p.part_rows; r += gridDim.x) p.part[(int64_t)r * 2 * C + i] = 0.f;
     }
   }
 }
@@ -400,10 +499,11 @@ template <int KS, int WAVES, bool PF> int mlp_fwd_launch_k(const MlpArgs& a, hip
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
 }
-template <int KS, int WAVES, bool PF, bool NTS = false, int ABL = 0, bool PAIR = false> int mlp_bwd_launch_k(const MlpArgs& a, hipStream_t st) {
+template <int KS, int WAVES, bool PF, bool NTS = false, int ABL = 0, bool PAIR = false, bool LNB = false> int mlp_bwd_launch_k(const MlpArgs& a, hipStream_t st) {
   const size_t smem = mlp_bwd_smem(32 * KS, a.ff);
   if (PAIR && a.ff % 64 != 0) return VTX_ERR_SHAPE;
-  auto kern = mlp_bwd_kernel<KS, WAVES, PF, NTS, ABL, PAIR>;
+  if (LNB && (!a.x1 || !a.mean || !a.rstd || !a.gamma || !a.part || a.part_rows < vtx_cu_count_cached())) return VTX_ERR_NULL;
+  auto kern = mlp_bwd_kernel<KS, WAVES, PF, NTS, ABL, PAIR, LNB>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
@@ -424,6 +524,10 @@ template <int KS> int mlp_fwd_launch(const MlpArgs& a, hipStream_t st) {
   }
 }
 template <int KS> int mlp_bwd_launch(const MlpArgs& a, hipStream_t st) {
+  if (a.x1 != nullptr) {                                     // LayerNorm-backward fold: the default variant (four waves, prefetching) only
+    if (a.ff % 64 != 0) return mlp_bwd_launch_k<KS, 4, true, false, 0, false, true>(a, st);
+    return mlp_bwd_launch_k<KS, 4, true, false, 0, true, true>(a, st);
+  }
   switch (mf_bwd_code()) {
     case 4: return mlp_bwd_launch_k<KS, 4, true>(a, st);
     case 5: return mlp_bwd_launch_k<KS, 4, true, true>(a, st);
@@ -480,6 +584,24 @@ int mlp_fused_bwd(const void* ln2, const void* dy, const void* w1, const float* 
   return VTX_ERR_SHAPE;
 }
 
+bool mlp_fused_ln_ok(int dtype, int64_t M, int C, int ff) {
+  return (vtx_opt(VTX_OPT_LN_FOLD) & 1) != 0 && mlp_fused_ok(dtype, M, C, ff) && vtx_layernorm_bwd_blocks(M, C) >= vtx_cu_count_cached();
+}
+
+int mlp_fused_bwd_ln(const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
+                     int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
+                     void* dx1, float* part, int part_rows, int64_t M, int C, int ff, hipStream_t st) {
+  if (!ln2 || !dy || !w1 || !w2 || !h || !dz || !x1 || !mean || !rstd || !gamma || !dx1 || !part) return VTX_ERR_NULL;
+  MlpArgs a = {};
+  a.a = (const bf16*)ln2; a.dy = (const bf16*)dy; a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.b1 = b1;
+  a.h = (bf16*)h; a.dz = (bf16*)dz; a.dx = (bf16*)dx1; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+  a.M = (int)M; a.ff = ff;
+  a.x1 = (const bf16*)x1; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.part = part; a.part_rows = part_rows;
+  if (C == 96) return mlp_bwd_launch<3>(a, st);
+  if (C == 64) return mlp_bwd_launch<2>(a, st);
+  return VTX_ERR_SHAPE;
+}
+
 extern "C" {
 
 int vtx_mlp_fused_ok(int dtype, int64_t M, int C, int ff) { return mlp_fused_ok(dtype, M, C, ff) ? 1 : 0; }
@@ -496,6 +618,18 @@ int vtx_mlp_bwd(int dtype, const void* ln2, const void* dy, const void* w1, cons
   if (dtype != VTX_BF16) return VTX_ERR_DTYPE;
   if (M <= 0 || !mlp_fused_ok(dtype, M > 32768 ? M : 32768, C, ff)) return VTX_ERR_SHAPE;
   return mlp_fused_bwd(ln2, dy, w1, b1, w2, rowscale, rows_per_scale, h, dz, dln2, M, C, ff, (hipStream_t)stream);
+}
+
+/* vtx_mlp_bwd with the LayerNorm backward of norm_ff folded into its epilogue (round 6, option LN_FOLD): dx1 = dy + LN'(dln2) -- the
+ * bits of vtx_mlp_bwd followed by vtx_layernorm_bwd(dln2, x1, mean, rstd, gamma, dres = dy); part: [part_rows][2 C] fp32 dgamma | dbeta
+ * partial rows for vtx_colreduce / vtx_colreduce_multi (part_rows >= compute units; rows this launch does not own are zeroed). */
+int vtx_mlp_bwd_ln(int dtype, const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
+                   int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
+                   void* dx1, float* part, int part_rows, int64_t M, int C, int ff, void* stream) {
+  if (dtype != VTX_BF16) return VTX_ERR_DTYPE;
+  if (M <= 0 || !mlp_fused_ok(dtype, M > 32768 ? M : 32768, C, ff)) return VTX_ERR_SHAPE;
+  return mlp_fused_bwd_ln(ln2, dy, w1, b1, w2, rowscale, rows_per_scale, h, dz, x1, mean, rstd, gamma, dx1, part, part_rows, M, C, ff,
+                          (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -150,6 +150,24 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// LayerNorm backward, element level -- shared by ln_bwd_kernel (csrc/layernorm.hip) and the fold of that kernel into the fused-MLP
+// backward (csrc/mlp_fused.hip, round 6): the SAME expressions (hence the same fp contraction by hipcc) in both, so that the folded
+// path reproduces the stand-alone launch's dx bit for bit as long as the row sums are formed in group_sum<16>'s order.
+//   accum: xh = (x - mu) rs;  gv = d gamma;  s1 += gv;  s2 += gv xh      (d = the incoming gradient dln, x = the LayerNorm's input)
+//   out:   dx = dres + rs (gv - c1 - xh c2)   with c1 = mean(gv), c2 = mean(gv xh) over the row
+__device__ __forceinline__ void ln_bwd_elem_accum(float d, float x, float mu, float rs, float gm, float& s1, float& s2, float& xh, float& gv) {
+  xh = (x - mu) * rs;
+  gv = d * gm;
+  s1 += gv;
+  s2 += gv * xh;
+}
+__device__ __forceinline__ float ln_bwd_elem_out(float dres, float rs, float gv, float c1, float xh, float c2) {
+  return dres + rs * (gv - c1 - xh * c2);
+}
+__device__ __forceinline__ float ln_bwd_elem_out(float rs, float gv, float c1, float xh, float c2) {
+  return rs * (gv - c1 - xh * c2);
+}
+
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: these run once per output element in GEMM epilogues
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoidf_(z); }

@@ -101,6 +101,12 @@ class GradAllReduce:
             self.broadcast_state()
         self.buckets = assign_buckets(named, bucket_bytes, first_bucket_bytes, last_bucket_bytes)
         self._avg = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else None
+        # A forced ONE-rank group (force=True: tests, bench.py --force-ddp): the mean over one rank is the identity, and RCCL runs AVG on one
+        # rank as a `oneRankReduce<FuncPreMulSum>` copy kernel over the whole bucket (Swin-S: 189 MB through 6 launches = 0.5 ms per step,
+        # profiles/round6_ddp_overhead_one_gpu.txt) -- a kernel the N > 1 run does not have (its ring kernel averages on the fly).  SUM in
+        # place is what a one-rank collective degenerates to: the call, its stream / event bookkeeping and work.wait() stay live.
+        if self.world == 1:
+            self._avg = dist.ReduceOp.SUM
         self._slot = {}
         self._sunk = set()         # ids of the parameters whose bucket slot was handed out as a gradient sink since finish()
         self._sync = True          # False inside no_sync(): hooks do not count, nothing is reduced
@@ -336,7 +342,7 @@ class GradAllReduce:
                                "since the last finish()")
         for b in self.buckets:
             b.work.wait()
-            if self._avg is None:
+            if self._avg is None and self.world > 1:
                 b.flat.div_(self.world)
             for p, v in zip(b.params, b.views):
                 p.grad = v

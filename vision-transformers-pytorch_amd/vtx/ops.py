@@ -316,9 +316,13 @@ def _describe_timer_rec(r):
                  {4: "4, true, false, 0, false", 5: "4, true, true, 0, false", 6: "4, true, false, 0, true", 7: "8, true, false, 0, false",
                   8: "8, false, false, 0, false", 9: "8, false, true, 0, false"}).get(code, str(code))
         waves = targs
-        # forward: ln2, x1 in, y out (2 products); backward: ln2, dy in, dln2, h, dz out (z and dh recomputed: 3 products)
+        lnb = bwd and bool(fl & 1)          # (flag 1 on a backward record: the norm_ff backward folded into the epilogue, option LN_FOLD)
+        if lnb:
+            waves = ("4, true, false, 0, true, true" if k % 64 == 0 else "4, true, false, 0, false, true")
+        # forward: ln2, x1 in, y out (2 products); backward: ln2, dy in, dln2, h, dz out (z and dh recomputed: 3 products); with the
+        # LayerNorm backward folded in: ln2, dy, x1 in, dx1, h, dz out (4 C + 2 ff per row) -- the two launches it replaces move 7 C + 2 ff
         return (f"mlp_{'bwd' if bwd else 'fwd'}_kernel<{n // 32}, {waves}>", (6.0 if bwd else 4.0) * rows * n * k,
-                float(es * rows * ((3 * n + 2 * k) if bwd else 3 * n) + 2 * es * n * k), r.ms)
+                float(es * rows * (((4 if lnb else 3) * n + 2 * k) if bwd else 3 * n) + 2 * es * n * k), r.ms)
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
 
 
