@@ -128,6 +128,12 @@ int vtx_mlp_bwd(int dtype, const void* ln2, const void* dy, const void* w1, cons
 int vtx_mlp_bwd_ln(int dtype, const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
                    int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
                    void* dx1, float* part, int part_rows, int64_t M, int C, int ff, void* stream);
+/* ---- Narrow-layer input gradient with the LayerNorm backward in its epilogue (round 6, option LN_FOLD bit 1; csrc/gemm_skinny.hip):
+ * dx = dres + LN'(dy . W) -- the bits of vtx_gemm(dy [M, K], wt [C, K] = W^T) followed by vtx_layernorm_bwd(dln, x, mean, rstd, gamma,
+ * dres); the intermediate dln [M, C] is never stored.  bf16, C in {64, 96, 128}, K = 3 C (a packed qkv projection, reference
+ * models/swin_transformer.py:128,194) or K = C.  part: as in vtx_mlp_bwd_ln. */
+int vtx_dgrad_ln(int dtype, const void* dy, const void* wt, const void* x, const float* mean, const float* rstd, const float* gamma,
+                 const void* dres, void* dx, float* part, int part_rows, int64_t M, int C, int K, void* stream);
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
 /* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
  * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that
@@ -372,7 +378,9 @@ enum { VTX_T_LN_FWD = 1, VTX_T_GEMM = 2, VTX_T_WATTN_FWD = 3, VTX_T_ATTN_FWD = 4
        VTX_T_SRATTN_FWD = 9, VTX_T_SRATTN_BWD = 10, VTX_T_WGRAD_SR_A = 11, VTX_T_WGRAD_SR_B = 12, VTX_T_WGRAD_SPLITK = 13,
        VTX_T_GATHER = 14,
        /* the fused MLP of the narrow stages (vtx_mlp_fwd / vtx_mlp_bwd inside vtx_layer_*): rows, n = C, k = ff */
-       VTX_T_MLP_FWD = 15, VTX_T_MLP_BWD = 16 };
+       VTX_T_MLP_FWD = 15, VTX_T_MLP_BWD = 16,
+       /* round 6: a dgrad with the LayerNorm backward in its epilogue (csrc/gemm_skinny.hip dgrad_ln_kernel): rows x C (n) over k */
+       VTX_T_DGRAD_LN = 17 };
 typedef struct VtxTimerRec { int tag, n, k, flags; int64_t rows; float ms; } VtxTimerRec;
 int vtx_timer_start(void);
 int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */

@@ -69,6 +69,45 @@ def main():
         print(f"  LayerNorm backward alone          {tl:8.1f} us ({4 * unit / tl:.2f} TB/s of 4 units)")
         print(f"  the two launches back to back     {tt:8.1f} us")
         print(f"  folded (vtx_mlp_bwd_ln)           {tf:8.1f} us ({(4 + 2 * r) * unit / tf:.2f} TB/s of {4 + 2 * r:.0f} units)   -> {tt - tf:+.1f} us, {100 * (tf / tt - 1):+.1f} %")
+    # ---- the qkv input gradient + norm_attn backward (gemm_skinny.hip dgrad_ln_kernel, option LN_FOLD bit 1)
+    for (M, C, K) in ((401408, 96, 288), (401408, 64, 192)):
+        sets = []
+        nb = lib.vtx_layernorm_bwd_blocks(M, C)
+        wsb = lib.vtx_layernorm_bwd_workspace(M, C)
+        for k in range(3):
+            g = torch.Generator().manual_seed(200 + k)
+            d = torch.device("cuda")
+            bf = lambda *s, std=1.0: (torch.randn(*s, generator=g) * std).to(torch.bfloat16).to(d)
+            dy, x, dres, w = bf(M, K, std=0.05), bf(M, C), bf(M, C, std=0.05), bf(K, C, std=C ** -0.5)
+            gamma = (1.0 + 0.1 * torch.randn(C)).to(d)
+            _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros_like(gamma), 1e-6)
+            e = lambda n: torch.empty(M, n, dtype=torch.bfloat16, device=d)
+            sets.append(dict(dy=dy, x=x, dres=dres, w=w, wt=w.t().contiguous(), mean=mean, rstd=rstd, gamma=gamma, dln=e(C), dx=e(C),
+                             ws=torch.empty(wsb, dtype=torch.uint8, device=d)))
+        st = ops._stream()
+
+        def f_dgrad(o):
+            lib.vtx_gemm(0, 1, p(o["dy"]), p(o["wt"]), p(o["dln"]), M, C, K, K, K, C, None, None, None, 1, None, None, 0, st)
+
+        def f_ln(o):
+            _lib.check(lib.vtx_layernorm_bwd(p(o["dln"]), p(o["x"]), p(o["mean"]), p(o["rstd"]), p(o["gamma"]), p(o["dres"]), p(o["dx"]), None, None, p(o["ws"]), wsb,
+                                             M, C, 1, 0, 0, 0, st), "ln_bwd")
+
+        def f_two(o):
+            f_dgrad(o); f_ln(o)
+
+        def f_fold(o):
+            _lib.check(lib.vtx_dgrad_ln(1, p(o["dy"]), p(o["wt"]), p(o["x"]), p(o["mean"]), p(o["rstd"]), p(o["gamma"]), p(o["dres"]), p(o["dx"]), p(o["ws"]), nb,
+                                        M, C, K, st), "dgrad_ln")
+
+        unit = M * C * 2 / 1e6
+        r = K / C
+        tg, tl, tt, tf = timed(f_dgrad, sets), timed(f_ln, sets), timed(f_two, sets), timed(f_fold, sets)
+        print(f"== dgrad + LayerNorm backward: M = {M}, C = {C}, K = {K}  (one unit = {unit:.1f} MB)")
+        print(f"  input gradient alone (vtx_gemm)   {tg:8.1f} us ({(r + 1) * unit / tg:.2f} TB/s of {r + 1:.0f} units)")
+        print(f"  LayerNorm backward alone          {tl:8.1f} us ({4 * unit / tl:.2f} TB/s of 4 units)")
+        print(f"  the two launches back to back     {tt:8.1f} us")
+        print(f"  folded (vtx_dgrad_ln)             {tf:8.1f} us ({(r + 3) * unit / tf:.2f} TB/s of {r + 3:.0f} units)   -> {tt - tf:+.1f} us, {100 * (tf / tt - 1):+.1f} %")
 
 
 if __name__ == "__main__":

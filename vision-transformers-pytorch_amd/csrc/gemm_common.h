@@ -193,6 +193,11 @@ bool mlp_fused_ln_ok(int dtype, int64_t M, int C, int ff);
 int mlp_fused_bwd_ln(const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
                      int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
                      void* dx1, float* part, int part_rows, int64_t M, int C, int ff, hipStream_t st);
+// dx = dres + LN'(dy . W) in one launch (gemm_skinny.hip dgrad_ln_kernel; option LN_FOLD bit 1): wt = the transposed bf16 weight copy [C][K]
+bool dgrad_ln_ok(int dtype, int64_t M, int C, int K);
+bool dgrad_ln_shape_ok(int C, int K);
+int dgrad_ln_launch(const void* dy, const void* wt, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
+                    void* dx, float* part, int part_rows, int64_t M, int C, int K, hipStream_t st);
 extern "C" int vtx_layernorm_bwd_blocks(int64_t rows, int C);
 extern "C" size_t vtx_layernorm_bwd_workspace(int64_t rows, int C);
 // mapped (compacted) launch: bf16, mode 0, N % 128 == 0, K % 64 == 0, wave-private epilogue -- else VTX_ERR_SHAPE

@@ -17,6 +17,7 @@
 // Measured (tools/probe/skinny_gemm.hip, M = 401 408, K = 96): N = 288 74 us (tiled 117), N = 384 with two outputs 168 us
 // (217), N = 96 26 us; floors at 6.3 TB/s: 49 / 110 / 24.5 us.
 #include "gemm_common.h"
+#include "ln_fold.h"
 #include "options.h"
 
 constexpr int SK_ROWS = 32;        // rows of A per wave iteration (two 16-row MFMA tiles)
@@ -161,6 +162,162 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, 
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// DGRAD + LayerNorm BACKWARD in one launch (round 6, option LN_FOLD bit 1): dx = dres + LN'(dy . W) for a narrow layer -- the qkv input
+// gradient of Swin-S stage 1 (dln1 = dqkv . Wqkv: K = 3 C = 288 -> N = C = 96 over 401 408 rows) followed by the norm_attn backward
+// (models/swin_transformer.py:194: out = input + drop_path(attn(norm_attn(input)))).  Stand-alone these are a register-staged GEMM that
+// writes dln1 (83 us) and ln_bwd_kernel reading it back with x and the residual-stream gradient (76 us).  Here the weight (the
+// transposed bf16 copy [C][K], <= 57 KB) is LDS-resident as above, a wave streams 32-row blocks of dqkv into operand registers
+// (K / 32 k-steps), all C output columns of the block end up in accumulators in the row-operand layout, and ln_fold.h runs the
+// LayerNorm backward on them: dln1 never exists in memory.  Same k order as the tiled kernels, bf16 rounding of dln1 kept: dx
+// bit-identical to the two launches; dgamma / dbeta to fp32 summation order.
+struct DgradLnArgs {
+  const bf16* x;        // [M][C] the norm's input
+  const float* mean;    // [M]
+  const float* rstd;    // [M]
+  const float* gamma;   // [C]
+  const bf16* dres;     // [M][C] gradient of the residual stream that bypasses the norm
+  bf16* dx;             // [M][C]
+  float* part;          // [part_rows][2 C]
+  int part_rows;
+};
+
+template <int KS, int NPR, int SK_WAVES>
+__global__ __launch_bounds__(64 * SK_WAVES) void dgrad_ln_kernel(GemmArgs p, DgradLnArgs q) {
+  constexpr int K = 32 * KS, C = 32 * NPR, WSTR = K + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+  bf16* ws = reinterpret_cast<bf16*>(sk_smem);
+  const int M = p.M;
+  const bf16* __restrict__ A = (const bf16*)p.A;
+  const bf16* __restrict__ W = (const bf16*)p.B;
+  for (int i = threadIdx.x; i < C * (K / 8); i += 64 * SK_WAVES) {
+    const int n = i / (K / 8), kq = i - n * (K / 8);
+    *reinterpret_cast<bf16x8*>(ws + n * WSTR + kq * 8) = *reinterpret_cast<const bf16x8*>(W + (int64_t)n * p.ldb + kq * 8);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int nrb = (M + SK_ROWS - 1) / SK_ROWS;
+  const int stride = gridDim.x * SK_WAVES;
+  LnFold<NPR> lnf;
+  lnf.init(q.gamma, g);
+
+  bf16x8 an[2][KS];
+  auto load_a = [&](int rb) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = min(rb * SK_ROWS + mt * 16 + c, M - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) an[mt][ks] = *reinterpret_cast<const bf16x8*>(A + (int64_t)row * p.lda + ks * 32 + g * 8);
+    }
+  };
+  int rb = blockIdx.x * SK_WAVES + wave;
+  if (rb < nrb) load_a(rb);
+  for (; rb < nrb; rb += stride) {
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[mt][ks] = an[mt][ks];
+    if (rb + stride < nrb) load_a(rb + stride);
+    int row[2];
+    bool ok[2];
+    float mu[2], rs[2];
+    bf16x8 xr[2][NPR], dr[2][NPR];                        // the LayerNorm's row operands: requested in front of the products
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      row[mt] = rb * SK_ROWS + mt * 16 + c;
+      ok[mt] = row[mt] < M;
+      const int rc = min(row[mt], M - 1);
+      mu[mt] = q.mean[rc];
+      rs[mt] = q.rstd[rc];
+#pragma unroll
+      for (int tp = 0; tp < NPR; ++tp) {
+        xr[mt][tp] = *reinterpret_cast<const bf16x8*>(q.x + (int64_t)rc * C + tp * 32 + g * 8);
+        dr[mt][tp] = *reinterpret_cast<const bf16x8*>(q.dres + (int64_t)rc * C + tp * 32 + g * 8);
+      }
+    }
+    Vec8<bf16> dl[2][NPR];
+#pragma unroll
+    for (int np = 0; np < NPR; ++np) {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = np * 32 + 8 * (c >> 2) + 4 * j + (c & 3);       // the W row this lane supplies as MFMA A-operand row c
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Vec8<bf16> wf;
+          wf.v = *reinterpret_cast<const bf16x8*>(ws + n * WSTR + ks * 32 + g * 8);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            Vec8<bf16> af;
+            af.v = a[mt][ks];
+            mma16(wf, af, acc[mt][j]);
+          }
+        }
+      }
+      // acc[mt][j][r] = (A . W^T)[row = 32 rb + 16 mt + c][col = 32 np + 8 g + 4 j + r]; the plain epilogue of the tiled kernels
+      // (no bias, scale 1, no residual: `v * 1 + 0`) and the bf16 rounding of the dln store
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dl[mt][np].set(r, (acc[mt][0][r] + 0.f) * 1.f + 0.f); dl[mt][np].set(4 + r, (acc[mt][1][r] + 0.f) * 1.f + 0.f); }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) lnf.row(dl[mt], xr[mt], dr[mt], mu[mt], rs[mt], ok[mt], q.dx + (int64_t)row[mt] * C + 8 * g);
+  }
+  lnf.template finish<SK_WAVES>(reinterpret_cast<float*>(sk_smem), q.part, q.part_rows, wave, c, g);
+}
+
+// dx = dres + LN'(dy . W): dy [M][K] (ld = K), wt = the transposed bf16 weight copy [C][K]
+bool dgrad_ln_ok(int dtype, int64_t M, int C, int K) {
+  if ((vtx_opt(VTX_OPT_LN_FOLD) & 2) == 0 || dtype != VTX_BF16) return false;
+  if (C != 64 && C != 96 && C != 128) return false;
+  if (!dgrad_ln_shape_ok(C, K) || M < 32768 || M > 0x7fffffff) return false;
+  return vtx_layernorm_bwd_blocks(M, C) >= vtx_cu_count_cached() && (size_t)C * (K + 8) * 2 <= 150 * 1024;
+}
+
+template <int KS, int NPR> static int dgrad_ln_launch_k(const GemmArgs& a, const DgradLnArgs& q, hipStream_t st) {
+  const size_t smem = (size_t)32 * NPR * (32 * KS + 8) * 2;
+  auto kern = dgrad_ln_kernel<KS, NPR, 4>;
+  if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(256), smem, st, a, q);
+  return vtx_check_launch();
+}
+
+int dgrad_ln_launch(const void* dy, const void* wt, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
+                    void* dx, float* part, int part_rows, int64_t M, int C, int K, hipStream_t st) {
+  if (!dy || !wt || !x || !mean || !rstd || !gamma || !dres || !dx || !part) return VTX_ERR_NULL;
+  if (part_rows < vtx_cu_count_cached()) return VTX_ERR_WORKSPACE;
+  GemmArgs a = {};
+  a.A = dy; a.B = wt; a.M = (int)M; a.N = C; a.K = K; a.lda = K; a.ldb = K; a.ldc = C;
+  DgradLnArgs q = {(const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, part, part_rows};
+  // (K = 3 C: the packed qkv projection; K = C: a plain projection)
+  if (C == 96 && K == 288) return dgrad_ln_launch_k<9, 3>(a, q, st);
+  if (C == 64 && K == 192) return dgrad_ln_launch_k<6, 2>(a, q, st);
+  if (C == 128 && K == 384) return dgrad_ln_launch_k<12, 4>(a, q, st);
+  if (C == 96 && K == 96) return dgrad_ln_launch_k<3, 3>(a, q, st);
+  if (C == 64 && K == 64) return dgrad_ln_launch_k<2, 2>(a, q, st);
+  if (C == 128 && K == 128) return dgrad_ln_launch_k<4, 4>(a, q, st);
+  return VTX_ERR_SHAPE;
+}
+bool dgrad_ln_shape_ok(int C, int K) { return (K == 3 * C || K == C) && (C == 64 || C == 96 || C == 128); }
+
+extern "C" {
+/* Test / tool entry of the fold (the layer calls take it through csrc/layer.hip): dx = dres + LN'(dy . W), the bits of
+ * vtx_gemm(dy, wt) followed by vtx_layernorm_bwd(.., dres); part as in vtx_mlp_bwd_ln. */
+int vtx_dgrad_ln(int dtype, const void* dy, const void* wt, const void* x, const float* mean, const float* rstd, const float* gamma,
+                 const void* dres, void* dx, float* part, int part_rows, int64_t M, int C, int K, void* stream) {
+  if (dtype != VTX_BF16) return VTX_ERR_DTYPE;
+  if (M <= 0 || M > 0x7fffffff || !dgrad_ln_shape_ok(C, K)) return VTX_ERR_SHAPE;
+  return dgrad_ln_launch(dy, wt, x, mean, rstd, gamma, dres, dx, part, part_rows, M, C, K, (hipStream_t)stream);
+}
+}  // extern "C"
 
 static size_t skinny_smem(int N, int K) { return (size_t)N * (K + 8) * 2 + (size_t)N * 4; }
 // column chunks (1, 2, 4) so that a chunk of the weight fits LDS; 0: none does

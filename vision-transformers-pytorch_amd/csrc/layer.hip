@@ -261,11 +261,19 @@ int vtx_layer_bwd(const VtxLayerBwd* a, void* stream, void* side_stream) {
     else
       return VTX_ERR_SHAPE;
     if (rc) return rc;
-    rc = TCALL(VTX_T_GEMM, M, C, 3 * C, 0, stream, layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream));
-    if (rc) return rc;
-    rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
-               vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
-                                 M, C, dt, 0, 0, 0, stream));
+    if (a->wqt != nullptr && dgrad_ln_ok(dt, M, C, 3 * C)) {
+      // (option LN_FOLD bit 1) narrow layers: the qkv input gradient and the norm_attn backward in ONE launch, dln1 never stored
+      if (a->ln_ws_bytes < vtx_layernorm_bwd_workspace(M, C)) return VTX_ERR_WORKSPACE;
+      rc = TCALL(VTX_T_DGRAD_LN, M, C, 3 * C, 0, stream,
+                 dgrad_ln_launch(a->dqkv, a->wqt, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, (float*)a->ln1_ws, vtx_layernorm_bwd_blocks(M, C),
+                                 M, C, 3 * C, (hipStream_t)stream));
+    } else {
+      rc = TCALL(VTX_T_GEMM, M, C, 3 * C, 0, stream, layer_dgrad(dt, a->dqkv, a->wq, a->wqt, a->dln1, M, C, 3 * C, nullptr, nullptr, 1, nullptr, 0, stream));
+      if (rc) return rc;
+      rc = TCALL(VTX_T_LN_BWD, M, C, 0, 0, stream,
+                 vtx_layernorm_bwd(a->dln1, a->x, a->mean1, a->rstd1, a->ln1_w, a->dx1, a->dx, nullptr, nullptr, a->ln1_ws, a->ln_ws_bytes,
+                                   M, C, dt, 0, 0, 0, stream));
+    }
     if (rc) return rc;
   }
   // ---- the four weight gradients + the layer's column reductions: one grouped launch + one reduce launch, on the side

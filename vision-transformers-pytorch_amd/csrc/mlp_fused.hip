@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "gemm_common.h"
+#include "ln_fold.h"
 #include "options.h"
 
 namespace {
@@ -266,17 +267,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
   // second half of the k-slots), 4-column piece at column 8 (c & 3) (+ 4 j)
   const int tr_off = (8 * g + (c >> 2)) * S1 + 8 * (c & 3);
 
-  float gmv[LNB ? KS : 1][8], dgacc[LNB ? KS : 1][8], dbacc[LNB ? KS : 1][8];
-  if constexpr (LNB) {
-#pragma unroll
-    for (int tp = 0; tp < KS; ++tp) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + tp * 32 + 8 * g), g1 = *reinterpret_cast<const f32x4*>(p.gamma + tp * 32 + 8 * g + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { gmv[tp][e] = g0[e]; gmv[tp][4 + e] = g1[e]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { dgacc[tp][e] = 0.f; dbacc[tp][e] = 0.f; }
-    }
-  }
+  LnFold<LNB ? KS : 2> lnf;                                // (ln_fold.h)
+  if constexpr (LNB) lnf.init(p.gamma, g);
 
   bf16x8 an[2][KS], dn[2][KS];
   int rb = blockIdx.x * WAVES + wave;
@@ -425,67 +417,20 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
         }
       }
     } else {
-      constexpr float invC = 1.f / (float)C;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        float xh[KS][8], gv[KS][8], q1[KS], q2[KS];
+        Vec8<bf16> dl[KS];
 #pragma unroll
-        for (int tp = 0; tp < KS; ++tp) {
-          Vec8<bf16> dl, xv;
+        for (int tp = 0; tp < KS; ++tp)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { dl.set(r, xacc[mt][2 * tp][r]); dl.set(4 + r, xacc[mt][2 * tp + 1][r]); }      // (the bf16 the stand-alone path stores)
-          xv.v = xr[mt][tp];
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = dl.get(e);
-            ln_bwd_elem_accum(d, xv.get(e), lmu[mt], lrs[mt], gmv[tp][e], s1, s2, xh[tp][e], gv[tp][e]);
-            if (ok[mt]) { dgacc[tp][e] += d * xh[tp][e]; dbacc[tp][e] += d; }
-          }
-          // vector v = 4 tp + g of the row: pairs (g, g ^ 1), then the quad -- the first two steps of group_sum<16>
-          s1 += shfl_xor_f(s1, 16);
-          s2 += shfl_xor_f(s2, 16);
-          q1[tp] = s1 + shfl_xor_f(s1, 32);
-          q2[tp] = s2 + shfl_xor_f(s2, 32);
-        }
-        // 8-lane halves (q0 + q1), (q2 + q3), then their sum; quads past C / 32 hold zeros in the stand-alone kernel
-        float c1, c2;
-        if constexpr (KS == 2) { c1 = ((q1[0] + q1[1]) + 0.f) * invC; c2 = ((q2[0] + q2[1]) + 0.f) * invC; }
-        else if constexpr (KS == 3) { c1 = ((q1[0] + q1[1]) + (q1[2] + 0.f)) * invC; c2 = ((q2[0] + q2[1]) + (q2[2] + 0.f)) * invC; }
-        else { c1 = ((q1[0] + q1[1]) + (q1[2] + q1[KS - 1])) * invC; c2 = ((q2[0] + q2[1]) + (q2[2] + q2[KS - 1])) * invC; }
-        if (!ok[mt]) continue;
-#pragma unroll
-        for (int tp = 0; tp < KS; ++tp) {
-          Vec8<bf16> dv, o;
-          dv.v = d[mt][tp];                                    // the residual-stream gradient that bypasses the norm: dy itself
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o.set(e, ln_bwd_elem_out(dv.get(e), lrs[mt], gv[tp][e], c1, xh[tp][e], c2));
-          store8<bf16>(p.dx + (int64_t)row[mt] * C + tp * 32 + 8 * g, o);
-        }
+          for (int r = 0; r < 4; ++r) { dl[tp].set(r, xacc[mt][2 * tp][r]); dl[tp].set(4 + r, xacc[mt][2 * tp + 1][r]); }      // (the bf16 the stand-alone path stores)
+        // (dres: the residual-stream gradient that bypasses the norm is dy itself, already here as the second product's row operand)
+        lnf.row(dl, xr[mt], d[mt], lmu[mt], lrs[mt], ok[mt], p.dx + (int64_t)row[mt] * C + 8 * g);
       }
     }
   }
-  if constexpr (LNB) {
-    // dgamma / dbeta: sum over the 16 lanes c of a DPP row (they hold the same columns), then over the waves through the (now dead) W1
-    // image, in wave order; one partial row per workgroup, the workspace rows nobody owns zeroed for the deferred column reduce
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(mf_smem);            // [WAVES][2 C]
-#pragma unroll
-    for (int tp = 0; tp < KS; ++tp)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float a = group_sum<16>(dgacc[tp][e]), b = group_sum<16>(dbacc[tp][e]);
-        if (c == 0) { red[wave * 2 * C + tp * 32 + 8 * g + e] = a; red[wave * 2 * C + C + tp * 32 + 8 * g + e] = b; }
-      }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += NT) {
-      float a = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) a += red[w * 2 * C + i];
-      p.part[(int64_t)blockIdx.x * 2 * C + i] = a;
-      for (int r = blockIdx.x + gridDim.x; r < p.part_rows; r += gridDim.x) p.part[(int64_t)r * 2 * C + i] = 0.f;
-    }
-  }
+  // dgamma / dbeta partial row of the workgroup; the scratch is the (now dead) W1 image
+  if constexpr (LNB) lnf.template finish<WAVES>(reinterpret_cast<float*>(mf_smem), p.part, p.part_rows, wave, c, g);
 }
 
 size_t mlp_fwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 2 + (size_t)C * (ff + 8) * 2 + (size_t)(ff + C) * 4; }

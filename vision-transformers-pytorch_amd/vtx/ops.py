@@ -323,6 +323,10 @@ def _describe_timer_rec(r):
         # LayerNorm backward folded in: ln2, dy, x1 in, dx1, h, dz out (4 C + 2 ff per row) -- the two launches it replaces move 7 C + 2 ff
         return (f"mlp_{'bwd' if bwd else 'fwd'}_kernel<{n // 32}, {waves}>", (6.0 if bwd else 4.0) * rows * n * k,
                 float(es * rows * (((4 if lnb else 3) * n + 2 * k) if bwd else 3 * n) + 2 * es * n * k), r.ms)
+    if r.tag == 17:                                                     # dgrad + LayerNorm backward in one launch: rows x C (n) over k
+        # dy [rows, k] and the weight in; x and the residual-stream gradient in, dx out (the dln tensor is never stored: the two launches
+        # it replaces move rows x (k + 5 n) elements)
+        return (f"dgrad_ln_kernel<{k // 32}, {n // 32}, 4>", 2.0 * rows * n * k, float(es * (rows * (k + 3 * n) + n * k) + 8.0 * rows), r.ms)
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
 
 
