@@ -160,7 +160,7 @@ def test_swin_layers_with_the_fused_mlp_are_bitwise_the_unfused_ones(dim, ff, mo
         torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
     with options.override(MLP_FUSED=812, LN_FOLD=0):
         out_c, g_c = _layer_io(model, x, True, 78, True)
-    with options.override(MLP_FUSED=0):
+    with options.override(MLP_FUSED=0, LN_FOLD=0):
         out_b, g_b = _layer_io(model, x, True, 78, True)
     assert torch.isfinite(out_a).all()
     for tag, out_o, g_o in (("MLP_FUSED = 0", out_b, g_b), ("MLP_FUSED = 812", out_c, g_c)):
