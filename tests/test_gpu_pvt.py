@@ -269,17 +269,21 @@ def test_sr_layers_through_one_c_call_are_bitwise_the_call_by_call_path(monkeypa
 
     monkeypatch.setattr(VF.PvtLayerFn, "_forward_one_call", staticmethod(spy))
     res = {}
-    for one_call in (True, False):
-        for side in (True, False):
-            monkeypatch.setattr(VF, "_LAYER_CALL", one_call)
-            torch.manual_seed(5)
-            model.zero_grad(set_to_none=True)
-            with VF.deferred_wgrad(side):
-                with torch.autocast("cuda", dtype=torch.bfloat16):
-                    out = model(x)
-                out.float().square().mean().backward()
-                VF.side_join()
-            res[(one_call, side)] = (out.clone(), [p.grad.clone() for p in model.parameters()])
+    from vtx import options
+    # (round 6: with option LN_FOLD the one-call layers run the norm_ff backward inside the fused-MLP backward -- another grouping of the rows
+    #  of dgamma / dbeta; that path has its own tests, tests/test_gpu_mlp_fused.py and test_gpu_ln_fold.py.  Here: the launch-for-launch contract.)
+    with options.override(LN_FOLD=0):
+        for one_call in (True, False):
+            for side in (True, False):
+                monkeypatch.setattr(VF, "_LAYER_CALL", one_call)
+                torch.manual_seed(5)
+                model.zero_grad(set_to_none=True)
+                with VF.deferred_wgrad(side):
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        out = model(x)
+                    out.float().square().mean().backward()
+                    VF.side_join()
+                res[(one_call, side)] = (out.clone(), [p.grad.clone() for p in model.parameters()])
     n_layers = sum(M.PVT_SMALL["depths"]) if family == "pvt_small" else sum(M.TWINS_SVT_S["depths"])
     assert calls == [True] * (2 * n_layers), f"one-call path not taken on every layer: {calls}"
     ref = res[(False, False)]

@@ -10,7 +10,7 @@ LOG=gpurun_out/r6_$J.log
 case "$J" in
   tests)      # the GPU test suite (optionally a file first, then -k expr ...)
     if [ $# -gt 0 ] && [ -e "$1" ]; then T="$1"; shift; else T=tests; fi
-    timeout 2400 python -m pytest $T -m gpu -x -q "$@" 2>&1 | tail -40 > $LOG; tail -40 $LOG ;;
+    timeout 2400 python -m pytest $T -m gpu ${XFLAG:--x} -q "$@" 2>&1 | tail -40 > $LOG; tail -40 $LOG ;;
   bench)      # headline (+ secondaries unless flags say otherwise)
     timeout 1200 python bench.py --steps 20 --warmup 5 "$@" 2>&1 | grep '"metric"' > $LOG; cut -c1-600 $LOG ;;
   ab)         # same-box A/B of one option on one model: tools/r6/job.sh ab swin_s OPTION v0 v1 ...   (REPS, STEPS from the environment)
