@@ -134,6 +134,17 @@ int vtx_mlp_bwd_ln(int dtype, const void* ln2, const void* dy, const void* w1, c
  * models/swin_transformer.py:128,194) or K = C.  part: as in vtx_mlp_bwd_ln. */
 int vtx_dgrad_ln(int dtype, const void* dy, const void* wt, const void* x, const float* mean, const float* rstd, const float* gamma,
                  const void* dres, void* dx, float* part, int part_rows, int64_t M, int C, int K, void* stream);
+/* ---- LayerNorm FORWARD folded into its consumer (round 6, option LN_FOLD bits 2, 3): the norm runs on the row operands of a row-streaming
+ * launch (csrc/ln_fold.h); the normalised rows and the statistics are stored on the side for the backward; outputs bit-identical to
+ * vtx_layernorm_fwd followed by the consumer.
+ *   vtx_mlp_fwd_ln: LN(x1; gamma, beta, eps) -> ln2, mean, rstd;  y = x1 + rowscale * MLP(ln2)      (vtx_layernorm_fwd + vtx_mlp_fwd)
+ *   vtx_ln_gemm:    LN(x) -> ln_out, mean, rstd;  y = ln_out . w^T + bias, w [N][C]                   (vtx_layernorm_fwd + vtx_gemm)
+ * bf16; C in {64, 96} (MLP) / {64, 96, 128} (GEMM, N % 32 == 0). */
+int vtx_mlp_fwd_ln(int dtype, const void* x1, const float* gamma, const float* beta, float eps, void* ln2, float* mean, float* rstd,
+                   const void* w1, const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y,
+                   int64_t M, int C, int ff, void* stream);
+int vtx_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* ln_out, float* mean, float* rstd,
+                const void* w, const float* bias, void* y, int64_t M, int C, int N, void* stream);
 size_t vtx_wgrad_workspace(int64_t mtok, int N, int Kin);
 /* dW[N,Kin] = sum_m s[m] dy[m,:]^T x[m,:] (fp32, overwritten); dbias[N] = sum_m s[m] dy[m,:] (optional,
  * computed inside the same kernel).  s = rowscale[m / rows_per_scale] or 1.  scale_const > 0 declares that
@@ -380,7 +391,9 @@ enum { VTX_T_LN_FWD = 1, VTX_T_GEMM = 2, VTX_T_WATTN_FWD = 3, VTX_T_ATTN_FWD = 4
        /* the fused MLP of the narrow stages (vtx_mlp_fwd / vtx_mlp_bwd inside vtx_layer_*): rows, n = C, k = ff */
        VTX_T_MLP_FWD = 15, VTX_T_MLP_BWD = 16,
        /* round 6: a dgrad with the LayerNorm backward in its epilogue (csrc/gemm_skinny.hip dgrad_ln_kernel): rows x C (n) over k */
-       VTX_T_DGRAD_LN = 17 };
+       VTX_T_DGRAD_LN = 17,
+       /* a LayerNorm forward on the row operands of the GEMM that consumes it (gemm_skinny.hip, LNF): rows x n over k = C */
+       VTX_T_LN_GEMM = 18 };
 typedef struct VtxTimerRec { int tag, n, k, flags; int64_t rows; float ms; } VtxTimerRec;
 int vtx_timer_start(void);
 int vtx_timer_stop(VtxTimerRec* out, int cap);   /* sizeof(VtxLayerFwd) (0) / sizeof(VtxLayerBwd) (1), for bindings */

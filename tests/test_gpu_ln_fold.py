@@ -95,12 +95,16 @@ def test_dgrad_layernorm_fold_at_the_bench_size_and_in_the_model(monkeypatch):
     model.to(d).train()
     monkeypatch.setattr(VF, "_LAYER_CALL", True)
     res = {}
-    for v in (3, 1, 0):
+    for v in (15, 12, 3, 1, 0):
         with options.override(LN_FOLD=v):
             res[v] = _layer_io(model, xin, True, 78, True)
+    # the FORWARD folds (bits 2, 3) alone change no bit anywhere
+    assert torch.equal(res[12][0], res[0][0])
+    for k, g0 in res[0][1].items():
+        assert torch.equal(res[12][1][k], g0), f"LN_FOLD = 12 (forward folds only): gradient of {k} differs"
     folded = [k for k in res[0][1] if k.startswith("block1.") and (".norm_ff." in k or ".norm_attn." in k)]
     assert len(folded) == 8
-    for v in (3, 1):
+    for v in (15, 3, 1):
         assert torch.equal(res[v][0], res[0][0])
         for k, g0 in res[0][1].items():
             g = res[v][1][k]
@@ -109,3 +113,57 @@ def test_dgrad_layernorm_fold_at_the_bench_size_and_in_the_model(monkeypatch):
                 assert err < 1e-5, f"LN_FOLD = {v}, {k}: rel-L2 {err:.3e}"
             else:
                 assert torch.equal(g, g0), f"LN_FOLD = {v}: gradient of {k} differs: {(g - g0).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("M,C,ff,drop", [(34496, 96, 384, 0.0), (32777, 96, 384, 0.25), (401, 96, 384, 0.0), (33001, 96, 288, 0.25),
+                                         (37632, 64, 256, 0.25), (33001, 64, 512, 0.1)])
+def test_layernorm_forward_on_the_row_operands_of_the_fused_mlp(M, C, ff, drop):
+    """vtx_mlp_fwd_ln = vtx_layernorm_fwd(x1) + vtx_mlp_fwd(ln2, resid = x1) in one launch: ln2, mean, rstd and y bit for bit."""
+    from vtx import _lib, ops
+    from test_gpu_mlp_fused import _operands
+    lib = _lib.load()
+    rps = 49
+    _, x1, _, w1, b1, w2, b2, s = _operands(M, C, ff, 9 + M % 5, drop, rps)
+    d = x1.device
+    g = torch.Generator().manual_seed(4)
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.1 * torch.randn(C, generator=g)).to(d)
+    p = lambda t: None if t is None else t.data_ptr()
+    ln_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x1, gamma, beta, 1e-6)
+    y_ref = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+    _lib.check(lib.vtx_mlp_fwd(1, p(ln_ref), p(w1), p(b1), p(w2), p(b2), p(x1), p(s), rps, p(y_ref), None, None, M, C, ff, ops._stream()), "vtx_mlp_fwd")
+    ln = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+    y = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+    mean = torch.full((M,), float("nan"), device=d)
+    rstd = torch.full((M,), float("nan"), device=d)
+    _lib.check(lib.vtx_mlp_fwd_ln(1, p(x1), p(gamma), p(beta), 1e-6, p(ln), p(mean), p(rstd), p(w1), p(b1), p(w2), p(b2), p(s), rps, p(y), M, C, ff,
+                                  ops._stream()), "vtx_mlp_fwd_ln")
+    for name, a, b in (("ln2", ln, ln_ref), ("mean", mean, mean_ref), ("rstd", rstd, rstd_ref), ("y", y, y_ref)):
+        assert torch.isfinite(a.float()).all(), f"{name}: non-finite or unwritten elements"
+        assert torch.equal(a, b), f"LayerNorm forward fold (MLP): {name} differs ({(a.float() - b.float()).abs().max().item():.3e} max)"
+
+
+@pytest.mark.parametrize("M,C,N", [(34496, 96, 288), (32777, 96, 288), (401, 96, 288), (33001, 64, 192), (32801, 128, 384), (33001, 64, 64),
+                                   (401408, 96, 288)])
+def test_layernorm_forward_on_the_row_operands_of_the_streaming_gemm(M, C, N):
+    """vtx_ln_gemm = vtx_layernorm_fwd(x) + vtx_gemm(ln, w, bias) in one launch: ln, mean, rstd and the product bit for bit."""
+    from vtx import _lib, ops
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(13 + M % 3)
+    bf = lambda *sh, std=1.0: (torch.randn(*sh, generator=g) * std).to(torch.bfloat16).to(d)
+    x, w = bf(M, C), bf(N, C, std=C ** -0.5)
+    bias = (0.2 * torch.randn(N, generator=g)).to(d)
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.1 * torch.randn(C, generator=g)).to(d)
+    p = lambda t: t.data_ptr()
+    ln_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x, gamma, beta, 1e-6)
+    y_ref = ops.gemm(ln_ref, w, 0, bias=bias)
+    ln = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=d)
+    mean = torch.full((M,), float("nan"), device=d)
+    rstd = torch.full((M,), float("nan"), device=d)
+    _lib.check(lib.vtx_ln_gemm(1, p(x), p(gamma), p(beta), 1e-6, p(ln), p(mean), p(rstd), p(w), p(bias), p(y), M, C, N, ops._stream()), "vtx_ln_gemm")
+    for name, a, b in (("ln", ln, ln_ref), ("mean", mean, mean_ref), ("rstd", rstd, rstd_ref), ("y", y, y_ref)):
+        assert torch.isfinite(a.float()).all(), f"{name}: non-finite or unwritten elements"
+        assert torch.equal(a, b), f"LayerNorm forward fold (GEMM): {name} differs ({(a.float() - b.float()).abs().max().item():.3e} max)"

@@ -21,9 +21,9 @@ sys.path.insert(0, os.path.join(REPO, "vision-transformers-pytorch_amd"))
 from vtx.build import FLAGS   # the flags of the shipped library: a scan validates THAT binary
 
 # (kernel, KS, WAVES, rest of the template list as mangled by hipcc)
-DEFAULTS = [("mlp_fwd_kernel", ks, 12, "Lb0ELb0EE") for ks in (2, 3)] + \
+DEFAULTS = [("mlp_fwd_kernel", ks, 12, f"Lb0ELb0ELb{lnf}EE") for ks in (2, 3) for lnf in (0, 1)] + \
            [("mlp_bwd_kernel", ks, 4, f"Lb1ELb0ELi0ELb{pair}ELb{lnb}EE") for ks in (2, 3) for pair in (1, 0) for lnb in (0, 1)]
-# (backward: paired stores | the ff = 32 x odd fallback, each plain | with the LayerNorm backward folded into the epilogue: option LN_FOLD)
+# (forward: plain | norm_ff on its row operands, option LN_FOLD bit 2;  backward: paired stores | the ff = 32 x odd fallback, each plain | with the LayerNorm backward folded into the epilogue: option LN_FOLD)
 
 
 def main():

@@ -108,6 +108,46 @@ def main():
         print(f"  LayerNorm backward alone          {tl:8.1f} us ({4 * unit / tl:.2f} TB/s of 4 units)")
         print(f"  the two launches back to back     {tt:8.1f} us")
         print(f"  folded (vtx_dgrad_ln)             {tf:8.1f} us ({(r + 3) * unit / tf:.2f} TB/s of {r + 3:.0f} units)   -> {tt - tf:+.1f} us, {100 * (tf / tt - 1):+.1f} %")
+    # ---- forward folds (option LN_FOLD bits 2, 3)
+    for (M, C, ff) in ((401408, 96, 384), (401408, 64, 512)):
+        rps = 3136
+        sets = []
+        for k in range(3):
+            _, x1, _, w1, b1, w2, b2, s = T._operands(M, C, ff, 300 + k, 0.1, rps)
+            d = x1.device
+            gamma = (1.0 + 0.1 * torch.randn(C)).to(d); beta = torch.zeros_like(gamma)
+            e = lambda n: torch.empty(M, n, dtype=torch.bfloat16, device=d)
+            sets.append(dict(x1=x1, w1=w1, b1=b1, w2=w2, b2=b2, s=s, gamma=gamma, beta=beta, ln=e(C), y=e(C), mean=torch.empty(M, device=d), rstd=torch.empty(M, device=d),
+                             wq=(torch.randn(3 * C, C) * C ** -0.5).to(torch.bfloat16).to(d), bq=torch.zeros(3 * C, device=d), qkv=e(3 * C)))
+        st = ops._stream()
+
+        def f_lnf(o):
+            _lib.check(lib.vtx_layernorm_fwd(p(o["x1"]), p(o["gamma"]), p(o["beta"]), p(o["ln"]), p(o["mean"]), p(o["rstd"]), M, C, 1e-6, 1, 0, 0, 0, st), "ln")
+
+        def f_mlp(o):
+            _lib.check(lib.vtx_mlp_fwd(1, p(o["ln"]), p(o["w1"]), p(o["b1"]), p(o["w2"]), p(o["b2"]), p(o["x1"]), p(o["s"]), rps, p(o["y"]), None, None, M, C, ff, st), "fwd")
+
+        def f_two(o):
+            f_lnf(o); f_mlp(o)
+
+        def f_fold(o):
+            _lib.check(lib.vtx_mlp_fwd_ln(1, p(o["x1"]), p(o["gamma"]), p(o["beta"]), 1e-6, p(o["ln"]), p(o["mean"]), p(o["rstd"]), p(o["w1"]), p(o["b1"]), p(o["w2"]), p(o["b2"]),
+                                          p(o["s"]), rps, p(o["y"]), M, C, ff, st), "fwd_ln")
+
+        def g_gemm(o):
+            lib.vtx_gemm(0, 1, p(o["ln"]), p(o["wq"]), p(o["qkv"]), M, 3 * C, C, C, C, 3 * C, p(o["bq"]), None, None, 1, None, None, 0, st)
+
+        def g_two(o):
+            f_lnf(o); g_gemm(o)
+
+        def g_fold(o):
+            _lib.check(lib.vtx_ln_gemm(1, p(o["x1"]), p(o["gamma"]), p(o["beta"]), 1e-6, p(o["ln"]), p(o["mean"]), p(o["rstd"]), p(o["wq"]), p(o["bq"]), p(o["qkv"]), M, C, 3 * C, st), "ln_gemm")
+
+        tl, tm, tt, tf = timed(f_lnf, sets), timed(f_mlp, sets), timed(f_two, sets), timed(f_fold, sets)
+        print(f"== forward: M = {M}, C = {C}, ff = {ff}")
+        print(f"  LayerNorm forward alone {tl:8.1f} us | fused-MLP forward alone {tm:8.1f} us | back to back {tt:8.1f} us | folded (vtx_mlp_fwd_ln) {tf:8.1f} us -> {tt - tf:+.1f} us, {100 * (tf / tt - 1):+.1f} %")
+        tg, tt, tf = timed(g_gemm, sets), timed(g_two, sets), timed(g_fold, sets)
+        print(f"  qkv GEMM alone          {tg:8.1f} us | LayerNorm + GEMM back to back {tt:8.1f} us | folded (vtx_ln_gemm) {tf:8.1f} us -> {tt - tf:+.1f} us, {100 * (tf / tt - 1):+.1f} %")
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ const OptDef kOptDefs[VTX_OPT_COUNT] = {
     {"VTX_WATTN_BWD4", 1},  {"VTX_GEMM_SKINNY", 1}, {"VTX_GEMM_ASTAT", 1},
     {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1}, {"VTX_GEMM_PP", 1},
     {"VTX_LN_ROWS", 0},     {"VTX_SKINNY_WAVES", 4}, {"VTX_WATTN_FAST", 3}, {"VTX_WATTN_FWD4", 1},
-    {"VTX_MLP_FUSED", 1}, {"VTX_LN_FOLD", 3},
+    {"VTX_MLP_FUSED", 1}, {"VTX_LN_FOLD", 15},
 };
 struct OptTable {
   std::atomic<int> v[VTX_OPT_COUNT];
@@ -93,7 +93,7 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 24; }
+int vtx_abi_version(void) { return 25; }
 
 int vtx_cu_count(void) { return vtx_cu_count_cached(); }
 

@@ -190,6 +190,15 @@ int mlp_fused_bwd(const void* ln2, const void* dy, const void* w1, const float* 
 // the same with the LayerNorm backward of the layer's norm_ff in its epilogue (option LN_FOLD bit 0): dx1 = dy + LN'(dln2) out, dln2 never stored;
 // part: the [part_rows][2 C] workspace of vtx_layernorm_bwd's deferred dgamma / dbeta partial rows (part_rows = vtx_layernorm_bwd_blocks)
 bool mlp_fused_ln_ok(int dtype, int64_t M, int C, int ff);
+// LayerNorm FORWARD folds (option LN_FOLD bits 2, 3): norm_ff on the row operands of the fused-MLP forward; a narrow norm on the row operands
+// of the weight-resident streaming GEMM that consumes it (gemm_skinny.hip)
+bool mlp_fused_lnf_ok(int dtype, int64_t M, int C, int ff);
+int mlp_fused_fwd_ln(const void* x1, const float* gamma, const float* beta, float eps, void* ln2, float* mean, float* rstd, const void* w1,
+                     const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, int64_t M, int C,
+                     int ff, hipStream_t st);
+bool ln_gemm_ok(int dtype, int64_t M, int C, int N);
+int ln_gemm_launch(const void* x, const float* gamma, const float* beta, float eps, void* ln_out, float* mean, float* rstd, const void* w,
+                   const float* bias, void* y, int64_t M, int C, int N, hipStream_t st);
 int mlp_fused_bwd_ln(const void* ln2, const void* dy, const void* w1, const float* b1, const void* w2, const float* rowscale,
                      int rows_per_scale, void* h, void* dz, const void* x1, const float* mean, const float* rstd, const float* gamma,
                      void* dx1, float* part, int part_rows, int64_t M, int C, int ff, hipStream_t st);

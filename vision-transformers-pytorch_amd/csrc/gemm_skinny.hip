@@ -25,8 +25,21 @@ constexpr int SK_ROWS = 32;        // rows of A per wave iteration (two 16-row M
 
 // K = 32 KS; ACT = GemmArgs::act, VEC = the epilogue reads a vector per output vector (z for act', else the residual) --
 // both compile-time: the per-pair loop of a plain / activation forward carries no loads, no selects, no dead operands
-template <int KS, int ACT, bool VEC, int SK_WAVES>
-__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, int nchunk) {
+// LNF (round 6, option LN_FOLD bit 3): A holds the RAW rows x of a LayerNorm whose output is this product's row operand (K = C: the qkv
+// projection behind norm_attn, models/swin_transformer.py:128,194); the rows are normalised in registers (ln_fold.h LnFwdFold) and the
+// normalised rows / mean / rstd stored on the side (workgroups of column chunk 0 only) -- the stand-alone LayerNorm launch and its
+// read of x disappear; outputs bit-identical.
+struct SkLnArgs {
+  const float* gamma;
+  const float* beta;
+  float eps;
+  bf16* ln_out;         // [M][K]
+  float* mean;
+  float* rstd;
+};
+
+template <int KS, int ACT, bool VEC, int SK_WAVES, bool LNF = false>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, int nchunk, SkLnArgs q) {
   constexpr int K = 32 * KS, WSTR = K + 8;             // LDS row stride of W (elements): 16 B of padding per row
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
   bf16* ws = reinterpret_cast<bf16*>(sk_smem);
@@ -43,6 +56,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, 
     *reinterpret_cast<bf16x8*>(ws + n * WSTR + q * 8) = *reinterpret_cast<const bf16x8*>(W + (int64_t)n * p.ldb + q * 8);
   }
   for (int i = threadIdx.x; i < N; i += 64 * SK_WAVES) bs[i] = p.bias ? p.bias[ncol0 + i] : 0.f;
+  float* lgs = bs + N;                                  // LNF: gamma | beta [2][K]
+  if constexpr (LNF)
+    for (int i = threadIdx.x; i < K; i += 64 * SK_WAVES) { lgs[i] = q.gamma[i]; lgs[K + i] = q.beta[i]; }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -82,6 +98,21 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmArgs p, 
       row[mt] = rb * SK_ROWS + mt * 16 + c;
       ok[mt] = row[mt] < M;
       rsc[mt] = (ok[mt] && p.rowscale) ? p.rowscale[row[mt] / p.rows_per_scale] : 1.f;
+    }
+    if constexpr (LNF) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        bf16x8 yv[KS];
+        float mu, rs;
+        LnFwdFold<KS>::row(a[mt], lgs, lgs + K, q.eps, g, yv, mu, rs);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[mt][ks] = yv[ks];
+        if (chunk == 0 && ok[mt]) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<bf16x8*>(q.ln_out + (int64_t)row[mt] * K + ks * 32 + g * 8) = yv[ks];
+          if (g == 0) { q.mean[row[mt]] = mu; q.rstd[row[mt]] = rs; }
+        }
+      }
     }
     // epilogue vectors of the first column pair (z for act', else the residual); the next pair's are requested one pair ahead
     const bf16* __restrict__ vsrc = act_bwd ? aux_in : resid;
@@ -319,7 +350,7 @@ int vtx_dgrad_ln(int dtype, const void* dy, const void* wt, const void* x, const
 }
 }  // extern "C"
 
-static size_t skinny_smem(int N, int K) { return (size_t)N * (K + 8) * 2 + (size_t)N * 4; }
+static size_t skinny_smem(int N, int K) { return (size_t)N * (K + 8) * 2 + (size_t)N * 4 + (size_t)2 * K * 4; }
 // column chunks (1, 2, 4) so that a chunk of the weight fits LDS; 0: none does
 static int skinny_chunks(int N, int K) {
   for (int nc = 1; nc <= 4; nc *= 2)
@@ -347,9 +378,46 @@ template <int KS, int ACT, bool VEC, int WAVES> static int skinny_launch_kavw(co
   if (smem > 64 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return VTX_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a, nc);   // one persistent workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a, nc, SkLnArgs{});   // one persistent workgroup per CU
   return vtx_check_launch();
 }
+
+// y = LN(x) . W^T + bias with the LayerNorm in the row-operand path (LNF): x [M][K = C], W [N][K]; ln_out / mean / rstd on the side
+bool ln_gemm_ok(int dtype, int64_t M, int C, int N) {
+  if ((vtx_opt(VTX_OPT_LN_FOLD) & 8) == 0 || dtype != VTX_BF16 || vtx_opt(VTX_OPT_GEMM_SKINNY) == 0) return false;
+  if (C != 64 && C != 96 && C != 128) return false;
+  if (N < 32 || N % 32 != 0 || M < 32768 || M > 0x7fffffff) return false;
+  return skinny_chunks(N, C) != 0;
+}
+template <int KS> static int ln_gemm_launch_k(const GemmArgs& a, const SkLnArgs& q, hipStream_t st) {
+  const int nc = skinny_chunks(a.N, a.K);
+  const size_t smem = skinny_smem(a.N / nc, a.K);
+  auto kern = gemm_skinny_kernel<KS, 0, false, 4, true>;
+  if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(256), smem, st, a, nc, q);
+  return vtx_check_launch();
+}
+int ln_gemm_launch(const void* x, const float* gamma, const float* beta, float eps, void* ln_out, float* mean, float* rstd, const void* w,
+                   const float* bias, void* y, int64_t M, int C, int N, hipStream_t st) {
+  if (!x || !gamma || !beta || !ln_out || !mean || !rstd || !w || !y) return VTX_ERR_NULL;
+  if (skinny_chunks(N, C) == 0) return VTX_ERR_SHAPE;
+  GemmArgs a = {};
+  a.A = x; a.B = w; a.C = y; a.M = (int)M; a.N = N; a.K = C; a.lda = C; a.ldb = C; a.ldc = N; a.bias = bias; a.rows_per_scale = 1;
+  SkLnArgs q = {gamma, beta, eps, (bf16*)ln_out, mean, rstd};
+  if (C == 64) return ln_gemm_launch_k<2>(a, q, st);
+  if (C == 96) return ln_gemm_launch_k<3>(a, q, st);
+  if (C == 128) return ln_gemm_launch_k<4>(a, q, st);
+  return VTX_ERR_SHAPE;
+}
+extern "C" {
+/* vtx_layernorm_fwd(x -> ln, mean, rstd) + vtx_gemm(ln, w, bias -> y) in one launch (round 6, option LN_FOLD bit 3): the same bits. */
+int vtx_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* ln_out, float* mean, float* rstd,
+                const void* w, const float* bias, void* y, int64_t M, int C, int N, void* stream) {
+  if (dtype != VTX_BF16) return VTX_ERR_DTYPE;
+  if (M <= 0 || M > 0x7fffffff || (C != 64 && C != 96 && C != 128) || N < 32 || N % 32) return VTX_ERR_SHAPE;
+  return ln_gemm_launch(x, gamma, beta, eps, ln_out, mean, rstd, w, bias, y, M, C, N, (hipStream_t)stream);
+}
+}  // extern "C"
 template <int KS, int ACT, bool VEC> static int skinny_launch_kav(const GemmArgs& a, hipStream_t st) {
   switch (vtx_opt(VTX_OPT_SKINNY_WAVES)) {
     case 16: return skinny_launch_kavw<KS, ACT, VEC, 16>(a, st);

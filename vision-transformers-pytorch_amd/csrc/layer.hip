@@ -148,10 +148,18 @@ int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
     if (rc) return rc;
     return TCALL(VTX_T_GEMM, M2, C, ff, F_MAPPED | F_RESID, stream, layer_gemm_mapped(a->h, a->w2, a->y, M, M2, C, ff, a->b2, a->x1, a->s2, T, nullptr, nullptr, 0, a->perm2, stream));
   }
-  int rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream));
-  if (rc) return rc;
-  rc = TCALL(VTX_T_GEMM, M, 3 * C, C, 0, stream, vtx_gemm(0, dt, a->ln1, a->wq, a->qkv, M, 3 * C, C, C, C, 3 * C, a->bq, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
-  if (rc) return rc;
+  int rc;
+  if (ln_gemm_ok(dt, M, C, 3 * C)) {
+    // (option LN_FOLD bit 3) narrow layers: norm_attn runs on the row operands of the qkv projection, ln1 / mean1 / rstd1 stored on the side
+    rc = TCALL(VTX_T_LN_GEMM, M, 3 * C, C, 0, stream,
+               ln_gemm_launch(a->x, a->ln1_w, a->ln1_b, a->eps, a->ln1, a->mean1, a->rstd1, a->wq, a->bq, a->qkv, M, C, 3 * C, (hipStream_t)stream));
+    if (rc) return rc;
+  } else {
+    rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream));
+    if (rc) return rc;
+    rc = TCALL(VTX_T_GEMM, M, 3 * C, C, 0, stream, vtx_gemm(0, dt, a->ln1, a->wq, a->qkv, M, 3 * C, C, C, C, 3 * C, a->bq, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
+    if (rc) return rc;
+  }
   if (a->attn_kind == VTX_ATTN_WINDOW)
     rc = TCALL(VTX_T_WATTN_FWD, M, a->nH, a->L, a->region ? F_MASKED : 0, stream,
                vtx_wattn_fwd(a->qkv, a->o, a->lse, a->rel_pos, a->pos, a->region, a->B, a->L, a->nH, a->H, a->W, a->win, a->shift, dt, stream));
@@ -163,6 +171,11 @@ int vtx_layer_fwd(const VtxLayerFwd* a, void* stream) {
   if (rc) return rc;
   rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream));
   if (rc) return rc;
+  // (option LN_FOLD bit 2) ... with norm_ff on its row operands: x1 in (it is the residual anyway), ln2 / mean2 / rstd2 and y out
+  if (mlp_fused_lnf_ok(dt, M, C, ff))
+    return TCALL(VTX_T_MLP_FWD, M, C, ff, F_RESID | F_AUXOUT, stream,
+                 mlp_fused_fwd_ln(a->x1, a->ln2_w, a->ln2_b, a->eps, a->ln2, a->mean2, a->rstd2, a->w1, a->b1, a->w2, a->b2, a->s2, a->rows_per_scale,
+                                  a->y, M, C, ff, (hipStream_t)stream));
   rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream));
   if (rc) return rc;
   // narrow stages (C = 64 / 96): the whole MLP in one launch, nothing ff-wide stored (the backward recomputes z and h: mlp_fused.hip)
@@ -359,6 +372,10 @@ int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream) {
   if (rc) return rc;
   rc = TCALL(VTX_T_GEMM, M, C, C, F_RESID, stream, vtx_gemm(0, dt, a->o, a->wo, a->x1, M, C, C, C, C, C, a->bo, a->x, a->s1, a->rows_per_scale, nullptr, nullptr, 0, stream));
   if (rc) return rc;
+  if (mlp_fused_lnf_ok(dt, M, C, ff))             // (as in vtx_layer_fwd: norm_ff on the row operands of the fused MLP)
+    return TCALL(VTX_T_MLP_FWD, M, C, ff, F_RESID | F_AUXOUT, stream,
+                 mlp_fused_fwd_ln(a->x1, a->ln2_w, a->ln2_b, a->eps, a->ln2, a->mean2, a->rstd2, a->w1, a->b1, a->w2, a->b2, a->s2, a->rows_per_scale,
+                                  a->y, M, C, ff, (hipStream_t)stream));
   rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x1, a->ln2_w, a->ln2_b, a->ln2, a->mean2, a->rstd2, a->M, C, a->eps, dt, 0, 0, 0, stream));
   if (rc) return rc;
   if (mlp_fused_ok(dt, M, C, ff))                 // (as in vtx_layer_fwd: PVT-Small / Twins-SVT-S stage 1, C = 64)

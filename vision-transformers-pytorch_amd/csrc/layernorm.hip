@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const int v = lig + k * G;
         if (v < nvec) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = xv[rr][k][e] - mu; q += d * d; }
+          for (int e = 0; e < 8; ++e) ln_fwd_elem_sq(xv[rr][k][e], mu, q);            // (vtx_common.h: shared with ln_fold.h)
         }
       }
       const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         if (v < nvec) {
           Vec8<T> o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o.set(e, (xv[rr][k][e] - mu) * rs * gm[k][e] + bt[k][e]);
+          for (int e = 0; e < 8; ++e) o.set(e, ln_fwd_elem_out(xv[rr][k][e], mu, rs, gm[k][e], bt[k][e]));
           store8<T>(y + orow[rr] * (int64_t)C + v * 8, o);
         }
       }

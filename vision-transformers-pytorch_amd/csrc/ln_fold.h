@@ -93,3 +93,57 @@ template <int NPR> struct LnFold {           // NPR = C / 32
     }
   }
 };
+
+// ---- LayerNorm FORWARD folded into the row-streaming kernel that consumes the normalised rows (option LN_FOLD bits 2, 3).
+// The kernel requests the RAW rows x in its operand layout (lane (c, g): vectors v = 4 tp + g of rows (mt, c)), normalises them in
+// registers -- these ARE the MFMA operands of its first product -- and stores the normalised rows and the statistics on the side
+// (the backward and the weight gradient read them): the stand-alone launch and its read of x disappear.
+// Bit-identical y, mean, rstd: ln_fwd_kernel<bf16, 16, 1>'s expressions (vtx_common.h ln_fwd_elem_*) and group_sum<16>'s association
+// (per-vector partials in element order, quads, (q0 + q1) + (q2 + q3) with zero quads past C / 32), two passes over the registers.
+template <int NPR> struct LnFwdFold {
+  // gamma / beta: [C] fp32, global or LDS; xv: the row's raw vectors; -> yv (bf16), mu, rs.  Every lane of the four-lane group gets mu / rs.
+  static __device__ __forceinline__ void row(const bf16x8 (&xv)[NPR], const float* gamma, const float* beta, float eps, int g,
+                                             bf16x8 (&yv)[NPR], float& mu, float& rs) {
+    static_assert(NPR >= 2 && NPR <= 4, "C = 64, 96 or 128");
+    constexpr float invC = 1.f / (float)(32 * NPR);
+    float x[NPR][8], qs[NPR];
+#pragma unroll
+    for (int tp = 0; tp < NPR; ++tp) {
+      Vec8<bf16> t;
+      t.v = xv[tp];
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[tp][e] = t.get(e); s += x[tp][e]; }
+      s += shfl_xor_f(s, 16);
+      qs[tp] = s + shfl_xor_f(s, 32);
+    }
+    if constexpr (NPR == 2) mu = ((qs[0] + qs[1]) + 0.f) * invC;
+    else if constexpr (NPR == 3) mu = ((qs[0] + qs[1]) + (qs[2] + 0.f)) * invC;
+    else mu = ((qs[0] + qs[1]) + (qs[2] + qs[NPR - 1])) * invC;
+#pragma unroll
+    for (int tp = 0; tp < NPR; ++tp) {
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ln_fwd_elem_sq(x[tp][e], mu, q);
+      q += shfl_xor_f(q, 16);
+      qs[tp] = q + shfl_xor_f(q, 32);
+    }
+    float var;
+    if constexpr (NPR == 2) var = ((qs[0] + qs[1]) + 0.f);
+    else if constexpr (NPR == 3) var = ((qs[0] + qs[1]) + (qs[2] + 0.f));
+    else var = ((qs[0] + qs[1]) + (qs[2] + qs[NPR - 1]));
+    rs = rsqrtf(var * invC + eps);
+#pragma unroll
+    for (int tp = 0; tp < NPR; ++tp) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + tp * 32 + 8 * g), g1 = *reinterpret_cast<const f32x4*>(gamma + tp * 32 + 8 * g + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + tp * 32 + 8 * g), b1 = *reinterpret_cast<const f32x4*>(beta + tp * 32 + 8 * g + 4);
+      Vec8<bf16> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o.set(e, ln_fwd_elem_out(x[tp][e], mu, rs, g0[e], b0[e]));
+        o.set(4 + e, ln_fwd_elem_out(x[tp][4 + e], mu, rs, g1[e], b1[e]));
+      }
+      yv[tp] = o.v;
+    }
+  }
+};

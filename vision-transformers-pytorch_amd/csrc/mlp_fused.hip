@@ -57,6 +57,13 @@ struct MlpArgs {
   const float* gamma;   // [C]
   float* part;          // [part_rows][2 C] fp32: dgamma | dbeta partial rows (the stand-alone launch's workspace layout)
   int part_rows;        // rows the deferred column reduce will sum: this launch writes gridDim.x of them and zeroes the rest
+  // LayerNorm-forward fold (forward, LNF): `a` is not read -- the rows come from `resid` (x1), are normalised in registers with
+  // gamma / beta / eps and stored to ln_out / mean_out / rstd_out on the side
+  const float* beta;
+  float eps;
+  bf16* ln_out;
+  float* mean_out;
+  float* rstd_out;
 };
 
 constexpr int MF_ROWS = 32;
@@ -77,7 +84,10 @@ template <int KS> __device__ __forceinline__ void mf_load_rows(bf16x8 (&f)[2][KS
 // registers less per lane
 // ZH: z and h are also written (tests; the layer calls never ask).  Rows past M (the last block only) are row M - 1 again -- operands and
 // addresses: the same bits stored to the same place, no exec-mask branch anywhere in the hidden loop.
-template <int KS, int WAVES, bool PF, bool ZH>
+// LNF (round 6, option LN_FOLD bit 2): the LayerNorm forward of norm_ff runs on the row operands (ln_fold.h LnFwdFold): the kernel reads
+// x1 -- which it reads anyway, as the residual -- instead of ln2, and writes ln2 / mean / rstd on the side for the backward and the
+// weight gradient: 3 units (x1 in, ln2 and y out) against the 5 of the two launches; ln2, mean, rstd, y bit-identical.
+template <int KS, int WAVES, bool PF, bool ZH, bool LNF = false>
 __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
   constexpr int C = 32 * KS, S1 = C + 8, NT = 64 * WAVES, MF_UNR = PF ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
@@ -96,6 +106,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
   }
   for (int i = threadIdx.x; i < ff; i += NT) b1s[i] = p.b1 ? p.b1[i] : 0.f;
   for (int i = threadIdx.x; i < C; i += NT) b2s[i] = p.b2 ? p.b2[i] : 0.f;
+  float* lgs = b2s + C;                                               // LNF: gamma | beta [2][C]
+  if constexpr (LNF)
+    for (int i = threadIdx.x; i < C; i += NT) { lgs[i] = p.gamma[i]; lgs[C + i] = p.beta[i]; }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -103,10 +116,11 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
   const int stride = gridDim.x * WAVES;
   const int npairs = ff >> 5;
   const int nperm = 8 * (c >> 2) + (c & 3);              // weight row this lane supplies as MFMA operand row c (+ 32 pair + 4 j)
+  const bf16* __restrict__ rows_src = LNF ? p.resid : p.a;
 
   bf16x8 an[2][KS];
   int rb = blockIdx.x * WAVES + wave;
-  if (PF && rb < nrb) mf_load_rows<KS>(an, p.a, rb, M, c, g);
+  if (PF && rb < nrb) mf_load_rows<KS>(an, rows_src, rb, M, c, g);
   for (; rb < nrb; rb += stride) {
     bf16x8 a[2][KS];
     if constexpr (PF) {
@@ -114,9 +128,26 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(MlpArgs p) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a[mt][ks] = an[mt][ks];
-      if (rb + stride < nrb) mf_load_rows<KS>(an, p.a, rb + stride, M, c, g);
+      if (rb + stride < nrb) mf_load_rows<KS>(an, rows_src, rb + stride, M, c, g);
     } else {
-      mf_load_rows<KS>(a, p.a, rb, M, c, g);
+      mf_load_rows<KS>(a, rows_src, rb, M, c, g);
+    }
+    if constexpr (LNF) {
+      // raw rows -> normalised rows, in place: these are the first product's operands; ln2 / mean / rstd go out on the side (rows past M
+      // are row M - 1 again: the same bits to the same place)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int rc = min(rb * MF_ROWS + mt * 16 + c, M - 1);
+        bf16x8 yv[KS];
+        float mu, rs;
+        LnFwdFold<KS>::row(a[mt], lgs, lgs + C, p.eps, g, yv, mu, rs);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a[mt][ks] = yv[ks];
+          *reinterpret_cast<bf16x8*>(p.ln_out + (int64_t)rc * C + ks * 32 + g * 8) = yv[ks];
+        }
+        if (g == 0) { p.mean_out[rc] = mu; p.rstd_out[rc] = rs; }
+      }
     }
     int row[2];
     float rsc[2];
@@ -433,13 +464,15 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(MlpArgs p) {
   if constexpr (LNB) lnf.template finish<WAVES>(reinterpret_cast<float*>(mf_smem), p.part, p.part_rows, wave, c, g);
 }
 
-size_t mlp_fwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 2 + (size_t)C * (ff + 8) * 2 + (size_t)(ff + C) * 4; }
+size_t mlp_fwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 2 + (size_t)C * (ff + 8) * 2 + (size_t)(ff + C) * 4 + (size_t)2 * C * 4; }
 size_t mlp_bwd_smem(int C, int ff) { return (size_t)ff * (C + 8) * 4 + (size_t)ff * 4; }
 
 template <int KS, int WAVES, bool PF> int mlp_fwd_launch_k(const MlpArgs& a, hipStream_t st) {
   const size_t smem = mlp_fwd_smem(32 * KS, a.ff);
   if ((a.z == nullptr) != (a.h == nullptr)) return VTX_ERR_NULL;             // (both or neither)
-  auto kern = a.z != nullptr ? mlp_fwd_kernel<KS, WAVES, PF, true> : mlp_fwd_kernel<KS, WAVES, PF, false>;
+  const bool lnf = a.ln_out != nullptr;
+  if (lnf && (a.z != nullptr || !a.resid || !a.gamma || !a.beta || !a.mean_out || !a.rstd_out)) return VTX_ERR_NULL;
+  auto kern = lnf ? mlp_fwd_kernel<KS, WAVES, PF, false, true> : (a.z != nullptr ? mlp_fwd_kernel<KS, WAVES, PF, true> : mlp_fwd_kernel<KS, WAVES, PF, false>);
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return VTX_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(vtx_cu_count_cached()), dim3(64 * WAVES), smem, st, a);
   return vtx_check_launch();
@@ -459,6 +492,7 @@ constexpr int MF_FWD_DEFAULT = 12, MF_BWD_DEFAULT = 6;      // (profiles/round5_
 int mf_fwd_code() { const int o = vtx_opt(VTX_OPT_MLP_FUSED); return o >= 100 ? o % 100 : MF_FWD_DEFAULT; }
 int mf_bwd_code() { const int o = vtx_opt(VTX_OPT_MLP_FUSED); return o >= 100 ? o / 100 : MF_BWD_DEFAULT; }
 template <int KS> int mlp_fwd_launch(const MlpArgs& a, hipStream_t st) {
+  if (a.ln_out != nullptr) return mlp_fwd_launch_k<KS, 12, false>(a, st);      // LayerNorm-forward fold: the default variant only
   switch (mf_fwd_code()) {
     case 4: return mlp_fwd_launch_k<KS, 4, true>(a, st);
     case 8: return mlp_fwd_launch_k<KS, 8, true>(a, st);
@@ -529,6 +563,22 @@ int mlp_fused_bwd(const void* ln2, const void* dy, const void* w1, const float* 
   return VTX_ERR_SHAPE;
 }
 
+bool mlp_fused_lnf_ok(int dtype, int64_t M, int C, int ff) { return (vtx_opt(VTX_OPT_LN_FOLD) & 4) != 0 && mlp_fused_ok(dtype, M, C, ff); }
+
+int mlp_fused_fwd_ln(const void* x1, const float* gamma, const float* beta, float eps, void* ln2, float* mean, float* rstd, const void* w1,
+                     const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y, int64_t M, int C,
+                     int ff, hipStream_t st) {
+  if (!x1 || !gamma || !beta || !ln2 || !mean || !rstd || !w1 || !w2 || !y) return VTX_ERR_NULL;
+  MlpArgs a = {};
+  a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.b1 = b1; a.b2 = b2; a.resid = (const bf16*)x1;
+  a.y = (bf16*)y; a.rowscale = rowscale; a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+  a.M = (int)M; a.ff = ff;
+  a.gamma = gamma; a.beta = beta; a.eps = eps; a.ln_out = (bf16*)ln2; a.mean_out = mean; a.rstd_out = rstd;
+  if (C == 96) return mlp_fwd_launch<3>(a, st);
+  if (C == 64) return mlp_fwd_launch<2>(a, st);
+  return VTX_ERR_SHAPE;
+}
+
 bool mlp_fused_ln_ok(int dtype, int64_t M, int C, int ff) {
   return (vtx_opt(VTX_OPT_LN_FOLD) & 1) != 0 && mlp_fused_ok(dtype, M, C, ff) && vtx_layernorm_bwd_blocks(M, C) >= vtx_cu_count_cached();
 }
@@ -575,6 +625,15 @@ int vtx_mlp_bwd_ln(int dtype, const void* ln2, const void* dy, const void* w1, c
   if (M <= 0 || !mlp_fused_ok(dtype, M > 32768 ? M : 32768, C, ff)) return VTX_ERR_SHAPE;
   return mlp_fused_bwd_ln(ln2, dy, w1, b1, w2, rowscale, rows_per_scale, h, dz, x1, mean, rstd, gamma, dx1, part, part_rows, M, C, ff,
                           (hipStream_t)stream);
+}
+
+/* vtx_layernorm_fwd(x1 -> ln2, mean, rstd) + vtx_mlp_fwd(ln2, .., resid = x1) in one launch (round 6, option LN_FOLD bit 2): the same bits. */
+int vtx_mlp_fwd_ln(int dtype, const void* x1, const float* gamma, const float* beta, float eps, void* ln2, float* mean, float* rstd,
+                   const void* w1, const float* b1, const void* w2, const float* b2, const float* rowscale, int rows_per_scale, void* y,
+                   int64_t M, int C, int ff, void* stream) {
+  if (dtype != VTX_BF16) return VTX_ERR_DTYPE;
+  if (M <= 0 || !mlp_fused_ok(dtype, M > 32768 ? M : 32768, C, ff)) return VTX_ERR_SHAPE;
+  return mlp_fused_fwd_ln(x1, gamma, beta, eps, ln2, mean, rstd, w1, b1, w2, b2, rowscale, rows_per_scale, y, M, C, ff, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -32,7 +32,7 @@ enum VtxOptionId {
   VTX_OPT_WATTN_FAST = 22,          // window-attention forward: bit 0, 7 x 7 windows run their 49th query as one row (4 scores per lane) instead of a padded 16-query tile | bit 1, windows of a masked layer whose tokens share one region id take the unmasked instruction stream
   VTX_OPT_WATTN_FWD4 = 23,          // 1: the bf16 window-attention forward shares a problem between the four waves of its workgroup (one 16-token tile per wave, rotating; next-problem prefetch) when a head has >= 4 096 (image, window) problems | 2: always | 0: one wave per problem
   VTX_OPT_MLP_FUSED = 24,          // 1: the MLP of bf16 layers with C = 64 / 96 over >= 32 768 rows runs as ONE launch each way with both weights resident in LDS (mlp_fused.hip: z and h never stored by the forward, recomputed by the backward) inside the one-call layers | 100 b + f: kernel variants (forward f in {4, 8, 9, 12, 16}, backward b in {4, 8}: mlp_fused.hip) | 0: four GEMM launches
-  VTX_OPT_LN_FOLD = 25,            // LayerNorm launches folded into their neighbours (round 6): bit 0, the norm_ff backward runs in the epilogue of the fused-MLP backward (mlp_bwd_kernel<.., LNB>: dln2 never stored, dx1 bit-identical to the stand-alone launch; layers that take the fused MLP) | bit 1, the qkv input gradient of a narrow window-attention layer (C = 64 / 96 / 128, >= 32 768 rows) and the norm_attn backward run as one weight-resident streaming launch (gemm_skinny.hip dgrad_ln_kernel: dln1 never stored, dx bit-identical) | 0: stand-alone launches
+  VTX_OPT_LN_FOLD = 25,            // LayerNorm launches folded into their neighbours (round 6): bit 0, the norm_ff backward runs in the epilogue of the fused-MLP backward (mlp_bwd_kernel<.., LNB>: dln2 never stored, dx1 bit-identical to the stand-alone launch; layers that take the fused MLP) | bit 1, the qkv input gradient of a narrow window-attention layer (C = 64 / 96 / 128, >= 32 768 rows) and the norm_attn backward run as one weight-resident streaming launch (gemm_skinny.hip dgrad_ln_kernel: dln1 never stored, dx bit-identical) | bit 2, norm_ff FORWARD on the row operands of the fused-MLP forward (mlp_fwd_kernel<.., LNF>: x1 in, ln2 / mean / rstd / y out) | bit 3, a narrow norm_attn forward on the row operands of the weight-resident streaming qkv GEMM (gemm_skinny_kernel<.., LNF>) | 0: stand-alone launches
   VTX_OPT_COUNT = 26
 };
 

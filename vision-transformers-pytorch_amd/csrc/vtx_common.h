@@ -168,6 +168,11 @@ __device__ __forceinline__ float ln_bwd_elem_out(float rs, float gv, float c1, f
   return rs * (gv - c1 - xh * c2);
 }
 
+// LayerNorm forward, element level -- shared by ln_fwd_kernel and its fold into the row-streaming kernels that consume the normalised
+// rows (ln_fold.h LnFwdFold): same expressions, same contraction.
+__device__ __forceinline__ void ln_fwd_elem_sq(float x, float mu, float& q) { const float d = x - mu; q += d * d; }
+__device__ __forceinline__ float ln_fwd_elem_out(float x, float mu, float rs, float gm, float bt) { return (x - mu) * rs * gm + bt; }
+
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: these run once per output element in GEMM epilogues
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_f(float z) { return z * sigmoidf_(z); }

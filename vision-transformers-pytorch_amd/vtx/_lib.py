@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class VtxError(RuntimeError):
@@ -122,6 +122,10 @@ _SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "vtx_dgrad_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                      c_int64, c_int, c_int, c_void_p]),
+    "vtx_mlp_fwd_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vtx_ln_gemm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                    c_int64, c_int, c_int, c_void_p]),
     "vtx_wgrad_workspace": (c_size_t, [c_int64, c_int, c_int]),
     "vtx_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64,
                           c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p]),

@@ -317,6 +317,8 @@ def _describe_timer_rec(r):
                   8: "8, false, false, 0, false", 9: "8, false, true, 0, false"}).get(code, str(code))
         waves = targs
         lnb = bwd and bool(fl & 1)          # (flag 1 on a backward record: the norm_ff backward folded into the epilogue, option LN_FOLD)
+        if not bwd and fl & 2:              # (flag 2 on a forward record: norm_ff on the row operands -- x1 in, ln2 and y out: 3 units as well)
+            waves = "12, false, false, true"
         if lnb:
             waves = ("4, true, false, 0, true, true" if k % 64 == 0 else "4, true, false, 0, false, true")
         # forward: ln2, x1 in, y out (2 products); backward: ln2, dy in, dln2, h, dz out (z and dh recomputed: 3 products); with the
@@ -327,6 +329,8 @@ def _describe_timer_rec(r):
         # dy [rows, k] and the weight in; x and the residual-stream gradient in, dx out (the dln tensor is never stored: the two launches
         # it replaces move rows x (k + 5 n) elements)
         return (f"dgrad_ln_kernel<{k // 32}, {n // 32}, 4>", 2.0 * rows * n * k, float(es * (rows * (k + 3 * n) + n * k) + 8.0 * rows), r.ms)
+    if r.tag == 18:                                                     # LayerNorm forward on the row operands of a streaming GEMM: rows x n over k = C
+        return (f"gemm_skinny_kernel<{k // 32}, 0, false, 4, true>", 2.0 * rows * n * k, float(es * (rows * (2 * k + n) + n * k) + 8.0 * rows), r.ms)
     return f"vtx_layer launch (tag {r.tag})", 0.0, 0.0, r.ms
 
 
