@@ -335,10 +335,18 @@ int vtx_srlayer_fwd(const VtxSrLayerFwd* a, void* stream) {
     return VTX_ERR_SHAPE;
   const int dt = a->dtype, M = (int)a->M, C = a->C, ff = a->ff, r = a->r;
   g_timer_base = (dt == VTX_BF16 ? F_BF16 : 0) | ((C / a->nH) << 8);
-  int rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream));
-  if (rc) return rc;
-  rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, vtx_gemm(0, dt, a->ln1, a->wq, a->q, M, C, C, C, C, C, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
-  if (rc) return rc;
+  int rc;
+  if (ln_gemm_ok(dt, M, C, C)) {
+    // (option LN_FOLD bit 3) narrow stages: norm_attn on the row operands of the q projection; ln1 (the reduction branch reads it) on the side
+    rc = TCALL(VTX_T_LN_GEMM, M, C, C, 0, stream,
+               ln_gemm_launch(a->x, a->ln1_w, a->ln1_b, a->eps, a->ln1, a->mean1, a->rstd1, a->wq, nullptr, a->q, M, C, C, (hipStream_t)stream));
+    if (rc) return rc;
+  } else {
+    rc = TCALL(VTX_T_LN_FWD, M, C, 0, 0, stream, vtx_layernorm_fwd(a->x, a->ln1_w, a->ln1_b, a->ln1, a->mean1, a->rstd1, a->M, C, a->eps, dt, 0, 0, 0, stream));
+    if (rc) return rc;
+    rc = TCALL(VTX_T_GEMM, M, C, C, 0, stream, vtx_gemm(0, dt, a->ln1, a->wq, a->q, M, C, C, C, C, C, nullptr, nullptr, nullptr, 1, nullptr, nullptr, 0, stream));
+    if (rc) return rc;
+  }
   const void* kvin = a->ln1;
   const int rows = a->B * a->Lk;
   if (r > 1) {
