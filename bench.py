@@ -696,7 +696,7 @@ def main():
             "world_size_observed": dist.get_world_size() if world > 1 else 1,
             "backend": (args.backend if world > 1 else None),
             "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if world > 1 and args.backend == "nccl" else None,
-            "side_stream_wgrad": bool(VF._SIDE_ENABLED), "ddp": res["ddp"],
+            "side_stream_wgrad": bool(VF._SIDE_ENABLED), "side_stream_probe": VF.side_stream_report or None, "ddp": res["ddp"],
             "roofline": res["roofline"], "measured_peaks": peaks, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line))

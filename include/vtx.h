@@ -56,6 +56,10 @@ int vtx_debug_lds_poison(unsigned pattern, int rounds, void* stream);
  * (v_mfma_f32_32x32x16_bf16, 32 768 FLOP each) on register operands, no memory traffic.  *flops receives the FLOPs of the launch; the caller
  * brackets the call with events on `stream`.  `sink`: any device buffer of >= 4 bytes. */
 int vtx_debug_mfma_peak(int iters, int waves_per_cu, void* sink, double* flops, void* stream);
+/* Measurement helper: one idle wavefront that occupies `stream` for `microseconds` of wall clock (<= 100 000) and touches no memory.  Two of
+ * them on two streams finish in one period when the streams run concurrently, in two when they share a hardware queue: vtx.functional picks
+ * the side stream of the weight gradients with it (round 6, profiles/round6_side_stream_queue.md). */
+int vtx_debug_spin(int microseconds, void* stream);
 
 /* ---- Dispatch switches (csrc/options.h).  Which kernel variant an entry point launches -- LDS-DMA vs register-staged
  * GEMM, tile height, waves per workgroup, split-K target, fused vs separate split-K reduction, persistent-grid sizes --

@@ -78,4 +78,5 @@ for name, B, dp in [m for m in (("swin_s", 128, 0.3), ("vit_s16", 256, 0.1)) if 
     off, on = min(res[False]), min(res[True])
     moff, mon = sum(res[False]) / len(res[False]), sum(res[True]) / len(res[True])
     print(f"{name:8s} best-of-{args.reps}: off {off:.3f} ms, ON {on:.3f} ms -> {100 * (on / off - 1):+.2f} %;  mean: off {moff:.3f}, ON {mon:.3f} -> {100 * (mon / moff - 1):+.2f} %\n")
+print("side-stream concurrency probe (vtx.functional._concurrent_stream):", VF.side_stream_report)
 dist.destroy_process_group()

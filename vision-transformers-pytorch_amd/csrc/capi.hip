@@ -69,6 +69,13 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) 
   if (s == 12345.678f) sink[0] = s;          // (keeps the chain alive; never true for these operands)
 }
 
+// One wavefront that holds its hardware queue for `ticks` of the 100-MHz wall clock and touches nothing (vtx_debug_spin): two of them on
+// two streams take one period when the streams are served concurrently and two when they share a hardware queue.
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 extern "C" {
 
 int vtx_option_count(void) { return VTX_OPT_COUNT; }
@@ -93,7 +100,7 @@ const char* vtx_strerror(int code) {
   }
 }
 
-int vtx_abi_version(void) { return 25; }
+int vtx_abi_version(void) { return 26; }
 
 int vtx_cu_count(void) { return vtx_cu_count_cached(); }
 
@@ -116,6 +123,15 @@ int vtx_debug_mfma_peak(int iters, int waves_per_cu, void* sink, double* flops, 
   const int grid = vtx_cu_count_cached() * (waves_per_cu / 4);
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, iters, (float*)sink);
   if (flops) *flops = (double)grid * 4.0 * (double)iters * 4.0 * 32768.0;
+  return vtx_check_launch();
+}
+
+/* Measurement helper: one idle wavefront that occupies `stream` for `microseconds` (wall clock) -- vtx.functional uses two of them to check
+ * that the side stream of the weight gradients is really served CONCURRENTLY with the compute stream (HIP multiplexes streams onto a few
+ * hardware queues: a side stream that shares the compute stream's queue serialises, profiles/round6_side_stream_queue.md). */
+int vtx_debug_spin(int microseconds, void* stream) {
+  if (microseconds <= 0 || microseconds > 100000) return VTX_ERR_SHAPE;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
   return vtx_check_launch();
 }
 

@@ -11,6 +11,7 @@ import ctypes
 import os
 import struct
 import threading
+import warnings
 
 import torch
 from torch.autograd import Function
@@ -181,9 +182,48 @@ _DEFER_REDUCE = os.environ.get("VTX_DEFER_REDUCE", "1") != "0"
 _deferred = False
 
 
+_SIDE_PROBE = os.environ.get("VTX_SIDE_PROBE", "1") != "0"
+side_stream_report = {}          # device -> what the concurrency probe saw (bench.py prints it)
+
+
+def _concurrent_stream(device, candidates=8, spin_us=150):
+    """A stream that the GPU really serves CONCURRENTLY with the current one.  HIP multiplexes its streams onto a handful of hardware
+    queues (4 by default) in creation order, and torch hands out pool streams round robin: the N-th stream a process asks for may share
+    the compute stream's queue -- and then every 'side-stream' weight gradient runs strictly behind the kernel before it, with a
+    cross-stream hand-off gap on top (measured: a process that created its RCCL communicator first got such a stream; Swin-S step
+    +0.4 ms, concurrency 1.00 in the kernel trace -- profiles/round6_side_stream_queue.md).  Probe: one idle wavefront that holds its
+    queue for `spin_us` on each of the two streams (libvtx vtx_debug_spin); concurrent streams take one period, a shared queue two."""
+    cur = torch.cuda.current_stream(device)
+    lib = _lib.load()
+    seen = []
+    first = None
+    for k in range(candidates):
+        st = torch.cuda.Stream(device=device)
+        first = first or st
+        best = None
+        for rep in range(2):                                  # (first pair: warm-up of the kernel and the streams)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            st.wait_event(e0)
+            _lib.check(lib.vtx_debug_spin(spin_us, cur.cuda_stream), "vtx_debug_spin")
+            _lib.check(lib.vtx_debug_spin(spin_us, st.cuda_stream), "vtx_debug_spin")
+            cur.wait_stream(st)
+            e1.record(cur)
+            e1.synchronize()
+            best = e0.elapsed_time(e1) * 1e3
+        seen.append(round(best, 1))
+        if best < 1.6 * spin_us:
+            side_stream_report[str(device)] = dict(chosen=k, pair_us=seen, spin_us=spin_us, concurrent=True)
+            return st
+    side_stream_report[str(device)] = dict(chosen=0, pair_us=seen, spin_us=spin_us, concurrent=False)
+    warnings.warn(f"vtx: none of {candidates} candidate streams runs concurrently with the compute stream (two {spin_us}-us spin kernels took "
+                  f"{seen} us): the side-stream weight gradients will serialise", RuntimeWarning)
+    return first
+
+
 class _SideState:
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = _concurrent_stream(device) if _SIDE_PROBE else torch.cuda.Stream(device=device)
         self.pending = False
         self.keep = []
 
