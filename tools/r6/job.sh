@@ -29,6 +29,14 @@ case "$J" in
       env VTX_LIBVTX=$R/$l timeout 600 python bench.py --model $M --steps ${STEPS:-30} --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-events 2>&1 | grep '"metric"' | cut -c1-200 >> $LOG
     done; done
     cat $LOG ;;
+  envab)      # same-box A/B of an ENVIRONMENT variable: tools/r6/job.sh envab swin_s "extra bench args" VAR v0 v1 ...
+    M=$1; X=$2; V=$3; shift 3
+    : > $LOG
+    for rep in $(seq 1 ${REPS:-2}); do for v in "$@"; do
+      echo "== $V=$v" >> $LOG
+      env $V=$v timeout 600 python bench.py --model $M --steps ${STEPS:-30} --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-events $X 2>&1 | grep '"metric"' | cut -c1-200 >> $LOG
+    done; done
+    cat $LOG ;;
   ddp)        # what the data-parallel machinery costs on one GPU (one-rank RCCL group, forced) vs the bypass
     timeout 1500 python tools/r6/ddp_overhead_one_gpu.py "$@" 2>&1 | grep -v amdgpu.ids > $LOG; cat $LOG ;;
   prof)       # rocprofv3 kernel stats of a short run of one model (single-stream so that durations are attributable): prof swin_s
