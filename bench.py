@@ -59,7 +59,7 @@ def pmc_traffic(model, kernel):
     run inside the timed process, so the figure comes from profiles/ (newest round first) together with the commit
     the profile was taken at (`_meta.commit` in the file; the kernels may have changed since: compare with HEAD);
     None when no summary is committed or the kernel is not in it."""
-    for rnd in (5, 4, 3, 2, 1):
+    for rnd in (6, 5, 4, 3, 2, 1):
         path = os.path.join(REPO, "profiles", f"round{rnd}_pmc_traffic_{model}.json")
         try:
             tab = json.load(open(path))

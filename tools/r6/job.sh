@@ -50,6 +50,15 @@ case "$J" in
     rm -f gpurun_out/r6_prof_$TAG/trace_results.db
     M=$TAG
     head -40 gpurun_out/r6_kernel_stats_$M.md ;;
+  battery)    # end-of-round measurements: bench lines of the five workloads, PMC traffic, GEMM micro-benchmark vs hipBLASLt, shape table
+    timeout 1200 python bench.py --steps 20 --warmup 5 --shape-table gpurun_out/r6_shape_table_swin_s.md 2>&1 | grep '"metric"' > gpurun_out/r6_bench_swin_s.json
+    for m in vit_s16 pvt_small; do timeout 900 python bench.py --model $m --steps 20 --warmup 5 --shape-table gpurun_out/r6_shape_table_$m.md 2>&1 | grep '"metric"' > gpurun_out/r6_bench_$m.json; done
+    timeout 900 python bench.py --model dino --steps 10 --warmup 3 --cpu-batch 2 --cpu-steps 1 2>&1 | grep '"metric"' > gpurun_out/r6_bench_dino.json
+    timeout 900 python bench.py --model twins_svt_s --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' > gpurun_out/r6_bench_twins_svt_s.json
+    for m in swin_s vit_s16 pvt_small; do timeout 1500 tools/pmc_traffic.sh $m > /dev/null 2>&1; done
+    timeout 900 python tools/bench_gemm.py --vendor 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_gemm_bench.log
+    timeout 300 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_attn_bench.log
+    for m in swin_s vit_s16 pvt_small dino twins_svt_s; do cut -c1-200 gpurun_out/r6_bench_$m.json; done ;;
   py)         # any python tool: tools/r6/job.sh py name script.py args...
     N=$1; shift
     timeout ${TMO:-1200} python "$@" 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_$N.log; tail -${TAIL:-60} gpurun_out/r6_$N.log ;;
