@@ -585,7 +585,7 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true", help="launcher plumbing only (gloo on CPU, no model)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short ViT-S/16 / PVT-Small / DINO / Twins-SVT-S runs that follow the headline at --gpus 1 (`secondary`)")
-    ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend of the N > 1 run: nccl (= RCCL, the product path) | gloo (TEST ONLY: lets the "
                          "world > 1 branch of this file run where RCCL cannot, e.g. two ranks on one GPU with --share-gpu)")
@@ -665,13 +665,13 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()               # the previous workload's model / activations: start from an empty allocator
             try:
-                r = run_workload(name, default_batch(name), args.secondary_steps, 3, args, dev, rank, world)
+                r = run_workload(name, default_batch(name), args.secondary_steps, 5, args, dev, rank, world)
             except Exception as exc:               # a secondary workload never takes the headline line down with it
                 secondary.append({"model": name, "error": f"{type(exc).__name__}: {exc}"[:300]})
                 continue
             rf = r["roofline"] or {}
             secondary.append({"workload": r["workload"], "model": name, "value": round(r["value"], 2), "unit": "images/sec",
-                              "ms_per_step": round(r["ms_per_step"], 3), "steps": args.secondary_steps, "warmup": 3,
+                              "ms_per_step": round(r["ms_per_step"], 3), "steps": args.secondary_steps, "warmup": 5,
                               "roofline": {k: rf.get(k) for k in ("kernel", "bound", "frac", "frac_hbm", "frac_mfma",
                                                                   "avg_launch_us", "launches_per_step", "end_to_end_frac",
                                                                   "executed_flop_frac")}})
