@@ -60,6 +60,9 @@ int vtx_debug_mfma_peak(int iters, int waves_per_cu, void* sink, double* flops, 
  * them on two streams finish in one period when the streams run concurrently, in two when they share a hardware queue: vtx.functional picks
  * the side stream of the weight gradients with it (round 6, profiles/round6_side_stream_queue.md). */
 int vtx_debug_spin(int microseconds, void* stream);
+/* waves per workgroup the ViT attention fast path (csrc/attention_seq.hip) runs sequences of L tokens with under the current SATTN_WAVES option
+ * (round 6: 6 / 7 / 8 so that the live 16-token tiles divide among the waves; the bindings name the kernel instantiation with it) */
+int vtx_sattn_waves(int L);
 
 /* ---- Dispatch switches (csrc/options.h).  Which kernel variant an entry point launches -- LDS-DMA vs register-staged
  * GEMM, tile height, waves per workgroup, split-K target, fused vs separate split-K reduction, persistent-grid sizes --

@@ -172,6 +172,35 @@ def test_global_attention_core(dtype, B, L, nH, D):
     check(f"global attn dqkv {dtype} L{L} h{nH} d{D}", dqkv, dqr, 2e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("L", [197, 224, 193, 177, 161, 145, 130, 37, 101])
+def test_vit_attention_wave_counts_are_bitwise_interchangeable(L):
+    """Round 6: the ViT attention fast path runs 6 / 7 / 8 waves per workgroup, whichever leaves the fewest idle 16-token tile slots
+    (option SATTN_WAVES = 1; L = 197: 13 live tiles on 7 waves).  A tile's arithmetic does not depend on the wave that runs it: o, lse and
+    dqkv of every wave count (and of round 1's four waves on pairs of tiles) agree bit for bit, NaN-filled outputs fully written."""
+    from vtx import _lib, ops, options
+    d = dev()
+    B, nH, D = 3, 6, 64
+    qkv = _mk((B, L, 3 * nH * D), 71, torch.bfloat16).to(d)
+    do = _mk((B, L, nH * D), 72, torch.bfloat16).to(d)
+    res = {}
+    for w in (1, 8, 7, 6, 4):
+        with options.override(SATTN_WAVES=w):
+            picked = _lib.load().vtx_sattn_waves(L)
+            o, lse = ops.attention_fwd(qkv, B, L, nH, D)
+            dqkv, _ = ops.attention_bwd(qkv, o, do, lse, B, L, nH, D)
+        res[w] = (picked, o, lse, dqkv)
+    nt = (L + 15) // 16
+    if L > 128:
+        waste = {w: -(-nt // w) * w - nt for w in (8, 7, 6)}
+        assert res[1][0] == min((8, 7, 6), key=lambda w: (waste[w], -w)), (L, res[1][0], waste)
+    else:
+        assert res[1][0] == 8
+    for w in (8, 7, 6, 4):
+        for name, a, b in zip(("o", "lse", "dqkv"), res[1][1:], res[w][1:]):
+            assert torch.isfinite(b.float()).all()
+            assert torch.equal(a, b), f"L = {L}: {name} differs between SATTN_WAVES = 1 (-> {res[1][0]} waves) and {w}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,nH,shift", [(2, 14, 14, 3, True), (2, 14, 14, 3, False), (3, 7, 7, 24, True),
                                             (1, 28, 28, 6, True), (2, 56, 56, 3, True)])

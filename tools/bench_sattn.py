@@ -28,17 +28,21 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     dev = torch.device("cuda")
-    for name, B, L, h in (("ViT-S/16 224^2", 256, 197, 6), ("DINO global", 128, 197, 6), ("DINO local 96^2", 512, 37, 6)):
-        C = h * 64
-        qkv = torch.randn(B * L, 3 * C, device=dev).bfloat16()
-        do = torch.randn(B * L, C, device=dev).bfloat16()
-        o, lse = ops.attention_fwd(qkv, B, L, h, 64)
-        tf = timeit(lambda: ops.attention_fwd(qkv, B, L, h, 64), a.iters)
-        tb = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, L, h, 64), a.iters)
-        fb, bb = 4.0 * B * L * C * 2, 8.0 * B * L * C * 2
-        fl = 4.0 * B * h * L * L * 64
-        print(f"{name:16s} B={B:4d} L={L:4d}  fwd {tf:7.1f} us ({fb / tf / 1e3:6.0f} GB/s, {fl / tf / 1e6:6.1f} TF/s)"
-              f"   bwd {tb:7.1f} us ({bb / tb / 1e3:6.0f} GB/s, {2.5 * fl / tb / 1e6:6.1f} TF/s)")
+    from vtx import options
+    for waves in (8, 7, 6, 1):
+      options.set("SATTN_WAVES", waves)
+      print(f"-- option SATTN_WAVES = {waves}" + (" (default: the wave count that leaves the fewest idle tile slots)" if waves == 1 else ""))
+      for name, B, L, h in (("ViT-S/16 224^2", 256, 197, 6), ("DINO global", 128, 197, 6), ("DINO local 96^2", 512, 37, 6)):
+          C = h * 64
+          qkv = torch.randn(B * L, 3 * C, device=dev).bfloat16()
+          do = torch.randn(B * L, C, device=dev).bfloat16()
+          o, lse = ops.attention_fwd(qkv, B, L, h, 64)
+          tf = timeit(lambda: ops.attention_fwd(qkv, B, L, h, 64), a.iters)
+          tb = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, B, L, h, 64), a.iters)
+          fb, bb = 4.0 * B * L * C * 2, 8.0 * B * L * C * 2
+          fl = 4.0 * B * h * L * L * 64
+          print(f"{name:16s} B={B:4d} L={L:4d}  fwd {tf:7.1f} us ({fb / tf / 1e3:6.0f} GB/s, {fl / tf / 1e6:6.1f} TF/s)"
+                f"   bwd {tb:7.1f} us ({bb / tb / 1e3:6.0f} GB/s, {2.5 * fl / tb / 1e6:6.1f} TF/s)")
 
 
 if __name__ == "__main__":

@@ -432,24 +432,53 @@ bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
 // wave (13 tiles at L = 197: 2 + 2 + ... vs 4 + 4 + 4 + 2) and twice the waves per SIMD to hide the LDS / exp latencies.
 // (Eight waves on pairs -- half the LDS fragment traffic per MFMA, but 170 registers = one workgroup per CU: backward
 //  112 -> 132 us.  Phase ablation, SA_ABLATE: staging + loads 23 us, phase A 44-54, phase B 36-46 of the 113-us backward.)
-template <int NKT> static int sattn_fwd_t(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {
+// Round 6: waves per workgroup chosen so that the LIVE 16-token tiles divide among them.  Every wave walks tiles wave, wave + NW, ...: at
+// L = 197 (13 live tiles) eight waves take 2 + 2 + 2 + 2 + 2 + 1 + 1 + 1 -- both phases last two tile periods with three waves idle in the
+// second (13 of 16 slots) -- seven waves take 2 x 6 + 1 (13 of 14).  Candidates 6, 7, 8 (two workgroups per CU either way); the
+// fewest idle slots wins, ties go to more waves.  A tile's arithmetic does not depend on the wave that runs it: bit-identical.
+// SATTN_WAVES: 1 = this rule (default) | 8, 7, 6 = forced | 4 = four waves on pairs of tiles (round 1).
+static int sa_pick_nw(int L, int nkt) {
+  const int o = vtx_opt(VTX_OPT_SATTN_WAVES);
+  if (o == 4 || o == 6 || o == 7 || o == 8) return (nkt != 14 && (o == 6 || o == 7)) ? 8 : o;
+  if (nkt != 14) return 8;
+  const int nt = (L + 15) >> 4;
+  int best = 8, waste = ((nt + 7) / 8) * 8 - nt;
+  for (int w = 7; w >= 6; --w) {
+    const int ws = ((nt + w - 1) / w) * w - nt;
+    if (ws < waste) { waste = ws; best = w; }
+  }
+  return best;
+}
+extern "C" int vtx_sattn_waves(int L) { return sa_pick_nw(L, L <= 64 ? 4 : (L <= 128 ? 8 : 14)); }
+
+template <int NKT, int TP, int NW> static int sattn_fwd_k(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB;
-  if (vtx_opt(VTX_OPT_SATTN_WAVES) == 8)
-    hipLaunchKernelGGL((sattn_fwd_kernel<NKT, 1, 8>), dim3(B * g.nH), dim3(512), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
-  else
-    hipLaunchKernelGGL((sattn_fwd_kernel<NKT, 2, 4>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
+  hipLaunchKernelGGL((sattn_fwd_kernel<NKT, TP, NW>), dim3(B * g.nH), dim3(64 * NW), smem, st, (const bf16*)qkv, (bf16*)o, lse, g);
+  return vtx_check_launch();
+}
+template <int NKT> static int sattn_fwd_t(const void* qkv, void* o, float* lse, int B, const SeqGeom& g, hipStream_t st) {
+  switch (sa_pick_nw(g.L, NKT)) {
+    case 4: return sattn_fwd_k<NKT, 2, 4>(qkv, o, lse, B, g, st);
+    case 6: if constexpr (NKT == 14) return sattn_fwd_k<NKT, 1, 6>(qkv, o, lse, B, g, st);
+    case 7: if constexpr (NKT == 14) return sattn_fwd_k<NKT, 1, 7>(qkv, o, lse, B, g, st);
+    default: return sattn_fwd_k<NKT, 1, 8>(qkv, o, lse, B, g, st);
+  }
+}
+template <int NKT, int TP, int NW> static int sattn_bwd_k(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                                                          int B, const SeqGeom& g, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB + 2 * NKT * 16 * sizeof(float);
+  hipLaunchKernelGGL((sattn_bwd_kernel<NKT, TP, NW>), dim3(B * g.nH), dim3(64 * NW), smem, st, (const bf16*)qkv, (const bf16*)o,
+                     (const bf16*)dout, lse, (bf16*)dqkv, g);
   return vtx_check_launch();
 }
 template <int NKT> static int sattn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
                                           int B, const SeqGeom& g, hipStream_t st) {
-  constexpr size_t smem = (size_t)2 * NKT * 16 * SA_ROWB + 2 * NKT * 16 * sizeof(float);
-  if (vtx_opt(VTX_OPT_SATTN_WAVES) == 8)
-    hipLaunchKernelGGL((sattn_bwd_kernel<NKT, 1, 8>), dim3(B * g.nH), dim3(512), smem, st, (const bf16*)qkv, (const bf16*)o,
-                       (const bf16*)dout, lse, (bf16*)dqkv, g);
-  else
-    hipLaunchKernelGGL((sattn_bwd_kernel<NKT, 2, 4>), dim3(B * g.nH), dim3(256), smem, st, (const bf16*)qkv, (const bf16*)o,
-                       (const bf16*)dout, lse, (bf16*)dqkv, g);
-  return vtx_check_launch();
+  switch (sa_pick_nw(g.L, NKT)) {
+    case 4: return sattn_bwd_k<NKT, 2, 4>(qkv, o, dout, lse, dqkv, B, g, st);
+    case 6: if constexpr (NKT == 14) return sattn_bwd_k<NKT, 1, 6>(qkv, o, dout, lse, dqkv, B, g, st);
+    case 7: if constexpr (NKT == 14) return sattn_bwd_k<NKT, 1, 7>(qkv, o, dout, lse, dqkv, B, g, st);
+    default: return sattn_bwd_k<NKT, 1, 8>(qkv, o, dout, lse, dqkv, B, g, st);
+  }
 }
 
 // key-tile count of the instantiation: 14 (L <= 224: ViT-S/16 at 224^2, L = 197), 8 (L <= 128), 4 (L <= 64: the 96^2 DINO

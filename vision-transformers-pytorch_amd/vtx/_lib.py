@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTX_LIBVTX") or os.path.join(_HERE, "libvtx.so")   # (override: A/B of two builds on one box)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 class VtxError(RuntimeError):
@@ -99,6 +99,7 @@ _SIGNATURES = {
     "vtx_cu_count": (c_int, []),
     "vtx_debug_lds_poison": (c_int, [c_uint, c_int, c_void_p]),
     "vtx_debug_spin": (c_int, [c_int, c_void_p]),
+    "vtx_sattn_waves": (c_int, [c_int]),
     "vtx_debug_mfma_peak": (c_int, [c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_void_p]),
     "vtx_option_count": (c_int, []),
     "vtx_option_name": (c_char_p, [c_int]),

@@ -280,7 +280,7 @@ def _describe_timer_rec(r):
         nprob = rows // k * n
         nkt = 4 if k <= 64 else (8 if k <= 128 else 14)
         fast = bf and D == 64 and k <= 224 and options.get("SATTN")
-        name = (f"sattn_{'bwd' if bwd else 'fwd'}_kernel<{nkt}, {_sattn_cfg()}>" if fast else
+        name = (f"sattn_{'bwd' if bwd else 'fwd'}_kernel<{nkt}, {_sattn_cfg(k)}>" if fast else
                 ("lattn_*_kernel" if k > 224 else f"attn_{'bwd' if bwd else 'fwd'}_kernel"))
         return name, (10.0 if bwd else 4.0) * nprob * k * k * D, (8.0 if bwd else 4.0) * rows * n * D * es, r.ms
     if r.tag == 8:                                                      # the layer's grouped weight gradient: n = C, k = ff
@@ -1175,9 +1175,10 @@ def pos_csr(pos, ntab):
     return order, offsets
 
 
-def _sattn_cfg():
-    """(tiles per wave step, waves) template arguments of the ViT attention kernels (mirrors attention_seq.hip)."""
-    return "1, 8" if options.get("SATTN_WAVES") == 8 else "2, 4"
+def _sattn_cfg(L=197):
+    """(tiles per wave step, waves) template arguments of the ViT attention kernels for sequences of L tokens (asks attention_seq.hip)."""
+    w = _lib.load().vtx_sattn_waves(int(L))
+    return "2, 4" if w == 4 else f"1, {w}"
 
 
 def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None, drop=None):
@@ -1195,7 +1196,7 @@ def attention_fwd(qkv, B, L, n_head, D, swin=None, bias=None, mask=None, drop=No
     fast = drop is None and swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224      # mirrors sattn_ok
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
     long_ = drop is None and swin is None and bias is None and mask is None and L > 224
-    ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
+    ev = _attn_bracket(f"sattn_fwd_kernel<{nkt}, {_sattn_cfg(L)}>" if fast else ("lattn_fwd_kernel" if long_ else "attn_fwd_kernel"),
                        B * nW * n_head, L, D, rows, n_head * D, qkv.element_size(), False)
     if drop is not None:
         dp, seed, keep = _drop_args(drop, qkv.device, B * nW * n_head * L * L)
@@ -1229,7 +1230,7 @@ def attention_bwd(qkv, o, dout, lse, B, L, n_head, D, swin=None, bias=None, mask
     fast = drop is None and swin is None and bias is None and qkv.dtype == torch.bfloat16 and D == 64 and L <= 224
     nkt = 4 if L <= 64 else (8 if L <= 128 else 14)
     long_ = drop is None and swin is None and bias is None and mask is None and L > 224
-    ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}, {_sattn_cfg()}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
+    ev = _attn_bracket(f"sattn_bwd_kernel<{nkt}, {_sattn_cfg(L)}>" if fast else ("lattn_bwd_*_kernel" if long_ else "attn_bwd_kernel"),
                        rows // L * n_head, L, D, rows, n_head * D, qkv.element_size(), True)
     if drop is not None:
         dp, seed, keep = _drop_args(drop, qkv.device, rows * n_head * L)
