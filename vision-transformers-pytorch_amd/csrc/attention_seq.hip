@@ -436,7 +436,10 @@ bool sattn_ok(int dtype, int L, int D, int swin, const void* bias) {
 // L = 197 (13 live tiles) eight waves take 2 + 2 + 2 + 2 + 2 + 1 + 1 + 1 -- both phases last two tile periods with three waves idle in the
 // second (13 of 16 slots) -- seven waves take 2 x 6 + 1 (13 of 14).  Candidates 6, 7, 8 (two workgroups per CU either way); the
 // fewest idle slots wins, ties go to more waves.  A tile's arithmetic does not depend on the wave that runs it: bit-identical.
-// SATTN_WAVES: 1 = this rule (default) | 8, 7, 6 = forced | 4 = four waves on pairs of tiles (round 1).
+// SATTN_WAVES: 8 (default) | 7, 6 = forced | 1 = this rule | 4 = four waves on pairs of tiles (round 1).
+// MEASURED (profiles/round6_sattn_wave_counts.txt): no gain -- ViT-S/16 B = 256 forward 44.6 (8 waves) / 45.8 (7) / 48.5 us (6), backward
+// 119.3 / 121.5 / 127.9 us, ViT-S/16 step 12.02 -> 12.11 ms with the rule: the idle waves of the second tile period cost nothing (the
+// other workgroup of the CU fills the SIMDs), fewer waves per SIMD hide less of the LDS -> MFMA -> exp chain.  The default stays 8.
 static int sa_pick_nw(int L, int nkt) {
   const int o = vtx_opt(VTX_OPT_SATTN_WAVES);
   if (o == 4 || o == 6 || o == 7 || o == 8) return (nkt != 14 && (o == 6 || o == 7)) ? 8 : o;

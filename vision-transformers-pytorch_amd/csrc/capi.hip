@@ -11,7 +11,7 @@ const OptDef kOptDefs[VTX_OPT_COUNT] = {
     {"VTX_GEMM_GLDS", 1},   {"VTX_GLDS_BM", 0},          {"VTX_GLDS_WAVES", 8},   {"VTX_WGRAD_GLDS", 1},
     {"VTX_WG_WAVES", 8},    {"VTX_WGRAD_BLOCKS", 512},   {"VTX_SATTN", 1},        {"VTX_WATTN_FWD_WAVES", 4096},
     {"VTX_WATTN_WAVES", 2048}, {"VTX_SRATTN_WGS", 2048}, {"VTX_WATTN_XCD_MAJOR", 1},
-    {"VTX_LN_FIT", 1},      {"VTX_GLDS_EPI", 1},    {"VTX_SATTN_WAVES", 1},
+    {"VTX_LN_FIT", 1},      {"VTX_GLDS_EPI", 1},    {"VTX_SATTN_WAVES", 8},
     {"VTX_WATTN_BWD4", 1},  {"VTX_GEMM_SKINNY", 1}, {"VTX_GEMM_ASTAT", 1},
     {"VTX_TWINS_SUB_LDS", 1}, {"VTX_WGRAD_WIDE", 1}, {"VTX_GEMM_PP", 1},
     {"VTX_LN_ROWS", 0},     {"VTX_SKINNY_WAVES", 4}, {"VTX_WATTN_FAST", 3}, {"VTX_WATTN_FWD4", 1},

@@ -20,7 +20,7 @@ enum VtxOptionId {
                                     //    128-byte line run back to back on one L2); 0: all blocks of head 0, then head 1, ...
   VTX_OPT_LN_FIT = 11,              // LayerNorm exact-fit lane groups for C = 384 / 768: bit 0 forward, bit 1 backward
   VTX_OPT_GLDS_EPI = 12,            // LDS-DMA GEMM epilogue (128-column tiles, 8 waves): 1 = wave-private staging, no workgroup barrier (default) | 0 = shared staging passes
-  VTX_OPT_SATTN_WAVES = 13,         // ViT attention fast path: 1 (default, round 6) = 6 / 7 / 8 waves on single 16-token tiles, whichever leaves the fewest idle tile slots (L = 197: 7) | 8, 7, 6 forced | 4 waves on pairs of tiles
+  VTX_OPT_SATTN_WAVES = 13,         // ViT attention fast path: 8 waves on single 16-token tiles (default) | 7, 6 | 1 = whichever of 6 / 7 / 8 leaves the fewest idle tile slots (round 6: L = 197 -> 7; measured no faster, profiles/round6_sattn_wave_counts.txt) | 4 waves on pairs of tiles
   VTX_OPT_WATTN_BWD4 = 14,          // 1: bf16 window-attention backward with four waves per problem (wattn_bwd4_kernel) | 0: one wave
   VTX_OPT_GEMM_SKINNY = 15,         // 1: bf16 GEMMs with K = 64 / 96 / 128 over >= 32 768 rows take the weight-resident streaming kernel (gemm_skinny.hip) | 0
   VTX_OPT_GEMM_ASTAT = 16,          // 1: bf16 GEMMs with 192 <= K <= 384 (K % 64 == 0, N % 128 == 0, N >= 256) and >= 2 tiles per CU take the A-stationary kernel (gemm_astat.hip) | 2: any row count | 3: >= 1.25 tiles per CU | 0
