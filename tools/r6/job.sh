@@ -46,6 +46,7 @@ case "$J" in
     VTX_SIDE_WGRAD=${SIDE:-0} timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r6_prof_$TAG -o trace -- python $R/bench.py --model $M --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-kernel-events "$@" > $R/gpurun_out/r6_prof_$TAG.log 2>&1
     cd $R
     python tools/rocpd_stats.py gpurun_out/r6_prof_$TAG/trace_results.db --steps 7 --top 70 > gpurun_out/r6_kernel_stats_$TAG.md 2>> gpurun_out/r6_prof_$TAG.log || true
+    [ -n "$OVERLAP" ] && python tools/r6/overlap_of.py gpurun_out/r6_prof_$TAG/trace_results.db "$OVERLAP" > gpurun_out/r6_overlap_$TAG.txt 2>&1
     [ -n "$GAPS" ] && python tools/rocpd_gaps.py gpurun_out/r6_prof_$TAG/trace_results.db --skip 0.5 > gpurun_out/r6_gaps_$TAG.txt 2>&1
     rm -f gpurun_out/r6_prof_$TAG/trace_results.db
     M=$TAG

@@ -16,6 +16,7 @@ per bucket filled by a single multi-tensor copy, averaged by the collective itse
 World size 1 bypasses all of it.  Works on CPU tensors with the gloo backend (used by the tests).
 """
 import contextlib
+import os
 from typing import List
 
 import torch
@@ -105,8 +106,8 @@ class GradAllReduce:
         # rank as a `oneRankReduce<FuncPreMulSum>` copy kernel over the whole bucket (Swin-S: 189 MB through 6 launches = 0.5 ms per step,
         # profiles/round6_ddp_overhead_one_gpu.txt) -- a kernel the N > 1 run does not have (its ring kernel averages on the fly).  SUM in
         # place is what a one-rank collective degenerates to: the call, its stream / event bookkeeping and work.wait() stay live.
-        if self.world == 1:
-            self._avg = dist.ReduceOp.SUM
+        if self.world == 1 and os.environ.get("VTX_DDP_ONE_RANK_AVG", "0") != "1":      # (=1: keep the copy kernel -- a stand-in for the N > 1
+            self._avg = dist.ReduceOp.SUM                                                 #  ring kernel when looking at stream overlap on one GPU)
         self._slot = {}
         self._sunk = set()         # ids of the parameters whose bucket slot was handed out as a gradient sink since finish()
         self._sync = True          # False inside no_sync(): hooks do not count, nothing is reduced
