@@ -477,7 +477,7 @@ def run_workload(model_name, batch, steps, warmup, args, dev, rank, world):
     if rank == 0:
         if timer is not None:
             allk = timer.summary()
-            if args.shape_table:
+            if args.shape_table and model_name == args.model:      # (the headline workload's table; the secondaries of the same process do not overwrite it)
                 rows_ = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms"])
                 with open(args.shape_table, "w") as f:
                     f.write(f"{model_name} B = {batch}: launches timed inside libvtx over {nsampled} sampled step(s), HIP events on the launch stream; "
