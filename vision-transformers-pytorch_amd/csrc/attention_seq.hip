@@ -18,6 +18,11 @@
 
 #include <type_traits>
 
+// (round 6) the o / dqkv stores of this file are non-temporal: -0.4 % on the ViT-S/16 step, same-box A/B; the same switch on the other
+// kernel files measured neutral or slower (profiles/round6_nt_store_screen.txt)
+#ifndef VTX_NT_STORE8
+#define VTX_NT_STORE8 1
+#endif
 #include "options.h"
 #include "vtx_common.h"
 

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) val[j] = gelu_f((float)z[j]);
       }
-      if constexpr (AUX) as_store4<true>(aux_out + n0p + off, z);
+      if constexpr (AUX) as_store4<true>(aux_out + n0p + off, z);      // (non-temporal for every ASTAT_NT != 0: read next by the backward only)
     } else if constexpr (act_bwd) {
       if constexpr (ACT == 2) {
 #pragma unroll
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
     } else if constexpr ((ASTAT_ABLATE & 512) != 0) {  // timing probe: the stores without the epilogue arithmetic (raw accumulator bits)
       as_store4<true>(Cout + n0p + (strip_p * AS_BM + wm * WROWS + i * 16 + g_ * 4 + r) * (int)p.ldc + wn * 64 + c_ * 4,
                 __builtin_bit_cast(bf16x4, u32x2{__builtin_bit_cast(unsigned, accp[i][0][r]), __builtin_bit_cast(unsigned, accp[i][1][r])}));
-    } else if (!(ASTAT_ABLATE & 4) || (float)o[0] + (float)o[1] + (float)o[2] + (float)o[3] == 12345.678f) as_store4<(ASTAT_NT > 1) || !RESID>(dst, o);
+    } else if (!(ASTAT_ABLATE & 4) || (float)o[0] + (float)o[1] + (float)o[2] + (float)o[3] == 12345.678f) as_store4<(ASTAT_NT == 1 && !RESID) || ASTAT_NT == 2 || (ASTAT_NT == 3 && ACT != 0 && !RESID)>(dst, o);      // (ASTAT_NT: 1 every output but the residual stream | 2 all | 3 only the ff-wide outputs of the activation kinds | 4 only z | 0 none -- tools/r6/build_variant.sh A/B)
   };
 
   if constexpr (VEC) {

@@ -76,8 +76,14 @@ template <> __device__ __forceinline__ Vec8<float> load8<float>(const float* p) 
   return r;
 }
 template <typename T> __device__ __forceinline__ void store8(T* p, const Vec8<T>& x);
+// VTX_NT_STORE8 (per translation unit; tools/r6/build_variant.sh A/B, profiles/round6_nt_store_screen.txt): every 16-byte bf16 output store of
+// the file non-temporal -- outputs that stream past the L2 instead of displacing the operands it holds (what ASTAT_NT does for gemm_astat.hip)
+#ifndef VTX_NT_STORE8
+#define VTX_NT_STORE8 0
+#endif
 template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const Vec8<bf16>& x) {
-  *reinterpret_cast<bf16x8*>(p) = x.v;
+  if constexpr (VTX_NT_STORE8 != 0) __builtin_nontemporal_store(x.v, reinterpret_cast<bf16x8*>(p));
+  else *reinterpret_cast<bf16x8*>(p) = x.v;
 }
 template <> __device__ __forceinline__ void store8<float>(float* p, const Vec8<float>& x) {
   f32x4 a, b;
