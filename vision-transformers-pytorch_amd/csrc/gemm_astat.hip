@@ -132,6 +132,9 @@ template <int V, int N> __device__ __forceinline__ u32x2 as_take() {
 // k-step barrier.  With three ring stages the request waves cannot run far enough ahead for the decoupling to pay, and a polled
 // LDS counter costs more than s_barrier: 33.9 vs 29.8 us on the stage-3 qkv forward, 16.3 vs 9.7 us with stores and DMA compiled out.)
 
+#ifndef ASTAT_AUX_A
+#define ASTAT_AUX_A 0       // cache-policy bits of the A strip's LDS-DMA (2 = nt: the strip is read once per launch) -- A/B: profiles/round6_nt_load_screen.txt
+#endif
 #ifndef ASTAT_NT
 #define ASTAT_NT 1          // non-temporal stores of C / z: the outputs stream past the L2 that holds the weight panel and the A strips (ViT-S/16 step -2.7 %, Swin-S -0.3 %)
 #endif
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(AS_NT) __attribute__((amdgpu_num_vgpr(AS_EV0))) voi
 #pragma unroll
         for (int j = 0; j < AS_LW; ++j)
           __builtin_amdgcn_global_load_lds((gbl_void_t*)((const bf16*)p.A + aoff[j] + kt * AS_BK),
-                                           (lds_void_t*)(sa + kt * AS_KT_BYTES + (lw * AS_RPW + j * 8) * ROWB), 16, 0, 0);
+                                           (lds_void_t*)(sa + kt * AS_KT_BYTES + (lw * AS_RPW + j * 8) * ROWB), 16, 0, ASTAT_AUX_A);
       };
       // weight k-tile q + 2 is requested in k-step q
       int tnw = tn, ktw = 0, stw = 0;

@@ -32,6 +32,10 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
+#ifndef PP_AUX_A
+#define PP_AUX_A 0          // cache-policy bits of the A requests (group 0): 2 = nt -- A/B: profiles/round6_nt_load_screen.txt
+#endif
+
 namespace {
 
 constexpr int PP_NT = 512;                 // 8 waves
@@ -146,8 +150,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p, const PpGrid& gr) {
       if (j < j0 || j >= j1) continue;
       const bool mine = (ABL & 8) ? grp != 0 : ((ABL & 16) ? grp == 0 : true);
       const int jj = j < NIMIN ? j : (j < ni ? j : ni - 1);            // (the repeated piece lands where its original does)
-      if (!(ABL & 24) || mine)
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src[j], (lds_void_t*)(base + jj * 1024), 16, 0, 0);
+      if (!(ABL & 24) || mine) {
+        if (PP_AUX_A != 0 && grp == 0) __builtin_amdgcn_global_load_lds((gbl_void_t*)src[j], (lds_void_t*)(base + jj * 1024), 16, 0, PP_AUX_A);
+        else __builtin_amdgcn_global_load_lds((gbl_void_t*)src[j], (lds_void_t*)(base + jj * 1024), 16, 0, 0);
+      }
       src[j] += 64;
     }
   };

@@ -14,6 +14,9 @@
 //     (their tokens contribute nothing), c is applied once to the accumulators;
 //   * bias gradient = column sums of the dy tile, accumulated from LDS with 16-byte reads by the blocks
 //     of the first Kin tile; split-K over tokens into fp32 slabs + fixed-order reduce (deterministic).
+#ifndef WG_AUX
+#define WG_AUX 0            // cache-policy bits of the operand LDS-DMA (both operands are streamed once): 2 = nt -- A/B: profiles/round6_nt_load_screen.txt
+#endif
 #include "gemm_common.h"
 #include "options.h"
 
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_gl
         const uint64_t ro = (uint64_t)(unsigned)nlive[j];
         const char* srca = reinterpret_cast<const char*>(pa[j]) + ro * inca[j];
         const char* srcb = reinterpret_cast<const char*>(pb[j]) + ro * incb[j];
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, WG_AUX);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, WG_AUX);
       }
 #pragma unroll
       for (int j = 0; j < IPW; ++j) {
@@ -293,8 +296,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_gl
         // dropped samples are never written (0 x garbage could be 0 x NaN)
         const bf16* srca = nlive[j] ? pa[j] : pz[j];
         const bf16* srcb = nlive[j] ? pb[j] : pz[j];
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, WG_AUX);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, WG_AUX);
         pa[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pa[j]) + inca[j]);
         pb[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pb[j]) + incb[j]);
       }
@@ -324,8 +327,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && MAPPED) ? 4 : 2) void wgrad_gl
         if (mapped && live) { const int sq = tok / rps; ro = (int64_t)perm_tab[sq - s0] + (tok - sq * rps); }
         const bf16* srcb = (live && k0 + (qq << 3) < Kin) ? gx + ro * ld_x + k0 + (qq << 3) : pz[j];
         const bf16* srca = (live && n0 + (qq << 3) < N) ? gdy + ro * ld_dy + n0 + (qq << 3) : pz[j];
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)(sa + j * 4 * ROWB), 16, 0, WG_AUX);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)srcb, (lds_void_t*)(sb + j * 4 * ROWB), 16, 0, WG_AUX);
       }
     }
   };
@@ -631,11 +634,11 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
           }
           const bool lv = MAPPED || nlive[j];                            // (a dropped sample's rows: the zero row in every panel)
           unsigned char* d = sa + j * 4 * 256;
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)((lv && a_ok) ? srca : reinterpret_cast<const char*>(pz)), (lds_void_t*)d, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)((lv && a_ok) ? srca : reinterpret_cast<const char*>(pz)), (lds_void_t*)d, 16, 0, WG_AUX);
 #pragma unroll
           for (int pn = 0; pn < NXP; ++pn)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)((lv && b_ok[pn]) ? srcb + pn * 256 : reinterpret_cast<const char*>(pz)),
-                                             (lds_void_t*)(d + (1 + pn) * WW_PANEL), 16, 0, 0);
+                                             (lds_void_t*)(d + (1 + pn) * WW_PANEL), 16, 0, WG_AUX);
           if (!MAPPED) {
             pa[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pa[j]) + inca);
             pb[j] = reinterpret_cast<const bf16*>(reinterpret_cast<const char*>(pb[j]) + incb);
@@ -660,10 +663,10 @@ __global__ __launch_bounds__(WW_NT, 1) void wgrad_wide_kernel(WgradArgs p) {
           const bf16* srca = (live && a_ok) ? gdy + ro * ld_dy + n0 + (qq << 3) : pz;
           const bf16* srcb = gx + ro * ld_x + k0 + (qq << 3);
           unsigned char* d = sa + j * 4 * 256;
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)d, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)srca, (lds_void_t*)d, 16, 0, WG_AUX);
 #pragma unroll
           for (int pn = 0; pn < NXP; ++pn)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)((live && b_ok[pn]) ? srcb + pn * 128 : pz), (lds_void_t*)(d + (1 + pn) * WW_PANEL), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)((live && b_ok[pn]) ? srcb + pn * 128 : pz), (lds_void_t*)(d + (1 + pn) * WW_PANEL), 16, 0, WG_AUX);
         }
       }
     };
